@@ -1,0 +1,139 @@
+"""ctypes binding of the C-ABI in include/cagroup3d_hip.h.
+
+The product binds `cagroup3d_amd/csrc/libcagroup3d_hip.so` (hand-written HIP for gfx950) and
+FAILS LOUDLY if it is missing or if an op is handed a non-GPU tensor: there is no CPU fallback.
+
+`bind(path)` returns a `Library` for any shared object exporting the same symbols; the parity
+tests use it to drive the CPU oracle (oracle/liboracle.so) through the identical binding, and
+`use_library()` lets tests / the bench's cpu_baseline leg run the host-side engine on it.  Nothing
+in this package ever loads the oracle by itself.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libcagroup3d_hip.so")
+
+CG3D_OK = 0
+_ERRORS = {-1: "CG3D_ERR_ARG (bad argument)", -2: "CG3D_ERR_LAUNCH (HIP launch/runtime error)",
+           -3: "CG3D_ERR_RANGE (coordinate outside packable range)"}
+
+P = c_void_p
+_SIGNATURES = {
+    "cg3d_is_device_library": (c_int32, []),
+    "cg3d_abi_version": (c_int32, []),
+    "cg3d_hash_capacity": (c_int64, [c_int64]),
+    "cg3d_coord_map_ws_bytes": (c_int64, [c_int64]),
+    "cg3d_coord_map_build": (c_int32, [P, c_int64, c_int32, P, P, c_int64, P, P, P, P, P, P]),
+    "cg3d_kernel_map": (c_int32, [P, c_int64, P, c_int32, P, P, c_int64, P, P]),
+    "cg3d_spconv_fwd": (c_int32, [P, P, P, P, P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, P]),
+    "cg3d_spconv_wgrad": (c_int32, [P, P, P, P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, P]),
+    "cg3d_pairs_ws_bytes": (c_int64, [c_int64]),
+    "cg3d_pairs_count": (c_int32, [P, c_int32, c_int64, P, P, P]),
+    "cg3d_pairs_fill": (c_int32, [P, c_int32, c_int64, P, P, P, P]),
+    "cg3d_spconv_pairs_fwd": (c_int32, [P, P, P, P, P, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P]),
+    "cg3d_spconv_pairs_wgrad": (c_int32, [P, P, P, P, P, c_int64, P, c_int32, c_int32, c_int32, c_int32, P]),
+    "cg3d_interp_map": (c_int32, [P, c_int64, c_int32, P, P, c_int64, P, P, P]),
+    "cg3d_interp_fwd": (c_int32, [P, P, P, P, c_int64, c_int32, P]),
+    "cg3d_interp_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, P]),
+    "cg3d_pool_map": (c_int32, [P, c_int64, c_int32, c_int32, P, P, c_int64, P, P]),
+    "cg3d_scatter_mean_fwd": (c_int32, [P, P, c_int32, P, P, c_int64, c_int64, c_int32, P]),
+    "cg3d_scatter_mean_bwd": (c_int32, [P, P, P, c_int32, P, c_int64, c_int64, c_int32, P]),
+    "cg3d_boxes_overlap_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
+    "cg3d_boxes_iou_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
+    "cg3d_nms": (c_int32, [P, c_int64, c_float, c_int32, P, P, P, P]),
+    "cg3d_nms_batched": (c_int32, [P, P, P, c_int32, c_int64, c_float, c_int32, P, P, P, P]),
+    "cg3d_knn": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P]),
+    "cg3d_sort_vertices": (c_int32, [c_int32, c_int32, c_int32, P, P, P, P, P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class CG3DError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded shared object exporting the cg3d_* C-ABI."""
+
+    def __init__(self, path):
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        self.is_device = bool(self._dll.cg3d_is_device_library())
+        self.device_type = "cuda" if self.is_device else "cpu"
+
+    def raw(self, name):
+        return getattr(self._dll, name)
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != CG3D_OK:
+            raise CG3DError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+
+    def stream(self):
+        if self.is_device:
+            return c_void_p(torch.cuda.current_stream().cuda_stream)
+        return c_void_p(0)
+
+    def check(self, *tensors):
+        """Every tensor must live where this library computes and be contiguous."""
+        for t in tensors:
+            if t is None:
+                continue
+            if t.device.type != self.device_type:
+                raise CG3DError(
+                    "cagroup3d_amd op got a %s tensor but the bound library (%s) computes on %s; "
+                    "there is no CPU fallback in the product path" % (t.device.type, self.path, self.device_type))
+            if not t.is_contiguous():
+                raise CG3DError("cagroup3d_amd ops need contiguous tensors")
+
+
+def ptr(t):
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+_active = None
+
+
+def bind(path):
+    return Library(path)
+
+
+def get():
+    """The library the ops run on.  Default: the HIP library; raises if it has not been built."""
+    global _active
+    if _active is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise CG3DError(
+                "libcagroup3d_hip.so not found at %s -- build it with `python cagroup3d_amd/csrc/build.py` "
+                "(hipcc --offload-arch=gfx950).  The product path has no CPU fallback." % HIP_LIB_PATH)
+        _active = Library(HIP_LIB_PATH)
+    return _active
+
+
+class use_library:
+    """Context manager that points the host-side engine at another C-ABI implementation.
+
+    Used only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg with the CPU
+    oracle -- as the checker, never as the product."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _active
+        self.prev = _active
+        _active = self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self.prev
+        return False

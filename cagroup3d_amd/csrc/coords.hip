@@ -1,0 +1,345 @@
+// coords.hip -- hash-built voxel grid for gfx950: coordinate-map build (insert, first-occurrence
+// representative, ordered compaction), kernel maps, interpolation maps, pooling maps.
+//
+// Replaces what the reference gets from MinkowskiEngine's CoordinateManager (un-vendored; call
+// sites: pcdet/models/detectors/cagroup3d.py:18-25, backbones_3d/biresnet.py (every strided
+// conv), dense_heads/cagroup_head.py:254-276, roi_heads/cagroup_roi_head.py:62-69).
+// All integer work: HBM/L2-latency bound random probes; kernels are one thread per probe with
+// coalesced coordinate reads and coalesced map writes (k-major maps: nbr[k][row]).
+#include "cg3d_common.h"
+
+extern "C" int cg3d_is_device_library(void) { return 1; }
+extern "C" int cg3d_abi_version(void) { return 1; }
+
+extern "C" int64_t cg3d_hash_capacity(int64_t n) {
+    int64_t cap = 64;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+extern "C" int64_t cg3d_coord_map_ws_bytes(int64_t n) { return (2 * n + n / 1024 + 64) * (int64_t)sizeof(int32_t); }
+
+// ------------------------------------------------------------------ build
+__device__ static inline bool quantised_key(const int32_t *__restrict__ coords, int64_t i, int32_t qs, int4 *c,
+                                            uint64_t *key) {
+    int4 v = reinterpret_cast<const int4 *>(coords)[i];
+    if (qs > 1) {
+        v.y = cg3d_floordiv(v.y, qs) * qs;
+        v.z = cg3d_floordiv(v.z, qs) * qs;
+        v.w = cg3d_floordiv(v.w, qs) * qs;
+    }
+    *c = v;
+    return cg3d_pack(v.x, v.y, v.z, v.w, key);
+}
+
+__global__ void k_insert(const int32_t *__restrict__ coords, int64_t n, int32_t qs, unsigned long long *keys,
+                         int32_t *vals, uint64_t capm1, int32_t *slot_of, int32_t *status) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c;
+    uint64_t key;
+    if (!quantised_key(coords, i, qs, &c, &key)) {
+        *status = CG3D_ERR_RANGE;
+        slot_of[i] = -1;
+        return;
+    }
+    uint64_t slot = cg3d_hash(key) & capm1;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&keys[slot], CG3D_EMPTY_KEY, (unsigned long long)key);
+        if (prev == CG3D_EMPTY_KEY || prev == key) {
+            atomicMin(&vals[slot], (int32_t)i);  // representative = first occurrence
+            slot_of[i] = (int32_t)slot;
+            return;
+        }
+        slot = (slot + 1) & capm1;
+    }
+}
+
+__global__ void k_flag(int64_t n, const int32_t *__restrict__ vals, const int32_t *__restrict__ slot_of,
+                       int32_t *flag) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t s = slot_of[i];
+    flag[i] = (s >= 0 && vals[s] == (int32_t)i) ? 1 : 0;
+}
+
+// three-kernel exclusive scan over int32 (2048 elements per block)
+#define SCAN_ELEMS 2048
+__global__ __launch_bounds__(256) void k_scan_reduce(const int32_t *__restrict__ in, int64_t n, int32_t *bsum) {
+    __shared__ int32_t red[256];
+    int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS;
+    int32_t s = 0;
+    for (int j = threadIdx.x; j < SCAN_ELEMS; j += 256) {
+        int64_t i = base + j;
+        if (i < n) s += in[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_scan_bsums(int32_t *bsum, int64_t nb, int32_t *total) {
+    __shared__ int32_t buf[256];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256) {
+        int64_t i = base + threadIdx.x;
+        int32_t v = (i < nb) ? bsum[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int32_t t = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int32_t incl = buf[threadIdx.x];
+        if (i < nb) bsum[i] = carry + incl - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void k_scan_apply(int32_t *data, int64_t n, const int32_t *__restrict__ bsum) {
+    // in-place exclusive scan of one 2048-element block: 8 elements per thread
+    __shared__ int32_t tsum[256];
+    int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS + threadIdx.x * 8;
+    int32_t v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v[j] = (base + j < n) ? data[base + j] : 0;
+        s += v[j];
+    }
+    tsum[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int32_t t = (threadIdx.x >= (unsigned)o) ? tsum[threadIdx.x - o] : 0;
+        __syncthreads();
+        tsum[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int32_t run = bsum[blockIdx.x] + tsum[threadIdx.x] - s;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (base + j < n) data[base + j] = run;
+        run += v[j];
+    }
+}
+
+__global__ void k_compact(const int32_t *__restrict__ coords, int64_t n, int32_t qs,
+                          const int32_t *__restrict__ vals, const int32_t *__restrict__ slot_of,
+                          const int32_t *__restrict__ pos, int32_t *out_coords, int32_t *unique_index,
+                          int32_t *inverse) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t s = slot_of[i];
+    if (s < 0) { inverse[i] = -1; return; }
+    int32_t rep = vals[s];
+    int32_t m = pos[rep];
+    inverse[i] = m;
+    if (rep == (int32_t)i) {
+        int4 c;
+        uint64_t key;
+        quantised_key(coords, i, qs, &c, &key);
+        reinterpret_cast<int4 *>(out_coords)[m] = c;
+        unique_index[m] = (int32_t)i;
+    }
+}
+__global__ void k_retarget(int64_t n, int32_t *vals, const int32_t *__restrict__ slot_of,
+                           const int32_t *__restrict__ unique_index, const int32_t *__restrict__ n_out) {
+    // table value: representative input row -> compact output row
+    int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (m >= *n_out) return;
+    vals[slot_of[unique_index[m]]] = (int32_t)m;
+}
+
+extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride, uint64_t *keys, int32_t *vals,
+                                    int64_t cap, void *ws, int32_t *out_coords, int32_t *unique_index,
+                                    int32_t *inverse, int32_t *n_out, cg3d_stream_t stream) {
+    if (n < 0 || qstride < 1 || cap < 2 * n || (cap & (cap - 1)) || cap > (1LL << 30)) return CG3D_ERR_ARG;
+    if (((uintptr_t)coords & 15) || ((uintptr_t)out_coords & 15)) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    if (hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(n_out, 0, sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (n == 0) return CG3D_OK;
+    int32_t *slot_of = (int32_t *)ws;
+    int32_t *pos = slot_of + n;
+    int64_t nb = cg3d_divup(n, SCAN_ELEMS);
+    int32_t *bsum = pos + n;
+    int32_t *status = bsum + nb + 1;
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t), s);
+    unsigned g = (unsigned)cg3d_divup(n, 256);
+    hipLaunchKernelGGL(k_insert, dim3(g), dim3(256), 0, s, coords, n, qstride, (unsigned long long *)keys, vals,
+                       (uint64_t)(cap - 1), slot_of, status);
+    hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, s, n, vals, slot_of, pos);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, pos, n, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, s, bsum, nb, n_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, pos, n, bsum);
+    hipLaunchKernelGGL(k_compact, dim3(g), dim3(256), 0, s, coords, n, qstride, vals, slot_of, pos, out_coords,
+                       unique_index, inverse);
+    hipLaunchKernelGGL(k_retarget, dim3(g), dim3(256), 0, s, n, vals, slot_of, unique_index, n_out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------ kernel map
+__global__ void k_kernel_map(const int32_t *__restrict__ q, int64_t nq, const int32_t *__restrict__ off, int32_t K,
+                             const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint64_t capm1,
+                             int32_t *__restrict__ nbr) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int4 c = reinterpret_cast<const int4 *>(q)[i];
+    for (int32_t k = blockIdx.y; k < K; k += gridDim.y) {
+        uint64_t key;
+        int32_t r = -1;
+        if (cg3d_pack(c.x, c.y + off[k * 3], c.z + off[k * 3 + 1], c.w + off[k * 3 + 2], &key))
+            r = cg3d_lookup(keys, vals, capm1, key);
+        nbr[(int64_t)k * nq + i] = r;
+    }
+}
+extern "C" int cg3d_kernel_map(const int32_t *q, int64_t nq, const int32_t *off, int32_t K, const uint64_t *keys,
+                               const int32_t *vals, int64_t cap, int32_t *nbr, cg3d_stream_t stream) {
+    if (nq < 0 || K < 1 || ((uintptr_t)q & 15)) return CG3D_ERR_ARG;
+    if (nq == 0) return CG3D_OK;
+    unsigned gy = (unsigned)(K < 1024 ? K : 1024);
+    hipLaunchKernelGGL(k_kernel_map, dim3((unsigned)cg3d_divup(nq, 256), gy), dim3(256), 0, cg3d_hs(stream), q, nq, off,
+                       K, keys, vals, (uint64_t)(cap - 1), nbr);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------ interpolation map
+__global__ void k_interp_map(const float *__restrict__ q, int64_t nq, int32_t ts, const uint64_t *__restrict__ keys,
+                             const int32_t *__restrict__ vals, uint64_t capm1, int32_t *__restrict__ idx,
+                             float *__restrict__ w) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t >> 3;
+    int j = (int)(t & 7);
+    if (i >= nq) return;
+    float4 v = reinterpret_cast<const float4 *>(q)[i];
+    const float fts = (float)ts;
+    float qv[3] = {v.y, v.z, v.w};
+    int dsel[3] = {(j >> 2) & 1, (j >> 1) & 1, j & 1};
+    int32_t c[3];
+    float wd[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        float fl = floorf(qv[d] / fts);
+        float lo = fl * fts;
+        float r = (qv[d] - lo) / fts;
+        c[d] = (int32_t)lo + dsel[d] * ts;
+        wd[d] = dsel[d] ? r : (1.0f - r);
+    }
+    float wt = (wd[0] * wd[1]) * wd[2];
+    uint64_t key;
+    int32_t r = -1;
+    if (cg3d_pack((int32_t)v.x, c[0], c[1], c[2], &key)) r = cg3d_lookup(keys, vals, capm1, key);
+    idx[t] = r;
+    w[t] = wt;
+}
+extern "C" int cg3d_interp_map(const float *q, int64_t nq, int32_t ts, const uint64_t *keys, const int32_t *vals,
+                               int64_t cap, int32_t *idx, float *w, cg3d_stream_t stream) {
+    if (nq < 0 || ts < 1 || ((uintptr_t)q & 15)) return CG3D_ERR_ARG;
+    if (nq == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_interp_map, dim3((unsigned)cg3d_divup(nq * 8, 256)), dim3(256), 0, cg3d_hs(stream), q, nq, ts,
+                       keys, vals, (uint64_t)(cap - 1), idx, w);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------ pooling map
+__global__ void k_pool_map(const int32_t *__restrict__ in, int64_t n_in, int32_t os, int32_t half,
+                           const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint64_t capm1,
+                           int32_t *__restrict__ pmap) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= n_in) return;
+    int4 c = reinterpret_cast<const int4 *>(in)[i];
+    int32_t cc[3] = {c.y, c.z, c.w};
+    int32_t dd[3] = {j / 9 - 1, (j / 3) % 3 - 1, j % 3 - 1};
+    int32_t o[3];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        o[d] = (cg3d_floordiv(cc[d], os) + dd[d]) * os;
+        int32_t diff = o[d] - cc[d];
+        diff = diff < 0 ? -diff : diff;
+        ok = ok && (diff <= half);
+    }
+    int32_t r = -1;
+    uint64_t key;
+    if (ok && cg3d_pack(c.x, o[0], o[1], o[2], &key)) r = cg3d_lookup(keys, vals, capm1, key);
+    pmap[(int64_t)j * n_in + i] = r;
+}
+extern "C" int cg3d_pool_map(const int32_t *in, int64_t n_in, int32_t out_stride, int32_t half_extent,
+                             const uint64_t *keys, const int32_t *vals, int64_t cap, int32_t *pmap,
+                             cg3d_stream_t stream) {
+    if (n_in < 0 || out_stride < 1 || half_extent < 0 || ((uintptr_t)in & 15)) return CG3D_ERR_ARG;
+    if (n_in == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_pool_map, dim3((unsigned)cg3d_divup(n_in, 256), 27), dim3(256), 0, cg3d_hs(stream), in, n_in,
+                       out_stride, half_extent, keys, vals, (uint64_t)(cap - 1), pmap);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------ pair-compacted kernel maps
+extern "C" int64_t cg3d_pairs_ws_bytes(int64_t total) { return (total + total / 1024 + 64) * (int64_t)sizeof(int32_t); }
+
+__global__ void k_pair_flags(const int32_t *__restrict__ nbr, int64_t total, int32_t *__restrict__ pos) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < total) pos[t] = nbr[t] >= 0 ? 1 : 0;
+}
+__global__ void k_pair_offsets(const int32_t *__restrict__ pos, int32_t K, int64_t n_out, const int32_t *total,
+                               int32_t *__restrict__ pair_off) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) pair_off[k] = pos[(int64_t)k * n_out];
+    if (k == K) pair_off[K] = *total;
+}
+extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off,
+                                cg3d_stream_t stream) {
+    if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    const int64_t total = (int64_t)K * n_out;
+    if (total >= (1LL << 31)) return CG3D_ERR_ARG;
+    if (total == 0) {
+        if (hipMemsetAsync(pair_off, 0, (K + 1) * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+        return CG3D_OK;
+    }
+    int32_t *pos = (int32_t *)ws;
+    const int64_t nb = cg3d_divup(total, SCAN_ELEMS);
+    int32_t *bsum = pos + total;
+    int32_t *tot = bsum + nb + 1;
+    hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, nbr, total, pos);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, s, bsum, nb, tot);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)cg3d_divup(K + 1, 256)), dim3(256), 0, s, pos, K, n_out, tot,
+                       pair_off);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+__global__ void k_pair_fill(const int32_t *__restrict__ nbr, int64_t total, int64_t n_out,
+                            const int32_t *__restrict__ pos, int32_t *__restrict__ pin, int32_t *__restrict__ pout) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int32_t i = nbr[t];
+    if (i < 0) return;
+    int32_t p = pos[t];
+    pin[p] = i;
+    pout[p] = (int32_t)(t % n_out);
+}
+extern "C" int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in,
+                               int32_t *pair_out, cg3d_stream_t stream) {
+    if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
+    const int64_t total = (int64_t)K * n_out;
+    if (total == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_pair_fill, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream), nbr, total,
+                       n_out, (const int32_t *)ws, pair_in, pair_out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -1,0 +1,138 @@
+// gather_scatter.hip -- HBM-bound row gathers/scatters for gfx950: trilinear feature
+// interpolation (SparseTensor.features_at_coordinates, reference call sites
+// pcdet/models/backbones_3d/biresnet.py:182-197,376,389,394) and the "scatter mean" behind
+// MinkowskiAvgPooling (biresnet.py:109-127) and ME.SparseTensor(UNWEIGHTED_AVERAGE)
+// (pcdet/models/dense_heads/cagroup_head.py:257-271).
+// One thread owns 4 consecutive channels of one row (16-byte accesses, rows contiguous across the
+// wave); index/weight rows are wave-broadcast reads.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include "cg3d_common.h"
+
+// ---------------------------------------------------------------- interpolation
+template <bool VEC>
+__global__ void k_interp_fwd(const float *__restrict__ F, const int32_t *__restrict__ idx,
+                             const float *__restrict__ w, float *__restrict__ out, int64_t nq, int32_t c,
+                             int32_t cq /* channel groups per row */) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / cq;
+    int g = (int)(t % cq);
+    if (i >= nq) return;
+    if (VEC) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int32_t r = idx[i * 8 + j];
+            if (r < 0) continue;
+            float wt = w[i * 8 + j];
+            float4 f = reinterpret_cast<const float4 *>(F + (int64_t)r * c)[g];
+            acc.x += wt * f.x; acc.y += wt * f.y; acc.z += wt * f.z; acc.w += wt * f.w;
+        }
+        reinterpret_cast<float4 *>(out + i * c)[g] = acc;
+    } else {
+        float acc = 0.f;
+        for (int j = 0; j < 8; j++) {
+            int32_t r = idx[i * 8 + j];
+            if (r < 0) continue;
+            acc += w[i * 8 + j] * F[(int64_t)r * c + g];
+        }
+        out[i * c + g] = acc;
+    }
+}
+extern "C" int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *w, float *out, int64_t nq, int32_t c,
+                               cg3d_stream_t stream) {
+    if (nq < 0 || c < 1) return CG3D_ERR_ARG;
+    if (nq == 0) return CG3D_OK;
+    const bool vec = (c % 4 == 0) && !(((uintptr_t)F | (uintptr_t)out) & 15);
+    const int32_t cq = vec ? c / 4 : c;
+    const unsigned g = (unsigned)cg3d_divup(nq * cq, 256);
+    if (vec) hipLaunchKernelGGL(k_interp_fwd<true>, dim3(g), dim3(256), 0, cg3d_hs(stream), F, idx, w, out, nq, c, cq);
+    else hipLaunchKernelGGL(k_interp_fwd<false>, dim3(g), dim3(256), 0, cg3d_hs(stream), F, idx, w, out, nq, c, cq);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+__global__ void k_interp_bwd(const float *__restrict__ dout, const int32_t *__restrict__ idx,
+                             const float *__restrict__ w, float *__restrict__ dF, int64_t nq, int32_t c) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / c;
+    int a = (int)(t % c);
+    if (i >= nq) return;
+    float d = dout[i * c + a];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int32_t r = idx[i * 8 + j];
+        if (r < 0) continue;
+        unsafeAtomicAdd(&dF[(int64_t)r * c + a], w[i * 8 + j] * d);
+    }
+}
+extern "C" int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF, int64_t nq,
+                               int32_t c, cg3d_stream_t stream) {
+    if (nq < 0 || c < 1) return CG3D_ERR_ARG;
+    if (nq == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)cg3d_divup(nq * c, 256)), dim3(256), 0, cg3d_hs(stream), dout, idx,
+                       w, dF, nq, c);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ---------------------------------------------------------------- scatter mean
+__global__ void k_scatter_sum(const float *__restrict__ F, const int32_t *__restrict__ map, int32_t J,
+                              float *__restrict__ out, float *__restrict__ cnt, int64_t n_in, int32_t c) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / c;
+    int a = (int)(t % c);
+    if (i >= n_in) return;
+    float f = F[i * c + a];
+    for (int32_t j = 0; j < J; j++) {
+        int32_t m = map[(int64_t)j * n_in + i];
+        if (m < 0) continue;
+        unsafeAtomicAdd(&out[(int64_t)m * c + a], f);
+        if (a == 0) unsafeAtomicAdd(&cnt[m], 1.0f);
+    }
+}
+__global__ void k_div_rows(float *__restrict__ out, const float *__restrict__ cnt, int64_t n_out, int32_t c) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n_out * c) return;
+    float n = cnt[t / c];
+    if (n > 0.f) out[t] = out[t] / n;
+}
+extern "C" int cg3d_scatter_mean_fwd(const float *F, const int32_t *map, int32_t J, float *out, float *cnt,
+                                     int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t stream) {
+    if (n_in < 0 || n_out < 0 || c < 1 || J < 1) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    if (n_out == 0) return CG3D_OK;
+    if (hipMemsetAsync(out, 0, n_out * c * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(cnt, 0, n_out * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (n_in > 0)
+        hipLaunchKernelGGL(k_scatter_sum, dim3((unsigned)cg3d_divup(n_in * c, 256)), dim3(256), 0, s, F, map, J, out, cnt,
+                           n_in, c);
+    hipLaunchKernelGGL(k_div_rows, dim3((unsigned)cg3d_divup(n_out * c, 256)), dim3(256), 0, s, out, cnt, n_out, c);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+__global__ void k_scatter_mean_bwd(const float *__restrict__ dout, const float *__restrict__ cnt,
+                                   const int32_t *__restrict__ map, int32_t J, float *__restrict__ dF,
+                                   int64_t n_in, int32_t c) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / c;
+    int a = (int)(t % c);
+    if (i >= n_in) return;
+    float acc = 0.f;
+    for (int32_t j = 0; j < J; j++) {
+        int32_t m = map[(int64_t)j * n_in + i];
+        if (m < 0) continue;
+        acc += dout[(int64_t)m * c + a] / cnt[m];
+    }
+    dF[i * c + a] = acc;
+}
+extern "C" int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *map, int32_t J, float *dF,
+                                     int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t stream) {
+    (void)n_out;
+    if (n_in < 0 || c < 1 || J < 1) return CG3D_ERR_ARG;
+    if (n_in == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_scatter_mean_bwd, dim3((unsigned)cg3d_divup(n_in * c, 256)), dim3(256), 0, cg3d_hs(stream),
+                       dout, cnt, map, J, dF, n_in, c);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

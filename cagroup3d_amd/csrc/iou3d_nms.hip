@@ -1,0 +1,358 @@
+// iou3d_nms.hip -- rotated / axis-aligned BEV overlap, IoU and NMS for gfx950.
+//
+// Replaces pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu (boxes_overlap_kernel :236-249,
+// boxes_iou_bev_kernel :251-265, nms_kernel :267-311, nms_normal_kernel :328-372) and the HOST
+// greedy scan of iou3d_nms.cpp:117-132 / :167-182, which here runs on the device.
+//
+// MI355X mapping: one wavefront IS the 64-box suppression tile -- lane j tests (row box, column
+// box j) and the 64-bit mask word is a single wave ballot.  Only tiles on/above the diagonal are
+// produced (the greedy scan never reads the others).  The scan processes the boxes 64 at a time:
+// the in-tile dependency chain runs on the diagonal words held in registers (readlane), then the
+// rows of the kept boxes are OR-ed into the running removal words with coalesced 8-byte loads.
+// Built with -ffp-contract=off: IoU values are bit-identical to the CPU oracle.
+#include "cg3d_common.h"
+
+// ---------------------------------------------------------------- deterministic fp32 trig
+// Same Cephes-style polynomials as the oracle (oracle/oracle_geom.c); device libm is avoided so
+// that host and device agree bit-for-bit.
+#define DG_FOPI 1.27323954473516f
+#define DG_DP1 0.78515625f
+#define DG_DP2 2.4187564849853515625e-4f
+#define DG_DP3 3.77489497744594108e-8f
+
+__device__ static inline float dg_poly_sin(float x, float z) {
+    float p = -1.9515295891E-4f;
+    p = p * z + 8.3321608736E-3f;
+    p = p * z + -1.6666654611E-1f;
+    return p * z * x + x;
+}
+__device__ static inline float dg_poly_cos(float z) {
+    float p = 2.443315711809948E-005f;
+    p = p * z + -1.388731625493765E-003f;
+    p = p * z + 4.166664568298827E-002f;
+    return p * z * z - 0.5f * z + 1.0f;
+}
+__device__ static inline float dg_sinf(float x) {
+    float sign = 1.0f;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    int j = (int)(DG_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sign = -sign; j -= 4; }
+    x = ((x - y * DG_DP1) - y * DG_DP2) - y * DG_DP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? dg_poly_cos(z) : dg_poly_sin(x, z);
+    return sign * r;
+}
+__device__ static inline float dg_cosf(float x) {
+    float sign = 1.0f;
+    if (x < 0.0f) x = -x;
+    int j = (int)(DG_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sign = -sign; j -= 4; }
+    if (j > 1) sign = -sign;
+    x = ((x - y * DG_DP1) - y * DG_DP2) - y * DG_DP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? dg_poly_sin(x, z) : dg_poly_cos(z);
+    return sign * r;
+}
+__device__ static inline float dg_atanf(float x) {
+    float sign = 1.0f, y;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032E-1f;
+    p = p * z + 1.99777106478E-1f;
+    p = p * z - 3.33329491539E-1f;
+    y += p * z * x + x;
+    return sign * y;
+}
+__device__ static inline float dg_atan2f(float y, float x) {
+    const float PIF = 3.141592653589793f, PIO2F = 1.5707963267948966f;
+    int code = 0;
+    if (x < 0.0f) code = 2;
+    if (y < 0.0f) code |= 1;
+    if (x == 0.0f) {
+        if (code & 1) return -PIO2F;
+        if (y == 0.0f) return 0.0f;
+        return PIO2F;
+    }
+    if (y == 0.0f) return (code & 2) ? PIF : 0.0f;
+    float w = (code == 2) ? PIF : ((code == 3) ? -PIF : 0.0f);
+    return w + dg_atanf(y / x);
+}
+
+// ---------------------------------------------------------------- rotated BEV overlap
+#define DG_EPS 1e-8f
+struct dpt { float x, y; };
+
+__device__ static inline float d_cross3(dpt p1, dpt p2, dpt p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+__device__ static inline float d_min(float a, float b) { return a > b ? b : a; }
+__device__ static inline float d_max(float a, float b) { return a > b ? a : b; }
+__device__ static inline bool d_rect_cross(dpt p1, dpt p2, dpt q1, dpt q2) {
+    return d_min(p1.x, p2.x) <= d_max(q1.x, q2.x) && d_min(q1.x, q2.x) <= d_max(p1.x, p2.x) &&
+           d_min(p1.y, p2.y) <= d_max(q1.y, q2.y) && d_min(q1.y, q2.y) <= d_max(p1.y, p2.y);
+}
+// corner-in-box test with the box's cos(-h), sin(-h) hoisted by the caller
+__device__ static inline bool d_in_box2d(const float *box, float ac, float as, dpt p) {
+    const float MARGIN = 1e-2f;
+    float cx = box[0], cy = box[1];
+    float rx = (p.x - cx) * ac + (p.y - cy) * (-as);
+    float ry = (p.x - cx) * as + (p.y - cy) * ac;
+    return (fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN);
+}
+__device__ static inline bool d_intersection(dpt p1, dpt p0, dpt q1, dpt q0, dpt *ans) {
+    if (!d_rect_cross(p0, p1, q0, q1)) return false;
+    float s1 = d_cross3(q0, p1, p0);
+    float s2 = d_cross3(p1, q1, p0);
+    float s3 = d_cross3(p0, q1, q0);
+    float s4 = d_cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    float s5 = d_cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > DG_EPS) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+__device__ static inline dpt d_rot(dpt c, float ac, float as, dpt p) {
+    dpt r;
+    r.x = (p.x - c.x) * ac + (p.y - c.y) * (-as) + c.x;
+    r.y = (p.x - c.x) * as + (p.y - c.y) * ac + c.y;
+    return r;
+}
+
+__device__ static float d_box_overlap(const float *a, const float *b) {
+    float adx = a[3] / 2, bdx = b[3] / 2, ady = a[4] / 2, bdy = b[4] / 2;
+    float ax1 = a[0] - adx, ay1 = a[1] - ady, ax2 = a[0] + adx, ay2 = a[1] + ady;
+    float bx1 = b[0] - bdx, by1 = b[1] - bdy, bx2 = b[0] + bdx, by2 = b[1] + bdy;
+    dpt ca = {a[0], a[1]}, cb = {b[0], b[1]};
+    dpt A[5] = {{ax1, ay1}, {ax2, ay1}, {ax2, ay2}, {ax1, ay2}, {0.f, 0.f}};
+    dpt B[5] = {{bx1, by1}, {bx2, by1}, {bx2, by2}, {bx1, by2}, {0.f, 0.f}};
+    float aco = dg_cosf(a[6]), asi = dg_sinf(a[6]), bco = dg_cosf(b[6]), bsi = dg_sinf(b[6]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { A[k] = d_rot(ca, aco, asi, A[k]); B[k] = d_rot(cb, bco, bsi, B[k]); }
+    A[4] = A[0]; B[4] = B[0];
+
+    dpt cp[16];
+    float ang[16];
+    dpt ctr = {0.f, 0.f};
+    int cnt = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            dpt t;
+            if (d_intersection(A[i + 1], A[i], B[j + 1], B[j], &t)) {
+                cp[cnt] = t; ctr.x = ctr.x + t.x; ctr.y = ctr.y + t.y; cnt++;
+            }
+        }
+    // cos(-h) / sin(-h) evaluated once per box (same operands as the per-corner calls)
+    float nac = dg_cosf(-a[6]), nas = dg_sinf(-a[6]), nbc = dg_cosf(-b[6]), nbs = dg_sinf(-b[6]);
+    for (int k = 0; k < 4; k++) {
+        if (d_in_box2d(a, nac, nas, B[k])) { ctr.x = ctr.x + B[k].x; ctr.y = ctr.y + B[k].y; cp[cnt++] = B[k]; }
+        if (d_in_box2d(b, nbc, nbs, A[k])) { ctr.x = ctr.x + A[k].x; ctr.y = ctr.y + A[k].y; cp[cnt++] = A[k]; }
+    }
+    ctr.x /= cnt; ctr.y /= cnt;
+    for (int i = 0; i < cnt; i++) ang[i] = dg_atan2f(cp[i].y - ctr.y, cp[i].x - ctr.x);
+    for (int j = 0; j < cnt - 1; j++)
+        for (int i = 0; i < cnt - j - 1; i++)
+            if (ang[i] > ang[i + 1]) {
+                dpt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; k++) {
+        float ux = cp[k].x - cp[0].x, uy = cp[k].y - cp[0].y;
+        float vx = cp[k + 1].x - cp[0].x, vy = cp[k + 1].y - cp[0].y;
+        area += ux * vy - uy * vx;
+    }
+    return fabsf(area) / 2.0f;
+}
+__device__ static inline float d_iou_bev(const float *a, const float *b) {
+    float sa = a[3] * a[4], sb = b[3] * b[4];
+    float so = d_box_overlap(a, b);
+    return so / fmaxf(sa + sb - so, DG_EPS);
+}
+__device__ static inline float d_iou_normal(const float *a, const float *b) {
+    float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    float inter = width * height;
+    float Sa = a[3] * a[4], Sb = b[3] * b[4];
+    return inter / fmaxf(Sa + Sb - inter, DG_EPS);
+}
+
+// ---------------------------------------------------------------- pairwise overlap / IoU
+template <bool IOU>
+__global__ __launch_bounds__(256) void k_pairwise(const float *__restrict__ A, int64_t na, const float *__restrict__ B,
+                                                  int64_t nb, float *__restrict__ out) {
+    // 16 x 16 pairs per workgroup; column boxes staged in LDS, consecutive lanes -> consecutive b
+    __shared__ float sb[16 * 7], sa[16 * 7];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t a0 = (int64_t)blockIdx.y * 16, b0 = (int64_t)blockIdx.x * 16;
+    if (threadIdx.x < 112) {
+        int64_t bi = b0 + threadIdx.x / 7;
+        sb[threadIdx.x] = bi < nb ? B[b0 * 7 + threadIdx.x] : 0.f;
+    } else if (threadIdx.x >= 128 && threadIdx.x < 240) {
+        int t = threadIdx.x - 128;
+        int64_t ai = a0 + t / 7;
+        sa[t] = ai < na ? A[a0 * 7 + t] : 0.f;
+    }
+    __syncthreads();
+    const int64_t ai = a0 + ty, bi = b0 + tx;
+    if (ai >= na || bi >= nb) return;
+    float ba[7], bb[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { ba[i] = sa[ty * 7 + i]; bb[i] = sb[tx * 7 + i]; }
+    out[ai * nb + bi] = IOU ? d_iou_bev(ba, bb) : d_box_overlap(ba, bb);
+}
+extern "C" int cg3d_boxes_overlap_bev(const float *A, int64_t na, const float *B, int64_t nb, float *out,
+                                      cg3d_stream_t stream) {
+    if (na < 0 || nb < 0) return CG3D_ERR_ARG;
+    if (na == 0 || nb == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_pairwise<false>, dim3((unsigned)cg3d_divup(nb, 16), (unsigned)cg3d_divup(na, 16)), dim3(256), 0,
+                       cg3d_hs(stream), A, na, B, nb, out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_boxes_iou_bev(const float *A, int64_t na, const float *B, int64_t nb, float *out,
+                                  cg3d_stream_t stream) {
+    if (na < 0 || nb < 0) return CG3D_ERR_ARG;
+    if (na == 0 || nb == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_pairwise<true>, dim3((unsigned)cg3d_divup(nb, 16), (unsigned)cg3d_divup(na, 16)), dim3(256), 0,
+                       cg3d_hs(stream), A, na, B, nb, out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ---------------------------------------------------------------- NMS
+// grid: x = column tile, y = row tile, z = segment.  One wave per (row tile, column tile): the 64
+// row boxes are walked sequentially, lane j tests column box j, the mask word is the ballot.
+template <bool ROTATED>
+__global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes_all, const int64_t *__restrict__ seg_off,
+                                                 const int64_t *__restrict__ mask_off, int64_t n_single, float thr,
+                                                 unsigned long long *__restrict__ mask_all) {
+    const int seg = blockIdx.z;
+    const int64_t o = seg_off ? seg_off[seg] : 0;
+    const int64_t n = seg_off ? seg_off[seg + 1] - o : n_single;
+    const float *boxes = boxes_all + o * 7;
+    unsigned long long *mask = mask_all + (mask_off ? mask_off[seg] : 0);
+    const int64_t cb = (n + 63) / 64;
+    const int64_t rt = blockIdx.y, ct = blockIdx.x;
+    if (rt >= cb || ct >= cb || ct < rt) return;
+    __shared__ float rows[64 * 7];
+    const int lane = threadIdx.x;
+    const int64_t rsz = (n - rt * 64 < 64) ? n - rt * 64 : 64;
+    const int64_t csz = (n - ct * 64 < 64) ? n - ct * 64 : 64;
+    for (int i = lane; i < rsz * 7; i += 64) rows[i] = boxes[rt * 64 * 7 + i];
+    float cbx[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) cbx[i] = (lane < csz) ? boxes[(ct * 64 + lane) * 7 + i] : 0.f;
+    __syncthreads();
+    for (int i = 0; i < rsz; i++) {
+        float rb[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) rb[q] = rows[i * 7 + q];
+        bool hit = false;
+        const int start = (rt == ct) ? i + 1 : 0;
+        if (lane >= start && lane < csz) {
+            float iou = ROTATED ? d_iou_bev(rb, cbx) : d_iou_normal(rb, cbx);
+            hit = iou > thr;
+        }
+        unsigned long long word = __ballot(hit);
+        if (lane == 0) mask[(rt * 64 + i) * cb + ct] = word;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nms_scan(const int64_t *__restrict__ seg_off, const int64_t *__restrict__ mask_off,
+                                                 int64_t n_single, const unsigned long long *__restrict__ mask_all,
+                                                 int64_t *__restrict__ keep_all, int32_t *__restrict__ num_keep) {
+    extern __shared__ unsigned long long remv[];  // cb words
+    const int seg = blockIdx.x;
+    const int64_t o = seg_off ? seg_off[seg] : 0;
+    const int64_t n = seg_off ? seg_off[seg + 1] - o : n_single;
+    const unsigned long long *mask = mask_all + (mask_off ? mask_off[seg] : 0);
+    int64_t *keep = keep_all + o;
+    const int64_t cb = (n + 63) / 64;
+    const int lane = threadIdx.x;
+    for (int64_t j = lane; j < cb; j += 64) remv[j] = 0ULL;
+    __syncthreads();
+    int32_t nk = 0;
+    for (int64_t blk = 0; blk < cb; blk++) {
+        const int64_t bsz = (n - blk * 64 < 64) ? n - blk * 64 : 64;
+        // diagonal word of my row in this tile
+        unsigned long long diag = (lane < bsz) ? mask[(blk * 64 + lane) * cb + blk] : 0ULL;
+        unsigned long long cur = remv[blk];
+        unsigned long long kept = 0ULL;
+        for (int b = 0; b < bsz; b++) {
+            unsigned long long d = __shfl(diag, b);
+            if (!((cur >> b) & 1ULL)) { kept |= 1ULL << b; cur |= d; }
+        }
+        // emit kept indices in ascending order
+        if ((kept >> lane) & 1ULL) {
+            int pos = __popcll(kept & ((1ULL << lane) - 1ULL));
+            keep[nk + pos] = blk * 64 + lane;
+        }
+        nk += __popcll(kept);
+        // OR the rows of the kept boxes into the later removal words
+        for (int64_t j = blk + 1 + lane; j < cb; j += 64) {
+            unsigned long long acc = remv[j];
+            unsigned long long kk = kept;
+            while (kk) {
+                int b = __ffsll((long long)kk) - 1;
+                kk &= kk - 1;
+                acc |= mask[(blk * 64 + b) * cb + j];
+            }
+            remv[j] = acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) num_keep[seg] = nk;
+}
+
+static int nms_launch(const float *boxes, const int64_t *seg_off, const int64_t *mask_off, int32_t nseg,
+                      int64_t max_seg, float thr, int32_t rotated, uint64_t *mask_ws, int64_t *keep,
+                      int32_t *num_keep, hipStream_t s) {
+    if (max_seg < 0 || nseg < 0) return CG3D_ERR_ARG;
+    if (nseg == 0) return CG3D_OK;
+    if (hipMemsetAsync(num_keep, 0, sizeof(int32_t) * nseg, s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (max_seg == 0) return CG3D_OK;
+    const int64_t cb = cg3d_divup(max_seg, 64);
+    if (cb > 65535 || nseg > 65535) return CG3D_ERR_ARG;
+    if (cb * 8 > 160 * 1024) return CG3D_ERR_ARG;  // removal words live in LDS
+    dim3 g((unsigned)cb, (unsigned)cb, (unsigned)nseg);
+    if (rotated)
+        hipLaunchKernelGGL(k_nms_mask<true>, g, dim3(64), 0, s, boxes, seg_off, mask_off, max_seg, thr,
+                           (unsigned long long *)mask_ws);
+    else
+        hipLaunchKernelGGL(k_nms_mask<false>, g, dim3(64), 0, s, boxes, seg_off, mask_off, max_seg, thr,
+                           (unsigned long long *)mask_ws);
+    hipLaunchKernelGGL(k_nms_scan, dim3((unsigned)nseg), dim3(64), (size_t)cb * 8, s, seg_off, mask_off, max_seg,
+                       (const unsigned long long *)mask_ws, keep, num_keep);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+extern "C" int cg3d_nms(const float *boxes, int64_t n, float thresh, int32_t rotated, uint64_t *mask_ws,
+                        int64_t *keep, int32_t *num_keep, cg3d_stream_t stream) {
+    if (n < 0) return CG3D_ERR_ARG;
+    return nms_launch(boxes, nullptr, nullptr, 1, n, thresh, rotated, mask_ws, keep, num_keep, cg3d_hs(stream));
+}
+extern "C" int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off, int32_t nseg,
+                                int64_t max_seg, float thresh, int32_t rotated, uint64_t *mask_ws, int64_t *keep,
+                                int32_t *num_keep, cg3d_stream_t stream) {
+    return nms_launch(boxes, seg_off, mask_off, nseg, max_seg, thresh, rotated, mask_ws, keep, num_keep,
+                      cg3d_hs(stream));
+}

@@ -1,0 +1,436 @@
+// spconv.hip -- sparse 3D convolution for gfx950 as an output-stationary implicit GEMM on the
+// matrix cores: gather rows through the kernel map -> per-offset [rows x Cin] x [Cin x Cout]
+// contraction on MFMA -> direct store (no scatter, no atomics in the forward / data-gradient).
+//
+// Replaces MinkowskiEngine's ConvolutionForwardGPU / ConvolutionBackwardGPU (gather -> GEMM ->
+// scatter-add per offset; un-vendored) for every MinkowskiConvolution /
+// MinkowskiConvolutionTranspose / MinkowskiGenerativeConvolutionTranspose call site in
+// pcdet/models/backbones_3d/biresnet.py, dense_heads/cagroup_head.py and
+// roi_heads/cagroup_roi_head.py:69.
+//
+// Tiling (wave64, v_mfma_f32_32x32x2_f32 = exact fp32 products, fp32 accumulate):
+//   workgroup = 4 waves = 128 output rows x CT output channels; wave = 32 rows x CT.
+//   The MFMA's two k-slices are mapped to the two HALVES of a 64-channel chunk, so lane (r, h)
+//   reads 32 CONTIGUOUS input channels of its gathered row straight into registers (8 x 16-byte
+//   loads, no LDS round trip, no transposition), and the matching B fragment W[k][c][n0 + r] is a
+//   coalesced 128-byte row read by the 32 lanes of a half-wave (L1/L2 resident: every workgroup
+//   streams the same W[k]).
+//   Offsets with no valid neighbour in the wave's 32 rows are skipped with one wave ballot.
+// The weight gradient consumes rows two at a time (k-slices = two rows), so its ballot skips at
+// 2-row granularity -- almost all padding work vanishes on the sparse high-resolution maps.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include "cg3d_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- forward / data gradient
+// KH = channels handled per k-slice (32 for Cin >= 64 chunks, 2 for Cin <= 4)
+template <int NT, int KH, bool VEC4>
+__global__ __launch_bounds__(256) void k_spconv_fwd(const float *__restrict__ X, const float *__restrict__ W,
+                                                    const int32_t *__restrict__ nbr,
+                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                    int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+    const int n0 = blockIdx.y * (NT * 32);
+    const bool row_ok = row < n_out;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    bool col_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) col_ok[t] = (n0 + t * 32 + r) < cout;
+
+    for (int32_t k = 0; k < K; k++) {
+        int32_t idx = row_ok ? nbr[(int64_t)k * n_out + row] : -1;
+        if (!__any(idx >= 0)) continue;  // wave-uniform skip
+        const float *xrow = X + (int64_t)(idx < 0 ? 0 : idx) * cin;
+        const float *wk = W + (int64_t)k * cin * cout;
+        for (int32_t c0 = 0; c0 < cin; c0 += 2 * KH) {
+            const int cb = c0 + h * KH;  // first channel of this lane's k-slice
+            float a[KH];
+            if (VEC4) {
+#pragma unroll
+                for (int t = 0; t < KH; t += 4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx >= 0 && cb + t < cin) v = *reinterpret_cast<const float4 *>(xrow + cb + t);
+                    a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KH; t++) a[t] = (idx >= 0 && cb + t < cin) ? xrow[cb + t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < KH; t++) {
+                const bool c_ok = (cb + t) < cin;
+                const float *wr = wk + (int64_t)(cb + t) * cout + n0 + r;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    float b = (c_ok && col_ok[nt]) ? wr[nt * 32] : 0.f;
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = n0 + nt * 32 + r;
+        if (col >= cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int64_t orow = row_base + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (orow < n_out) Y[orow * cout + col] = acc[nt][e] + bv;
+        }
+    }
+}
+
+extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
+                               int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                               int32_t precision, cg3d_stream_t stream) {
+    (void)n_in;
+    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision != 0) return CG3D_ERR_ARG;  // bf16 operand path: next round
+    if (n_out == 0) return CG3D_OK;
+    hipStream_t s = cg3d_hs(stream);
+    const unsigned gx = (unsigned)cg3d_divup(n_out, 128);
+    const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0);
+#define LAUNCH(NT, KH, V)                                                                                        \
+    hipLaunchKernelGGL((k_spconv_fwd<NT, KH, V>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, \
+                       W, nbr, bias, Y, n_out, K, cin, cout)
+    if (cin <= 4) {
+        if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
+    } else if (vec4) {
+        if (cout > 64) LAUNCH(4, 32, true); else if (cout > 32) LAUNCH(2, 32, true); else LAUNCH(1, 32, true);
+    } else {
+        if (cout > 64) LAUNCH(4, 32, false); else if (cout > 32) LAUNCH(2, 32, false); else LAUNCH(1, 32, false);
+    }
+#undef LAUNCH
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dW[k][ci][co] = sum_o X[nbr[k][o]][ci] * dY[o][co]
+// grid: x = row chunk, y = offset k, z = (ci tile, co tile) of 64x64.  Each wave walks its share of
+// the chunk in 64-row groups; an MFMA step contracts TWO rows (k-slice h = row t + 32*h).
+__global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ X, const float *__restrict__ dY,
+                                                      const int32_t *__restrict__ nbr, float *__restrict__ dW,
+                                                      int64_t n_out, int32_t cin, int32_t cout, int64_t chunk_rows,
+                                                      int32_t co_tiles, int32_t use_atomics) {
+    __shared__ float tile[64 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int32_t k = blockIdx.y;
+    const int ci0 = (blockIdx.z / co_tiles) * 64, co0 = (blockIdx.z % co_tiles) * 64;
+    const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t row_end = (row_begin + chunk_rows < n_out) ? row_begin + chunk_rows : n_out;
+
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) tile[i] = 0.f;
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const bool ci_ok[2] = {ci0 + r < cin, ci0 + 32 + r < cin};
+    const bool co_ok[2] = {co0 + r < cout, co0 + 32 + r < cout};
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+
+    for (int64_t g = row_begin + wave * 64; g < row_end; g += 256) {
+        const int64_t myrow = g + lane;
+        const int32_t myidx = (myrow < row_end) ? nk[myrow] : -1;
+        const unsigned long long valid = __ballot(myidx >= 0);
+        if (valid == 0ULL) continue;
+        for (int t = 0; t < 32; t++) {
+            if (((valid >> t) & 0x100000001ULL) == 0ULL) continue;  // both rows of this step absent
+            const int src = t + 32 * h;
+            const int32_t idx = __shfl(myidx, src);
+            const int64_t orow = g + src;
+            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+            if (idx >= 0) {
+                const float *xr = X + (int64_t)idx * cin + ci0 + r;
+                const float *dr = dY + orow * cout + co0 + r;
+                if (ci_ok[0]) a0 = xr[0];
+                if (ci_ok[1]) a1 = xr[32];
+                if (co_ok[0]) b0 = dr[0];
+                if (co_ok[1]) b1 = dr[32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // cross-wave reduction in LDS (ds_add_f32), then one store / global atomic per element
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                int tr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // ci within tile
+                int tc = j * 32 + r;                              // co within tile
+                atomicAdd(&tile[tr * 64 + tc], acc[i][j][e]);
+            }
+    __syncthreads();
+    float *dst = dW + (int64_t)k * cin * cout;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int ci = ci0 + (i >> 6), co = co0 + (i & 63);
+        if (ci < cin && co < cout) {
+            if (use_atomics) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], tile[i]);
+            else dst[(int64_t)ci * cout + co] = tile[i];
+        }
+    }
+}
+
+extern "C" int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float *dW, int64_t n_in,
+                                 int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
+                                 cg3d_stream_t stream) {
+    (void)n_in;
+    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision != 0) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    const int64_t nw = (int64_t)K * cin * cout;
+    if (n_out == 0) {
+        if (hipMemsetAsync(dW, 0, nw * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+        return CG3D_OK;
+    }
+    const int32_t ci_tiles = (cin + 63) / 64, co_tiles = (cout + 63) / 64;
+    const int64_t base_wgs = (int64_t)K * ci_tiles * co_tiles;
+    // enough workgroups to fill 256 CUs x 4; each chunk at least 512 rows
+    int64_t chunks = cg3d_divup(2048, base_wgs);
+    const int64_t max_chunks = cg3d_divup(n_out, 512);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535) chunks = 65535;
+    int64_t chunk_rows = cg3d_divup(cg3d_divup(n_out, chunks), 256) * 256;
+    chunks = cg3d_divup(n_out, chunk_rows);
+    const int use_atomics = chunks > 1;
+    if (use_atomics && hipMemsetAsync(dW, 0, nw * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (K > 65535) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_spconv_wgrad, dim3((unsigned)chunks, (unsigned)K, (unsigned)(ci_tiles * co_tiles)), dim3(256), 0,
+                       s, X, dY, nbr, dW, n_out, cin, cout, chunk_rows, co_tiles, use_atomics);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// =====================================================================================
+// Pair-compacted path: gather -> MFMA -> atomic scatter.  No work on absent neighbours.
+// Workgroup = one segment of <= 128 pairs of ONE offset k (4 waves x 32 pairs) x one group of
+// NT*32 output channels.  W[k][chunk of 64 input channels][column group] is staged in LDS once per
+// workgroup and shared by the 4 waves (ds_read_b32 of 32 consecutive columns: conflict-free);
+// the gathered rows go straight to registers (32 contiguous channels per lane, 16-byte loads).
+// Results are added to Y with fp32 global atomics: 32 lanes x 4 B = one 128-byte row segment per
+// instruction half.
+// =====================================================================================
+template <int NT, int KH, bool VEC4>
+__global__ __launch_bounds__(256) void k_spconv_pairs(const float *__restrict__ X, const float *__restrict__ W,
+                                                      const int32_t *__restrict__ pin,
+                                                      const int32_t *__restrict__ pout,
+                                                      const int32_t *__restrict__ seg, float *__restrict__ Y,
+                                                      int32_t cin, int32_t cout) {
+    constexpr int CT = NT * 32;
+    __shared__ float Ws[2 * KH * CT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int n0 = blockIdx.y * CT;
+    const int local = wave * 32 + r;
+    const bool valid = local < count;
+    const int32_t irow = valid ? pin[start + local] : -1;
+    const int32_t orow = valid ? pout[start + local] : -1;
+    const bool wave_active = wave * 32 < count;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    const float *xrow = X + (int64_t)(irow < 0 ? 0 : irow) * cin;
+    const float *wk = W + (int64_t)k * cin * cout;
+    const bool wvec = VEC4 && (cout % 4 == 0);
+
+    for (int32_t c0 = 0; c0 < cin; c0 += 2 * KH) {
+        __syncthreads();
+        // stage W[k][c0 .. c0+2KH) x [n0 .. n0+CT) into LDS
+        if (wvec) {
+            for (int i = tid; i < 2 * KH * (CT / 4); i += 256) {
+                const int row = i / (CT / 4), c4 = (i % (CT / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + row < cin && n0 + c4 < cout)
+                    v = *reinterpret_cast<const float4 *>(wk + (int64_t)(c0 + row) * cout + n0 + c4);
+                *reinterpret_cast<float4 *>(&Ws[row * CT + c4]) = v;
+            }
+        } else {
+            for (int i = tid; i < 2 * KH * CT; i += 256) {
+                const int row = i / CT, c = i % CT;
+                Ws[i] = (c0 + row < cin && n0 + c < cout) ? wk[(int64_t)(c0 + row) * cout + n0 + c] : 0.f;
+            }
+        }
+        // gather this lane's 32 (KH) input channels
+        const int cb = c0 + h * KH;
+        float a[KH];
+        if (VEC4) {
+#pragma unroll
+            for (int t = 0; t < KH; t += 4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (irow >= 0 && cb + t < cin) v = *reinterpret_cast<const float4 *>(xrow + cb + t);
+                a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KH; t++) a[t] = (irow >= 0 && cb + t < cin) ? xrow[cb + t] : 0.f;
+        }
+        __syncthreads();
+        if (wave_active) {
+#pragma unroll
+            for (int t = 0; t < KH; t++) {
+                const float *wr = &Ws[(h * KH + t) * CT + r];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], wr[nt * 32], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int rowl = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int32_t orow_e = __shfl(orow, rowl);
+        if (orow_e < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int col = n0 + nt * 32 + r;
+            if (col < cout) unsafeAtomicAdd(&Y[(int64_t)orow_e * cout + col], acc[nt][e]);
+        }
+    }
+}
+
+__global__ void k_init_rows(float *__restrict__ Y, const float *__restrict__ bias, int64_t total, int32_t cout) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < total) Y[t] = bias[t % cout];
+}
+
+extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in, const int32_t *pair_out,
+                                     const int32_t *seg, int64_t nseg, const float *bias, float *Y, int64_t n_out,
+                                     int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
+    if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision != 0) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    if (n_out == 0) return CG3D_OK;
+    const int64_t total = n_out * cout;
+    if (bias) hipLaunchKernelGGL(k_init_rows, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, Y, bias, total, cout);
+    else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (nseg == 0) return CG3D_OK;
+    const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
+#define LAUNCH(NT, KH, V)                                                                                     \
+    hipLaunchKernelGGL((k_spconv_pairs<NT, KH, V>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)),   \
+                       dim3(256), 0, s, X, W, pair_in, pair_out, seg, Y, cin, cout)
+    if (cin <= 4) {
+        if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
+    } else if (vec4) {
+        if (cout > 64) LAUNCH(4, 32, true); else if (cout > 32) LAUNCH(2, 32, true); else LAUNCH(1, 32, true);
+    } else {
+        if (cout > 64) LAUNCH(4, 32, false); else if (cout > 32) LAUNCH(2, 32, false); else LAUNCH(1, 32, false);
+    }
+#undef LAUNCH
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// weight gradient over compacted pairs: every MFMA step contracts two real pairs.
+__global__ __launch_bounds__(256) void k_spconv_pairs_wgrad(const float *__restrict__ X, const float *__restrict__ dY,
+                                                            const int32_t *__restrict__ pin,
+                                                            const int32_t *__restrict__ pout,
+                                                            const int32_t *__restrict__ seg, float *__restrict__ dW,
+                                                            int32_t cin, int32_t cout, int32_t co_tiles) {
+    __shared__ float tile[64 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int ci0 = (blockIdx.y / co_tiles) * 64, co0 = (blockIdx.y % co_tiles) * 64;
+
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) tile[i] = 0.f;
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const bool ci_ok[2] = {ci0 + r < cin, ci0 + 32 + r < cin};
+    const bool co_ok[2] = {co0 + r < cout, co0 + 32 + r < cout};
+
+    for (int32_t g = wave * 64; g < count; g += 256) {
+        const int32_t p = g + lane;
+        const int32_t my_in = (p < count) ? pin[start + p] : -1;
+        const int32_t my_out = (p < count) ? pout[start + p] : -1;
+        const int steps = (count - g >= 64) ? 32 : (count - g + 1) / 2;
+        for (int t = 0; t < steps; t++) {
+            const int src = 2 * t + h;  // consecutive pairs -> the two k-slices
+            const int32_t ii = __shfl(my_in, src);
+            const int32_t oo = __shfl(my_out, src);
+            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+            if (ii >= 0) {
+                const float *xr = X + (int64_t)ii * cin + ci0 + r;
+                const float *dr = dY + (int64_t)oo * cout + co0 + r;
+                if (ci_ok[0]) a0 = xr[0];
+                if (ci_ok[1]) a1 = xr[32];
+                if (co_ok[0]) b0 = dr[0];
+                if (co_ok[1]) b1 = dr[32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                int tr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                int tc = j * 32 + r;
+                atomicAdd(&tile[tr * 64 + tc], acc[i][j][e]);
+            }
+    __syncthreads();
+    float *dst = dW + (int64_t)k * cin * cout;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int ci = ci0 + (i >> 6), co = co0 + (i & 63);
+        if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], tile[i]);
+    }
+}
+
+extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in,
+                                       const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
+                                       int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
+    if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision != 0) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    if (hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (nseg == 0) return CG3D_OK;
+    const int32_t ci_tiles = (cin + 63) / 64, co_tiles = (cout + 63) / 64;
+    if ((int64_t)ci_tiles * co_tiles > 65535) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_spconv_pairs_wgrad, dim3((unsigned)nseg, (unsigned)(ci_tiles * co_tiles)), dim3(256), 0, s, X,
+                       dY, pair_in, pair_out, seg, dW, cin, cout, co_tiles);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -1,0 +1,106 @@
+"""Mirror of pcdet/ops/iou3d_nms/iou3d_nms_utils.py:48-116 on the gfx950 C-ABI.
+
+Same function names, argument meaning and return values as the reference.  Differences by design:
+the greedy NMS scan runs on the device (no mask D2H copy, no host loop); only the kept COUNT is read
+back, because the reference API returns a variable-length index tensor."""
+from ctypes import c_float, c_int32, c_int64
+
+import torch
+
+from .. import _lib
+from .._lib import ptr
+
+
+def _pair(name, boxes_a, boxes_b):
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    lib = _lib.get()
+    a, b = boxes_a.contiguous().float(), boxes_b.contiguous().float()
+    lib.check(a, b)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    lib.call(name, ptr(a), c_int64(a.shape[0]), ptr(b), c_int64(b.shape[0]), ptr(out), lib.stream())
+    return out
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) rotated BEV intersection area (iou3d_nms.cpp:49-66)."""
+    return _pair("cg3d_boxes_overlap_bev", boxes_a, boxes_b)
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) rotated BEV IoU (iou3d_nms_utils.py:32-45)."""
+    return _pair("cg3d_boxes_iou_bev", boxes_a, boxes_b)
+
+
+def boxes_iou3d_gpu(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) 3D IoU = BEV overlap x height overlap / union (iou3d_nms_utils.py:48-81)."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    a_hmax = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
+    a_hmin = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
+    b_hmax = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)
+    b_hmin = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(1, -1)
+    overlaps_bev = boxes_overlap_bev(boxes_a, boxes_b)
+    overlaps_h = torch.clamp(torch.min(a_hmax, b_hmax) - torch.max(a_hmin, b_hmin), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)
+    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+
+
+def _nms_sorted(boxes_sorted, thresh, rotated):
+    """boxes already sorted by descending score -> (keep int64 [n] device, num_keep int32 [1] device)."""
+    lib = _lib.get()
+    lib.check(boxes_sorted)
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    cb = (n + 63) // 64
+    mask = torch.empty(max(n * cb, 1), dtype=torch.int64, device=dev)
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib.call("cg3d_nms", ptr(boxes_sorted), c_int64(n), c_float(thresh), c_int32(1 if rotated else 0), ptr(mask),
+             ptr(keep), ptr(num), lib.stream())
+    return keep, num, mask
+
+
+def _nms(boxes, scores, thresh, rotated, pre_maxsize=None):
+    assert boxes.shape[1] == 7
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    b = boxes[order].contiguous().float()
+    keep, num, _ = _nms_sorted(b, float(thresh), rotated)
+    return order[keep[:int(num.item())]].contiguous(), None
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """Rotated-BEV NMS (iou3d_nms_utils.py:84-100): indices into `boxes`, best first."""
+    return _nms(boxes, scores, thresh, True, pre_maxsize)
+
+
+def nms_normal_gpu(boxes, scores, thresh, **kwargs):
+    """Axis-aligned-BEV NMS (iou3d_nms_utils.py:103-116)."""
+    return _nms(boxes, scores, thresh, False)
+
+
+def nms_batched_sorted(boxes_sorted, seg_off_cpu, thresh, rotated):
+    """Many independent NMS problems in two launches.
+
+    boxes_sorted: (sum n_s, 7), each segment sorted by descending score; seg_off_cpu: python list /
+    CPU int64 tensor of nseg+1 offsets.  Returns (keep int64 [sum n_s] with per-segment LOCAL indices
+    at the segment's offset, num_keep int32 [nseg]) -- both on the device, no host sync."""
+    lib = _lib.get()
+    lib.check(boxes_sorted)
+    seg = torch.as_tensor(seg_off_cpu, dtype=torch.int64)
+    nseg = seg.numel() - 1
+    sizes = seg[1:] - seg[:-1]
+    max_seg = int(sizes.max().item()) if nseg > 0 else 0
+    words = sizes * ((sizes + 63) // 64)
+    moff = torch.zeros(nseg + 1, dtype=torch.int64)
+    moff[1:] = torch.cumsum(words, 0)
+    dev = boxes_sorted.device
+    seg_d, moff_d = seg.to(dev), moff[:-1].contiguous().to(dev)
+    mask = torch.empty(max(int(moff[-1].item()), 1), dtype=torch.int64, device=dev)
+    keep = torch.empty(max(boxes_sorted.shape[0], 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(max(nseg, 1), dtype=torch.int32, device=dev)
+    lib.call("cg3d_nms_batched", ptr(boxes_sorted), ptr(seg_d), ptr(moff_d), c_int32(nseg), c_int64(max_seg),
+             c_float(thresh), c_int32(1 if rotated else 0), ptr(mask), ptr(keep), ptr(num), lib.stream())
+    return keep, num[:nseg]

@@ -1,0 +1,216 @@
+/*
+ * cagroup3d_hip.h -- C-ABI of the MI355X (gfx950) hot-path library `libcagroup3d_hip.so`.
+ *
+ * Every entry point takes raw DEVICE pointers + sizes + a `hipStream_t` (passed as void*),
+ * allocates nothing (the caller owns outputs and workspaces), never calls exit(), and
+ * returns a status code (CG3D_OK == 0, negative == error).  No torch types appear here.
+ *
+ * The entry points are exactly what the reference's extension modules bind for this path
+ * (citations are into /root/reference):
+ *
+ *   reference pybind module `iou3d_nms_cuda`  (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17)
+ *       boxes_overlap_bev_gpu -> cg3d_boxes_overlap_bev   (iou3d_nms.cpp:49-66,  kernel .cu:236-249)
+ *       boxes_iou_bev_gpu     -> cg3d_boxes_iou_bev       (iou3d_nms.cpp:68-88,  kernel .cu:251-265)
+ *       nms_gpu               -> cg3d_nms (rotated=1)     (iou3d_nms.cpp:90-136, kernel .cu:267-311)
+ *       nms_normal_gpu        -> cg3d_nms (rotated=0)     (iou3d_nms.cpp:139-186,kernel .cu:328-372)
+ *   reference pybind module `KNN_OP`          (pcdet/ops/knn/src/knn.cpp:28-45)
+ *       knn_wrapper           -> cg3d_knn                 (knn_cuda.cu:58-115)
+ *   reference pybind module `sort_vertices`   (pcdet/ops/rotated_iou/cuda_op/sort_vert.cpp:6-33)
+ *       sort_vertices_forward -> cg3d_sort_vertices       (sort_vert_kernel.cu:42-139)
+ *   MinkowskiEngine v0.5.4 (README.md:45; un-vendored) operators used by the four hot-path
+ *   modules -- coordinate maps, kernel maps, sparse convolution
+ *   forward/backward, trilinear feature interpolation, strided average pooling and
+ *   quantise-average:
+ *       ME.SparseTensor(coordinates=...)             -> cg3d_coord_map_build
+ *       CoordinateManager stride / kernel_map        -> cg3d_coord_map_build(qstride) / cg3d_kernel_map
+ *       MinkowskiConvolution{,Transpose} fwd / bwd   -> cg3d_spconv_fwd / cg3d_spconv_wgrad
+ *       SparseTensor.features_at_coordinates         -> cg3d_interp_map / _fwd / _bwd
+ *       MinkowskiAvgPooling, UNWEIGHTED_AVERAGE      -> cg3d_pool_map + cg3d_scatter_mean_fwd / _bwd
+ *
+ * The CPU oracle (`oracle/liboracle.so`, test infrastructure only) exports the SAME symbols on
+ * HOST pointers so the parity tests drive both through one binding.
+ */
+#ifndef CAGROUP3D_HIP_H
+#define CAGROUP3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG3D_OK            0
+#define CG3D_ERR_ARG      -1   /* bad size / null pointer / unsupported parameter   */
+#define CG3D_ERR_LAUNCH   -2   /* HIP launch or runtime error                      */
+#define CG3D_ERR_RANGE    -3   /* coordinate outside the packable range            */
+
+/* coordinate packing limits: |x|,|y|,|z| < 2^14, 0 <= batch < 2^19 */
+#define CG3D_COORD_LIMIT  16384
+#define CG3D_BATCH_LIMIT  524288
+
+typedef void *cg3d_stream_t; /* hipStream_t; ignored by the oracle */
+
+/* 1 for the HIP library, 0 for the CPU oracle. */
+int cg3d_is_device_library(void);
+/* ABI version, bumped when a signature changes. */
+int cg3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Coordinate maps (hash-built voxel grid).
+ *
+ * A coordinate row is int32 (batch, x, y, z).  The hash table is open-addressed:
+ * `keys` uint64[cap] (packed coordinate, ~0 == empty) and `vals` int32[cap]; cap is a power of
+ * two >= 2*n (use cg3d_hash_capacity).
+ *
+ * cg3d_coord_map_build: insert n rows; rows are first quantised to the lattice
+ *   x' = floor(x / qstride) * qstride (qstride >= 1; 1 == as is).  Duplicates are merged.
+ *   Representative of a voxel = its FIRST occurrence (lowest input row).  Output rows are
+ *   ordered by ascending representative row.
+ *     out_coords   int32 [>=n,4] : unique quantised coordinates (first *n_out rows valid)
+ *     unique_index int32 [>=n]   : representative input row of each output row
+ *     inverse      int32 [n]     : output row of each input row
+ *     n_out        int32 [1]     : number of unique voxels (device scalar)
+ *   After the call the table maps coordinate -> output row.
+ *   `ws` needs cg3d_coord_map_ws_bytes(n) bytes.
+ * ---------------------------------------------------------------------------------------- */
+int64_t cg3d_hash_capacity(int64_t n);
+int64_t cg3d_coord_map_ws_bytes(int64_t n);
+int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride,
+                         uint64_t *keys, int32_t *vals, int64_t cap, void *ws,
+                         int32_t *out_coords, int32_t *unique_index, int32_t *inverse,
+                         int32_t *n_out, cg3d_stream_t stream);
+
+/* cg3d_kernel_map: nbr[k*nq + q] = table row of (q.batch, q.xyz + offsets[k]) or -1.
+ *   q_coords int32 [nq,4]; offsets int32 [K,3] (already scaled by tensor stride/dilation). */
+int cg3d_kernel_map(const int32_t *q_coords, int64_t nq, const int32_t *offsets, int32_t K,
+                    const uint64_t *keys, const int32_t *vals, int64_t cap,
+                    int32_t *nbr, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution, output-stationary implicit GEMM:
+ *   Y[o, :] = bias + sum_k  X[nbr[k, o], :] @ W[k]         (rows with nbr < 0 contribute 0)
+ *   X float32 [n_in, cin], W float32 [K, cin, cout], nbr int32 [K, n_out], Y float32 [n_out, cout]
+ *   precision: 0 = fp32 operands (v_mfma_f32_32x32x2_f32, exact fp32 products),
+ *              1 = bf16 operands (RNE-rounded on the fly), fp32 accumulate.
+ *   The data gradient is the same call with (dY, W^T[k] as [K,cout,cin], transposed map).
+ * cg3d_spconv_wgrad:  dW[k] = sum_o X[nbr[k,o], :]^T (outer) dY[o, :]   -> float32 [K,cin,cout]
+ *   dW is overwritten (the callee zero-fills it when it accumulates with atomics).
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias,
+                    float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                    int32_t precision, cg3d_stream_t stream);
+int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float *dW,
+                      int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                      int32_t precision, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pair-compacted kernel maps and the gather -> MFMA -> atomic-scatter convolution built on them.
+ *
+ * cg3d_pairs_count: flags nbr >= 0 over the k-major table, exclusive-scans them into `ws`
+ *   (int32 [K*n_out + K*n_out/1024 + 64]) and writes pair_off int32 [K+1] (pairs of offset k are
+ *   [pair_off[k], pair_off[k+1]); pair_off[K] = P).  The host reads pair_off to size the lists.
+ * cg3d_pairs_fill: pair_in[p] = nbr[k,o], pair_out[p] = o, ordered by (k, o) -- deterministic.
+ *   Within one offset every output row (and every input row) appears at most once.
+ *
+ * cg3d_spconv_pairs_fwd: Y = bias (or 0), then for every segment s = (k, start, count<=128) of
+ *   `seg` int32 [nseg,3] (all pairs of a segment share the offset k):
+ *       Y[pair_out[p], :] += X[pair_in[p], :] @ W[k]          p in [start, start+count)
+ *   accumulated with fp32 global atomics (order is not deterministic; fp32 tolerance applies).
+ *   The data gradient is the same call with the two pair lists swapped and W^T.
+ * cg3d_spconv_pairs_wgrad: dW[k] = sum_p X[pair_in[p]]^T (outer) dY[pair_out[p]] over the
+ *   segments (any count); dW [K,cin,cout] is overwritten.
+ * ---------------------------------------------------------------------------------------- */
+int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
+int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off,
+                     cg3d_stream_t stream);
+int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in,
+                    int32_t *pair_out, cg3d_stream_t stream);
+int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in, const int32_t *pair_out,
+                          const int32_t *seg, int64_t nseg, const float *bias, float *Y, int64_t n_out,
+                          int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream);
+int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in, const int32_t *pair_out,
+                            const int32_t *seg, int64_t nseg, float *dW, int32_t K, int32_t cin, int32_t cout,
+                            int32_t precision, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates
+ * (SparseTensor.features_at_coordinates; reference call sites biresnet.py:182-197,376,389,394).
+ *   q float32 [nq,4] (batch, x, y, z) in input-grid units.
+ *   idx int32 [nq,8] source rows (-1 = absent corner, contributes 0, no renormalisation),
+ *   w float32 [nq,8] weights prod_d (1 - |q_d - c_d| / ts).
+ *   fwd: out[q,:] = sum_j w[q,j] F[idx[q,j],:];  bwd: dF[idx[q,j],:] += w[q,j] dout[q,:]
+ *   (dF must be zero-filled by the caller).
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_interp_map(const float *q, int64_t nq, int32_t ts,
+                    const uint64_t *keys, const int32_t *vals, int64_t cap,
+                    int32_t *idx, float *w, cg3d_stream_t stream);
+int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *w, float *out,
+                    int64_t nq, int32_t c, cg3d_stream_t stream);
+int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF,
+                    int64_t nq, int32_t c, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Average pooling / quantise-average as "scatter mean".
+ * cg3d_pool_map: for every input row i and each of the 27 lattice candidates
+ *   o = (floor(c_i / out_stride) + d) * out_stride, d in {-1,0,1}^3, pmap[j*n_in + i] = table
+ *   row of o if it exists and |o - c_i| <= half_extent on every axis, else -1.
+ *   (MinkowskiAvgPooling(kernel k, stride s) on a tensor-stride-ts map: out_stride = s*ts,
+ *    half_extent = (k-1)/2 * ts; reference call sites biresnet.py:109-127.)
+ * cg3d_scatter_mean_fwd: out[m,:] = mean over {(j,i): map[j,i]==m} of F[i,:];
+ *   cnt float32 [n_out] receives the member count (0 rows stay 0).  J maps of n_in rows.
+ *   The quantise-average of ME.SparseTensor(..., UNWEIGHTED_AVERAGE) (cagroup_head.py:257-271)
+ *   is J == 1 with map == `inverse` from cg3d_coord_map_build.
+ * cg3d_scatter_mean_bwd: dF[i,:] = sum_j dout[map[j,i],:] / cnt[map[j,i]].
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_pool_map(const int32_t *in_coords, int64_t n_in, int32_t out_stride, int32_t half_extent,
+                  const uint64_t *keys, const int32_t *vals, int64_t cap,
+                  int32_t *pmap, cg3d_stream_t stream);
+int cg3d_scatter_mean_fwd(const float *F, const int32_t *map, int32_t J, float *out, float *cnt,
+                          int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t stream);
+int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *map, int32_t J,
+                          float *dF, int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * iou3d_nms (boxes are float32 [n,7] = x,y,z,dx,dy,dz,heading, contiguous).
+ *   cg3d_boxes_overlap_bev: out[a,b] = rotated-rectangle BEV intersection AREA.
+ *   cg3d_boxes_iou_bev:     out[a,b] = overlap / max(sa + sb - overlap, 1e-8).
+ *   cg3d_nms: boxes sorted by descending score.  rotated=1 uses the rotated BEV IoU, rotated=0
+ *     the axis-aligned BEV IoU (x,y,dx,dy only).  The 64x64 suppression tiles go to
+ *     `mask_ws` uint64 [n * ceil(n/64)]; the greedy scan runs ON DEVICE (the reference copies
+ *     the mask to the host and scans there, iou3d_nms.cpp:111-132); `keep` int64 [n] receives
+ *     the kept indices (ascending), `num_keep` int32 [1] their count -- both device memory.
+ *   cg3d_nms_batched: `nseg` independent sorted segments, segment s = boxes
+ *     [seg_off[s], seg_off[s+1]); keep holds per-segment LOCAL indices at the segment's offset,
+ *     num_keep int32 [nseg].  mask_ws uint64 [sum_s n_s*ceil(n_s/64)] laid out by mask_off int64 [nseg].
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_boxes_overlap_bev(const float *boxes_a, int64_t na, const float *boxes_b, int64_t nb,
+                           float *out, cg3d_stream_t stream);
+int cg3d_boxes_iou_bev(const float *boxes_a, int64_t na, const float *boxes_b, int64_t nb,
+                       float *out, cg3d_stream_t stream);
+int cg3d_nms(const float *boxes, int64_t n, float thresh, int32_t rotated,
+             uint64_t *mask_ws, int64_t *keep, int32_t *num_keep, cg3d_stream_t stream);
+int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off,
+                     int32_t nseg, int64_t max_seg, float thresh, int32_t rotated,
+                     uint64_t *mask_ws, int64_t *keep, int32_t *num_keep, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * kNN (brute force; reference knn_cuda.cu:58-94): for every query new_xyz[b,m,:] the k nearest
+ *   of xyz[b,n,:] by squared distance, ascending; a candidate replaces the current worst only
+ *   if strictly closer (ties keep the lower index).  1 <= k <= 100.
+ *   idx int32 [b,m,k], dist2 float32 [b,m,k].
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const float *new_xyz,
+             int32_t *idx, float *dist2, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * sort_vertices (reference sort_vert_kernel.cu:42-134): per box pair, order the <= 8 valid
+ *   polygon vertices (of m candidates, m == 24 in the reference) anticlockwise.
+ *   vertices float32 [b,n,m,2], mask uint8/bool [b,n,m], num_valid int32 [b,n] -> idx int32 [b,n,9].
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_sort_vertices(int32_t b, int32_t n, int32_t m, const float *vertices, const uint8_t *mask,
+                       const int32_t *num_valid, int32_t *idx, cg3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAGROUP3D_HIP_H */

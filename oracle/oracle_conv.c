@@ -1,0 +1,152 @@
+/*
+ * oracle_conv.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Sparse convolution forward and weight gradient as gather -> multiply-accumulate over the kernel
+ * map, the MinkowskiEngine ConvolutionForward / ConvolutionBackward algorithm (SURVEY.md 3.3;
+ * ME v0.5.4 is not vendored -- PARITY UNPINNED against ME, pinned against dense conv3d in tests/).
+ * Split from oracle_sparse.c only so this file can be built with FMA contraction and OpenMP for
+ * the bench.py cpu_baseline leg; results are compared to the HIP kernels with a tolerance.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/cagroup3d_hip.h"
+
+/* bf16 round-to-nearest-even of an fp32 value, returned as fp32 (precision==1 operands) */
+static inline float os_bf16(float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v; /* NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    float r; memcpy(&r, &u, 4);
+    return r;
+}
+
+int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
+                    int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
+                    cg3d_stream_t s) {
+    (void)s; (void)n_in;
+    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    float *Wq = NULL;
+    if (precision == 1) {
+        int64_t nw = (int64_t)K * cin * cout;
+        Wq = (float *)malloc((size_t)nw * sizeof(float));
+        for (int64_t i = 0; i < nw; i++) Wq[i] = os_bf16(W[i]);
+        W = Wq;
+    }
+#pragma omp parallel
+    {
+        float *xq = (float *)malloc((size_t)cin * sizeof(float));
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t o = 0; o < n_out; o++) {
+            float *y = Y + o * cout;
+            for (int32_t c = 0; c < cout; c++) y[c] = bias ? bias[c] : 0.f;
+            for (int32_t k = 0; k < K; k++) {
+                int32_t i = nbr[(int64_t)k * n_out + o];
+                if (i < 0) continue;
+                const float *x = X + (int64_t)i * cin;
+                if (precision == 1) { for (int32_t a = 0; a < cin; a++) xq[a] = os_bf16(x[a]); x = xq; }
+                const float *w = W + (int64_t)k * cin * cout;
+                for (int32_t a = 0; a < cin; a++) {
+                    float xa = x[a];
+                    const float *wr = w + (int64_t)a * cout;
+                    for (int32_t c = 0; c < cout; c++) y[c] += xa * wr[c];
+                }
+            }
+        }
+        free(xq);
+    }
+    free(Wq);
+    return CG3D_OK;
+}
+
+int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float *dW, int64_t n_in,
+                      int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
+                      cg3d_stream_t s) {
+    (void)s; (void)n_in;
+    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    const int32_t AB = 16; /* cin block owned by one task */
+    int32_t nab = (cin + AB - 1) / AB;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int32_t k = 0; k < K; k++)
+        for (int32_t ab = 0; ab < nab; ab++) {
+            int32_t a0 = ab * AB, a1 = a0 + AB < cin ? a0 + AB : cin;
+            float *w = dW + (int64_t)k * cin * cout;
+            for (int32_t a = a0; a < a1; a++)
+                for (int32_t c = 0; c < cout; c++) w[(int64_t)a * cout + c] = 0.f;
+            float *dq = precision == 1 ? (float *)malloc((size_t)cout * sizeof(float)) : NULL;
+            for (int64_t o = 0; o < n_out; o++) {
+                int32_t i = nbr[(int64_t)k * n_out + o];
+                if (i < 0) continue;
+                const float *x = X + (int64_t)i * cin;
+                const float *d = dY + o * cout;
+                if (precision == 1) { for (int32_t c = 0; c < cout; c++) dq[c] = os_bf16(d[c]); d = dq; }
+                for (int32_t a = a0; a < a1; a++) {
+                    float xa = precision == 1 ? os_bf16(x[a]) : x[a];
+                    float *wr = w + (int64_t)a * cout;
+                    for (int32_t c = 0; c < cout; c++) wr[c] += xa * d[c];
+                }
+            }
+            free(dq);
+        }
+    return CG3D_OK;
+}
+
+
+/* Pair-list form (ME's in/out kernel maps): per offset k, Y[out] += X[in] W[k]. */
+int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, const int32_t *pout, const int32_t *seg,
+                          int64_t nseg, const float *bias, float *Y, int64_t n_out, int32_t cin, int32_t cout,
+                          int32_t precision, cg3d_stream_t s) {
+    (void)s;
+    if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    for (int64_t o = 0; o < n_out; o++)
+        for (int32_t c = 0; c < cout; c++) Y[o * cout + c] = bias ? bias[c] : 0.f;
+    /* segments of one offset never share an output row, segments of different offsets may:
+       run the offsets one after the other, the pairs of an offset in parallel */
+    for (int64_t g = 0; g < nseg; g++) {
+        int32_t k = seg[g * 3], start = seg[g * 3 + 1], count = seg[g * 3 + 2];
+        const float *w = W + (int64_t)k * cin * cout;
+#pragma omp parallel for schedule(static)
+        for (int32_t p = start; p < start + count; p++) {
+            const float *x = X + (int64_t)pin[p] * cin;
+            float *y = Y + (int64_t)pout[p] * cout;
+            for (int32_t a = 0; a < cin; a++) {
+                float xa = precision == 1 ? os_bf16(x[a]) : x[a];
+                const float *wr = w + (int64_t)a * cout;
+                if (precision == 1) { for (int32_t c = 0; c < cout; c++) y[c] += xa * os_bf16(wr[c]); }
+                else { for (int32_t c = 0; c < cout; c++) y[c] += xa * wr[c]; }
+            }
+        }
+    }
+    return CG3D_OK;
+}
+int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pin, const int32_t *pout,
+                            const int32_t *seg, int64_t nseg, float *dW, int32_t K, int32_t cin, int32_t cout,
+                            int32_t precision, cg3d_stream_t s) {
+    (void)s;
+    if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    memset(dW, 0, (size_t)K * cin * cout * sizeof(float));
+    const int32_t AB = 16;
+    int32_t nab = (cin + AB - 1) / AB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t ab = 0; ab < nab; ab++) {
+        int32_t a0 = ab * AB, a1 = a0 + AB < cin ? a0 + AB : cin;
+        for (int64_t g = 0; g < nseg; g++) {
+            int32_t k = seg[g * 3], start = seg[g * 3 + 1], count = seg[g * 3 + 2];
+            float *w = dW + (int64_t)k * cin * cout;
+            for (int32_t p = start; p < start + count; p++) {
+                const float *x = X + (int64_t)pin[p] * cin;
+                const float *d = dY + (int64_t)pout[p] * cout;
+                for (int32_t a = a0; a < a1; a++) {
+                    float xa = precision == 1 ? os_bf16(x[a]) : x[a];
+                    float *wr = w + (int64_t)a * cout;
+                    if (precision == 1) { for (int32_t c = 0; c < cout; c++) wr[c] += xa * os_bf16(d[c]); }
+                    else { for (int32_t c = 0; c < cout; c++) wr[c] += xa * d[c]; }
+                }
+            }
+        }
+    }
+    return CG3D_OK;
+}

@@ -1,0 +1,269 @@
+/*
+ * oracle_sparse.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the sparse-voxel engine the reference gets from MinkowskiEngine v0.5.4
+ * (README.md:45; NOT vendored under /root/reference and not installable here, so its arithmetic
+ * is restated from the published algorithm and anchored on the reference's own call sites --
+ * SURVEY.md section 2.3).  PARITY UNPINNED against ME itself: the reference holds no golden
+ * vectors for these operators.  The restatement is instead pinned by
+ * independent dense references in tests/ (torch.nn.functional.conv3d on an occupancy grid,
+ * explicit trilinear / pooling loops).
+ *
+ * Exports the same C-ABI as the HIP library (include/cagroup3d_hip.h) on HOST pointers.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Semantics fixed here (each is what the reference call sites rely on):
+ *  - coordinate map: duplicates merged, representative = first occurrence, output rows in
+ *    ascending representative order (cagroup3d.py:18-25; cagroup_roi_head.py:70-72 relies on
+ *    "already unique coordinates keep their order").
+ *  - stride map: floor(c / s) * s, de-duplicated (biresnet.py strided convs).
+ *  - kernel map: nbr[k, o] = row of (o + offset_k) (ME kernel_map).
+ *  - convolution: Y[o] = sum_k X[nbr[k,o]] W[k]  (ConvolutionForward gather-GEMM-scatter).
+ *  - interpolation: 8-corner trilinear on the source lattice, absent corners contribute 0
+ *    (features_at_coordinates, biresnet.py:182-197,376,389,394).
+ *  - average pooling / quantise-average: mean over PRESENT inputs only.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/cagroup3d_hip.h"
+
+int cg3d_is_device_library(void) { return 0; }
+int cg3d_abi_version(void) { return 1; }
+
+#define OS_EMPTY (~0ULL)
+
+static inline int os_pack(int32_t b, int32_t x, int32_t y, int32_t z, uint64_t *key) {
+    if (b < 0 || b >= CG3D_BATCH_LIMIT) return 0;
+    if (x < -CG3D_COORD_LIMIT || x >= CG3D_COORD_LIMIT || y < -CG3D_COORD_LIMIT || y >= CG3D_COORD_LIMIT ||
+        z < -CG3D_COORD_LIMIT || z >= CG3D_COORD_LIMIT)
+        return 0;
+    *key = ((uint64_t)b << 45) | ((uint64_t)(x + CG3D_COORD_LIMIT) << 30) |
+           ((uint64_t)(y + CG3D_COORD_LIMIT) << 15) | (uint64_t)(z + CG3D_COORD_LIMIT);
+    return 1;
+}
+static inline uint64_t os_hash(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+static inline int32_t os_floordiv(int32_t a, int32_t s) {
+    int32_t q = a / s;
+    if ((a % s != 0) && ((a < 0) != (s < 0))) q--;
+    return q;
+}
+static inline int32_t os_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, uint64_t key) {
+    uint64_t slot = os_hash(key) & (uint64_t)(cap - 1);
+    for (;;) {
+        uint64_t k = keys[slot];
+        if (k == key) return vals[slot];
+        if (k == OS_EMPTY) return -1;
+        slot = (slot + 1) & (uint64_t)(cap - 1);
+    }
+}
+
+int64_t cg3d_hash_capacity(int64_t n) {
+    int64_t cap = 64;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+int64_t cg3d_coord_map_ws_bytes(int64_t n) { return (2 * n + n / 1024 + 64) * (int64_t)sizeof(int32_t); }
+
+int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride, uint64_t *keys, int32_t *vals,
+                         int64_t cap, void *ws, int32_t *out_coords, int32_t *unique_index,
+                         int32_t *inverse, int32_t *n_out, cg3d_stream_t s) {
+    (void)s; (void)ws;
+    if (n < 0 || qstride < 1 || cap < 2 * n || (cap & (cap - 1))) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < cap; i++) keys[i] = OS_EMPTY;
+    int32_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int32_t b = coords[i * 4], x = coords[i * 4 + 1], y = coords[i * 4 + 2], z = coords[i * 4 + 3];
+        if (qstride > 1) {
+            x = os_floordiv(x, qstride) * qstride;
+            y = os_floordiv(y, qstride) * qstride;
+            z = os_floordiv(z, qstride) * qstride;
+        }
+        uint64_t key;
+        if (!os_pack(b, x, y, z, &key)) return CG3D_ERR_RANGE;
+        uint64_t slot = os_hash(key) & (uint64_t)(cap - 1);
+        for (;;) {
+            if (keys[slot] == key) { inverse[i] = vals[slot]; break; }
+            if (keys[slot] == OS_EMPTY) {
+                keys[slot] = key; vals[slot] = m;
+                out_coords[m * 4] = b; out_coords[m * 4 + 1] = x; out_coords[m * 4 + 2] = y; out_coords[m * 4 + 3] = z;
+                unique_index[m] = (int32_t)i; inverse[i] = m; m++;
+                break;
+            }
+            slot = (slot + 1) & (uint64_t)(cap - 1);
+        }
+    }
+    *n_out = m;
+    return CG3D_OK;
+}
+
+int cg3d_kernel_map(const int32_t *q, int64_t nq, const int32_t *off, int32_t K, const uint64_t *keys,
+                    const int32_t *vals, int64_t cap, int32_t *nbr, cg3d_stream_t s) {
+    (void)s;
+    if (nq < 0 || K < 1) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; i++)
+        for (int32_t k = 0; k < K; k++) {
+            uint64_t key;
+            int32_t r = -1;
+            if (os_pack(q[i * 4], q[i * 4 + 1] + off[k * 3], q[i * 4 + 2] + off[k * 3 + 1],
+                        q[i * 4 + 3] + off[k * 3 + 2], &key))
+                r = os_lookup(keys, vals, cap, key);
+            nbr[(int64_t)k * nq + i] = r;
+        }
+    return CG3D_OK;
+}
+
+int cg3d_interp_map(const float *q, int64_t nq, int32_t ts, const uint64_t *keys, const int32_t *vals,
+                    int64_t cap, int32_t *idx, float *w, cg3d_stream_t s) {
+    (void)s;
+    if (nq < 0 || ts < 1) return CG3D_ERR_ARG;
+    const float fts = (float)ts;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; i++) {
+        int32_t b = (int32_t)q[i * 4];
+        int32_t base[3]; float w0[3], w1[3];
+        for (int d = 0; d < 3; d++) {
+            float v = q[i * 4 + 1 + d];
+            float fl = floorf(v / fts);
+            float lo = fl * fts;
+            float r = (v - lo) / fts;
+            base[d] = (int32_t)lo; w0[d] = 1.0f - r; w1[d] = r;
+        }
+        for (int j = 0; j < 8; j++) {
+            int dx = (j >> 2) & 1, dy = (j >> 1) & 1, dz = j & 1;
+            float wt = ((dx ? w1[0] : w0[0]) * (dy ? w1[1] : w0[1])) * (dz ? w1[2] : w0[2]);
+            uint64_t key; int32_t r = -1;
+            if (os_pack(b, base[0] + dx * ts, base[1] + dy * ts, base[2] + dz * ts, &key))
+                r = os_lookup(keys, vals, cap, key);
+            idx[i * 8 + j] = r; w[i * 8 + j] = wt;
+        }
+    }
+    return CG3D_OK;
+}
+int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *w, float *out, int64_t nq, int32_t c,
+                    cg3d_stream_t s) {
+    (void)s;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; i++) {
+        float *o = out + i * c;
+        for (int32_t a = 0; a < c; a++) o[a] = 0.f;
+        for (int j = 0; j < 8; j++) {
+            int32_t r = idx[i * 8 + j];
+            if (r < 0) continue;
+            float wt = w[i * 8 + j];
+            const float *f = F + (int64_t)r * c;
+            for (int32_t a = 0; a < c; a++) o[a] += wt * f[a];
+        }
+    }
+    return CG3D_OK;
+}
+int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF, int64_t nq, int32_t c,
+                    cg3d_stream_t s) {
+    (void)s;
+    for (int64_t i = 0; i < nq; i++)
+        for (int j = 0; j < 8; j++) {
+            int32_t r = idx[i * 8 + j];
+            if (r < 0) continue;
+            float wt = w[i * 8 + j];
+            float *f = dF + (int64_t)r * c;
+            const float *d = dout + i * c;
+            for (int32_t a = 0; a < c; a++) f[a] += wt * d[a];
+        }
+    return CG3D_OK;
+}
+
+int cg3d_pool_map(const int32_t *in, int64_t n_in, int32_t out_stride, int32_t half_extent,
+                  const uint64_t *keys, const int32_t *vals, int64_t cap, int32_t *pmap, cg3d_stream_t s) {
+    (void)s;
+    if (n_in < 0 || out_stride < 1 || half_extent < 0) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_in; i++) {
+        int32_t b = in[i * 4], c[3] = {in[i * 4 + 1], in[i * 4 + 2], in[i * 4 + 3]};
+        int32_t base[3];
+        for (int d = 0; d < 3; d++) base[d] = os_floordiv(c[d], out_stride);
+        for (int j = 0; j < 27; j++) {
+            int32_t dd[3] = {j / 9 - 1, (j / 3) % 3 - 1, j % 3 - 1};
+            int32_t o[3]; int ok = 1;
+            for (int d = 0; d < 3; d++) {
+                o[d] = (base[d] + dd[d]) * out_stride;
+                int32_t diff = o[d] - c[d];
+                if (diff < 0) diff = -diff;
+                if (diff > half_extent) ok = 0;
+            }
+            int32_t r = -1; uint64_t key;
+            if (ok && os_pack(b, o[0], o[1], o[2], &key)) r = os_lookup(keys, vals, cap, key);
+            pmap[(int64_t)j * n_in + i] = r;
+        }
+    }
+    return CG3D_OK;
+}
+int cg3d_scatter_mean_fwd(const float *F, const int32_t *map, int32_t J, float *out, float *cnt, int64_t n_in,
+                          int64_t n_out, int32_t c, cg3d_stream_t s) {
+    (void)s;
+    memset(out, 0, (size_t)(n_out * c) * sizeof(float));
+    memset(cnt, 0, (size_t)n_out * sizeof(float));
+    for (int32_t j = 0; j < J; j++)
+        for (int64_t i = 0; i < n_in; i++) {
+            int32_t m = map[(int64_t)j * n_in + i];
+            if (m < 0) continue;
+            cnt[m] += 1.0f;
+            float *o = out + (int64_t)m * c;
+            const float *f = F + i * c;
+            for (int32_t a = 0; a < c; a++) o[a] += f[a];
+        }
+    for (int64_t m = 0; m < n_out; m++)
+        if (cnt[m] > 0.f) {
+            float *o = out + m * c;
+            for (int32_t a = 0; a < c; a++) o[a] = o[a] / cnt[m];
+        }
+    return CG3D_OK;
+}
+int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *map, int32_t J, float *dF,
+                          int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t s) {
+    (void)s; (void)n_out;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_in; i++) {
+        float *f = dF + i * c;
+        for (int32_t a = 0; a < c; a++) f[a] = 0.f;
+        for (int32_t j = 0; j < J; j++) {
+            int32_t m = map[(int64_t)j * n_in + i];
+            if (m < 0) continue;
+            const float *d = dout + (int64_t)m * c;
+            float inv = cnt[m];
+            for (int32_t a = 0; a < c; a++) f[a] += d[a] / inv;
+        }
+    }
+    return CG3D_OK;
+}
+
+/* ---------------------------------------------------------------- pair-compacted kernel maps */
+int64_t cg3d_pairs_ws_bytes(int64_t total) { return (total + total / 1024 + 64) * (int64_t)sizeof(int32_t); }
+int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off, cg3d_stream_t s) {
+    (void)s;
+    if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
+    int32_t *pos = (int32_t *)ws;
+    int32_t run = 0;
+    for (int32_t k = 0; k < K; k++) {
+        pair_off[k] = run;
+        for (int64_t o = 0; o < n_out; o++) {
+            int64_t t = (int64_t)k * n_out + o;
+            pos[t] = run;
+            if (nbr[t] >= 0) run++;
+        }
+    }
+    pair_off[K] = run;
+    return CG3D_OK;
+}
+int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in, int32_t *pair_out,
+                    cg3d_stream_t s) {
+    (void)s;
+    const int32_t *pos = (const int32_t *)ws;
+    for (int64_t t = 0; t < (int64_t)K * n_out; t++)
+        if (nbr[t] >= 0) { pair_in[pos[t]] = nbr[t]; pair_out[pos[t]] = (int32_t)(t % n_out); }
+    return CG3D_OK;
+}

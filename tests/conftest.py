@@ -1,0 +1,40 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_oracle():
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_geom.c", "oracle_sparse.c", "oracle_conv.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return so
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle bound through the same ctypes binding as the HIP library (checker only)."""
+    from cagroup3d_amd import _lib
+    return _lib.bind(_build_oracle())
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library; -m gpu tests fail (not skip) if it is missing or no GPU is visible."""
+    import torch
+    from cagroup3d_amd import _lib
+    if os.environ.get("CG3D_PARITY_SELFTEST") == "1":   # dev aid: exercise the TEST CODE on a GPU-less box
+        return None
+    assert os.path.exists(_lib.HIP_LIB_PATH), "libcagroup3d_hip.so not built"
+    assert torch.cuda.is_available(), "gpu test needs a GPU"
+    return _lib.get()
