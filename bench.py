@@ -1,0 +1,175 @@
+"""bench.py -- scenes/s forward+backward(+optimiser step) of CAGroup3D on synthetic ScanNet-shaped
+scenes (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one training iteration of the ScanNetV2 CAGroup3D.yaml configuration on a batch of 4
+synthetic 50k-point scenes per GPU (BASELINE.json configs[1]): voxelisation (hash build), BiResNet,
+CAGroup3DHead (+ stage-1 NMS, target assignment, kNN), CAGroup3DRoIHead, all losses, backward,
+grad-norm clip, AdamW step; inputs are resident in HBM when the timed region starts.  Scenes shard
+one batch per rank (weak scaling); the only collectives are DDP's gradient all-reduce and the
+fused 3-scalar reduce_mean per scene, over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_spconv_pairs: gather ->
+fp32 MFMA -> atomic scatter), timed live with HIP events on the launch stream; `cpu_baseline`
+times the CPU oracle (oracle/liboracle.so, the checker -- never the product) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cagroup3d_amd import _lib, build_model, me  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="scenes per GPU (CAGroup3D.yaml BATCH_SIZE_PER_GPU)")
+    ap.add_argument("--config", default="S50k")
+    ap.add_argument("--dataset", default="scannet")
+    ap.add_argument("--natural", action="store_true", help="untrained-net selection instead of forced GT selection")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="S50k:1", help="config:scenes timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def fresh(batch):
+    b = dict(batch)
+    b["points"] = batch["points"].clone()   # forward normalises colours in place
+    return b
+
+
+def make_model(dataset, forced, device):
+    model, cfg = build_model.build_cagroup3d(dataset, seed=0)
+    if forced:
+        model.dense_head.force_gt_selection = True
+        # trained-like stage-1 score level so that proposals survive SCORE_THR and NMS sees real loads
+        torch.nn.init.constant_(model.dense_head.cls_conv.bias, 2.0)
+    return model.to(device), cfg
+
+
+def train_step(model, opt, batch, clip):
+    opt.zero_grad(set_to_none=True)
+    ret, tb, disp = model(fresh(batch))
+    ret["loss"].backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    return tb
+
+
+def cpu_baseline(args, forced):
+    """Same training step on the host CPU with the oracle library bound in place of the HIP one."""
+    oracle_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(oracle_so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    cfgname, nsc = args.cpu_sample.split(":")
+    nsc = int(nsc)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with _lib.use_library(_lib.bind(oracle_so)):
+        model, cfg = make_model(args.dataset, forced, "cpu")
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
+        batch = build_model.synthetic_batch(cfgname, nsc, device="cpu")
+        t0 = time.time()
+        train_step(model, opt, batch, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        dt = time.time() - t0
+    return {"value": nsc / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "%d scene(s) of %s, one fwd+bwd+AdamW step of the full detector on the CPU oracle "
+                      "(OpenMP + torch CPU threads), %.1f s" % (nsc, cfgname, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+    forced = not args.natural
+
+    model, cfg = make_model(args.dataset, forced, dev)
+    model.train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
+    clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
+    # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
+    batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)
+
+    for _ in range(args.warmup):
+        tb = train_step(net, opt, batch, clip)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    me.KernelProfile.reset()
+    me.KernelProfile.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tb = train_step(net, opt, batch, clip)
+    barrier()
+    dt = time.perf_counter() - t0
+    me.KernelProfile.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        prof = me.KernelProfile.summary()
+        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        roof = {"kernel": "k_spconv_pairs (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
+                "algorithmic_gbytes_per_s": prof["bytes"] / (prof["ms"] * 1e-3) / 1e9 if prof["ms"] > 0 else 0.0,
+                "kernel_time_share": prof["ms"] * 1e-3 / dt}
+        out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
+               "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "ScanNetV2 CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
+                   args.batch, args.config, "forced GT selection + stage-1 score bias (trained-like loads)" if forced
+                   else "natural selection of the untrained net"),
+                          "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
+                          "voxel_size_m": 0.02, "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
+                          "last_loss": tb.get("loss_all")},
+               "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, forced)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -326,14 +326,17 @@ __global__ void k_init_rows(float *__restrict__ Y, const float *__restrict__ bia
 
 extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in, const int32_t *pair_out,
                                      const int32_t *seg, int64_t nseg, const float *bias, float *Y, int64_t n_out,
-                                     int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
+                                     int32_t cin, int32_t cout, int32_t precision, int32_t accumulate,
+                                     cg3d_stream_t stream) {
     if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
     if (precision != 0) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (n_out == 0) return CG3D_OK;
     const int64_t total = n_out * cout;
-    if (bias) hipLaunchKernelGGL(k_init_rows, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, Y, bias, total, cout);
-    else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (!accumulate) {
+        if (bias) hipLaunchKernelGGL(k_init_rows, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, Y, bias, total, cout);
+        else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    }
     if (nseg == 0) return CG3D_OK;
     const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
 #define LAUNCH(NT, KH, V)                                                                                     \

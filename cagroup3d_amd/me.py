@@ -230,13 +230,44 @@ def _seg_len_fwd():
     return FWD_SEG if _lib.get().is_device else (1 << 30)
 
 
-def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out):
+class KernelProfile:
+    """Optional live timing of the dominant kernel (k_spconv_pairs) with HIP events on the launch
+    stream; bench.py turns it on for the timed region (roofline.achieved)."""
+    enabled = False
+    records = []   # (start_event, end_event, flops, bytes)
+
+    @classmethod
+    def reset(cls):
+        cls.records = []
+
+    @classmethod
+    def summary(cls):
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in cls.records)
+        return {"launches": len(cls.records), "ms": ms, "flops": float(sum(r[2] for r in cls.records)),
+                "bytes": float(sum(r[3] for r in cls.records))}
+
+
+def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0):
     lib = _lib.get()
     K, cin, cout = w3.shape
     lib.check(x, w3, pin, pout, seg, bias)
-    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(w3), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(bias), ptr(y),
-             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
+    # Y initialised here (torch fill / broadcast copy) so that the C call launches exactly one kernel
+    if bias is None:
+        y = torch.zeros((n_out, cout), dtype=torch.float32, device=x.device)
+    else:
+        y = bias.view(1, -1).expand(n_out, cout).contiguous()
+    prof = KernelProfile.enabled and lib.is_device
+    if prof:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(w3), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(None), ptr(y),
+             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(0), c_int32(1), lib.stream())
+    if prof:
+        ev1.record()
+        # algorithmic work of one launch: 2*P*cin*cout flops; bytes = gathered rows + atomically added rows
+        # (read-modify-write) + the weights once + the two pair lists (SURVEY.md 8(d))
+        KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
+                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout + K * cin * cout) + 8.0 * n_pairs))
     return y
 
 
@@ -259,7 +290,8 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.kmap, ctx.has_bias = kmap, bias is not None
         pin, pout, _, _ = kmap.pairs()
         seg, nseg = kmap.segments(_seg_len_fwd())
-        return _conv_pairs(x, w3, pin, pout, seg, nseg, bias.contiguous() if bias is not None else None, kmap.n_out)
+        return _conv_pairs(x, w3, pin, pout, seg, nseg, bias.contiguous() if bias is not None else None, kmap.n_out,
+                           kmap.pairs()[3])
 
     @staticmethod
     def backward(ctx, dy):
@@ -272,7 +304,7 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = w3.transpose(1, 2).contiguous()
             seg, nseg = kmap.segments(_seg_len_fwd())
-            dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in)   # lists swapped
+            dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
             K, cin, cout = w3.shape
             dw = torch.empty_like(w3)

@@ -1,0 +1,430 @@
+"""CAGroup3DHead: semantic + vote branch, class-aware local regrouping, proposal decode + NMS,
+stage-1 losses (mirror of pcdet/models/dense_heads/cagroup_head.py:14-797) on the gfx950 engine.
+
+Data flow of one class branch: SURVEY.md Appendix B."""
+import numpy as np
+import torch
+from torch import nn
+
+from .... import me as ME
+from ....ops.iou3d_nms_utils import nms_gpu, nms_normal_gpu
+from ....ops.knn import knn
+from ...config import AttrDict
+from ...utils.iou3d_loss import IoU3DLoss
+from ...utils.loss_utils import CrossEntropy, FocalLoss, SmoothL1Loss
+from ..model_utils.cagroup_utils import Scale, bias_init_with_prob, parse_params, reduce_mean
+from .target_assigner.cagroup3d_assigner import CAGroup3DAssigner, find_points_in_boxes
+
+# mean box size per class (the reference hard-codes them, cagroup_head.py:75-104); the class voxel
+# size is half of it clipped to [0.04, 1.0] m (:105-106)
+SCANNET_CLASS_SIZES = [[0.2309, 0.2435, 0.2777], [0.5631, 0.5528, 0.3579], [0.1840, 0.1845, 0.2155],
+                       [0.4187, 0.4536, 0.2503], [0.2938, 0.3203, 0.1899], [0.1595, 0.1787, 0.5250],
+                       [0.2887, 0.2174, 0.3445], [0.2497, 0.3147, 0.5063], [0.0634, 0.1262, 0.1612],
+                       [0.4332, 0.5691, 0.0810], [0.3088, 0.4212, 0.2627], [0.4130, 0.1966, 0.5044],
+                       [0.1995, 0.2133, 0.3897], [0.1260, 0.1137, 0.5254], [0.1781, 0.1774, 0.2218],
+                       [0.1526, 0.1520, 0.0904], [0.3453, 0.3164, 0.1491], [0.1426, 0.1477, 0.1741]]
+SUNRGBD_CLASS_SIZES = [[0.6343, 0.4861, 0.2782], [0.2373, 0.3839, 0.2155], [0.2771, 0.5602, 0.2536],
+                       [0.1776, 0.1659, 0.2482], [0.2097, 0.1363, 0.2269], [0.2086, 0.4039, 0.2209],
+                       [0.1586, 0.3008, 0.3519], [0.1502, 0.1896, 0.2050], [0.1214, 0.3213, 0.5067],
+                       [0.2298, 0.4195, 0.1418]]
+
+
+def _conv_bn_elu(cin, cout, k):
+    return nn.Sequential(ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3),
+                         ME.MinkowskiBatchNorm(cout), ME.MinkowskiELU())
+
+
+class CAGroup3DHead(nn.Module):
+    def __init__(self, model_cfg, yaw_parametrization="fcaf3d", predict_boxes=True, **kwargs):
+        super().__init__()
+        cfg = model_cfg
+        self.n_classes = n_classes = cfg.N_CLASSES
+        out_channels = cfg.OUT_CHANNELS
+        n_reg_outs = cfg.N_REG_OUTS
+        self.voxel_size = cfg.VOXEL_SIZE
+        self.semantic_threshold = cfg.SEMANTIC_THR
+        self.expand = cfg.EXPAND_RATIO
+        self.with_yaw = cfg.WITH_YAW
+        self.use_sem_score = cfg.USE_SEM_SCORE
+        self.cls_kernel = cfg.CLS_KERNEL
+        self.yaw_parametrization = yaw_parametrization
+        self.predict_boxes = predict_boxes
+        self.gt_per_seed = 3  # SUN RGB-D only
+        # benchmark aid (SURVEY.md 8(d) "forced-selection"): an untrained net selects ~nothing per class;
+        # when set, class c selects the voxels inside its GT boxes so the class branches see trained-like sizes
+        self.force_gt_selection = False
+
+        def sub(name, default):
+            return cfg.get(name, AttrDict(default))
+        self.assigner = CAGroup3DAssigner(cfg.ASSIGNER)
+        self.loss_centerness = CrossEntropy(**parse_params(sub("LOSS_CENTERNESS", dict(NAME="CrossEntropyLoss", USE_SIGMOID=True, LOSS_WEIGHT=1.0))))
+        self.loss_bbox = IoU3DLoss(**parse_params(sub("LOSS_BBOX", dict(NAME="IoU3DLoss", LOSS_WEIGHT=1.0))))
+        focal = dict(NAME="FocalLoss", USE_SIGMOID=True, GAMMA=2.0, ALPHA=0.25, LOSS_WEIGHT=1.0)
+        self.loss_cls = FocalLoss(**parse_params(sub("LOSS_CLS", focal)))
+        self.loss_sem = FocalLoss(**parse_params(sub("LOSS_SEM", focal)))
+        self.loss_offset = SmoothL1Loss(**parse_params(sub("LOSS_OFFSET", dict(NAME="SmoothL1Loss", BETA=0.04, REDUCTION="sum", LOSS_WEIGHT=1.0))))
+        self.nms_cfg = sub("NMS_CONFIG", dict(SCORE_THR=0.01, NMS_PRE=1000, IOU_THR=0.5))
+
+        sizes = SCANNET_CLASS_SIZES if n_classes == 18 else SUNRGBD_CLASS_SIZES
+        self.voxel_size_list = np.clip(np.array(sizes) / 2., 0.04, 1.0).tolist()
+
+        c = out_channels
+        n_vote = 3 if self.with_yaw else 1
+        self.offset_block = nn.Sequential(
+            ME.MinkowskiConvolution(c, c, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(c), ME.MinkowskiELU(),
+            ME.MinkowskiConvolution(c, c, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(c), ME.MinkowskiELU(),
+            ME.MinkowskiConvolution(c, 3 * n_vote, kernel_size=1, dimension=3))
+        self.feature_offset = _conv_bn_elu(c, c * n_vote, 3)
+        self.semantic_conv = ME.MinkowskiConvolution(c, n_classes, kernel_size=1, bias=True, dimension=3)
+        self.centerness_conv = ME.MinkowskiConvolution(c, 1, kernel_size=1, dimension=3)
+        self.reg_conv = ME.MinkowskiConvolution(c, n_reg_outs, kernel_size=1, dimension=3)
+        self.cls_conv = ME.MinkowskiConvolution(c, n_classes, kernel_size=1, bias=True, dimension=3)
+        self.scales = nn.ModuleList([Scale(1.) for _ in range(n_classes)])
+        self.cls_individual_out = nn.ModuleList([_conv_bn_elu(c, c, self.cls_kernel) for _ in range(n_classes)])
+        self.cls_individual_up = nn.ModuleList([nn.ModuleList([
+            ME.MinkowskiGenerativeConvolutionTranspose(c, c, kernel_size=self.expand, stride=self.expand, dimension=3),
+            nn.Sequential(ME.MinkowskiBatchNorm(c), ME.MinkowskiELU())]) for _ in range(n_classes)])
+        self.cls_individual_fuse = nn.ModuleList([_conv_bn_elu(c * 2, c, 1) for _ in range(n_classes)])
+        self.cls_individual_expand_out = nn.ModuleList([_conv_bn_elu(c, c, 5) for _ in range(n_classes)])
+        self.init_weights()
+
+    def init_weights(self):
+        """(cagroup_head.py:190-198)"""
+        for conv in (self.centerness_conv, self.reg_conv, self.cls_conv, self.semantic_conv):
+            nn.init.normal_(conv.kernel, std=.01)
+        nn.init.constant_(self.cls_conv.bias, bias_init_with_prob(.01))
+        nn.init.constant_(self.semantic_conv.bias, bias_init_with_prob(.01))
+        for blk in self.cls_individual_out:
+            nn.init.normal_(blk[0].kernel, std=.01)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_dict, return_middle_feature=True):
+        batch_size = input_dict["batch_size"]
+        out = input_dict["sp_tensor"]
+        semantic_scores = self.semantic_conv(out)
+        pad_id = torch.stack([p[0] for p in semantic_scores.decomposition_permutations]).long()  # first row of every scene
+        ts = out.coordinate_map_key.get_key()[0][0]
+        xyz_vox = out.C[:, 1:]
+        max_bound = (xyz_vox.max(0)[0] + ts) * self.voxel_size
+        min_bound = (xyz_vox.min(0)[0] - ts) * self.voxel_size
+
+        voxel_offsets = self.offset_block(out)
+        offset_features = self.feature_offset(out).F
+        n_vote = 3 if self.with_yaw else 1
+        ori_xyz = xyz_vox.float() * self.voxel_size
+        voted = ori_xyz.view(-1, 1, 3) + voxel_offsets.F.detach().view(-1, n_vote, 3)
+        voted = torch.max(torch.min(voted, max_bound.view(1, 1, 3)), min_bound.view(1, 1, 3))
+        batch_col = out.C[:, :1].float()
+        offset_features = offset_features.view(offset_features.shape[0], n_vote, -1)
+        sem_prob = semantic_scores.F.detach().sigmoid()
+        forced = self._forced_selection(input_dict, out, ori_xyz) if self.force_gt_selection else None
+
+        outs = []
+        for cls_id in range(self.n_classes):
+            with torch.no_grad():
+                hit = sem_prob[:, cls_id] > self.semantic_threshold
+                if forced is not None:
+                    hit = hit | forced[:, cls_id]
+                sel = torch.nonzero(hit).squeeze(1)
+                sel = torch.cat([sel, pad_id])
+            b = batch_col[sel]
+            vote_rows = torch.cat([b.view(-1, 1, 1).expand(-1, n_vote, 1), voted[sel]], dim=2).reshape(-1, 4)
+            fuse_xyz = torch.cat([vote_rows, torch.cat([b, ori_xyz[sel]], dim=1)], dim=0)       # (n_vote+1)*n rows
+            fuse_feat = torch.cat([offset_features[sel].reshape(-1, offset_features.shape[-1]), out.F[sel]], dim=0)
+
+            vsize = fuse_xyz.new_tensor(self.voxel_size_list[cls_id])
+            fine = fuse_xyz.clone()
+            fine[:, 1:] = torch.floor(fuse_xyz[:, 1:] / vsize)
+            cls_map = ME.SparseTensor(coordinates=fine, features=fuse_feat,
+                                      quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+            fine_C = cls_map.C
+            cls_map = self.cls_individual_out[cls_id](cls_map)
+
+            coarse = fuse_xyz.clone()
+            coarse[:, 1:] = torch.floor(fuse_xyz[:, 1:] / (vsize * self.expand)) * self.expand
+            cls_exp = ME.SparseTensor(coordinates=coarse, features=fuse_feat, tensor_stride=self.expand,
+                                      quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+            cls_exp = self.cls_individual_expand_out[cls_id](cls_exp)
+            up = self.cls_individual_up[cls_id][0](cls_exp, fine_C)
+            up = self.cls_individual_up[cls_id][1](up)
+            fused = ME.SparseTensor(coordinates=fine_C, features=torch.cat([up.F, cls_map.F], dim=-1))
+            fused = self.cls_individual_fuse[cls_id](fused)
+            outs.append(self.forward_single(fused, self.scales[cls_id], self.voxel_size_list[cls_id]))
+
+        centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
+        out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
+                    "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
+        if self.predict_boxes:
+            out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
+                                                         [None] * batch_size, rescale=False)
+            if "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
+                out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
+        return out_dict
+
+    def _forced_selection(self, input_dict, out, ori_xyz):
+        """bool [N, n_classes]: voxel lies inside a GT box of that class."""
+        gt = input_dict["gt_boxes"]
+        mask = torch.zeros((ori_xyz.shape[0], self.n_classes), dtype=torch.bool, device=ori_xyz.device)
+        for b, perm in enumerate(out.decomposition_permutations):
+            g = gt[b][~(gt[b] == 0).all(dim=-1)]
+            if len(g) == 0:
+                continue
+            inside = find_points_in_boxes(ori_xyz[perm], g[:, :7])                     # (n, G)
+            onehot = torch.nn.functional.one_hot(g[:, 7].long(), self.n_classes).bool()   # (G, C)
+            mask[perm] = (inside.unsqueeze(2) & onehot.unsqueeze(0)).any(dim=1)
+        return mask
+
+    def forward_single(self, x, scale, voxel_size):
+        """Per-class prediction heads (cagroup_head.py:627-652); returns per-scene lists."""
+        centerness = self.centerness_conv(x).F
+        cls_score = self.cls_conv(x).F
+        reg = self.reg_conv(x).F
+        bbox_pred = torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1)
+        perms = x.decomposition_permutations
+        vs = cls_score.new_tensor(voxel_size)
+        points = [c * vs for c in x.decomposed_coordinates]
+        for p in points:
+            assert len(p) > 0, "forward empty"
+        return ([centerness[p] for p in perms], [bbox_pred[p] for p in perms], [cls_score[p] for p in perms], points)
+
+    # ------------------------------------------------------------------ losses
+    def loss(self, centernesses, bbox_preds, cls_scores, points, semantic_scores, voxel_offset, gt_bboxes, gt_labels,
+             scene_points, img_metas, pts_semantic_mask, pts_instance_mask):
+        nb = len(img_metas)
+        if pts_semantic_mask is None:
+            pts_semantic_mask = pts_instance_mask = [None] * nb
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == nb \
+            == len(gt_bboxes) == len(gt_labels) == len(pts_instance_mask) == len(pts_semantic_mask) == len(scene_points)
+        sem_perms = semantic_scores.decomposition_permutations
+        off_perms = voxel_offset.decomposition_permutations
+        terms = []
+        for i in range(nb):
+            terms.append(self._loss_single(
+                centernesses=[x[i] for x in centernesses], bbox_preds=[x[i] for x in bbox_preds],
+                cls_scores=[x[i] for x in cls_scores], points=[x[i] for x in points],
+                voxel_offset_preds=voxel_offset.F[off_perms[i]],
+                original_points=voxel_offset.C[off_perms[i], 1:] * self.voxel_size,
+                semantic_scores=semantic_scores.F[sem_perms[i]],
+                semantic_points=semantic_scores.C[sem_perms[i], 1:] * self.voxel_size,
+                img_meta=img_metas[i], gt_bboxes=gt_bboxes[i], gt_labels=gt_labels[i], scene_points=scene_points[i],
+                pts_semantic_mask=pts_semantic_mask[i], pts_instance_mask=pts_instance_mask[i]))
+        names = ("loss_centerness", "loss_bbox", "loss_cls", "loss_sem", "loss_vote")
+        means = [torch.mean(torch.stack([t[j] for t in terms])) for j in range(5)]
+        loss = means[0] + means[1] + means[2] + means[3] + means[4]
+        vals = torch.stack(means + [loss]).detach().cpu().tolist()      # ONE device->host copy for the log
+        tb_dict = dict(zip(names + ("one_stage_loss",), vals))
+        return loss, tb_dict
+
+    def _vote_targets_yaw(self, original_points, gt_bboxes, gt_labels):
+        """SUN RGB-D: up to gt_per_seed box-centre votes per voxel (cagroup_head.py:418-452)."""
+        n = original_points.shape[0]
+        vote_targets = original_points.new_zeros([n, 3 * self.gt_per_seed])
+        vote_masks = original_points.new_zeros([n], dtype=torch.long)
+        vote_idx = original_points.new_zeros([n], dtype=torch.long)
+        inside_all = find_points_in_boxes(points=original_points, gt_bboxes=gt_bboxes)
+        for i in range(gt_labels.shape[0]):
+            ind = torch.nonzero(inside_all[:, i], as_tuple=False).squeeze(-1)
+            pts = original_points[ind]
+            vote_masks[ind] = 1
+            tmp = vote_targets[ind]
+            votes = gt_bboxes[i, :3].unsqueeze(0).to(pts.device) - pts[:, :3]
+            for j in range(self.gt_per_seed):
+                col = torch.nonzero(vote_idx[ind] == j, as_tuple=False).squeeze(-1)
+                tmp[col, int(j * 3):int(j * 3 + 3)] = votes[col]
+                if j == 0:
+                    tmp[col] = votes[col].repeat(1, self.gt_per_seed)
+            vote_targets[ind] = tmp
+            vote_idx[ind] = torch.clamp(vote_idx[ind] + 1, max=2)
+        return vote_targets, vote_masks
+
+    def _vote_targets_masks(self, original_points, gt_bboxes, scene_points, sem_mask, ins_mask):
+        """ScanNet: nearest raw point (kNN k=1) gives each voxel its instance; the target is the offset to
+        the centre of the GT box nearest to that instance's bbox centre (cagroup_head.py:454-498)."""
+        n_ins = int(ins_mask.max()) + 1
+        instance_center = scene_points.new_zeros((n_ins, 3))
+        for i in torch.unique(ins_mask):
+            ind = torch.nonzero(ins_mask == i, as_tuple=False).squeeze(-1)
+            if sem_mask[ind[0]] < self.n_classes:
+                pts = scene_points[ind, :3]
+                center = 0.5 * (pts.min(0)[0] + pts.max(0)[0])
+                match = torch.argmin(torch.cdist(center.view(1, 1, 3), gt_bboxes[:, :3].unsqueeze(0).to(center.device)).view(-1))
+                instance_center[i] = gt_bboxes[:, :3][match].to(center.device)
+            else:
+                instance_center[i] = -10000.
+        idx = knn(1, scene_points[None, :, :3].contiguous(), original_points[None, ::].contiguous())[0].long()  # (1, n)
+        instance_idx = ins_mask[idx.view(-1)].view(idx.shape[0], idx.shape[1])
+        valid = (instance_idx == instance_idx[0]).all(0)
+        # majority instance over the k neighbours; with k == 1 it is the neighbour's instance
+        votes = (instance_idx[None] == torch.arange(n_ins, device=idx.device).view(-1, 1, 1)).sum(1)
+        offset_t = instance_center[torch.argmax(votes, dim=0)] - original_points
+        offset_m = torch.where(offset_t < -100., torch.zeros_like(offset_t), torch.ones_like(offset_t)).all(1)
+        offset_t = torch.where(offset_t < -100., torch.zeros_like(offset_t), offset_t)
+        return offset_t, offset_m * valid
+
+    def _loss_single(self, centernesses, bbox_preds, cls_scores, points, voxel_offset_preds, original_points,
+                     semantic_scores, semantic_points, img_meta, gt_bboxes, gt_labels, scene_points,
+                     pts_semantic_mask, pts_instance_mask):
+        with torch.no_grad():
+            semantic_labels, _ = self.assigner.assign_semantic(semantic_points, gt_bboxes, gt_labels, self.n_classes)
+            centerness_targets, bbox_targets, labels = self.assigner.assign(points, gt_bboxes, gt_labels)
+            if self.with_yaw:
+                offset_targets, offset_masks = self._vote_targets_yaw(original_points, gt_bboxes, gt_labels)
+            elif pts_semantic_mask is not None and pts_instance_mask is not None:
+                offset_targets, offset_masks = self._vote_targets_masks(original_points, gt_bboxes, scene_points,
+                                                                        pts_semantic_mask, pts_instance_mask)
+            else:
+                raise NotImplementedError
+        centerness = torch.cat(centernesses)
+        bbox_preds = torch.cat(bbox_preds)
+        cls_scores = torch.cat(cls_scores)
+        points = torch.cat(points)
+
+        if self.with_yaw:
+            w = (offset_masks.float() / (offset_masks.float().sum() + 1e-6)).unsqueeze(1).repeat(1, 9)
+            base = original_points.repeat(1, self.gt_per_seed)
+            loss_offset = self.loss_offset(base + voxel_offset_preds, base + offset_targets, weight=w)
+        else:
+            # the reference's operator precedence (cagroup_head.py:518): every weight gets +1e-6
+            w = (offset_masks.float() / torch.ones_like(offset_masks).float().sum() + 1e-6).unsqueeze(1).repeat(1, 3)
+            loss_offset = self.loss_offset(voxel_offset_preds, offset_targets, weight=w)
+
+        pos = labels >= 0
+        # the three cross-rank means of the reference (:523,530,538) in ONE all-reduce
+        stats = torch.stack([(semantic_labels >= 0).sum().float(), pos.sum().float(),
+                             centerness_targets[pos].sum().detach()])
+        stats = reduce_mean(stats)
+        sem_n_pos, n_pos = stats[0].clamp(min=1.), stats[1].clamp(min=1.)
+        centerness_denorm = stats[2].clamp(min=1e-6)
+
+        loss_sem = self.loss_sem(semantic_scores, semantic_labels, avg_factor=sem_n_pos)
+        loss_cls = self.loss_cls(cls_scores, labels, avg_factor=n_pos)
+        pos_inds = torch.nonzero(pos).squeeze(1)
+        pos_centerness, pos_bbox_preds = centerness[pos_inds], bbox_preds[pos_inds]
+        pos_ctr_targets = centerness_targets[pos_inds].unsqueeze(1)
+        if len(pos_inds) > 0:
+            loss_centerness = self.loss_centerness(pos_centerness, pos_ctr_targets, avg_factor=n_pos)
+            loss_bbox = self.loss_bbox(self._bbox_pred_to_bbox(points[pos_inds], pos_bbox_preds), bbox_targets[pos_inds],
+                                       weight=pos_ctr_targets.squeeze(1), avg_factor=centerness_denorm)
+        else:
+            loss_centerness, loss_bbox = pos_centerness.sum(), pos_bbox_preds.sum()
+        return loss_centerness, loss_bbox, loss_cls, loss_sem, loss_offset
+
+    # ------------------------------------------------------------------ proposals
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, img_metas, rescale=False):
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == len(img_metas)
+        return [self._get_bboxes_single([x[i] for x in centernesses], [x[i] for x in bbox_preds],
+                                        [x[i] for x in cls_scores], [x[i] for x in points], img_metas[i])
+                for i in range(len(img_metas))]
+
+    def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, img_meta):
+        """score = sigmoid(cls) * sigmoid(centerness); top NMS_PRE per class map; per-class NMS
+        (cagroup_head.py:579-624)."""
+        all_boxes, all_scores, all_sem = [], [], []
+        for centerness, bbox_pred, cls_score, point in zip(centernesses, bbox_preds, cls_scores, points):
+            scores = cls_score.sigmoid() * centerness.sigmoid()
+            sem = cls_score.sigmoid() if self.use_sem_score else None
+            if len(scores) > self.nms_cfg.NMS_PRE > 0:
+                _, ids = scores.max(dim=1)[0].topk(self.nms_cfg.NMS_PRE)
+                bbox_pred, scores, point = bbox_pred[ids], scores[ids], point[ids]
+                sem = sem[ids] if sem is not None else None
+            all_boxes.append(self._bbox_pred_to_bbox(point, bbox_pred))
+            all_scores.append(scores)
+            if sem is not None:
+                all_sem.append(sem)
+        bboxes, scores = torch.cat(all_boxes), torch.cat(all_scores)
+        sem_scores = torch.cat(all_sem) if self.use_sem_score else None
+        agnostic = self.training and self.nms_cfg.get("SCORE_THR_AGNOSTIC", None) is not None
+        fn = self.class_agnostic_nms if agnostic else self._nms
+        return fn(bboxes, scores, img_meta, sem_scores=sem_scores) if self.use_sem_score else fn(bboxes, scores, img_meta)
+
+    def _bbox_pred_to_bbox(self, points, bbox_pred):
+        """(dx-,dx+,dy-,dy+,dz-,dz+[, yaw params]) at a point -> (x,y,z,w,l,h[,alpha]) (cagroup_head.py:654-703)."""
+        if bbox_pred.shape[0] == 0:
+            return bbox_pred
+        xc = points[:, 0] + (bbox_pred[:, 1] - bbox_pred[:, 0]) / 2
+        yc = points[:, 1] + (bbox_pred[:, 3] - bbox_pred[:, 2]) / 2
+        zc = points[:, 2] + (bbox_pred[:, 5] - bbox_pred[:, 4]) / 2
+        base = torch.stack([xc, yc, zc, bbox_pred[:, 0] + bbox_pred[:, 1], bbox_pred[:, 2] + bbox_pred[:, 3],
+                            bbox_pred[:, 4] + bbox_pred[:, 5]], -1)
+        if bbox_pred.shape[1] == 6:
+            return base
+        if self.yaw_parametrization == "naive":
+            return torch.cat((base, bbox_pred[:, 6:7]), -1)
+        if self.yaw_parametrization == "sin-cos":
+            norm = torch.pow(torch.pow(bbox_pred[:, 6:7], 2) + torch.pow(bbox_pred[:, 7:8], 2), 0.5)
+            return torch.cat((base, torch.atan2(bbox_pred[:, 6:7] / norm, bbox_pred[:, 7:8] / norm)), -1)
+        # 'fcaf3d': (sin(2a) ln q, cos(2a) ln q)
+        scale = bbox_pred[:, 0] + bbox_pred[:, 1] + bbox_pred[:, 2] + bbox_pred[:, 3]
+        q = torch.exp(torch.sqrt(torch.pow(bbox_pred[:, 6], 2) + torch.pow(bbox_pred[:, 7], 2)))
+        alpha = 0.5 * torch.atan2(bbox_pred[:, 6], bbox_pred[:, 7])
+        return torch.stack((xc, yc, zc, scale / (1 + q), scale / (1 + q) * q, bbox_pred[:, 5] + bbox_pred[:, 4], alpha), dim=-1)
+
+    def _finish_nms(self, bboxes, n_classes, yaw_flag, parts, sem_scores):
+        if len(parts[0]):
+            cat = [torch.cat(p, dim=0) for p in parts[:3]]
+            sem = torch.cat(parts[3], dim=0) if sem_scores is not None else None
+        else:
+            cat = [bboxes.new_zeros((0, 7 if not yaw_flag else bboxes.shape[1])), bboxes.new_zeros((0,)), bboxes.new_zeros((0,))]
+            sem = bboxes.new_zeros((0, n_classes)) if sem_scores is not None else None
+        nb = cat[0]
+        if not yaw_flag:
+            nb = torch.cat([nb[:, :6], nb.new_zeros(nb.shape[0], 1)], dim=1)
+        return (nb, cat[1], cat[2], sem) if sem_scores is not None else (nb, cat[1], cat[2])
+
+    def _nms(self, bboxes, scores, img_meta, sem_scores=None):
+        """Per-class NMS above SCORE_THR (cagroup_head.py:747-797); no yaw -> axis-aligned BEV NMS."""
+        n_classes = scores.shape[1]
+        yaw_flag = bboxes.shape[1] == 7
+        parts = ([], [], [], [])
+        above = scores > self.nms_cfg.SCORE_THR
+        has_any = above.any(dim=0).tolist()          # one host sync for all classes
+        for i in range(n_classes):
+            if not has_any[i]:
+                continue
+            ids = above[:, i]
+            class_scores, class_bboxes = scores[ids, i], bboxes[ids]
+            if yaw_flag:
+                nms_boxes = class_bboxes.clone()
+                nms_boxes[..., 6] *= -1              # heading sign fix before NMS (:770)
+                keep, _ = nms_gpu(nms_boxes, class_scores, self.nms_cfg.IOU_THR)
+            else:
+                class_bboxes = torch.cat((class_bboxes, torch.zeros_like(class_bboxes[:, :1])), dim=1)
+                keep, _ = nms_normal_gpu(class_bboxes, class_scores, self.nms_cfg.IOU_THR)
+            parts[0].append(class_bboxes[keep])
+            parts[1].append(class_scores[keep])
+            parts[2].append(bboxes.new_full(class_scores[keep].shape, i, dtype=torch.long))
+            if sem_scores is not None:
+                parts[3].append(sem_scores[ids][keep])
+        return self._finish_nms(bboxes, n_classes, yaw_flag, parts, sem_scores)
+
+    def class_agnostic_nms(self, bboxes, scores, img_meta, sem_scores=None):
+        """(cagroup_head.py:705-745); unused by the shipped configs (no SCORE_THR_AGNOSTIC)."""
+        n_classes = scores.shape[1]
+        yaw_flag = bboxes.shape[1] == 7
+        max_scores, labels = scores.max(dim=1)
+        if not yaw_flag:
+            bboxes = torch.cat((bboxes, torch.zeros_like(bboxes[:, :1])), dim=1)
+        ids = max_scores > self.nms_cfg.SCORE_THR_AGNOSTIC
+        parts = ([], [], [], [])
+        if ids.any():
+            cb, cs, cl = bboxes[ids], max_scores[ids], labels[ids]
+            nb = cb.clone()
+            if yaw_flag:
+                nb[..., 6] *= -1
+            keep, _ = (nms_gpu if yaw_flag else nms_normal_gpu)(nb, cs, self.nms_cfg.IOU_THR)
+            parts[0].append(cb[keep]); parts[1].append(cs[keep]); parts[2].append(cl[keep])
+            if sem_scores is not None:
+                parts[3].append(sem_scores[ids][keep])
+        return self._finish_nms(bboxes, n_classes, yaw_flag, parts, sem_scores)
+
+
+def split_gt_boxes(gt_boxes, label_dtype=torch.long):
+    """Zero-padded [B, Gmax, 8] -> per-scene (boxes [G,7], labels [G]) lists
+    (cagroup_head.py:298-318, cagroup3d.py:118-135)."""
+    boxes, labels = [], []
+    valid = ~(gt_boxes == 0.).all(dim=-1)
+    for b in range(gt_boxes.shape[0]):
+        g = gt_boxes[b][valid[b]]
+        boxes.append(g[:, :7].contiguous())
+        labels.append(g[:, 7].to(label_dtype))
+    return boxes, labels

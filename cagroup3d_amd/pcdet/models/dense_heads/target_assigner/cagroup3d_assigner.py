@@ -1,0 +1,94 @@
+"""FCOS-style target assignment of CAGroup3D (mirror of
+pcdet/models/dense_heads/target_assigner/cagroup3d_assigner.py:1-152; pure torch, training only)."""
+import torch
+
+from ...model_utils.cagroup_utils import rotation_3d_in_axis
+
+FLOAT_MAX = 1e8
+
+
+def volume(boxes):
+    return boxes[:, 3] * boxes[:, 4] * boxes[:, 5]
+
+
+def _face_distances(points, gt_bboxes):
+    """points (n,3), gt (m,7) -> (n,m,7): distances to the 6 faces in the box frame + heading
+    (the shared body of find_points_in_boxes :9-36 and CAGroup3DAssigner.assign :83-98)."""
+    n, m = len(points), len(gt_bboxes)
+    gt = gt_bboxes.to(points.device).expand(n, m, 7)
+    pts = points.unsqueeze(1).expand(n, m, 3)
+    shift = torch.stack((pts[..., 0] - gt[..., 0], pts[..., 1] - gt[..., 1], pts[..., 2] - gt[..., 2]),
+                        dim=-1).permute(1, 0, 2)
+    shift = rotation_3d_in_axis(shift, -gt[0, :, 6], axis=2).permute(1, 0, 2)
+    ctr = gt[..., :3] + shift
+    return torch.stack((ctr[..., 0] - gt[..., 0] + gt[..., 3] / 2, gt[..., 0] + gt[..., 3] / 2 - ctr[..., 0],
+                        ctr[..., 1] - gt[..., 1] + gt[..., 4] / 2, gt[..., 1] + gt[..., 4] / 2 - ctr[..., 1],
+                        ctr[..., 2] - gt[..., 2] + gt[..., 5] / 2, gt[..., 2] + gt[..., 5] / 2 - ctr[..., 2],
+                        gt[..., 6]), dim=-1)
+
+
+def find_points_in_boxes(points, gt_bboxes, expanded_volumes=None):
+    """(n,3) x (m,7) -> bool (n,m): strictly inside the (rotated) box."""
+    return _face_distances(points, gt_bboxes)[..., :6].min(-1)[0] > 0
+
+
+def compute_centerness(bbox_targets):
+    """sqrt of the product over axes of min/max face distance (:39-46)."""
+    x, y, z = bbox_targets[..., [0, 1]], bbox_targets[..., [2, 3]], bbox_targets[..., [4, 5]]
+    c = x.min(dim=-1)[0] / x.max(dim=-1)[0] * y.min(dim=-1)[0] / y.max(dim=-1)[0] * z.min(dim=-1)[0] / z.max(dim=-1)[0]
+    return torch.sqrt(c)
+
+
+class CAGroup3DAssigner(object):
+    def __init__(self, cfg):
+        self.limit = cfg.LIMIT
+        self.topk = cfg.TOPK
+        self.n_scales = cfg.N_SCALES
+        self.return_ins_label = cfg.get("RETURN_INS_LABEL", True)
+
+    def assign(self, points_list, gt_bboxes_ori, gt_labels_ori):
+        """Per class: a point is positive for the smallest-volume same-class GT box it lies in,
+        restricted to the top-k most central points of that box (:62-130)."""
+        ctr_all, box_all, lab_all = [], [], []
+        for cls_id, points in enumerate(points_list):
+            n = len(points)
+            assert n > 0, "empty points in class {}".format(cls_id)
+            sel = torch.nonzero(gt_labels_ori == cls_id).squeeze(1)
+            if len(sel) == 0:
+                lab_all.append(torch.full((n,), -1, dtype=torch.long, device=points.device))
+                box_all.append(torch.zeros((n, 7), dtype=torch.float, device=points.device))
+                ctr_all.append(torch.zeros((n,), dtype=torch.float, device=points.device))
+                continue
+            m = len(sel)
+            gt = gt_bboxes_ori[sel].clone().to(points.device)
+            gt_labels = gt_labels_ori[sel].clone()
+            vols = volume(gt_bboxes_ori).to(points.device)[sel].expand(n, m).contiguous()
+            targets = _face_distances(points, gt)
+            inside = targets[..., :6].min(-1)[0] > 0
+            cness = compute_centerness(targets)
+            cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
+            kth = torch.topk(cness, min(self.topk + 1, len(cness)), dim=0).values[-1]
+            in_top = cness > kth.unsqueeze(0)
+            vols = torch.where(inside, vols, torch.ones_like(vols) * FLOAT_MAX)
+            vols = torch.where(in_top, vols, torch.ones_like(vols) * FLOAT_MAX)
+            min_vol, min_ind = vols.min(dim=1)
+            labels = gt_labels[min_ind]
+            labels = torch.where(min_vol == FLOAT_MAX, -labels.new_ones(labels.shape), labels)
+            rows = torch.arange(n, device=points.device)
+            ctr_all.append(compute_centerness(targets[rows, min_ind]))
+            box_all.append(gt.expand(n, m, 7)[rows, min_ind].clone())
+            lab_all.append(labels)
+        return torch.cat(ctr_all), torch.cat(box_all), torch.cat(lab_all)
+
+    @classmethod
+    def assign_semantic(cls, points, gt_bboxes, gt_labels, n_classes):
+        """Semantic label of a voxel = class of the smallest GT box containing it (:132-152)."""
+        n, m = len(points), len(gt_bboxes)
+        vols = volume(gt_bboxes).to(points.device).expand(n, m).contiguous()
+        inside = find_points_in_boxes(points, gt_bboxes)
+        vols = torch.where(inside, vols, torch.ones_like(vols) * FLOAT_MAX)
+        bk = inside.sum(dim=1) != 0
+        min_vol, min_ind = vols.min(dim=1)
+        labels = gt_labels[min_ind]
+        labels = torch.where(min_vol == FLOAT_MAX, -labels.new_ones(labels.shape), labels)
+        return labels, (min_ind + 1) * bk

@@ -1,0 +1,102 @@
+"""The part of pcdet/models/detectors/detector3d_template.py that CAGroup3D exercises:
+name-keyed module construction in topology order (:35-51,69-84,126-144,165-179), global step,
+checkpoint loading (:337-418)."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import backbones_3d, dense_heads, roi_heads
+
+
+class Detector3DTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg, self.num_class, self.dataset = model_cfg, num_class, dataset
+        self.class_names = dataset.class_names
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        self.module_topology = ["backbone_3d", "dense_head", "roi_head"]
+
+    @property
+    def mode(self):
+        return "TRAIN" if self.training else "TEST"
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        info = {"module_list": [], "num_point_features": getattr(self.dataset, "num_point_features", 3),
+                "grid_size": getattr(self.dataset, "grid_size", None),
+                "point_cloud_range": getattr(self.dataset, "point_cloud_range", None),
+                "voxel_size": getattr(self.dataset, "voxel_size", None)}
+        for name in self.module_topology:
+            module, info = getattr(self, "build_%s" % name)(model_info_dict=info)
+            self.add_module(name, module)
+        return info["module_list"]
+
+    def build_backbone_3d(self, model_info_dict):
+        cfg = self.model_cfg.get("BACKBONE_3D", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = backbones_3d.__all__[cfg.NAME](model_cfg=cfg, input_channels=model_info_dict["num_point_features"],
+                                           grid_size=model_info_dict["grid_size"], voxel_size=model_info_dict["voxel_size"],
+                                           point_cloud_range=model_info_dict["point_cloud_range"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_point_features"] = m.num_point_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        cfg = self.model_cfg.get("DENSE_HEAD", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = dense_heads.__all__[cfg.NAME](
+            model_cfg=cfg, input_channels=model_info_dict["num_point_features"],
+            num_class=self.num_class if not cfg.get("CLASS_AGNOSTIC", False) else 1, class_names=self.class_names,
+            grid_size=model_info_dict["grid_size"], point_cloud_range=model_info_dict["point_cloud_range"],
+            predict_boxes_when_training=self.model_cfg.get("ROI_HEAD", False),
+            voxel_size=model_info_dict.get("voxel_size", False))
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def build_roi_head(self, model_info_dict):
+        cfg = self.model_cfg.get("ROI_HEAD", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = roi_heads.__all__[cfg.NAME](
+            model_cfg=cfg, input_channels=model_info_dict["num_point_features"],
+            backbone_channels=model_info_dict.get("backbone_channels", None),
+            point_cloud_range=model_info_dict["point_cloud_range"], voxel_size=model_info_dict["voxel_size"],
+            num_class=self.num_class if not cfg.get("CLASS_AGNOSTIC", False) else 1)
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    # ------------------------------------------------------------------ checkpoints
+    def _load_state_dict(self, model_state_disk, strict=True):
+        state = self.state_dict()
+        update = {k: v for k, v in model_state_disk.items() if k in state and state[k].shape == v.shape}
+        if strict:
+            self.load_state_dict(model_state_disk)
+        else:
+            state.update(update)
+            self.load_state_dict(state)
+        return state, update
+
+    def load_params_from_file(self, filename, logger=None, to_cpu=False):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        state, update = self._load_state_dict(ckpt["model_state"], strict=False)
+        if logger is not None:
+            for k in state:
+                if k not in update:
+                    logger.info("Not updated weight %s: %s" % (k, str(state[k].shape)))
+            logger.info("==> Done (loaded %d/%d)" % (len(update), len(state)))
+
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        self._load_state_dict(ckpt["model_state"], strict=True)
+        if optimizer is not None and ckpt.get("optimizer_state") is not None:
+            optimizer.load_state_dict(ckpt["optimizer_state"])
+        return ckpt.get("it", 0.0), ckpt.get("epoch", -1)

@@ -112,7 +112,8 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
  * cg3d_pairs_fill: pair_in[p] = nbr[k,o], pair_out[p] = o, ordered by (k, o) -- deterministic.
  *   Within one offset every output row (and every input row) appears at most once.
  *
- * cg3d_spconv_pairs_fwd: Y = bias (or 0), then for every segment s = (k, start, count<=128) of
+ * cg3d_spconv_pairs_fwd: Y = bias (or 0) -- skipped when `accumulate` != 0 (the caller initialised Y,
+ *   only the MFMA kernel is launched) --, then for every segment s = (k, start, count<=128) of
  *   `seg` int32 [nseg,3] (all pairs of a segment share the offset k):
  *       Y[pair_out[p], :] += X[pair_in[p], :] @ W[k]          p in [start, start+count)
  *   accumulated with fp32 global atomics (order is not deterministic; fp32 tolerance applies).
@@ -127,7 +128,8 @@ int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws
                     int32_t *pair_out, cg3d_stream_t stream);
 int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in, const int32_t *pair_out,
                           const int32_t *seg, int64_t nseg, const float *bias, float *Y, int64_t n_out,
-                          int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream);
+                          int32_t cin, int32_t cout, int32_t precision, int32_t accumulate,
+                          cg3d_stream_t stream);
 int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in, const int32_t *pair_out,
                             const int32_t *seg, int64_t nseg, float *dW, int32_t K, int32_t cin, int32_t cout,
                             int32_t precision, cg3d_stream_t stream);

@@ -98,11 +98,12 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
 /* Pair-list form (ME's in/out kernel maps): per offset k, Y[out] += X[in] W[k]. */
 int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, const int32_t *pout, const int32_t *seg,
                           int64_t nseg, const float *bias, float *Y, int64_t n_out, int32_t cin, int32_t cout,
-                          int32_t precision, cg3d_stream_t s) {
+                          int32_t precision, int32_t accumulate, cg3d_stream_t s) {
     (void)s;
     if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    for (int64_t o = 0; o < n_out; o++)
-        for (int32_t c = 0; c < cout; c++) Y[o * cout + c] = bias ? bias[c] : 0.f;
+    if (!accumulate)
+        for (int64_t o = 0; o < n_out; o++)
+            for (int32_t c = 0; c < cout; c++) Y[o * cout + c] = bias ? bias[c] : 0.f;
     /* segments of one offset never share an output row, segments of different offsets may:
        run the offsets one after the other, the pairs of an offset in parallel */
     for (int64_t g = 0; g < nseg; g++) {
