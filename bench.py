@@ -58,8 +58,9 @@ def make_model(dataset, forced, device):
     model, cfg = build_model.build_cagroup3d(dataset, seed=0)
     if forced:
         model.dense_head.force_gt_selection = True
-        # trained-like stage-1 score level so that proposals survive SCORE_THR and NMS sees real loads
-        torch.nn.init.constant_(model.dense_head.cls_conv.bias, 2.0)
+        # trained-like stage-1 scores: the map of class c fires for class c, so proposals survive
+        # SCORE_THR and every per-class NMS sees up to NMS_PRE candidates per scene
+        model.dense_head.force_class_logit_boost = 6.0
     return model.to(device), cfg
 
 
@@ -154,7 +155,7 @@ def main():
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "ScanNetV2 CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
-                   args.batch, args.config, "forced GT selection + stage-1 score bias (trained-like loads)" if forced
+                   args.batch, args.config, "forced GT selection + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
                           "voxel_size_m": 0.02, "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",

@@ -294,20 +294,26 @@ __global__ void k_pair_flags(const int32_t *__restrict__ nbr, int64_t total, int
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t < total) pos[t] = nbr[t] >= 0 ? 1 : 0;
 }
-__global__ void k_pair_offsets(const int32_t *__restrict__ pos, int32_t K, int64_t n_out, const int32_t *total,
+__global__ void k_pair_offsets(const int32_t *__restrict__ pos, int32_t K, int64_t n_out,
+                               const int32_t *__restrict__ row_bounds, int32_t G, const int32_t *total,
                                int32_t *__restrict__ pair_off) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < K) pair_off[k] = pos[(int64_t)k * n_out];
-    if (k == K) pair_off[K] = *total;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < K * G) {
+        const int k = t / G, g = t % G;
+        const int64_t r = row_bounds ? row_bounds[g] : 0;
+        const int64_t at = (int64_t)k * n_out + r;
+        pair_off[t] = (at < (int64_t)K * n_out) ? pos[at] : *total;
+    }
+    if (t == K * G) pair_off[t] = *total;
 }
-extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off,
-                                cg3d_stream_t stream) {
-    if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
+extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
+                                void *ws, int32_t *pair_off, cg3d_stream_t stream) {
+    if (K < 1 || n_out < 0 || G < 1) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     const int64_t total = (int64_t)K * n_out;
     if (total >= (1LL << 31)) return CG3D_ERR_ARG;
     if (total == 0) {
-        if (hipMemsetAsync(pair_off, 0, (K + 1) * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+        if (hipMemsetAsync(pair_off, 0, ((int64_t)K * G + 1) * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
         return CG3D_OK;
     }
     int32_t *pos = (int32_t *)ws;
@@ -318,8 +324,8 @@ extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, vo
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, s, bsum, nb, tot);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
-    hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)cg3d_divup(K + 1, 256)), dim3(256), 0, s, pos, K, n_out, tot,
-                       pair_off);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)cg3d_divup((int64_t)K * G + 1, 256)), dim3(256), 0, s, pos, K, n_out,
+                       row_bounds, G, tot, pair_off);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

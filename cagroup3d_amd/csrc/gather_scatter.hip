@@ -136,3 +136,45 @@ extern "C" int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const 
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ---------------------------------------------------------------- row gather / scatter-add
+template <bool VEC>
+__global__ void k_gather_rows(const float *__restrict__ F, const int32_t *__restrict__ idx, float *__restrict__ out,
+                              int64_t n, int32_t c, int32_t cq) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / cq;
+    int g = (int)(t % cq);
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    if (VEC) reinterpret_cast<float4 *>(out + i * c)[g] = reinterpret_cast<const float4 *>(F + r * c)[g];
+    else out[i * c + g] = F[r * c + g];
+}
+extern "C" int cg3d_gather_rows(const float *F, const int32_t *idx, float *out, int64_t n, int32_t c,
+                                cg3d_stream_t stream) {
+    if (n < 0 || c < 1) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    const bool vec = (c % 4 == 0) && !(((uintptr_t)F | (uintptr_t)out) & 15);
+    const int32_t cq = vec ? c / 4 : c;
+    const unsigned g = (unsigned)cg3d_divup(n * cq, 256);
+    if (vec) hipLaunchKernelGGL(k_gather_rows<true>, dim3(g), dim3(256), 0, cg3d_hs(stream), F, idx, out, n, c, cq);
+    else hipLaunchKernelGGL(k_gather_rows<false>, dim3(g), dim3(256), 0, cg3d_hs(stream), F, idx, out, n, c, cq);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+__global__ void k_scatter_add_rows(const float *__restrict__ dout, const int32_t *__restrict__ idx,
+                                   float *__restrict__ dF, int64_t n, int32_t c) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = t / c;
+    int a = (int)(t % c);
+    if (i >= n) return;
+    unsafeAtomicAdd(&dF[(int64_t)idx[i] * c + a], dout[t]);
+}
+extern "C" int cg3d_scatter_add_rows(const float *dout, const int32_t *idx, float *dF, int64_t n, int32_t c,
+                                     cg3d_stream_t stream) {
+    if (n < 0 || c < 1) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)cg3d_divup(n * c, 256)), dim3(256), 0, cg3d_hs(stream), dout,
+                       idx, dF, n, c);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -85,38 +85,61 @@ class KernelMap:
             self._nbrT = self._make_T()
         return self._nbrT
 
-    def pairs(self):
+    @staticmethod
+    def identity(n, device):
+        """The 1-offset map o -> o (a 1x1x1 convolution; used for grouped per-class linear layers)."""
+        nbr = torch.arange(n, dtype=torch.int32, device=device).view(1, n)
+        return KernelMap(nbr, 1, n, n, lambda: nbr)
+
+    def pairs(self, row_bounds=None):
+        """(pair_in, pair_out, pair_off host int64 [K*G+1], P).  row_bounds: host tuple of G+1 output-row
+        boundaries (contiguous groups with their own weights) or None for a single group."""
         if self._pairs is None:
+            self._pairs = {}
+        hit = self._pairs.get(row_bounds)
+        if hit is None:
             lib = _lib.get()
             dev = self.nbr.device
             total = self.K * self.n_out
+            G = 1 if row_bounds is None else len(row_bounds) - 1
+            rb = None if row_bounds is None else torch.tensor(row_bounds, dtype=torch.int32).to(dev)
             ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
-            off = torch.zeros(self.K + 1, dtype=torch.int32, device=dev)
-            lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(ws), ptr(off),
-                     lib.stream())
-            off_h = off.cpu().numpy().astype(np.int64)  # host sync, once per kernel map
+            off = torch.zeros(self.K * G + 1, dtype=torch.int32, device=dev)
+            lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
+                     ptr(off), lib.stream())
+            any_hit = next(iter(self._pairs.values()), None)
+            off_h = off.cpu().numpy().astype(np.int64)  # host sync, once per kernel map (and grouping)
             P = int(off_h[-1])
-            pin = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-            pout = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-            lib.call("cg3d_pairs_fill", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(ws), ptr(pin),
-                     ptr(pout), lib.stream())
-            self._pairs = (pin, pout, off_h, P)
-        return self._pairs
+            if any_hit is not None:
+                pin, pout = any_hit[0], any_hit[1]       # the lists do not depend on the grouping
+            else:
+                pin = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+                pout = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+                lib.call("cg3d_pairs_fill", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(ws), ptr(pin),
+                         ptr(pout), lib.stream())
+            hit = (pin, pout, off_h, P)
+            self._pairs[row_bounds] = hit
+        return hit
 
-    def segments(self, maxlen):
-        """int32 [nseg,3] (k, start, count<=maxlen) covering every pair; cached per maxlen."""
-        seg = self._segs.get(maxlen)
+    def segments(self, maxlen, row_bounds=None):
+        """int32 [nseg,3] (weight index, start, count<=maxlen) covering every pair; cached.
+        Weight index = g*K + k for group g, offset k (weights stacked as [G*K, cin, cout])."""
+        ck = (maxlen, row_bounds)
+        seg = self._segs.get(ck)
         if seg is None:
-            pin, _, off, _ = self.pairs()
+            pin, _, off, _ = self.pairs(row_bounds)
+            G = 1 if row_bounds is None else len(row_bounds) - 1
+            nslot = self.K * G
             counts = off[1:] - off[:-1]
-            nseg_k = (counts + maxlen - 1) // maxlen
-            ks = np.repeat(np.arange(self.K, dtype=np.int64), nseg_k)
-            first = np.repeat(np.cumsum(nseg_k) - nseg_k, nseg_k)
-            start = off[ks] + (np.arange(ks.shape[0], dtype=np.int64) - first) * maxlen
-            cnt = np.minimum(maxlen, off[ks + 1] - start)
-            tab = np.stack([ks, start, cnt], 1).astype(np.int32)
+            nseg_s = (counts + maxlen - 1) // maxlen
+            slot = np.repeat(np.arange(nslot, dtype=np.int64), nseg_s)
+            first = np.repeat(np.cumsum(nseg_s) - nseg_s, nseg_s)
+            start = off[slot] + (np.arange(slot.shape[0], dtype=np.int64) - first) * maxlen
+            cnt = np.minimum(maxlen, off[slot + 1] - start)
+            widx = (slot % G) * self.K + slot // G
+            tab = np.stack([widx, start, cnt], 1).astype(np.int32)
             seg = (torch.from_numpy(tab).to(pin.device).contiguous(), int(tab.shape[0]))
-            self._segs[maxlen] = seg
+            self._segs[ck] = seg
         return seg
 
 
@@ -280,41 +303,74 @@ def _wgrad_seg_len(P, cin, cout):
 
 
 class SparseConvFunction(torch.autograd.Function):
-    """Y = conv(X, W) on a kernel map; gather -> MFMA -> atomic scatter over the pair lists."""
+    """Y = conv(X, W) on a kernel map; gather -> MFMA -> atomic scatter over the pair lists.
+
+    With `row_bounds` (host tuple of G+1 output-row boundaries) the output rows form G groups with
+    their own weights: weight is [G*K, cin, cout] and group g uses weight[g*K + k]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kmap):
+    def forward(ctx, x, weight, bias, kmap, row_bounds=None):
         x = x.contiguous()
         w3 = weight.contiguous()
         ctx.save_for_backward(x, w3)
-        ctx.kmap, ctx.has_bias = kmap, bias is not None
-        pin, pout, _, _ = kmap.pairs()
-        seg, nseg = kmap.segments(_seg_len_fwd())
-        return _conv_pairs(x, w3, pin, pout, seg, nseg, bias.contiguous() if bias is not None else None, kmap.n_out,
-                           kmap.pairs()[3])
+        ctx.kmap, ctx.has_bias, ctx.row_bounds = kmap, bias is not None, row_bounds
+        pin, pout, _, P = kmap.pairs(row_bounds)
+        seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
+        return _conv_pairs(x, w3, pin, pout, seg, nseg, bias.contiguous() if bias is not None else None, kmap.n_out, P)
 
     @staticmethod
     def backward(ctx, dy):
         x, w3 = ctx.saved_tensors
-        kmap = ctx.kmap
+        kmap, rb = ctx.kmap, ctx.row_bounds
         dy = dy.contiguous()
         lib = _lib.get()
-        pin, pout, _, P = kmap.pairs()
+        pin, pout, _, P = kmap.pairs(rb)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = w3.transpose(1, 2).contiguous()
-            seg, nseg = kmap.segments(_seg_len_fwd())
+            seg, nseg = kmap.segments(_seg_len_fwd(), rb)
             dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
-            K, cin, cout = w3.shape
+            KK, cin, cout = w3.shape
             dw = torch.empty_like(w3)
-            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout))
+            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout), rb)
             lib.check(x, dy, pin, pout, seg)
             lib.call("cg3d_spconv_pairs_wgrad", ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
-                     c_int32(K), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
+                     c_int32(KK), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
+
+
+class GatherRowsFunction(torch.autograd.Function):
+    """out = F[idx] with a scatter-add backward (atomics) instead of torch's sort-based index_put."""
+
+    @staticmethod
+    def forward(ctx, feats, idx):
+        lib = _lib.get()
+        feats = feats.contiguous()
+        idx = idx.to(torch.int32).contiguous()
+        lib.check(feats, idx)
+        n, c = idx.shape[0], feats.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        lib.call("cg3d_gather_rows", ptr(feats), ptr(idx), ptr(out), c_int64(n), c_int32(c), lib.stream())
+        ctx.save_for_backward(idx)
+        ctx.n_src = feats.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        lib = _lib.get()
+        dout = dout.contiguous()
+        c = dout.shape[1]
+        df = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=dout.device)
+        lib.call("cg3d_scatter_add_rows", ptr(dout), ptr(idx), ptr(df), c_int64(idx.shape[0]), c_int32(c), lib.stream())
+        return df, None
+
+
+def gather_rows(feats, idx):
+    return GatherRowsFunction.apply(feats, idx)
 
 
 class ImplicitConvFunction(torch.autograd.Function):

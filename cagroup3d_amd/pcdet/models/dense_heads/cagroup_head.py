@@ -53,6 +53,10 @@ class CAGroup3DHead(nn.Module):
         # benchmark aid (SURVEY.md 8(d) "forced-selection"): an untrained net selects ~nothing per class;
         # when set, class c selects the voxels inside its GT boxes so the class branches see trained-like sizes
         self.force_gt_selection = False
+        self.force_class_logit_boost = 0.0   # added to class c's own logit on class c's map (trained-like scores)
+        # batched = all class branches share one coordinate space (class folded into the batch index) and
+        # run as grouped launches; False = the reference's 18-iteration loop (kept for the equivalence test)
+        self.batched = True
 
         def sub(name, default):
             return cfg.get(name, AttrDict(default))
@@ -119,6 +123,34 @@ class CAGroup3DHead(nn.Module):
         sem_prob = semantic_scores.F.detach().sigmoid()
         forced = self._forced_selection(input_dict, out, ori_xyz) if self.force_gt_selection else None
 
+        branch = self._class_branches_batched if self.batched else self._class_branches_loop
+        outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
+        centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
+        out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
+                    "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
+        if self.predict_boxes:
+            out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
+                                                         [None] * batch_size, rescale=False)
+            if "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
+                out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
+        return out_dict
+
+    def _forced_selection(self, input_dict, out, ori_xyz):
+        """bool [N, n_classes]: voxel lies inside a GT box of that class."""
+        gt = input_dict["gt_boxes"]
+        mask = torch.zeros((ori_xyz.shape[0], self.n_classes), dtype=torch.bool, device=ori_xyz.device)
+        for b, perm in enumerate(out.decomposition_permutations):
+            g = gt[b][~(gt[b] == 0).all(dim=-1)]
+            if len(g) == 0:
+                continue
+            inside = find_points_in_boxes(ori_xyz[perm], g[:, :7])                     # (n, G)
+            onehot = torch.nn.functional.one_hot(g[:, 7].long(), self.n_classes).bool()   # (G, C)
+            mask[perm] = (inside.unsqueeze(2) & onehot.unsqueeze(0)).any(dim=1)
+        return mask
+
+    def _class_branches_loop(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
+                             batch_size):
+        """The reference's per-class loop (cagroup_head.py:227-282), one class at a time."""
         outs = []
         for cls_id in range(self.n_classes):
             with torch.no_grad():
@@ -149,35 +181,120 @@ class CAGroup3DHead(nn.Module):
             up = self.cls_individual_up[cls_id][1](up)
             fused = ME.SparseTensor(coordinates=fine_C, features=torch.cat([up.F, cls_map.F], dim=-1))
             fused = self.cls_individual_fuse[cls_id](fused)
-            outs.append(self.forward_single(fused, self.scales[cls_id], self.voxel_size_list[cls_id]))
+            outs.append(self.forward_single(fused, self.scales[cls_id], self.voxel_size_list[cls_id], cls_id))
 
-        centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
-        out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
-                    "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
-        if self.predict_boxes:
-            out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
-                                                         [None] * batch_size, rescale=False)
-            if "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
-                out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
-        return out_dict
+        return outs
 
-    def _forced_selection(self, input_dict, out, ori_xyz):
-        """bool [N, n_classes]: voxel lies inside a GT box of that class."""
-        gt = input_dict["gt_boxes"]
-        mask = torch.zeros((ori_xyz.shape[0], self.n_classes), dtype=torch.bool, device=ori_xyz.device)
-        for b, perm in enumerate(out.decomposition_permutations):
-            g = gt[b][~(gt[b] == 0).all(dim=-1)]
-            if len(g) == 0:
-                continue
-            inside = find_points_in_boxes(ori_xyz[perm], g[:, :7])                     # (n, G)
-            onehot = torch.nn.functional.one_hot(g[:, 7].long(), self.n_classes).bool()   # (G, C)
-            mask[perm] = (inside.unsqueeze(2) & onehot.unsqueeze(0)).any(dim=1)
-        return mask
+    @staticmethod
+    def _grouped_bn_act(feats, bounds, bns, act):
+        """Per-class BatchNorm (+ activation) over contiguous row groups."""
+        return act(torch.cat([bn.bn(feats[bounds[c]:bounds[c + 1]]) for c, bn in enumerate(bns)], dim=0))
 
-    def forward_single(self, x, scale, voxel_size):
+    def _class_branches_batched(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
+                                batch_size):
+        """All class branches at once: rows of class c live at batch index c*B + b of ONE coordinate map,
+        class-major, so every hash build / kernel map / convolution / NMS is a single (grouped) launch.
+        Row order inside a class equals the loop version's, so results match it up to fp32 summation order."""
+        C, B, dev = self.n_classes, batch_size, out.F.device
+        N, ch = out.F.shape
+        elu = torch.nn.functional.elu
+        with torch.no_grad():
+            hit = sem_prob > self.semantic_threshold
+            if forced is not None:
+                hit = hit | forced
+            sel_cls, sel_row = torch.nonzero(hit.t(), as_tuple=True)                 # class-major, rows ascending
+            ar_c = torch.arange(C, device=dev)
+            all_cls = torch.cat([sel_cls, ar_c.repeat_interleave(B)])
+            all_pos = torch.cat([sel_row, N + torch.arange(B, device=dev).repeat(C)])  # pads go last in a class
+            all_row = torch.cat([sel_row, pad_id.repeat(C)])
+            order = torch.argsort(all_cls * (N + B) + all_pos)
+            e_cls, e_row = all_cls[order], all_row[order]
+            E = e_cls.shape[0]
+            n_c = torch.bincount(e_cls, minlength=C)
+            start_c = torch.cumsum(n_c, 0) - n_c
+            j = torch.arange(E, device=dev) - start_c[e_cls]
+            base = start_c[e_cls] * (n_vote + 1)
+            dest_vote = (base + j * n_vote).unsqueeze(1) + torch.arange(n_vote, device=dev).unsqueeze(0)
+            dest_ori = base + n_c[e_cls] * n_vote + j
+            total = E * (n_vote + 1)
+            src = torch.empty(total, dtype=torch.long, device=dev)          # row of the [votes ; originals] table
+            src[dest_vote.reshape(-1)] = (e_row.unsqueeze(1) * n_vote + torch.arange(n_vote, device=dev).unsqueeze(0)).reshape(-1)
+            src[dest_ori] = N * n_vote + e_row
+            row_cls = torch.empty(total, dtype=torch.long, device=dev)
+            row_cls[dest_vote.reshape(-1)] = e_cls.unsqueeze(1).expand(-1, n_vote).reshape(-1)
+            row_cls[dest_ori] = e_cls
+            src_vox = torch.where(src < N * n_vote, src // n_vote, src - N * n_vote)      # backbone row of each fused row
+            xyz_tab = torch.cat([voted.reshape(-1, 3), ori_xyz], dim=0)
+            fuse_xyz = xyz_tab[src]
+            bprime = row_cls.float() * B + batch_col[src_vox, 0]
+            vs_tab = fuse_xyz.new_tensor(self.voxel_size_list)
+            vs = vs_tab[row_cls]
+            fine = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / vs)], dim=1)
+            coarse = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / (vs * self.expand)) * self.expand], dim=1)
+        feat_tab = torch.cat([offset_features.reshape(N * n_vote, -1), out.F], dim=0)
+        fuse_feat = ME.gather_rows(feat_tab, src)
+
+        avg = ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
+        cls_map = ME.SparseTensor(coordinates=fine, features=fuse_feat, quantization_mode=avg)
+        cls_exp = ME.SparseTensor(coordinates=coarse, features=fuse_feat, tensor_stride=self.expand, quantization_mode=avg)
+        fine_C = cls_map.C
+        with torch.no_grad():                                             # ONE host read for all group sizes
+            fb, cb = fine_C[:, 0].long(), cls_exp.C[:, 0].long()
+            sizes = torch.cat([torch.bincount(fb // B, minlength=C), torch.bincount(cb // B, minlength=C),
+                               torch.bincount(fb, minlength=C * B)]).cpu()
+        fine_bounds = (0,) + tuple(torch.cumsum(sizes[:C], 0).tolist())
+        coarse_bounds = (0,) + tuple(torch.cumsum(sizes[C:2 * C], 0).tolist())
+        per_scene = sizes[2 * C:].tolist()
+
+        def stacked(mods, pick):
+            w = torch.stack([pick(m).kernel for m in mods], dim=0)
+            return w.view(-1, w.shape[-2], w.shape[-1])
+        mgr = cls_map.coordinate_manager
+        km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, self.cls_kernel, 1, False)
+        a = ME.SparseConvFunction.apply(cls_map.F, stacked(self.cls_individual_out, lambda m: m[0]), None, km9, fine_bounds)
+        a = self._grouped_bn_act(a, fine_bounds, [m[1] for m in self.cls_individual_out], elu)
+
+        emgr = cls_exp.coordinate_manager
+        km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
+        e = ME.SparseConvFunction.apply(cls_exp.F, stacked(self.cls_individual_expand_out, lambda m: m[0]), None, km5, coarse_bounds)
+        e = self._grouped_bn_act(e, coarse_bounds, [m[1] for m in self.cls_individual_expand_out], elu)
+        tgt_key, _, _ = emgr.insert(fine_C, 1)                             # generative transposed conv onto the fine voxels
+        km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, self.expand, 1, True)
+        u = ME.SparseConvFunction.apply(e, stacked(self.cls_individual_up, lambda m: m[0]), None, km_up, fine_bounds)
+        u = self._grouped_bn_act(u, fine_bounds, [m[1][0] for m in self.cls_individual_up], elu)
+
+        ident = ME.KernelMap.identity(fine_C.shape[0], dev)
+        f = ME.SparseConvFunction.apply(torch.cat([u, a], dim=1), stacked(self.cls_individual_fuse, lambda m: m[0]), None,
+                                        ident, fine_bounds)
+        f = self._grouped_bn_act(f, fine_bounds, [m[1] for m in self.cls_individual_fuse], elu)
+
+        with torch.no_grad():
+            rc = fb // B                                                   # class of every fine row
+        centerness = f @ self.centerness_conv.kernel
+        cls_score = f @ self.cls_conv.kernel + self.cls_conv.bias.view(1, -1)
+        if self.force_class_logit_boost:
+            cls_score = cls_score + torch.nn.functional.one_hot(rc, C).float() * self.force_class_logit_boost
+        reg = f @ self.reg_conv.kernel
+        scale_vec = torch.stack([sc.scale for sc in self.scales])
+        bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
+        points = fine_C[:, 1:].float() * vs_tab[rc]
+        perm = torch.sort(fb, stable=True)[1]                              # (class, scene)-major, rows ascending inside
+        pieces = [torch.split(t[perm], per_scene) for t in (centerness, bbox_pred, cls_score, points)]
+        outs = []
+        for c in range(C):
+            sl = slice(c * B, (c + 1) * B)
+            for p in pieces[3][sl]:
+                assert len(p) > 0, "forward empty"
+            outs.append((list(pieces[0][sl]), list(pieces[1][sl]), list(pieces[2][sl]), list(pieces[3][sl])))
+        return outs
+
+    def forward_single(self, x, scale, voxel_size, cls_id=None):
         """Per-class prediction heads (cagroup_head.py:627-652); returns per-scene lists."""
         centerness = self.centerness_conv(x).F
         cls_score = self.cls_conv(x).F
+        if self.force_class_logit_boost and cls_id is not None:
+            cls_score = cls_score.clone()
+            cls_score[:, cls_id] += self.force_class_logit_boost
         reg = self.reg_conv(x).F
         bbox_pred = torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1)
         perms = x.decomposition_permutations

@@ -107,8 +107,11 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
  * Pair-compacted kernel maps and the gather -> MFMA -> atomic-scatter convolution built on them.
  *
  * cg3d_pairs_count: flags nbr >= 0 over the k-major table, exclusive-scans them into `ws`
- *   (int32 [K*n_out + K*n_out/1024 + 64]) and writes pair_off int32 [K+1] (pairs of offset k are
- *   [pair_off[k], pair_off[k+1]); pair_off[K] = P).  The host reads pair_off to size the lists.
+ *   (int32 [K*n_out + K*n_out/1024 + 64]) and writes pair_off int32 [K*G+1].  Output rows may be
+ *   split into G contiguous groups by row_bounds int32 [G+1] (device; NULL == one group): the pairs
+ *   of (offset k, group g) are [pair_off[k*G+g], pair_off[k*G+g+1]); pair_off[K*G] = P.  Groups
+ *   let one launch convolve many independent maps with different weights (the 18 class branches of
+ *   cagroup_head.py:227-282).  The host reads pair_off to size the lists.
  * cg3d_pairs_fill: pair_in[p] = nbr[k,o], pair_out[p] = o, ordered by (k, o) -- deterministic.
  *   Within one offset every output row (and every input row) appears at most once.
  *
@@ -122,8 +125,8 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
  *   segments (any count); dW [K,cin,cout] is overwritten.
  * ---------------------------------------------------------------------------------------- */
 int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
-int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off,
-                     cg3d_stream_t stream);
+int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
+                     void *ws, int32_t *pair_off, cg3d_stream_t stream);
 int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in,
                     int32_t *pair_out, cg3d_stream_t stream);
 int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in, const int32_t *pair_out,
@@ -150,6 +153,17 @@ int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *w, float *o
                     int64_t nq, int32_t c, cg3d_stream_t stream);
 int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF,
                     int64_t nq, int32_t c, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row gather / scatter-add (the forward / backward of every `features[index]` on the path:
+ * cagroup_head.py:234-252, cagroup_roi_head.py:72).
+ *   cg3d_gather_rows:      out[i,:]  = F[idx[i],:]            idx int32 [n] (all >= 0)
+ *   cg3d_scatter_add_rows: dF[idx[i],:] += dout[i,:]          dF zero-filled by the caller
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_gather_rows(const float *F, const int32_t *idx, float *out, int64_t n, int32_t c,
+                     cg3d_stream_t stream);
+int cg3d_scatter_add_rows(const float *dout, const int32_t *idx, float *dF, int64_t n, int32_t c,
+                          cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Average pooling / quantise-average as "scatter mean".

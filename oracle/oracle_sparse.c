@@ -243,20 +243,25 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
 
 /* ---------------------------------------------------------------- pair-compacted kernel maps */
 int64_t cg3d_pairs_ws_bytes(int64_t total) { return (total + total / 1024 + 64) * (int64_t)sizeof(int32_t); }
-int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, void *ws, int32_t *pair_off, cg3d_stream_t s) {
+int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G, void *ws,
+                     int32_t *pair_off, cg3d_stream_t s) {
     (void)s;
-    if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
+    if (K < 1 || n_out < 0 || G < 1) return CG3D_ERR_ARG;
     int32_t *pos = (int32_t *)ws;
     int32_t run = 0;
-    for (int32_t k = 0; k < K; k++) {
-        pair_off[k] = run;
+    for (int32_t k = 0; k < K; k++)
         for (int64_t o = 0; o < n_out; o++) {
             int64_t t = (int64_t)k * n_out + o;
             pos[t] = run;
             if (nbr[t] >= 0) run++;
         }
-    }
-    pair_off[K] = run;
+    for (int32_t k = 0; k < K; k++)
+        for (int32_t g = 0; g < G; g++) {
+            int64_t r = row_bounds ? row_bounds[g] : 0;
+            int64_t t = (int64_t)k * n_out + r;
+            pair_off[k * G + g] = (t < (int64_t)K * n_out) ? pos[t] : run;
+        }
+    pair_off[K * G] = run;
     return CG3D_OK;
 }
 int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in, int32_t *pair_out,
@@ -265,5 +270,22 @@ int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws
     const int32_t *pos = (const int32_t *)ws;
     for (int64_t t = 0; t < (int64_t)K * n_out; t++)
         if (nbr[t] >= 0) { pair_in[pos[t]] = nbr[t]; pair_out[pos[t]] = (int32_t)(t % n_out); }
+    return CG3D_OK;
+}
+
+/* ---------------------------------------------------------------- row gather / scatter-add */
+int cg3d_gather_rows(const float *F, const int32_t *idx, float *out, int64_t n, int32_t c, cg3d_stream_t s) {
+    (void)s;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) memcpy(out + i * c, F + (int64_t)idx[i] * c, (size_t)c * sizeof(float));
+    return CG3D_OK;
+}
+int cg3d_scatter_add_rows(const float *dout, const int32_t *idx, float *dF, int64_t n, int32_t c, cg3d_stream_t s) {
+    (void)s;
+    for (int64_t i = 0; i < n; i++) {
+        float *f = dF + (int64_t)idx[i] * c;
+        const float *d = dout + i * c;
+        for (int32_t a = 0; a < c; a++) f[a] += d[a];
+    }
     return CG3D_OK;
 }
