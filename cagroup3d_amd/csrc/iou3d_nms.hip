@@ -277,50 +277,56 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes
     }
 }
 
-__global__ __launch_bounds__(64) void k_nms_scan(const int64_t *__restrict__ seg_off, const int64_t *__restrict__ mask_off,
-                                                 int64_t n_single, const unsigned long long *__restrict__ mask_all,
-                                                 int64_t *__restrict__ keep_all, int32_t *__restrict__ num_keep) {
-    extern __shared__ unsigned long long remv[];  // cb words
+__global__ __launch_bounds__(256) void k_nms_scan(const int64_t *__restrict__ seg_off, const int64_t *__restrict__ mask_off,
+                                                  int64_t n_single, const unsigned long long *__restrict__ mask_all,
+                                                  int64_t *__restrict__ keep_all, int32_t *__restrict__ num_keep) {
+    // Greedy scan, 64 boxes per step.  Wave 0 resolves the in-tile chain on the diagonal words
+    // (registers + readlane); then all 4 waves OR the mask rows of the kept boxes into the later
+    // removal words: thread (q, jj) folds the kept boxes b == q (mod 4) for column word j -- 16
+    // independent 8-byte loads in flight per thread, one LDS atomic per (thread, word).
+    extern __shared__ unsigned long long remv[];  // cb words + 1 (kept of the current tile)
     const int seg = blockIdx.x;
     const int64_t o = seg_off ? seg_off[seg] : 0;
     const int64_t n = seg_off ? seg_off[seg + 1] - o : n_single;
     const unsigned long long *mask = mask_all + (mask_off ? mask_off[seg] : 0);
     int64_t *keep = keep_all + o;
     const int64_t cb = (n + 63) / 64;
-    const int lane = threadIdx.x;
-    for (int64_t j = lane; j < cb; j += 64) remv[j] = 0ULL;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    unsigned long long *kept_sh = remv + cb;
+    for (int64_t j = tid; j < cb; j += 256) remv[j] = 0ULL;
     __syncthreads();
     int32_t nk = 0;
     for (int64_t blk = 0; blk < cb; blk++) {
         const int64_t bsz = (n - blk * 64 < 64) ? n - blk * 64 : 64;
-        // diagonal word of my row in this tile
-        unsigned long long diag = (lane < bsz) ? mask[(blk * 64 + lane) * cb + blk] : 0ULL;
-        unsigned long long cur = remv[blk];
-        unsigned long long kept = 0ULL;
-        for (int b = 0; b < bsz; b++) {
-            unsigned long long d = __shfl(diag, b);
-            if (!((cur >> b) & 1ULL)) { kept |= 1ULL << b; cur |= d; }
-        }
-        // emit kept indices in ascending order
-        if ((kept >> lane) & 1ULL) {
-            int pos = __popcll(kept & ((1ULL << lane) - 1ULL));
-            keep[nk + pos] = blk * 64 + lane;
-        }
-        nk += __popcll(kept);
-        // OR the rows of the kept boxes into the later removal words
-        for (int64_t j = blk + 1 + lane; j < cb; j += 64) {
-            unsigned long long acc = remv[j];
-            unsigned long long kk = kept;
-            while (kk) {
-                int b = __ffsll((long long)kk) - 1;
-                kk &= kk - 1;
-                acc |= mask[(blk * 64 + b) * cb + j];
+        if (q == 0) {
+            unsigned long long diag = (lane < bsz) ? mask[(blk * 64 + lane) * cb + blk] : 0ULL;
+            unsigned long long cur = remv[blk];
+            unsigned long long kept = 0ULL;
+            for (int b = 0; b < bsz; b++) {
+                unsigned long long d = __shfl(diag, b);
+                if (!((cur >> b) & 1ULL)) { kept |= 1ULL << b; cur |= d; }
             }
-            remv[j] = acc;
+            if ((kept >> lane) & 1ULL) {
+                int pos = __popcll(kept & ((1ULL << lane) - 1ULL));
+                keep[nk + pos] = blk * 64 + lane;
+            }
+            nk += __popcll(kept);
+            if (lane == 0) *kept_sh = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = *kept_sh;
+        for (int64_t j = blk + 1 + lane; j < cb; j += 64) {
+            unsigned long long acc = 0ULL;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int bit = b * 4 + q;
+                if ((kept >> bit) & 1ULL) acc |= mask[(blk * 64 + bit) * cb + j];
+            }
+            if (acc) atomicOr(&remv[j], acc);
         }
         __syncthreads();
     }
-    if (lane == 0) num_keep[seg] = nk;
+    if (tid == 0) num_keep[seg] = nk;
 }
 
 static int nms_launch(const float *boxes, const int64_t *seg_off, const int64_t *mask_off, int32_t nseg,
@@ -332,7 +338,7 @@ static int nms_launch(const float *boxes, const int64_t *seg_off, const int64_t 
     if (max_seg == 0) return CG3D_OK;
     const int64_t cb = cg3d_divup(max_seg, 64);
     if (cb > 65535 || nseg > 65535) return CG3D_ERR_ARG;
-    if (cb * 8 > 160 * 1024) return CG3D_ERR_ARG;  // removal words live in LDS
+    if ((cb + 1) * 8 > 64 * 1024) return CG3D_ERR_ARG;  // removal words live in LDS
     dim3 g((unsigned)cb, (unsigned)cb, (unsigned)nseg);
     if (rotated)
         hipLaunchKernelGGL(k_nms_mask<true>, g, dim3(64), 0, s, boxes, seg_off, mask_off, max_seg, thr,
@@ -340,7 +346,7 @@ static int nms_launch(const float *boxes, const int64_t *seg_off, const int64_t 
     else
         hipLaunchKernelGGL(k_nms_mask<false>, g, dim3(64), 0, s, boxes, seg_off, mask_off, max_seg, thr,
                            (unsigned long long *)mask_ws);
-    hipLaunchKernelGGL(k_nms_scan, dim3((unsigned)nseg), dim3(64), (size_t)cb * 8, s, seg_off, mask_off, max_seg,
+    hipLaunchKernelGGL(k_nms_scan, dim3((unsigned)nseg), dim3(256), (size_t)(cb + 1) * 8, s, seg_off, mask_off, max_seg,
                        (const unsigned long long *)mask_ws, keep, num_keep);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;

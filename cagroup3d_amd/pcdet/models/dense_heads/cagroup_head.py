@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .... import me as ME
-from ....ops.iou3d_nms_utils import nms_gpu, nms_normal_gpu
+from ....ops.iou3d_nms_utils import nms_batched_sorted, nms_gpu, nms_normal_gpu
 from ....ops.knn import knn
 from ...config import AttrDict
 from ...utils.iou3d_loss import IoU3DLoss
@@ -123,14 +123,19 @@ class CAGroup3DHead(nn.Module):
         sem_prob = semantic_scores.F.detach().sigmoid()
         forced = self._forced_selection(input_dict, out, ori_xyz) if self.force_gt_selection else None
 
+        self._merged = None
         branch = self._class_branches_batched if self.batched else self._class_branches_loop
         outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
         centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
         out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
                     "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
         if self.predict_boxes:
-            out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
-                                                         [None] * batch_size, rescale=False)
+            if self._merged is not None and not self.use_sem_score and \
+                    not (self.training and self.nms_cfg.get("SCORE_THR_AGNOSTIC", None) is not None):
+                out_dict["pred_bbox_list"] = self.get_bboxes_batched(self._merged, batch_size)
+            else:
+                out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
+                                                             [None] * batch_size, rescale=False)
             if "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
                 out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
         return out_dict
@@ -279,7 +284,10 @@ class CAGroup3DHead(nn.Module):
         bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
         points = fine_C[:, 1:].float() * vs_tab[rc]
         perm = torch.sort(fb, stable=True)[1]                              # (class, scene)-major, rows ascending inside
-        pieces = [torch.split(t[perm], per_scene) for t in (centerness, bbox_pred, cls_score, points)]
+        merged = [t[perm] for t in (centerness, bbox_pred, cls_score, points)]
+        self._merged = {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2], "points": merged[3],
+                        "seg": fb[perm], "per_scene": per_scene}
+        pieces = [torch.split(t, per_scene) for t in merged]
         outs = []
         for c in range(C):
             sl = slice(c * B, (c + 1) * B)
@@ -356,24 +364,36 @@ class CAGroup3DHead(nn.Module):
 
     def _vote_targets_masks(self, original_points, gt_bboxes, scene_points, sem_mask, ins_mask):
         """ScanNet: nearest raw point (kNN k=1) gives each voxel its instance; the target is the offset to
-        the centre of the GT box nearest to that instance's bbox centre (cagroup_head.py:454-498)."""
+        the centre of the GT box nearest to that instance's bbox centre (cagroup_head.py:454-498).
+        Instance statistics are segment reductions (the reference loops over torch.unique with a host
+        sync per instance)."""
+        dev = scene_points.device
         n_ins = int(ins_mask.max()) + 1
-        instance_center = scene_points.new_zeros((n_ins, 3))
-        for i in torch.unique(ins_mask):
-            ind = torch.nonzero(ins_mask == i, as_tuple=False).squeeze(-1)
-            if sem_mask[ind[0]] < self.n_classes:
-                pts = scene_points[ind, :3]
-                center = 0.5 * (pts.min(0)[0] + pts.max(0)[0])
-                match = torch.argmin(torch.cdist(center.view(1, 1, 3), gt_bboxes[:, :3].unsqueeze(0).to(center.device)).view(-1))
-                instance_center[i] = gt_bboxes[:, :3][match].to(center.device)
-            else:
-                instance_center[i] = -10000.
-        idx = knn(1, scene_points[None, :, :3].contiguous(), original_points[None, ::].contiguous())[0].long()  # (1, n)
+        xyz = scene_points[:, :3]
+        idx3 = ins_mask.view(-1, 1).expand(-1, 3)
+        lo = torch.full((n_ins, 3), float("inf"), device=dev).scatter_reduce(0, idx3, xyz, "amin")
+        hi = torch.full((n_ins, 3), float("-inf"), device=dev).scatter_reduce(0, idx3, xyz, "amax")
+        first = torch.full((n_ins,), ins_mask.shape[0], dtype=torch.long, device=dev).scatter_reduce(
+            0, ins_mask, torch.arange(ins_mask.shape[0], device=dev), "amin")
+        present = first < ins_mask.shape[0]
+        sem_first = sem_mask[first.clamp(max=ins_mask.shape[0] - 1)]
+        is_obj = present & (sem_first < self.n_classes)
+        center = 0.5 * (lo + hi)
+        center = torch.where(is_obj.unsqueeze(1), center, torch.zeros_like(center))
+        gt_ctr = gt_bboxes[:, :3].to(dev)
+        match = torch.argmin(torch.cdist(center.unsqueeze(0), gt_ctr.unsqueeze(0)).squeeze(0), dim=1)
+        instance_center = torch.where(is_obj.unsqueeze(1), gt_ctr[match],
+                                      torch.where(present.unsqueeze(1), torch.full_like(center, -10000.),
+                                                  torch.zeros_like(center)))
+        idx = knn(1, xyz[None].contiguous(), original_points[None, ::].contiguous())[0].long()  # (1, n)
         instance_idx = ins_mask[idx.view(-1)].view(idx.shape[0], idx.shape[1])
         valid = (instance_idx == instance_idx[0]).all(0)
-        # majority instance over the k neighbours; with k == 1 it is the neighbour's instance
-        votes = (instance_idx[None] == torch.arange(n_ins, device=idx.device).view(-1, 1, 1)).sum(1)
-        offset_t = instance_center[torch.argmax(votes, dim=0)] - original_points
+        if idx.shape[0] == 1:
+            major = instance_idx[0]
+        else:  # majority instance over the k neighbours
+            votes = (instance_idx[None] == torch.arange(n_ins, device=dev).view(-1, 1, 1)).sum(1)
+            major = torch.argmax(votes, dim=0)
+        offset_t = instance_center[major] - original_points
         offset_m = torch.where(offset_t < -100., torch.zeros_like(offset_t), torch.ones_like(offset_t)).all(1)
         offset_t = torch.where(offset_t < -100., torch.zeros_like(offset_t), offset_t)
         return offset_t, offset_m * valid
@@ -383,7 +403,8 @@ class CAGroup3DHead(nn.Module):
                      pts_semantic_mask, pts_instance_mask):
         with torch.no_grad():
             semantic_labels, _ = self.assigner.assign_semantic(semantic_points, gt_bboxes, gt_labels, self.n_classes)
-            centerness_targets, bbox_targets, labels = self.assigner.assign(points, gt_bboxes, gt_labels)
+            assign = self.assigner.assign_all_classes if self.batched else self.assigner.assign
+            centerness_targets, bbox_targets, labels = assign(points, gt_bboxes, gt_labels)
             if self.with_yaw:
                 offset_targets, offset_masks = self._vote_targets_yaw(original_points, gt_bboxes, gt_labels)
             elif pts_semantic_mask is not None and pts_instance_mask is not None:
@@ -432,6 +453,62 @@ class CAGroup3DHead(nn.Module):
         return [self._get_bboxes_single([x[i] for x in centernesses], [x[i] for x in bbox_preds],
                                         [x[i] for x in cls_scores], [x[i] for x in points], img_metas[i])
                 for i in range(len(img_metas))]
+
+    @staticmethod
+    def _sort_seg_desc(seg, score):
+        """Permutation ordering entries by (segment ascending, score descending)."""
+        o1 = torch.sort(score, descending=True, stable=True)[1]
+        o2 = torch.sort(seg[o1], stable=True)[1]
+        return o1[o2]
+
+    def get_bboxes_batched(self, m, batch_size):
+        """_get_bboxes_single for every scene at once (cagroup_head.py:579-624,747-797): per class map the
+        top NMS_PRE candidates, then ONE batched NMS launch over all (scene, class) problems and three host
+        reads in total (the loop version syncs twice per class per scene)."""
+        C, B = self.n_classes, batch_size
+        dev = m["points"].device
+        scores = m["cls_score"].detach().sigmoid() * m["centerness"].detach().sigmoid()
+        seg = m["seg"]                                                     # c*B + b, non-decreasing
+        per = torch.tensor(m["per_scene"], device=dev)
+        pre = int(self.nms_cfg.NMS_PRE)
+        if pre > 0:
+            order = self._sort_seg_desc(seg, scores.max(dim=1)[0])
+            sseg = seg[order]
+            rank = torch.arange(sseg.shape[0], device=dev) - (torch.cumsum(per, 0) - per)[sseg]
+            cand = order[rank < pre]
+        else:
+            cand = torch.arange(seg.shape[0], device=dev)
+        c_scores = scores[cand]
+        c_scene = seg[cand] % B
+        boxes = self._bbox_pred_to_bbox(m["points"][cand].detach(), m["bbox_pred"][cand].detach())
+        yaw_flag = boxes.shape[1] == 7
+        if not yaw_flag:
+            boxes = torch.cat((boxes, torch.zeros_like(boxes[:, :1])), dim=1)
+        j, i = torch.nonzero(c_scores > self.nms_cfg.SCORE_THR, as_tuple=True)       # host read 1
+        e_seg = c_scene[j] * C + i
+        e_score = c_scores[j, i]
+        o = self._sort_seg_desc(e_seg, e_score)
+        j, i, e_seg, e_score = j[o], i[o], e_seg[o], e_score[o]
+        counts = torch.bincount(e_seg, minlength=B * C).cpu()                          # host read 2
+        seg_off = torch.zeros(B * C + 1, dtype=torch.int64)
+        seg_off[1:] = torch.cumsum(counts, 0)
+        e_boxes = boxes[j].contiguous()
+        nms_boxes = e_boxes
+        if yaw_flag:
+            nms_boxes = e_boxes.clone()
+            nms_boxes[:, 6] *= -1                                                      # heading sign fix (:770)
+        keep, num = nms_batched_sorted(nms_boxes, seg_off, float(self.nms_cfg.IOU_THR), yaw_flag)
+        num = num.cpu().numpy().astype(np.int64)                                       # host read 3
+        off = seg_off.numpy()
+        idx = np.concatenate([np.arange(off[g], off[g] + num[g]) for g in range(B * C)] + [np.zeros(0, np.int64)])
+        gof = np.repeat(np.arange(B * C), num)
+        idx_d = torch.from_numpy(idx).to(dev)
+        sel = keep[idx_d] + torch.from_numpy(off[gof]).to(dev)
+        out_boxes, out_scores = e_boxes[sel], e_score[sel]
+        out_labels = torch.from_numpy(gof % C).to(dev)
+        per_scene = num.reshape(B, C).sum(1).tolist()
+        return list(zip(torch.split(out_boxes, per_scene), torch.split(out_scores, per_scene),
+                        torch.split(out_labels, per_scene)))
 
     def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, img_meta):
         """score = sigmoid(cls) * sigmoid(centerness); top NMS_PRE per class map; per-class NMS

@@ -80,6 +80,36 @@ class CAGroup3DAssigner(object):
             lab_all.append(labels)
         return torch.cat(ctr_all), torch.cat(box_all), torch.cat(lab_all)
 
+    def assign_all_classes(self, points_list, gt_bboxes_ori, gt_labels_ori):
+        """`assign` for all classes in one pass (no per-class launches): a point of class map c only
+        competes for GT boxes of class c.  Same positives / targets as `assign` for every labelled point;
+        rows with label -1 carry unspecified (unused) box / centerness values."""
+        n_per = [len(p) for p in points_list]
+        points = torch.cat(points_list)
+        dev = points.device
+        n, m = len(points), len(gt_bboxes_ori)
+        if m == 0:
+            return (torch.zeros(n, device=dev), torch.zeros((n, 7), device=dev),
+                    torch.full((n,), -1, dtype=torch.long, device=dev))
+        pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev),
+                                         torch.tensor(n_per, device=dev))
+        gt = gt_bboxes_ori.to(dev)
+        gt_labels = gt_labels_ori.to(dev).long()
+        targets = _face_distances(points, gt)                                   # (n, m, 7)
+        inside = (targets[..., :6].min(-1)[0] > 0) & (pt_cls.unsqueeze(1) == gt_labels.unsqueeze(0))
+        cness = compute_centerness(targets)
+        cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
+        n_cls = torch.tensor(n_per, device=dev)[gt_labels.clamp(max=len(n_per) - 1)]   # points on the box's class map
+        k = torch.clamp(n_cls, max=self.topk + 1).clamp(min=1)
+        kth = torch.sort(cness, dim=0, descending=True)[0].gather(0, (k - 1).unsqueeze(0)).squeeze(0)
+        in_top = cness > kth.unsqueeze(0)
+        vols = volume(gt).unsqueeze(0).expand(n, m)
+        vols = torch.where(inside & in_top, vols, torch.ones_like(vols) * FLOAT_MAX)
+        min_vol, min_ind = vols.min(dim=1)
+        labels = torch.where(min_vol == FLOAT_MAX, -torch.ones_like(min_ind), gt_labels[min_ind])
+        rows = torch.arange(n, device=dev)
+        return compute_centerness(targets[rows, min_ind]), gt[min_ind].clone(), labels
+
     @classmethod
     def assign_semantic(cls, points, gt_bboxes, gt_labels, n_classes):
         """Semantic label of a voxel = class of the smallest GT box containing it (:132-152)."""

@@ -91,14 +91,11 @@ class ProposalTargetLayer(nn.Module):
 
     @staticmethod
     def get_max_iou_with_same_class(rois, roi_labels, gt_boxes, gt_labels):
-        """Per RoI: best 3D IoU against GT boxes of ITS class (:204-238)."""
-        max_ov = rois.new_zeros(rois.shape[0])
-        assign = roi_labels.new_zeros(roi_labels.shape[0])
-        for k in range(gt_labels.min().item(), gt_labels.max().item() + 1):
-            rm, gm = roi_labels == k, gt_labels == k
-            if rm.sum() > 0 and gm.sum() > 0:
-                iou = boxes_iou3d_gpu(rois[rm].contiguous(), gt_boxes[gm].contiguous())
-                best, arg = torch.max(iou, dim=1)
-                max_ov[rm] = best
-                assign[rm] = gm.nonzero().view(-1)[arg]
-        return max_ov, assign
+        """Per RoI: best 3D IoU against GT boxes of ITS class and that GT's index (:204-238).
+        One pairwise-overlap launch for all classes; RoIs whose class has no GT get (0, 0) like the
+        reference's zero-initialised outputs."""
+        iou = boxes_iou3d_gpu(rois.contiguous(), gt_boxes.contiguous())            # (R, G)
+        same = roi_labels.view(-1, 1) == gt_labels.view(1, -1)
+        best, arg = torch.max(torch.where(same, iou, torch.full_like(iou, -1.0)), dim=1)
+        has = best >= 0
+        return torch.where(has, best, torch.zeros_like(best)), torch.where(has, arg, torch.zeros_like(arg)).to(roi_labels.dtype)
