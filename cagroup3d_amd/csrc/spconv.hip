@@ -19,6 +19,7 @@
 // The weight gradient consumes rows two at a time (k-slices = two rows), so its ballot skips at
 // 2-row granularity -- almost all padding work vanishes on the sparse high-resolution maps.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdlib.h>
 #include "cg3d_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -235,6 +236,124 @@ extern "C" int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t 
 // Results are added to Y with fp32 global atomics: 32 lanes x 4 B = one 128-byte row segment per
 // instruction half.
 // =====================================================================================
+// Fast path (cin % 4 == 0, 16-byte aligned): both operands go through LDS in FULL cache lines.
+//   * gathered rows: one wave instruction reads 4 rows x 256 B (16 lanes x 16 B per row), so a
+//     128-byte line is consumed by a single instruction -- the direct per-lane fragment gather
+//     re-fetched every line up to 8x once the 4 waves' 32 KB of in-flight lines overflowed the L1;
+//   * the next chunk's global loads (W tile + rows) are issued into registers BEFORE the current
+//     chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides under the matrix pipe;
+template <int NT, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_lds(const float *__restrict__ X, const float *__restrict__ W,
+                                                          const int32_t *__restrict__ pin,
+                                                          const int32_t *__restrict__ pout,
+                                                          const int32_t *__restrict__ seg, float *__restrict__ Y,
+                                                          int32_t cin, int32_t cout) {
+    constexpr int CT = NT * 32;
+    constexpr int KC = 64;               // input channels per chunk
+    constexpr int AP = KC + 4;           // padded row of the gathered tile (bank-conflict-free b128 reads)
+    constexpr int WV = KC * CT / 4 / 256;  // float4 of the W tile per thread
+    __shared__ float Ws[KC * CT];
+    __shared__ float As[4 * 32 * AP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int n0 = blockIdx.y * CT;
+    const int local = wave * 32 + r;
+    const bool valid = local < count;
+    const int32_t irow = valid ? pin[start + local] : -1;
+    const int32_t orow = valid ? pout[start + local] : -1;
+    const bool wave_active = wave * 32 < count;
+    const float *wk = W + (int64_t)k * cin * cout;
+    const bool wvec = (cout % 4 == 0);
+    float *Aw = &As[wave * 32 * AP];
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    // row handled by this lane in gather instruction i: 4*i + (lane >> 4); its 16-byte column: lane & 15
+    int32_t grow[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) grow[i] = __shfl(irow, 4 * i + (lane >> 4));
+    const int gcol = (lane & 15) * 4;
+
+    float4 wreg[WV], areg[8];
+    auto issue_loads = [&](int32_t c0) {
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            const int idx = tid + i * 256;
+            const int row = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + row < cin) {
+                const float *src = wk + (int64_t)(c0 + row) * cout + n0 + c4;
+                if (wvec) { if (n0 + c4 < cout) v = *reinterpret_cast<const float4 *>(src); }
+                else {
+                    if (n0 + c4 < cout) v.x = src[0];
+                    if (n0 + c4 + 1 < cout) v.y = src[1];
+                    if (n0 + c4 + 2 < cout) v.z = src[2];
+                    if (n0 + c4 + 3 < cout) v.w = src[3];
+                }
+            }
+            wreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow[i] >= 0 && c0 + gcol < cin)
+                v = *reinterpret_cast<const float4 *>(X + (int64_t)grow[i] * cin + c0 + gcol);
+            areg[i] = v;
+        }
+    };
+    issue_loads(0);
+    for (int32_t c0 = 0; c0 < cin; c0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WV; i++) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<float4 *>(&Ws[(idx / (CT / 4)) * CT + (idx % (CT / 4)) * 4]) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            *reinterpret_cast<float4 *>(&Aw[(4 * i + (lane >> 4)) * AP + gcol]) = areg[i];
+        __syncthreads();
+        if (c0 + KC < cin) issue_loads(c0 + KC);      // in flight during the MFMAs below
+        if (wave_active) {
+            float a[32];
+#pragma unroll
+            for (int t = 0; t < 32; t += 4) {
+                float4 v = *reinterpret_cast<const float4 *>(&Aw[r * AP + h * 32 + t]);
+                a[t] = v.x; a[t + 1] = v.y; a[t + 2] = v.z; a[t + 3] = v.w;
+            }
+            const float *wbase = &Ws[(h * 32) * CT + r];
+#pragma unroll
+            for (int t = 0; t < 32; t++) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], wbase[t * CT + nt * 32], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int rowl = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int32_t orow_e = __shfl(orow, rowl);
+        if (orow_e < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int col = n0 + nt * 32 + r;
+            if (col < cout) {
+                if (DBG == 2) { if (acc[nt][e] == 12345.f) Y[0] = 1.f; }   // timing experiment only
+                else unsafeAtomicAdd(&Y[(int64_t)orow_e * cout + col], acc[nt][e]);
+            }
+        }
+    }
+}
+
+// Generic path (any cin / alignment; also the 3-channel input layer with KH = 2): per-lane fragment
+// gather straight to registers, W tile through LDS.
 template <int NT, int KH, bool VEC4>
 __global__ __launch_bounds__(256) void k_spconv_pairs(const float *__restrict__ X, const float *__restrict__ W,
                                                       const int32_t *__restrict__ pin,
@@ -261,26 +380,13 @@ __global__ __launch_bounds__(256) void k_spconv_pairs(const float *__restrict__ 
 
     const float *xrow = X + (int64_t)(irow < 0 ? 0 : irow) * cin;
     const float *wk = W + (int64_t)k * cin * cout;
-    const bool wvec = VEC4 && (cout % 4 == 0);
 
     for (int32_t c0 = 0; c0 < cin; c0 += 2 * KH) {
         __syncthreads();
-        // stage W[k][c0 .. c0+2KH) x [n0 .. n0+CT) into LDS
-        if (wvec) {
-            for (int i = tid; i < 2 * KH * (CT / 4); i += 256) {
-                const int row = i / (CT / 4), c4 = (i % (CT / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + row < cin && n0 + c4 < cout)
-                    v = *reinterpret_cast<const float4 *>(wk + (int64_t)(c0 + row) * cout + n0 + c4);
-                *reinterpret_cast<float4 *>(&Ws[row * CT + c4]) = v;
-            }
-        } else {
-            for (int i = tid; i < 2 * KH * CT; i += 256) {
-                const int row = i / CT, c = i % CT;
-                Ws[i] = (c0 + row < cin && n0 + c < cout) ? wk[(int64_t)(c0 + row) * cout + n0 + c] : 0.f;
-            }
+        for (int i = tid; i < 2 * KH * CT; i += 256) {
+            const int row = i / CT, c = i % CT;
+            Ws[i] = (c0 + row < cin && n0 + c < cout) ? wk[(int64_t)(c0 + row) * cout + n0 + c] : 0.f;
         }
-        // gather this lane's 32 (KH) input channels
         const int cb = c0 + h * KH;
         float a[KH];
         if (VEC4) {
@@ -338,18 +444,29 @@ extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32
         else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     }
     if (nseg == 0) return CG3D_OK;
-    const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
+    const bool aligned = (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
+    const char *dbg = getenv("CG3D_DBG_STORE");
+    const int d = dbg ? atoi(dbg) : 0;
+#define LAUNCH_LDS(NT, D)                                                                                          \
+    hipLaunchKernelGGL((k_spconv_pairs_lds<NT, D>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), \
+                       0, s, X, W, pair_in, pair_out, seg, Y, cin, cout)
 #define LAUNCH(NT, KH, V)                                                                                     \
     hipLaunchKernelGGL((k_spconv_pairs<NT, KH, V>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)),   \
                        dim3(256), 0, s, X, W, pair_in, pair_out, seg, Y, cin, cout)
-    if (cin <= 4) {
+    if (cin % 4 == 0 && cin >= 16 && aligned && d != 3) {
+        if (d == 2) { if (cout > 64) LAUNCH_LDS(4, 2); else LAUNCH_LDS(2, 2); }
+        else if (cout > 64) LAUNCH_LDS(4, 0);
+        else if (cout > 32) LAUNCH_LDS(2, 0);
+        else LAUNCH_LDS(1, 0);
+    } else if (cin <= 4) {
         if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
-    } else if (vec4) {
+    } else if (cin % 4 == 0 && aligned) {
         if (cout > 64) LAUNCH(4, 32, true); else if (cout > 32) LAUNCH(2, 32, true); else LAUNCH(1, 32, true);
     } else {
         if (cout > 64) LAUNCH(4, 32, false); else if (cout > 32) LAUNCH(2, 32, false); else LAUNCH(1, 32, false);
     }
 #undef LAUNCH
+#undef LAUNCH_LDS
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

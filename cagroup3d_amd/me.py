@@ -257,7 +257,8 @@ class KernelProfile:
     """Optional live timing of the dominant kernel (k_spconv_pairs) with HIP events on the launch
     stream; bench.py turns it on for the timed region (roofline.achieved)."""
     enabled = False
-    records = []   # (start_event, end_event, flops, bytes)
+    wgrad = False  # also time cg3d_spconv_pairs_wgrad (dev tool; the bench roofline is fwd/dgrad only)
+    records = []   # (start_event, end_event, flops, bytes, meta)
 
     @classmethod
     def reset(cls):
@@ -265,7 +266,7 @@ class KernelProfile:
 
     @classmethod
     def summary(cls):
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in cls.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in cls.records)
         return {"launches": len(cls.records), "ms": ms, "flops": float(sum(r[2] for r in cls.records)),
                 "bytes": float(sum(r[3] for r in cls.records))}
 
@@ -290,7 +291,8 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0):
         # algorithmic work of one launch: 2*P*cin*cout flops; bytes = gathered rows + atomically added rows
         # (read-modify-write) + the weights once + the two pair lists
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout + K * cin * cout) + 8.0 * n_pairs))
+                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout + K * cin * cout) + 8.0 * n_pairs,
+                                      ("pairs", K, cin, cout, n_pairs, n_out, nseg)))
     return y
 
 
@@ -335,8 +337,16 @@ class SparseConvFunction(torch.autograd.Function):
             dw = torch.empty_like(w3)
             seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout), rb)
             lib.check(x, dy, pin, pout, seg)
+            prof = KernelProfile.enabled and KernelProfile.wgrad and lib.is_device
+            if prof:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             lib.call("cg3d_spconv_pairs_wgrad", ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
                      c_int32(KK), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
+            if prof:
+                ev1.record()
+                KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout, 4.0 * (P * cin + P * cout + KK * cin * cout),
+                                              ("wgrad", KK, cin, cout, P, kmap.n_out, nseg)))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None

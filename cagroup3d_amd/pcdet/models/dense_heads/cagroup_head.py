@@ -370,11 +370,13 @@ class CAGroup3DHead(nn.Module):
         dev = scene_points.device
         n_ins = int(ins_mask.max()) + 1
         xyz = scene_points[:, :3]
-        idx3 = ins_mask.view(-1, 1).expand(-1, 3)
-        lo = torch.full((n_ins, 3), float("inf"), device=dev).scatter_reduce(0, idx3, xyz, "amin")
-        hi = torch.full((n_ins, 3), float("-inf"), device=dev).scatter_reduce(0, idx3, xyz, "amax")
-        first = torch.full((n_ins,), ins_mask.shape[0], dtype=torch.long, device=dev).scatter_reduce(
-            0, ins_mask, torch.arange(ins_mask.shape[0], device=dev), "amin")
+        # dense masked reductions over the few instances (atomic scatter_reduce contends on ~20 slots)
+        member = ins_mask.view(-1, 1) == torch.arange(n_ins, device=dev).view(1, -1)            # (n_pts, n_ins)
+        big = torch.full((1, 1, 1), float("inf"), device=dev)
+        lo = torch.where(member.unsqueeze(2), xyz.unsqueeze(1), big).amin(0)
+        hi = torch.where(member.unsqueeze(2), xyz.unsqueeze(1), -big).amax(0)
+        ar = torch.arange(ins_mask.shape[0], device=dev).view(-1, 1)
+        first = torch.where(member, ar, torch.full_like(ar, ins_mask.shape[0])).amin(0)
         present = first < ins_mask.shape[0]
         sem_first = sem_mask[first.clamp(max=ins_mask.shape[0] - 1)]
         is_obj = present & (sem_first < self.n_classes)

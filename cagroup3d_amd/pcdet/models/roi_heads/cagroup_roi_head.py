@@ -52,7 +52,7 @@ class SimplePoolingLayer(nn.Module):
                           (unq // gs[2]) % gs[1] - half, unq % gs[2] - half), dim=1)
         uc[:, 1:4] *= self.coord_key
         feat = self.grid_relu(self.grid_bn(self.grid_conv(sp_tensor, uc.int()))).F
-        new_features = feat[inv]
+        new_features = ME.gather_rows(feat, inv)   # scatter-add backward (atomics), not torch's sort-based index_put
         if not self.pooling:
             return new_features
         g3 = self.grid_num ** 3

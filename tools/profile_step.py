@@ -21,7 +21,21 @@ def main():
         t1 = time.perf_counter()
         print("%-28s %8.1f ms" % (label, (t1 - t0) * 1e3))
         return t1
-    for rep in range(2):
+    from cagroup3d_amd import me
+    me.KernelProfile.reset(); me.KernelProfile.enabled = True; me.KernelProfile.wgrad = True
+    bench.train_step(model, opt, batch, 10)
+    torch.cuda.synchronize()
+    me.KernelProfile.enabled = False
+    agg = {}
+    for r in me.KernelProfile.records:
+        k = r[4]
+        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += r[0].elapsed_time(r[1]); a[2] += r[2]
+    print("conv launches by shape (kind, K, cin, cout, pairs, n_out, nseg): calls, ms, TF/s")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+        print("  %-50s %3d  %7.3f ms  %6.1f TF" % (str(k), a[0], a[1], a[2] / a[1] / 1e9))
+    print("  total conv ms:", sum(a[1] for a in agg.values()))
+    for rep in range(1):
         print("---- step", rep)
         b = bench.fresh(batch)
         opt.zero_grad(set_to_none=True)
