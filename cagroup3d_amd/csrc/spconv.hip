@@ -472,6 +472,11 @@ extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32
 }
 
 // weight gradient over compacted pairs: every MFMA step contracts two real pairs.
+// The four operand loads of a step (X[ci0+r], X[ci0+32+r], dY[co0+r], dY[co0+32+r]; each a full
+// 128-byte line per half-wave) are issued a whole batch of 8 steps AHEAD of the MFMAs that consume
+// them (register double buffer, 64 loads in flight per wave) -- the plain loop waited an L2/HBM
+// round trip per step.
+#define WG_B 8
 __global__ __launch_bounds__(256) void k_spconv_pairs_wgrad(const float *__restrict__ X, const float *__restrict__ dY,
                                                             const int32_t *__restrict__ pin,
                                                             const int32_t *__restrict__ pout,
@@ -496,29 +501,52 @@ __global__ __launch_bounds__(256) void k_spconv_pairs_wgrad(const float *__restr
 
     const bool ci_ok[2] = {ci0 + r < cin, ci0 + 32 + r < cin};
     const bool co_ok[2] = {co0 + r < cout, co0 + 32 + r < cout};
+    // channel-tail lanes read a clamped in-row address and are zeroed afterwards
+    const int ca0 = ci_ok[0] ? ci0 + r : 0, ca1 = ci_ok[1] ? ci0 + 32 + r : 0;
+    const int cb0 = co_ok[0] ? co0 + r : 0, cb1 = co_ok[1] ? co0 + 32 + r : 0;
+    const float *Xb = X, *Db = dY;
+    const int off_a0 = ca0, off_a1 = ca1, off_b0 = cb0, off_b1 = cb1;
 
     for (int32_t g = wave * 64; g < count; g += 256) {
         const int32_t p = g + lane;
         const int32_t my_in = (p < count) ? pin[start + p] : -1;
         const int32_t my_out = (p < count) ? pout[start + p] : -1;
-        const int steps = (count - g >= 64) ? 32 : (count - g + 1) / 2;
-        for (int t = 0; t < steps; t++) {
-            const int src = 2 * t + h;  // consecutive pairs -> the two k-slices
-            const int32_t ii = __shfl(my_in, src);
-            const int32_t oo = __shfl(my_out, src);
-            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-            if (ii >= 0) {
-                const float *xr = X + (int64_t)ii * cin + ci0 + r;
-                const float *dr = dY + (int64_t)oo * cout + co0 + r;
-                if (ci_ok[0]) a0 = xr[0];
-                if (ci_ok[1]) a1 = xr[32];
-                if (co_ok[0]) b0 = dr[0];
-                if (co_ok[1]) b1 = dr[32];
+        const int nbatch = ((count - g >= 64 ? 64 : count - g) + 2 * WG_B - 1) / (2 * WG_B);
+        float va[2][WG_B][2], vb[2][WG_B][2];
+        auto issue = [&](int buf, int t0) {
+#pragma unroll
+            for (int tt = 0; tt < WG_B; tt++) {
+                const int src = 2 * (t0 + tt) + h;
+                const int32_t ii = __shfl(my_in, src);
+                const int32_t oo = __shfl(my_out, src);
+                // UNCONDITIONAL loads from clamped (always valid) addresses, masked afterwards: a load
+                // inside an exec-masked branch makes hipcc fall back to vmcnt(0) waits (no pipelining)
+                const float *xr = Xb + (int64_t)(ii < 0 ? 0 : ii) * cin;
+                const float *dr = Db + (int64_t)(oo < 0 ? 0 : oo) * cout;
+                va[buf][tt][0] = xr[off_a0]; va[buf][tt][1] = xr[off_a1];     // raw; masked at use
+                vb[buf][tt][0] = dr[off_b0]; vb[buf][tt][1] = dr[off_b1];
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        };
+        issue(0, 0);
+#pragma unroll
+        for (int bt = 0; bt < 32 / WG_B; bt++) {
+            if (bt < nbatch) {
+                if (bt + 1 < nbatch) issue((bt + 1) & 1, (bt + 1) * WG_B);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next batch's loads ahead of this batch's MFMAs
+#pragma unroll
+                for (int tt = 0; tt < WG_B; tt++) {
+                    const bool ok = __shfl(my_in, 2 * (bt * WG_B + tt) + h) >= 0;
+                    const float a0 = (ok && ci_ok[0]) ? va[bt & 1][tt][0] : 0.f;
+                    const float a1 = (ok && ci_ok[1]) ? va[bt & 1][tt][1] : 0.f;
+                    const float b0 = co_ok[0] ? vb[bt & 1][tt][0] : 0.f;
+                    const float b1 = co_ok[1] ? vb[bt & 1][tt][1] : 0.f;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #pragma unroll
