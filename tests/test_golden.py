@@ -1,0 +1,127 @@
+"""not gpu: this repo's host-side mirrors and CPU oracle against golden vectors produced by the
+REFERENCE's own code (tests/golden/make_fixtures.py imports /root/reference here; the .npz travels)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from cagroup3d_amd import _lib
+from cagroup3d_amd.ops import iou3d_nms_utils, rotated_iou
+from cagroup3d_amd.pcdet.config import AttrDict
+from cagroup3d_amd.pcdet.models.dense_heads.cagroup_head import CAGroup3DHead
+from cagroup3d_amd.pcdet.models.dense_heads.target_assigner import cagroup3d_assigner as asg
+from cagroup3d_amd.pcdet.models.model_utils import cagroup_utils as cu
+from cagroup3d_amd.pcdet.models.roi_heads.target_assigner.cagroup_proposal_target_layer import ProposalTargetLayer
+from cagroup3d_amd.pcdet.utils import common_utils, iou3d_loss, loss_utils
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def close(a, name, rtol=1e-5, atol=1e-6):
+    torch.testing.assert_close(a, t(name), rtol=rtol, atol=atol, equal_nan=True)   # unlabelled rows carry NaN centerness
+
+
+def test_rotation_and_coder():
+    for ax in (0, 1, 2):
+        close(cu.rotation_3d_in_axis(t("rot3d_points"), t("rot3d_angles"), axis=ax), "rot3d_axis%d" % ax)
+    c6 = cu.CAGroupResidualCoder(code_size=6)
+    enc = c6.encode_torch(t("coder6_boxes").clone(), t("coder6_anchors").clone())
+    close(enc, "coder6_enc")
+    close(c6.decode_torch(enc, t("coder6_anchors").clone()), "coder6_dec")
+    c7 = cu.CAGroupResidualCoder(code_size=7, encode_angle_by_sincos=True)
+    enc = c7.encode_torch(t("coder7_boxes").clone(), t("coder7_anchors").clone())
+    close(enc, "coder7_enc")
+    close(c7.decode_torch(enc, t("coder7_anchors").clone()), "coder7_dec")
+    assert abs(cu.bias_init_with_prob(0.01) - float(G["bias_init_001"])) < 1e-12
+
+
+def test_assigner_matches_reference():
+    gt, gl = t("assign_gt"), t("assign_gt_labels")
+    pts = [p for p in t("assign_points")]
+    a = asg.CAGroup3DAssigner(AttrDict(LIMIT=27, TOPK=18, N_SCALES=4))
+    ctr, boxes, labels = a.assign(pts, gt, gl)
+    assert torch.equal(labels, t("assign_labels"))
+    close(ctr, "assign_centerness")
+    close(boxes, "assign_boxes")
+    # the all-classes-at-once form: identical labels, identical targets on every labelled point
+    ctr2, boxes2, labels2 = a.assign_all_classes(pts, gt, gl)
+    assert torch.equal(labels2, t("assign_labels"))
+    pos = labels2 >= 0
+    assert pos.sum() > 20
+    torch.testing.assert_close(ctr2[pos], t("assign_centerness")[pos], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(boxes2[pos], t("assign_boxes")[pos])
+    sem, ins = asg.CAGroup3DAssigner.assign_semantic(torch.cat(pts), gt, gl, 4)
+    assert torch.equal(sem, t("assign_sem_labels")) and torch.equal(ins, t("assign_ins_labels"))
+    assert torch.equal(asg.find_points_in_boxes(torch.cat(pts), gt), t("assign_inside"))
+
+
+def test_losses_match_reference():
+    close(loss_utils.FocalLoss(gamma=2.0, alpha=0.25)(t("focal_pred"), t("focal_target").clone(), avg_factor=7.0), "focal_loss")
+    close(loss_utils.CrossEntropy(use_sigmoid=True)(t("bce_pred"), t("bce_target"), avg_factor=5.0), "bce_loss")
+    close(loss_utils.SmoothL1Loss(beta=0.04, reduction="sum")(t("sl1_pred"), t("sl1_target"), weight=t("sl1_weight")), "sl1_loss")
+    close(loss_utils.WeightedSmoothL1Loss(code_weights=None)(t("wsl1_pred"), t("wsl1_target")), "wsl1_loss")
+    close(loss_utils.axis_aligned_bbox_overlaps_3d(t("aa_b1"), t("aa_b2")), "aa_iou")
+    close(loss_utils.axis_aligned_bbox_overlaps_3d(t("aa_b1"), t("aa_b2"), mode="giou", is_aligned=True), "aa_giou_aligned")
+    close(iou3d_loss.IoU3DLoss(with_yaw=False, loss_weight=1.0)(t("aaloss_pred"), t("aaloss_target"),
+                                                                weight=t("aaloss_weight"), avg_factor=3.0), "aaloss")
+
+
+def test_rotated_iou_torch_half(oracle):
+    with _lib.use_library(oracle):
+        close(rotated_iou.box2corners_th(t("riou_a")[..., [0, 1, 3, 4, 6]]), "riou_corners")
+        close(rotated_iou.cal_iou_3d(t("riou_a"), t("riou_b")), "riou_3d", rtol=1e-4, atol=1e-5)
+        close(iou3d_loss.IoU3DLoss(with_yaw=True)(t("riou_a")[0], t("riou_b")[0], weight=torch.ones(200), avg_factor=10.0),
+              "riou_loss", rtol=1e-4, atol=1e-5)
+
+
+def test_bev_iou_oracle_vs_compiled_reference(oracle):
+    """oracle/_ref (the reference's iou3d_cpu.cpp, libm trig) pins the oracle's rotated BEV IoU."""
+    with _lib.use_library(oracle):
+        iou = iou3d_nms_utils.boxes_iou_bev(t("bev_a"), t("bev_b"))
+    assert (t("bev_iou_ref") > 0.05).sum() > 100
+    torch.testing.assert_close(iou, t("bev_iou_ref"), rtol=0, atol=1e-5)
+
+
+def test_rotated_3d_iou_two_independent_routes(oracle):
+    """cal_iou_3d (vertex-sorting route) == BEV overlap x height overlap (polygon-clipping route)."""
+    a, b = t("riou_a")[0], t("riou_b")[0]
+    with _lib.use_library(oracle):
+        pair = rotated_iou.cal_iou_3d(a[None], b[None])[0]
+        full = iou3d_nms_utils.boxes_iou3d_gpu(a, b)
+    # the clipping route accepts corners within a 1 cm margin (iou3d_nms_kernel.cu:46), hence the loose bound
+    d = (pair - torch.diagonal(full)).abs()
+    assert d.max() < 2e-2 and (d < 2e-3).float().mean() > 0.95
+
+
+def test_rotate_points_along_z():
+    close(common_utils.rotate_points_along_z(t("rotz_points"), t("rotz_angle")), "rotz_out")
+
+
+def test_proposal_target_layer_same_rng_streams(oracle):
+    layer = ProposalTargetLayer(roi_per_image=32, fg_ratio=0.9, reg_fg_thresh=0.3)
+    bd = dict(batch_size=2, rois=t("ptl_rois").clone(), roi_scores=t("ptl_scores").clone(), roi_labels=t("ptl_labels").clone(),
+              gt_bboxes_3d=[x.clone() for x in t("ptl_gt")], gt_labels_3d=[x.clone() for x in t("ptl_gt_labels")])
+    np.random.seed(7)
+    torch.manual_seed(7)
+    with _lib.use_library(oracle):
+        res = layer(bd)
+    for k in ("rois", "gt_of_rois", "gt_label_of_rois", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask",
+              "rcnn_cls_labels"):
+        ref = t("ptl_out_" + k)
+        if ref.dtype.is_floating_point:
+            torch.testing.assert_close(res[k], ref, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(res[k], ref), k
+    assert res["reg_valid_mask"].sum() > 5
+
+
+def test_bbox_pred_to_bbox():
+    fake = types.SimpleNamespace(yaw_parametrization="fcaf3d")
+    close(CAGroup3DHead._bbox_pred_to_bbox(fake, t("b2b_points"), t("b2b_pred8")), "b2b_box8")
+    close(CAGroup3DHead._bbox_pred_to_bbox(fake, t("b2b_points"), t("b2b_pred8")[:, :6]), "b2b_box6")

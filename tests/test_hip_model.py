@@ -1,0 +1,115 @@
+"""-m gpu: the full detector on the HIP library against the same detector on the CPU oracle (S5k scenes),
+and size-independent properties of the hot-path ops at BASELINE.json's full S50k sizes."""
+import numpy as np
+import pytest
+import torch
+
+from cagroup3d_amd import _lib, build_model, me, synthetic
+from cagroup3d_amd.ops import iou3d_nms_utils, knn as knn_mod
+from util import rand_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(model, cfgname, dev):
+    model.zero_grad()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    batch = build_model.synthetic_batch(cfgname, 2, device=dev)
+    ret, tb, _ = model(batch)
+    ret["loss"].backward()
+    return batch, tb, {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("dataset,cfgname", [("scannet", "S5k"), ("sunrgbd", "S5k-yaw")])
+def test_full_detector_hip_matches_oracle(oracle, hip, dataset, cfgname):
+    model, cfg = build_model.build_cagroup3d(dataset, seed=0)
+    model.train()
+    model.dense_head.force_gt_selection = True
+    model.dense_head.force_class_logit_boost = 6.0
+    with _lib.use_library(oracle):
+        b0, tb0, g0 = _step(model, cfgname, "cpu")
+    state = {k: v.clone() for k, v in model.state_dict().items()}       # BN running stats moved during step 0
+    model2, _ = build_model.build_cagroup3d(dataset, seed=0)
+    model2.dense_head.force_gt_selection = True
+    model2.dense_head.force_class_logit_boost = 6.0
+    model2 = model2.cuda().train()
+    with _lib.use_library(hip):
+        b1, tb1, g1 = _step(model2, cfgname, "cuda")
+    # voxelisation: bit-exact coordinates and row order
+    assert torch.equal(b0["sp_tensor"].C, b1["sp_tensor"].C.cpu())
+    # class-branch voxels: same count per class and scene
+    x0, x1 = b0["one_stage_results"][0], b1["one_stage_results"][0]
+    for c in range(len(x0[3])):
+        for s in range(2):
+            assert x0[3][c][s].shape == x1[3][c][s].shape
+            torch.testing.assert_close(x1[3][c][s].cpu(), x0[3][c][s], rtol=0, atol=1e-5)       # voxel positions
+            torch.testing.assert_close(x1[2][c][s].cpu(), x0[2][c][s], rtol=2e-3, atol=2e-3)    # class scores
+    for k in tb0:
+        assert abs(tb0[k] - tb1[k]) <= 2e-3 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    # proposals: same number per scene (NMS keep decisions are not flipped by fp32 summation-order noise here)
+    assert [len(p[0]) for p in b0["pred_bbox_list"]] == [len(p[0]) for p in b1["pred_bbox_list"]]
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
+
+
+def _s50k_tensor():
+    batch = synthetic.make_batch("S50k", 4)
+    pts = torch.from_numpy(batch["points"]).cuda()
+    coords = pts[:, :4].clone()
+    coords[:, 1:] /= 0.02
+    return me.SparseTensor(coordinates=coords, features=pts[:, 4:] / 255.), pts
+
+
+def test_full_size_coordinate_and_kernel_map_properties(hip):
+    x, pts = _s50k_tensor()
+    n = len(x)
+    assert 150000 < n < 200000
+    # idempotence: re-inserting the unique coordinates is the identity
+    out, keys, vals, cap, uniq, inv = me._build_map(x.C, 1)
+    assert torch.equal(out, x.C) and torch.equal(uniq.long(), torch.arange(n, device="cuda")) and torch.equal(inv, uniq)
+    # every input point maps to a voxel holding its floored coordinate
+    vox = torch.floor(pts[:, 1:4] / 0.02).int()
+    assert torch.equal(x.C[x.inverse_mapping.long(), 1:], vox)
+    # stride-1 k3 kernel map is symmetric: nbr[k][o] = i  <=>  nbr[26-k][i] = o
+    km = x.coordinate_manager.kernel_map(x.coordinate_map_key, x.coordinate_map_key, 3, 1, False)
+    nbr = km.nbr.long()
+    assert torch.equal(nbr[13], torch.arange(n, device="cuda"))
+    for k in (0, 5, 12):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        assert torch.equal(nbr[26 - k][nbr[k][o]], o)
+    assert torch.equal(km.nbrT, km.nbr.flip(0))
+    pin, pout, off, P = km.pairs()
+    assert P == int((km.nbr >= 0).sum()) and off[-1] == P
+    assert torch.equal(nbr[(torch.arange(P, device="cuda") >= torch.tensor(off[1:-1], device="cuda").view(-1, 1)).sum(0), pout[:P].long()], pin[:P].long())
+
+
+def test_full_size_conv_linearity_and_forms_agree(hip):
+    x, _ = _s50k_tensor()
+    mgr = x.coordinate_manager
+    k2 = mgr.stride(x.coordinate_map_key, 2)
+    km = mgr.kernel_map(x.coordinate_map_key, k2, 3, 1, False)
+    torch.manual_seed(0)
+    a, b = torch.randn(len(x), 64, device="cuda"), torch.randn(len(x), 64, device="cuda")
+    w = torch.randn(27, 64, 64, device="cuda") * 0.05
+    f = lambda t: me.SparseConvFunction.apply(t, w, None, km)
+    torch.testing.assert_close(f(2.0 * a - 3.0 * b), 2.0 * f(a) - 3.0 * f(b), rtol=1e-3, atol=1e-3)
+    # the atomic pair-list form and the output-stationary implicit form are the same operator
+    torch.testing.assert_close(f(a), me.ImplicitConvFunction.apply(a, w, None, km), rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_knn_self_query_and_nms_idempotence(hip):
+    _, pts = _s50k_tensor()
+    xyz = pts[pts[:, 0] == 0, 1:4].contiguous()[None]
+    xyz = torch.unique(xyz[0], dim=0)[None].contiguous()
+    idx, d2 = knn_mod.knn_with_dist(1, xyz, xyz)
+    assert torch.equal(idx.view(-1).long(), torch.arange(xyz.shape[1], device="cuda")) and float(d2.max()) == 0.0
+    boxes = rand_boxes(18000, seed=1, yaw=False, extent=6.0, device="cuda")
+    scores = torch.rand(18000, device="cuda")
+    keep, _ = iou3d_nms_utils.nms_normal_gpu(boxes, scores, 0.5)
+    keep2, _ = iou3d_nms_utils.nms_normal_gpu(boxes[keep], scores[keep], 0.5)
+    assert 0 < len(keep) < 18000 and len(keep2) == len(keep)
+    iou = iou3d_nms_utils.boxes_iou_bev(boxes[keep][:2000], boxes[keep][:2000])
+    iou.fill_diagonal_(0)
+    assert float(iou.max()) <= 0.5 + 1e-6           # no surviving pair overlaps more than the threshold
