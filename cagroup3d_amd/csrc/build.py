@@ -18,6 +18,7 @@ SOURCES = {
     "iou3d_nms.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
     "sort_vertices.hip": ["-ffp-contract=off"],
+    "bn_act.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

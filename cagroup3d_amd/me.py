@@ -471,6 +471,118 @@ class ScatterMeanFunction(torch.autograd.Function):
         return df, None, None
 
 
+# ----------------------------------------------------------------------------- fused BatchNorm (+res) (+act)
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+_BN_CHUNK = 256
+_chunk_cache = {}
+
+
+def _bn_chunks(bounds, device):
+    """int32 [nchunk,3] (group, first row, rows<=256) for row groups `bounds` (host tuple of G+1 offsets)."""
+    ck = (bounds, str(device))
+    hit = _chunk_cache.get(ck)
+    if hit is None:
+        rows = []
+        for g in range(len(bounds) - 1):
+            for r0 in range(bounds[g], bounds[g + 1], _BN_CHUNK):
+                rows.append((g, r0, min(_BN_CHUNK, bounds[g + 1] - r0)))
+        tab = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3).to(device)
+        hit = (tab, len(rows))
+        if len(_chunk_cache) > 512:
+            _chunk_cache.clear()
+        _chunk_cache[ck] = hit
+    return hit
+
+
+class FusedBNActFunction(torch.autograd.Function):
+    """y = act(BN_g(x) + residual) over row groups; statistics, running-stat inputs and all four kernels
+    are HIP (cg3d_bn_*).  Returns (y, batch_mean [G,C], batch_var_biased [G,C])."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps):
+        lib = _lib.get()
+        x = x.contiguous()
+        N, C = x.shape
+        G = len(bounds) - 1
+        chunks, nchunk = _bn_chunks(bounds, x.device)
+        gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
+        res = residual.contiguous() if residual is not None else None
+        lib.check(x, gamma, beta, res, chunks)
+        group_n = torch.tensor([max(bounds[g + 1] - bounds[g], 1) for g in range(G)], dtype=torch.float32).to(x.device)
+        if use_batch:
+            sums = torch.empty((2, G, C), dtype=torch.float64, device=x.device)
+            lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(sums), lib.stream())
+            n = group_n.double().view(G, 1)
+            mean64 = sums[0] / n
+            var64 = (sums[1] / n - mean64 * mean64).clamp_(min=0.0)
+            mean, var = mean64.float(), var64.float()
+        else:
+            mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
+        invstd = torch.rsqrt(var + eps)
+        y = torch.empty_like(x)
+        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean), ptr(invstd),
+                 ptr(gamma), ptr(beta), c_int32(act), ptr(y), lib.stream())
+        ctx.save_for_backward(x, y, mean, invstd, gamma, chunks, group_n)
+        ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, mean, invstd, gamma, chunks, group_n = ctx.saved_tensors
+        nchunk, G, C, act, use_batch, has_res = ctx.meta
+        lib = _lib.get()
+        dy = dy.contiguous()
+        sums = torch.empty((2, G, C), dtype=torch.float64, device=x.device)
+        lib.call("cg3d_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C),
+                 ptr(mean), ptr(invstd), c_int32(act), ptr(sums), lib.stream())
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean),
+                 ptr(invstd), ptr(gamma), ptr(sums), ptr(group_n), c_int32(G), c_int32(act), c_int32(1 if use_batch else 0),
+                 ptr(dx), ptr(dres), lib.stream())
+        dbeta, dgamma = sums[0].float(), sums[1].float()
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
+    """BatchNorm1d modules `bns` (one per contiguous row group of `bounds`) + residual + activation in
+    two launches (statistics, apply); updates the modules' running statistics like nn.BatchNorm1d."""
+    bns = list(bns)
+    G, N, C = len(bns), feats.shape[0], feats.shape[1]
+    if bounds is None:
+        bounds = (0, N)
+    assert len(bounds) == G + 1 and bounds[-1] == N
+    if C % 4 != 0:      # not on this path (every normalised tensor has C % 64 == 0)
+        out = torch.cat([bn(feats[bounds[g]:bounds[g + 1]]) for g, bn in enumerate(bns)], 0)
+        out = out if residual is None else out + residual
+        return torch.relu(out) if act == ACT_RELU else (torch.nn.functional.elu(out) if act == ACT_ELU else out)
+    b0 = bns[0]
+    use_batch = b0.training or not b0.track_running_stats
+    if G == 1:
+        gamma, beta = b0.weight.view(1, C), b0.bias.view(1, C)
+    else:
+        gamma, beta = torch.stack([b.weight for b in bns]), torch.stack([b.bias for b in bns])
+    mean_in = var_in = None
+    if not use_batch:
+        mean_in = torch.stack([b.running_mean for b in bns]) if G > 1 else b0.running_mean.view(1, C)
+        var_in = torch.stack([b.running_var for b in bns]) if G > 1 else b0.running_var.view(1, C)
+    y, mean, var = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in, b0.eps)
+    if b0.training and b0.track_running_stats:
+        with torch.no_grad():
+            m = b0.momentum
+            ns = [max(bounds[g + 1] - bounds[g], 1) for g in range(G)]
+            unb = var * var.new_tensor([n / max(n - 1, 1) for n in ns]).view(G, 1)
+            rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
+            torch._foreach_mul_(rms, 1 - m)
+            torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)
+            torch._foreach_mul_(rvs, 1 - m)
+            torch._foreach_add_(rvs, list(unb.unbind(0)), alpha=m)
+            for b in bns:
+                b.num_batches_tracked += 1
+    return y
+
+
 # ----------------------------------------------------------------------------- SparseTensor
 class SparseTensor:
     """ME.SparseTensor: features [N, C] on a coordinate map.
@@ -696,8 +808,9 @@ class MinkowskiBatchNorm(nn.Module):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
 
-    def forward(self, x):
-        return x._like(self.bn(x.F))
+    def forward(self, x, act=ACT_NONE, residual=None):
+        """BN, optionally fused with a residual add and ReLU/ELU (one statistics + one apply launch)."""
+        return x._like(fused_bn_act(x.F, [self.bn], None, act, residual.F if residual is not None else None))
 
 
 class _Pointwise(nn.Module):
@@ -715,6 +828,25 @@ class MinkowskiELU(_Pointwise):
     def __init__(self, inplace=False):
         super().__init__()
         self.fn = nn.ELU()
+
+
+class Sequential(nn.Sequential):
+    """nn.Sequential that runs `MinkowskiBatchNorm` followed by `MinkowskiReLU/ELU` as ONE fused launch pair
+    (statistics + apply).  Child indices -- and therefore state_dict keys -- are those of nn.Sequential."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, MinkowskiBatchNorm) and isinstance(nxt, (MinkowskiReLU, MinkowskiELU)):
+                x = m(x, act=ACT_RELU if isinstance(nxt, MinkowskiReLU) else ACT_ELU)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class utils:  # noqa: N801  (mirrors ME.utils)

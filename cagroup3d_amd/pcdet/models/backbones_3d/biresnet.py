@@ -37,9 +37,9 @@ class BasicBlock(nn.Module):
         self.downsample, self.no_relu = downsample, no_relu
 
     def forward(self, x):
-        out = self.norm2(self.conv2(self.relu(self.norm1(self.conv1(x)))))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return out if self.no_relu else self.relu(out)
+        out = self.conv2(self.norm1(self.conv1(x), act=ME.ACT_RELU))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.norm2(out, act=ME.ACT_NONE if self.no_relu else ME.ACT_RELU, residual=res)   # BN + add (+ReLU) fused
 
 
 class Bottleneck(nn.Module):
@@ -62,11 +62,10 @@ class Bottleneck(nn.Module):
         self.downsample, self.stride, self.no_relu = downsample, stride, no_relu
 
     def forward(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.relu(self.norm2(self.conv2(out)))
-        out = self.norm3(self.conv3(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return out if self.no_relu else self.relu(out)
+        out = self.norm1(self.conv1(x), act=ME.ACT_RELU)
+        out = self.norm2(self.conv2(out), act=ME.ACT_RELU)
+        res = x if self.downsample is None else self.downsample(x)
+        return self.norm3(self.conv3(out), act=ME.ACT_NONE if self.no_relu else ME.ACT_RELU, residual=res)
 
 
 def _pre_act(cin, cout, k, pool=None):
@@ -74,7 +73,7 @@ def _pre_act(cin, cout, k, pool=None):
     layers = [] if pool is None else [ME.MinkowskiAvgPooling(kernel_size=pool[0], stride=pool[1], dimension=3)]
     layers += [ME.MinkowskiBatchNorm(cin, momentum=BN_MOM), ME.MinkowskiReLU(inplace=True),
                ME.MinkowskiConvolution(cin, cout, kernel_size=k, bias=False, dimension=3)]
-    return nn.Sequential(*layers)
+    return ME.Sequential(*layers)
 
 
 class DAPPM(nn.Module):
@@ -120,7 +119,7 @@ class BiResNet(nn.Module):
         def plain(ci, co, k, stride=1):   # conv default bias=False in ME
             return ME.MinkowskiConvolution(ci, co, kernel_size=k, stride=stride, dimension=dim)
 
-        self.conv1 = nn.Sequential(plain(cin, planes, 3), ME.MinkowskiBatchNorm(planes, momentum=BN_MOM),
+        self.conv1 = ME.Sequential(plain(cin, planes, 3), ME.MinkowskiBatchNorm(planes, momentum=BN_MOM),
                                    ME.MinkowskiReLU(inplace=True),
                                    plain(planes, planes, 3), ME.MinkowskiBatchNorm(planes, momentum=BN_MOM),
                                    ME.MinkowskiReLU(inplace=True))
@@ -129,17 +128,17 @@ class BiResNet(nn.Module):
         self.layer2 = self._make_layer(block, planes, planes * 2, layers[1], stride=2, dimension=dim)
         self.layer3 = self._make_layer(block, planes * 2, planes * 4, layers[2], stride=2, dimension=dim)
         self.layer4 = self._make_layer(block, planes * 4, planes * 8, layers[3], stride=2, dimension=dim)
-        self.compression3 = nn.Sequential(*_conv_bn(planes * 4, hi, 1))
-        self.compression4 = nn.Sequential(*_conv_bn(planes * 8, hi, 1))
-        self.down3 = nn.Sequential(*_conv_bn(hi, planes * 4, 3, stride=2))
-        self.down4 = nn.Sequential(*(_conv_bn(hi, planes * 4, 3, stride=2, relu=True)
+        self.compression3 = ME.Sequential(*_conv_bn(planes * 4, hi, 1))
+        self.compression4 = ME.Sequential(*_conv_bn(planes * 8, hi, 1))
+        self.down3 = ME.Sequential(*_conv_bn(hi, planes * 4, 3, stride=2))
+        self.down4 = ME.Sequential(*(_conv_bn(hi, planes * 4, 3, stride=2, relu=True)
                                      + _conv_bn(planes * 4, planes * 8, 3, stride=2)))
         self.layer3_ = self._make_layer(block, planes * 2, hi, 2, dimension=dim)
         self.layer4_ = self._make_layer(block, hi, hi, 2, dimension=dim)
         self.layer5_ = self._make_layer(Bottleneck, hi, hi, 1, dimension=dim)
         self.layer5 = self._make_layer(Bottleneck, planes * 8, planes * 8, 1, stride=2, dimension=dim)
         self.spp = DAPPM(planes * 16, spp_planes, planes * 4, dimension=dim)
-        self.out = nn.Sequential(
+        self.out = ME.Sequential(
             ME.MinkowskiConvolutionTranspose(planes * 4, planes * 4, kernel_size=2, stride=2, dimension=dim),
             ME.MinkowskiBatchNorm(planes * 4, momentum=BN_MOM), ME.MinkowskiReLU(inplace=True),
             ME.MinkowskiConvolution(planes * 4, cout, kernel_size=1, bias=False, dimension=dim),
@@ -160,14 +159,14 @@ class BiResNet(nn.Module):
     def _make_layer(self, block, inplanes, planes, blocks, stride=1, dimension=-1):
         down = None
         if stride != 1 or inplanes != planes * block.expansion:
-            down = nn.Sequential(ME.MinkowskiConvolution(inplanes, planes * block.expansion, kernel_size=1,
+            down = ME.Sequential(ME.MinkowskiConvolution(inplanes, planes * block.expansion, kernel_size=1,
                                                          stride=stride, dimension=dimension),
                                  ME.MinkowskiBatchNorm(planes * block.expansion, momentum=BN_MOM))
         mods = [block(inplanes, planes, stride=stride, downsample=down, dimension=dimension)]
         inplanes = planes * block.expansion
         for i in range(1, blocks):
             mods.append(block(inplanes, planes, stride=1, no_relu=(i == blocks - 1), dimension=dimension))
-        return nn.Sequential(*mods)
+        return ME.Sequential(*mods)
 
     def forward(self, input_dict):
         x = self.conv1(input_dict["sp_tensor"])                       # ts 1

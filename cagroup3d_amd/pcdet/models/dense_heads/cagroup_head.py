@@ -30,7 +30,7 @@ SUNRGBD_CLASS_SIZES = [[0.6343, 0.4861, 0.2782], [0.2373, 0.3839, 0.2155], [0.27
 
 
 def _conv_bn_elu(cin, cout, k):
-    return nn.Sequential(ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3),
+    return ME.Sequential(ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3),
                          ME.MinkowskiBatchNorm(cout), ME.MinkowskiELU())
 
 
@@ -74,7 +74,7 @@ class CAGroup3DHead(nn.Module):
 
         c = out_channels
         n_vote = 3 if self.with_yaw else 1
-        self.offset_block = nn.Sequential(
+        self.offset_block = ME.Sequential(
             ME.MinkowskiConvolution(c, c, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(c), ME.MinkowskiELU(),
             ME.MinkowskiConvolution(c, c, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(c), ME.MinkowskiELU(),
             ME.MinkowskiConvolution(c, 3 * n_vote, kernel_size=1, dimension=3))
@@ -87,7 +87,7 @@ class CAGroup3DHead(nn.Module):
         self.cls_individual_out = nn.ModuleList([_conv_bn_elu(c, c, self.cls_kernel) for _ in range(n_classes)])
         self.cls_individual_up = nn.ModuleList([nn.ModuleList([
             ME.MinkowskiGenerativeConvolutionTranspose(c, c, kernel_size=self.expand, stride=self.expand, dimension=3),
-            nn.Sequential(ME.MinkowskiBatchNorm(c), ME.MinkowskiELU())]) for _ in range(n_classes)])
+            ME.Sequential(ME.MinkowskiBatchNorm(c), ME.MinkowskiELU())]) for _ in range(n_classes)])
         self.cls_individual_fuse = nn.ModuleList([_conv_bn_elu(c * 2, c, 1) for _ in range(n_classes)])
         self.cls_individual_expand_out = nn.ModuleList([_conv_bn_elu(c, c, 5) for _ in range(n_classes)])
         self.init_weights()
@@ -192,8 +192,8 @@ class CAGroup3DHead(nn.Module):
 
     @staticmethod
     def _grouped_bn_act(feats, bounds, bns, act):
-        """Per-class BatchNorm (+ activation) over contiguous row groups."""
-        return act(torch.cat([bn.bn(feats[bounds[c]:bounds[c + 1]]) for c, bn in enumerate(bns)], dim=0))
+        """Per-class BatchNorm + ELU over contiguous row groups: one fused launch pair for all classes."""
+        return ME.fused_bn_act(feats, [b.bn for b in bns], bounds, ME.ACT_ELU)
 
     def _class_branches_batched(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
                                 batch_size):

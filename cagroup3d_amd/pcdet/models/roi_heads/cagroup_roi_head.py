@@ -51,7 +51,7 @@ class SimplePoolingLayer(nn.Module):
         uc = torch.stack((unq // (gs[0] * gs[1] * gs[2]), (unq // (gs[1] * gs[2])) % gs[0] - half,
                           (unq // gs[2]) % gs[1] - half, unq % gs[2] - half), dim=1)
         uc[:, 1:4] *= self.coord_key
-        feat = self.grid_relu(self.grid_bn(self.grid_conv(sp_tensor, uc.int()))).F
+        feat = self.grid_bn(self.grid_conv(sp_tensor, uc.int()), act=ME.ACT_ELU).F      # BN + ELU fused
         new_features = ME.gather_rows(feat, inv)   # scatter-add backward (atomics), not torch's sort-based index_put
         if not self.pooling:
             return new_features

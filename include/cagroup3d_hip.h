@@ -187,6 +187,33 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
                           float *dF, int64_t n_in, int64_t n_out, int32_t c, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Grouped BatchNorm (+ residual) (+ activation) over the rows of a sparse tensor
+ * (ME.MinkowskiBatchNorm + MinkowskiReLU/ELU + the residual add of biresnet.py:33-50,78-103; one group
+ * per class branch in cagroup_head.py:117-127).  Rows are split into contiguous groups by the chunk
+ * table `chunks` int32 [nchunk,3] = (group, first row, row count); a chunk never straddles two groups.
+ *   act: 0 none, 1 ReLU, 2 ELU(alpha=1).
+ * cg3d_bn_stats:  sums float64 [2,G,C] (zero-filled by the callee) <- per group/channel sum(x), sum(x^2)
+ *                 accumulated in fp32 per thread and fp64 across threads.
+ * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*invstd[g] + beta[g] + residual)      (residual may be NULL)
+ *                 mean/invstd/gamma/beta float32 [G,C].
+ * cg3d_bn_bwd_reduce: with dz = dy * act'(y):  sums float64 [2,G,C] <- sum(dz), sum(dz * xhat)
+ * cg3d_bn_bwd_apply:  dx = gamma*invstd*(dz - (sum_dz + xhat*sum_dzxhat)/n[g])  (training statistics;
+ *                 use_batch_stats == 0: dx = gamma*invstd*dz), dres (may be NULL) = dz
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, double *sums,
+                  cg3d_stream_t stream);
+int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
+                  const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t act,
+                  float *Y, cg3d_stream_t stream);
+int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                       int32_t G, int32_t c, const float *mean, const float *invstd, int32_t act, double *sums,
+                       cg3d_stream_t stream);
+int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                      int32_t c, const float *mean, const float *invstd, const float *gamma, const double *sums,
+                      const float *group_n, int32_t G, int32_t act, int32_t use_batch_stats, float *dX, float *dRes,
+                      cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * iou3d_nms (boxes are float32 [n,7] = x,y,z,dx,dy,dz,heading, contiguous).
  *   cg3d_boxes_overlap_bev: out[a,b] = rotated-rectangle BEV intersection AREA.
  *   cg3d_boxes_iou_bev:     out[a,b] = overlap / max(sa + sb - overlap, 1e-8).

@@ -289,3 +289,101 @@ int cg3d_scatter_add_rows(const float *dout, const int32_t *idx, float *dF, int6
     }
     return CG3D_OK;
 }
+
+/* ---------------------------------------------------------------- grouped BatchNorm (+res) (+act)
+ * plain restatement of torch.nn.BatchNorm1d -> ReLU/ELU -> residual add as the reference chains them
+ * (biresnet.py:33-50; cagroup_head.py:117-127). */
+static inline float os_act_fwd(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+static inline float os_act_bwd(float y, int act) {
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
+}
+int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, double *sums,
+                  cg3d_stream_t s) {
+    (void)s;
+    const size_t ns = 2 * (size_t)G * c;
+    memset(sums, 0, sizeof(double) * ns);
+#pragma omp parallel
+    {
+        double *loc = (double *)calloc(ns, sizeof(double));
+#pragma omp for schedule(static)
+        for (int64_t k = 0; k < nchunk; k++) {
+            int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
+            for (int32_t r = r0; r < r0 + nr; r++)
+                for (int32_t a = 0; a < c; a++) {
+                    double v = X[(int64_t)r * c + a];
+                    loc[(int64_t)g * c + a] += v;
+                    loc[(int64_t)(G + g) * c + a] += v * v;
+                }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < ns; i++) sums[i] += loc[i];
+        free(loc);
+    }
+    return CG3D_OK;
+}
+int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
+                  const float *invstd, const float *gamma, const float *beta, int32_t act, float *Y, cg3d_stream_t s) {
+    (void)s;
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nchunk; k++) {
+        int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
+        for (int32_t r = r0; r < r0 + nr; r++)
+            for (int32_t a = 0; a < c; a++) {
+                int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
+                float y = (X[o] - mean[p]) * invstd[p] * gamma[p] + beta[p];
+                if (R) y += R[o];
+                Y[o] = os_act_fwd(y, act);
+            }
+    }
+    return CG3D_OK;
+}
+int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G,
+                       int32_t c, const float *mean, const float *invstd, int32_t act, double *sums, cg3d_stream_t s) {
+    (void)s;
+    const size_t ns = 2 * (size_t)G * c;
+    memset(sums, 0, sizeof(double) * ns);
+#pragma omp parallel
+    {
+        double *loc = (double *)calloc(ns, sizeof(double));
+#pragma omp for schedule(static)
+        for (int64_t k = 0; k < nchunk; k++) {
+            int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
+            for (int32_t r = r0; r < r0 + nr; r++)
+                for (int32_t a = 0; a < c; a++) {
+                    int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
+                    float d = dY[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
+                    loc[p] += d;
+                    loc[(int64_t)(G + g) * c + a] += (double)(d * (X[o] - mean[p]) * invstd[p]);
+                }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < ns; i++) sums[i] += loc[i];
+        free(loc);
+    }
+    return CG3D_OK;
+}
+int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t c,
+                      const float *mean, const float *invstd, const float *gamma, const double *sums, const float *group_n,
+                      int32_t G, int32_t act, int32_t use_batch, float *dX, float *dR, cg3d_stream_t s) {
+    (void)s;
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nchunk; k++) {
+        int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
+        float inv_n = use_batch ? 1.f / group_n[g] : 0.f;
+        for (int32_t r = r0; r < r0 + nr; r++)
+            for (int32_t a = 0; a < c; a++) {
+                int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
+                float d = dY[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
+                if (dR) dR[o] = d;
+                float xh = (X[o] - mean[p]) * invstd[p];
+                dX[o] = gamma[p] * invstd[p] * (d - ((float)sums[p] + xh * (float)sums[(int64_t)(G + g) * c + a]) * inv_n);
+            }
+    }
+    return CG3D_OK;
+}

@@ -226,6 +226,25 @@ def test_quantise_average_matches_oracle(oracle, hip):
     close(ref[3], out[3], 8.0)
 
 
+# ------------------------------------------------------------------ fused BN (+res) (+act)
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("c,bounds", [(64, (0, 30000)), (128, (0, 1, 700, 701, 5000)), (1024, (0, 1229)), (256, (0, 257, 257, 9000))])
+def test_fused_bn_act_matches_oracle(oracle, hip, act, c, bounds):
+    torch.manual_seed(c + act)
+    n, G = bounds[-1], len(bounds) - 1
+    x, res, dy = torch.randn(n, c) * 2 + 0.5, torch.randn(n, c), torch.randn(n, c)
+    gamma, beta = torch.rand(G, c) + 0.5, torch.randn(G, c)
+
+    def fn(x, res, dy, gamma, beta):
+        x, res, gamma, beta = [t.clone().requires_grad_(True) for t in (x, res, gamma, beta)]
+        y, mean, var = me.FusedBNActFunction.apply(x, gamma, beta, res, bounds, act, True, None, None, 1e-5)
+        (y * dy).sum().backward()
+        return y.detach(), mean, var, x.grad, res.grad, gamma.grad, beta.grad
+    ref, out = both(oracle, hip, fn, x, res, dy, gamma, beta)
+    for r, o in zip(ref, out):
+        close(r, o, float(r.abs().max()))
+
+
 # ------------------------------------------------------------------ iou3d_nms
 @pytest.mark.parametrize("na,nb", [(0, 5), (1, 1), (17, 33), (300, 257)])
 def test_boxes_overlap_and_iou_bit_exact(oracle, hip, na, nb):
