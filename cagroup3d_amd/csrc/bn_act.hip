@@ -6,10 +6,9 @@
 // normalise in ONE launch.  HBM-bound: X is read twice in the forward (statistics, apply) and dY/X/Y once
 // each per backward kernel; every access is a 16-byte vector per lane, a row (C*4 bytes) is covered by
 // C/4 consecutive lanes, so each wave reads whole 128-byte lines.
-// Statistics: fp32 partial sums per thread, fp64 across threads/workgroups (global fp64 atomics).
+// Statistics: fp32 partial sums per <=256-row chunk (plain stores, no atomics), then a finalise kernel
+// reduces the chunks of every group in fp64.
 #include "cg3d_common.h"
-
-#define BN_ROWS_PER_CHUNK 256   // rows a workgroup walks; the host builds the chunk table with this bound
 
 __device__ static inline float act_fwd(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -23,22 +22,27 @@ __device__ static inline float act_bwd(float y, int act) {
     return 1.f;
 }
 
-// thread t of the block owns channel quad (t % cq) and walks rows (t / cq), +rpb, ...
+// thread t of the block owns channel quad (t % tpr) and walks rows (t / tpr), +rpb, ...
 template <bool BWD>
-__global__ __launch_bounds__(256) void k_bn_reduce(const float *__restrict__ A, const float *__restrict__ X,
-                                                   const float *__restrict__ Yv, const int32_t *__restrict__ chunks,
-                                                   int32_t G, int32_t c, const float *__restrict__ mean,
-                                                   const float *__restrict__ invstd, int act, double *__restrict__ sums) {
+__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A, const float *__restrict__ X,
+                                                    const float *__restrict__ Yv, const int32_t *__restrict__ chunks,
+                                                    int32_t c, const float *__restrict__ mean,
+                                                    const float *__restrict__ var, float eps, int act,
+                                                    float *__restrict__ ws) {
     __shared__ float4 red0[256], red1[256];
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
     const int tpr = cq < 256 ? cq : 256;          // threads per row
     const int rpb = 256 / tpr;                    // rows per block pass
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    float *w0 = ws + (int64_t)blockIdx.x * 2 * c, *w1 = w0 + c;
     for (int q = tq; q < cq; q += tpr) {
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-        float4 mu = s0, is = s0;
-        if (BWD) { mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q]; is = reinterpret_cast<const float4 *>(invstd + (int64_t)g * c)[q]; }
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0, is = s0;
+        if (BWD) {
+            mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
+            float4 v = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
+            is = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
+        }
         if (tr < rpb) {
             for (int r = tr; r < nr; r += rpb) {
                 const int64_t off = (int64_t)(r0 + r) * cq + q;
@@ -67,42 +71,74 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float *__restrict__ A, 
                 s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
                 s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
             }
-            double *d0 = sums + ((int64_t)g * c + q * 4);
-            double *d1 = sums + ((int64_t)(G + g) * c + q * 4);
-            atomicAdd(d0, (double)s0.x); atomicAdd(d0 + 1, (double)s0.y); atomicAdd(d0 + 2, (double)s0.z); atomicAdd(d0 + 3, (double)s0.w);
-            atomicAdd(d1, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
+            reinterpret_cast<float4 *>(w0)[q] = s0;
+            reinterpret_cast<float4 *>(w1)[q] = s1;
         }
         __syncthreads();
     }
 }
 
-extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, double *sums,
-                             cg3d_stream_t stream) {
-    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || ((uintptr_t)X & 15)) return CG3D_ERR_ARG;
+// one thread per (group, channel): fp64 reduction over the group's chunks.
+// MODE 0: out0 = mean, out1 = biased variance (needs group row counts from the chunk table)
+// MODE 1: out0 = sum0 (dbeta), out1 = sum1 (dgamma)
+template <int MODE>
+__global__ void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
+                              const int32_t *__restrict__ gco, int32_t G, int32_t c, float *__restrict__ out0,
+                              float *__restrict__ out1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * c) return;
+    const int g = t / c, a = t % c;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t rows = 0;
+    for (int k = gco[g]; k < gco[g + 1]; k++) {
+        s0 += (double)ws[(int64_t)k * 2 * c + a];
+        s1 += (double)ws[(int64_t)k * 2 * c + c + a];
+        if (MODE == 0) rows += chunks[k * 3 + 2];
+    }
+    if (MODE == 0) {
+        const double n = rows > 0 ? (double)rows : 1.0;
+        const double m = s0 / n;
+        double v = s1 / n - m * m;
+        out0[t] = (float)m;
+        out1[t] = (float)(v > 0.0 ? v : 0.0);
+    } else {
+        out0[t] = (float)s0;
+        out1[t] = (float)s1;
+    }
+}
+
+static bool bad(const void *p) { return ((uintptr_t)p & 15) != 0; }
+
+extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off,
+                             int32_t G, int32_t c, float *ws, float *mean, float *var, cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(ws)) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * c, s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_reduce<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, G, c,
-                       nullptr, nullptr, 0, sums);
+    if (nchunk > 0)
+        hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, c,
+                           nullptr, nullptr, 0.f, 0, ws);
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)cg3d_divup((int64_t)G * c, 256)), dim3(256), 0, s, ws, chunks,
+                       group_chunk_off, G, c, mean, var);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
 extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                                  int32_t G, int32_t c, const float *mean, const float *invstd, int32_t act,
-                                  double *sums, cg3d_stream_t stream) {
-    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || (((uintptr_t)X | (uintptr_t)dY | (uintptr_t)Y) & 15)) return CG3D_ERR_ARG;
+                                  const int32_t *group_chunk_off, int32_t G, int32_t c, const float *mean,
+                                  const float *var, float eps, int32_t act, float *ws, float *dbeta, float *dgamma,
+                                  cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(ws)) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * c, s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_reduce<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, G, c, mean, invstd,
-                       act, sums);
+    if (nchunk > 0)
+        hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
+                           act, ws);
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)cg3d_divup((int64_t)G * c, 256)), dim3(256), 0, s, ws, chunks,
+                       group_chunk_off, G, c, dbeta, dgamma);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
 
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, const float *__restrict__ R,
                                                   const int32_t *__restrict__ chunks, int32_t c,
-                                                  const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                  const float *__restrict__ mean, const float *__restrict__ var, float eps,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, int act,
                                                   float *__restrict__ Y) {
     const int cq = c >> 2;
@@ -112,13 +148,13 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
         const int q = (int)(t % cq);
         const int64_t off = (int64_t)r0 * cq + t;
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
-        const float4 is = reinterpret_cast<const float4 *>(invstd + (int64_t)g * c)[q];
+        const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         const float4 be = reinterpret_cast<const float4 *>(beta + (int64_t)g * c)[q];
         float4 x = reinterpret_cast<const float4 *>(X)[off];
         float4 y;
-        y.x = (x.x - mu.x) * is.x * ga.x + be.x; y.y = (x.y - mu.y) * is.y * ga.y + be.y;
-        y.z = (x.z - mu.z) * is.z * ga.z + be.z; y.w = (x.w - mu.w) * is.w * ga.w + be.w;
+        y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * ga.x + be.x; y.y = (x.y - mu.y) * rsqrtf(vv.y + eps) * ga.y + be.y;
+        y.z = (x.z - mu.z) * rsqrtf(vv.z + eps) * ga.z + be.z; y.w = (x.w - mu.w) * rsqrtf(vv.w + eps) * ga.w + be.w;
         if (R) {
             float4 r = reinterpret_cast<const float4 *>(R)[off];
             y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
@@ -128,12 +164,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
     }
 }
 extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
-                             const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t act,
-                             float *Y, cg3d_stream_t stream) {
-    if (nchunk < 0 || c < 4 || (c & 3) || (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)residual) & 15)) return CG3D_ERR_ARG;
+                             const float *mean, const float *var, float eps, const float *gamma, const float *beta,
+                             int32_t act, float *Y, cg3d_stream_t stream) {
+    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual)) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean,
-                       invstd, gamma, beta, act, Y);
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean, var,
+                       eps, gamma, beta, act, Y);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
@@ -141,9 +177,10 @@ extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, const float *__restrict__ X,
                                                       const float *__restrict__ Yv, const int32_t *__restrict__ chunks,
                                                       int32_t c, const float *__restrict__ mean,
-                                                      const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                                      const double *__restrict__ sums, const float *__restrict__ group_n,
-                                                      int32_t G, int act, int use_batch, float *__restrict__ dX,
+                                                      const float *__restrict__ var, float eps,
+                                                      const float *__restrict__ gamma, const float *__restrict__ dbeta,
+                                                      const float *__restrict__ dgamma, const float *__restrict__ group_n,
+                                                      int act, int use_batch, float *__restrict__ dX,
                                                       float *__restrict__ dR) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
@@ -153,9 +190,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         const int q = (int)(t % cq);
         const int64_t off = (int64_t)r0 * cq + t;
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
-        const float4 is = reinterpret_cast<const float4 *>(invstd + (int64_t)g * c)[q];
+        const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
-        const double *s0 = sums + ((int64_t)g * c + q * 4), *s1 = sums + ((int64_t)(G + g) * c + q * 4);
+        const float4 sb = reinterpret_cast<const float4 *>(dbeta + (int64_t)g * c)[q];
+        const float4 sg = reinterpret_cast<const float4 *>(dgamma + (int64_t)g * c)[q];
+        const float4 is = make_float4(rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps));
         float4 d = reinterpret_cast<const float4 *>(dY)[off];
         float4 x = reinterpret_cast<const float4 *>(X)[off];
         if (act) {
@@ -164,22 +203,21 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         }
         if (dR) reinterpret_cast<float4 *>(dR)[off] = d;
         float4 o;
-        o.x = ga.x * is.x * (d.x - ((float)s0[0] + (x.x - mu.x) * is.x * (float)s1[0]) * inv_n);
-        o.y = ga.y * is.y * (d.y - ((float)s0[1] + (x.y - mu.y) * is.y * (float)s1[1]) * inv_n);
-        o.z = ga.z * is.z * (d.z - ((float)s0[2] + (x.z - mu.z) * is.z * (float)s1[2]) * inv_n);
-        o.w = ga.w * is.w * (d.w - ((float)s0[3] + (x.w - mu.w) * is.w * (float)s1[3]) * inv_n);
+        o.x = ga.x * is.x * (d.x - (sb.x + (x.x - mu.x) * is.x * sg.x) * inv_n);
+        o.y = ga.y * is.y * (d.y - (sb.y + (x.y - mu.y) * is.y * sg.y) * inv_n);
+        o.z = ga.z * is.z * (d.z - (sb.z + (x.z - mu.z) * is.z * sg.z) * inv_n);
+        o.w = ga.w * is.w * (d.w - (sb.w + (x.w - mu.w) * is.w * sg.w) * inv_n);
         reinterpret_cast<float4 *>(dX)[off] = o;
     }
 }
 extern "C" int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                                 int32_t c, const float *mean, const float *invstd, const float *gamma, const double *sums,
-                                 const float *group_n, int32_t G, int32_t act, int32_t use_batch_stats, float *dX,
-                                 float *dRes, cg3d_stream_t stream) {
-    if (nchunk < 0 || c < 4 || (c & 3) || (((uintptr_t)X | (uintptr_t)dY | (uintptr_t)Y | (uintptr_t)dX | (uintptr_t)dRes) & 15))
-        return CG3D_ERR_ARG;
+                                 int32_t c, const float *mean, const float *var, float eps, const float *gamma,
+                                 const float *dbeta, const float *dgamma, const float *group_n, int32_t act,
+                                 int32_t use_batch_stats, float *dX, float *dRes, cg3d_stream_t stream) {
+    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes)) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean,
-                       invstd, gamma, sums, group_n, G, act, use_batch_stats, dX, dRes);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var,
+                       eps, gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, dRes);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

@@ -22,7 +22,7 @@ import itertools
 import math
 
 import numpy as np
-from ctypes import c_int32, c_int64
+from ctypes import c_float, c_int32, c_int64
 from enum import Enum
 
 import torch
@@ -478,16 +478,19 @@ _chunk_cache = {}
 
 
 def _bn_chunks(bounds, device):
-    """int32 [nchunk,3] (group, first row, rows<=256) for row groups `bounds` (host tuple of G+1 offsets)."""
+    """(chunks int32 [nchunk,3] = (group, first row, rows<=256), nchunk, group_chunk_off int32 [G+1],
+    group_n float32 [G]) for row groups `bounds` (host tuple of G+1 offsets); cached on the device."""
     ck = (bounds, str(device))
     hit = _chunk_cache.get(ck)
     if hit is None:
-        rows = []
+        rows, gco = [], [0]
         for g in range(len(bounds) - 1):
             for r0 in range(bounds[g], bounds[g + 1], _BN_CHUNK):
                 rows.append((g, r0, min(_BN_CHUNK, bounds[g + 1] - r0)))
+            gco.append(len(rows))
         tab = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3).to(device)
-        hit = (tab, len(rows))
+        gn = torch.tensor([max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)], dtype=torch.float32)
+        hit = (tab, len(rows), torch.tensor(gco, dtype=torch.int32).to(device), gn.to(device))
         if len(_chunk_cache) > 512:
             _chunk_cache.clear()
         _chunk_cache[ck] = hit
@@ -495,8 +498,8 @@ def _bn_chunks(bounds, device):
 
 
 class FusedBNActFunction(torch.autograd.Function):
-    """y = act(BN_g(x) + residual) over row groups; statistics, running-stat inputs and all four kernels
-    are HIP (cg3d_bn_*).  Returns (y, batch_mean [G,C], batch_var_biased [G,C])."""
+    """y = act(BN_g(x) + residual) over row groups; statistics and all kernels are HIP (cg3d_bn_*).
+    Returns (y, batch_mean [G,C], batch_var_biased [G,C])."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps):
@@ -504,44 +507,42 @@ class FusedBNActFunction(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         G = len(bounds) - 1
-        chunks, nchunk = _bn_chunks(bounds, x.device)
+        chunks, nchunk, gco, group_n = _bn_chunks(bounds, x.device)
         gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
         res = residual.contiguous() if residual is not None else None
         lib.check(x, gamma, beta, res, chunks)
-        group_n = torch.tensor([max(bounds[g + 1] - bounds[g], 1) for g in range(G)], dtype=torch.float32).to(x.device)
         if use_batch:
-            sums = torch.empty((2, G, C), dtype=torch.float64, device=x.device)
-            lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(sums), lib.stream())
-            n = group_n.double().view(G, 1)
-            mean64 = sums[0] / n
-            var64 = (sums[1] / n - mean64 * mean64).clamp_(min=0.0)
-            mean, var = mean64.float(), var64.float()
+            ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
+            mean = torch.empty((G, C), dtype=torch.float32, device=x.device)
+            var = torch.empty((G, C), dtype=torch.float32, device=x.device)
+            lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G), c_int32(C), ptr(ws),
+                     ptr(mean), ptr(var), lib.stream())
         else:
             mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
-        invstd = torch.rsqrt(var + eps)
         y = torch.empty_like(x)
-        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean), ptr(invstd),
-                 ptr(gamma), ptr(beta), c_int32(act), ptr(y), lib.stream())
-        ctx.save_for_backward(x, y, mean, invstd, gamma, chunks, group_n)
-        ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None)
+        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean), ptr(var),
+                 c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), lib.stream())
+        ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n)
+        ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps))
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        x, y, mean, invstd, gamma, chunks, group_n = ctx.saved_tensors
-        nchunk, G, C, act, use_batch, has_res = ctx.meta
+        x, y, mean, var, gamma, chunks, gco, group_n = ctx.saved_tensors
+        nchunk, G, C, act, use_batch, has_res, eps = ctx.meta
         lib = _lib.get()
         dy = dy.contiguous()
-        sums = torch.empty((2, G, C), dtype=torch.float64, device=x.device)
-        lib.call("cg3d_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C),
-                 ptr(mean), ptr(invstd), c_int32(act), ptr(sums), lib.stream())
+        ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((G, C), dtype=torch.float32, device=x.device)
+        dgamma = torch.empty((G, C), dtype=torch.float32, device=x.device)
+        lib.call("cg3d_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G),
+                 c_int32(C), ptr(mean), ptr(var), c_float(eps), c_int32(act), ptr(ws), ptr(dbeta), ptr(dgamma), lib.stream())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean),
-                 ptr(invstd), ptr(gamma), ptr(sums), ptr(group_n), c_int32(G), c_int32(act), c_int32(1 if use_batch else 0),
-                 ptr(dx), ptr(dres), lib.stream())
-        dbeta, dgamma = sums[0].float(), sums[1].float()
+                 ptr(var), c_float(eps), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
+                 c_int32(1 if use_batch else 0), ptr(dx), ptr(dres), lib.stream())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 

@@ -192,26 +192,28 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  * per class branch in cagroup_head.py:117-127).  Rows are split into contiguous groups by the chunk
  * table `chunks` int32 [nchunk,3] = (group, first row, row count); a chunk never straddles two groups.
  *   act: 0 none, 1 ReLU, 2 ELU(alpha=1).
- * cg3d_bn_stats:  sums float64 [2,G,C] (zero-filled by the callee) <- per group/channel sum(x), sum(x^2)
- *                 accumulated in fp32 per thread and fp64 across threads.
- * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*invstd[g] + beta[g] + residual)      (residual may be NULL)
- *                 mean/invstd/gamma/beta float32 [G,C].
- * cg3d_bn_bwd_reduce: with dz = dy * act'(y):  sums float64 [2,G,C] <- sum(dz), sum(dz * xhat)
- * cg3d_bn_bwd_apply:  dx = gamma*invstd*(dz - (sum_dz + xhat*sum_dzxhat)/n[g])  (training statistics;
- *                 use_batch_stats == 0: dx = gamma*invstd*dz), dres (may be NULL) = dz
+ *   `group_chunk_off` int32 [G+1]: chunks of group g are [group_chunk_off[g], group_chunk_off[g+1]).
+ *   `ws` float32 [nchunk*2*C] scratch for per-chunk partial sums (no atomics; the per-group reduction over
+ *   chunks runs in fp64 inside the finalise kernel).
+ * cg3d_bn_stats:  mean, var (biased) float32 [G,C] of every group.
+ * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL)
+ * cg3d_bn_bwd_reduce: with dz = dy * act'(y), xhat = (x-mean)*rsqrt(var+eps):
+ *                 dbeta = sum(dz), dgamma = sum(dz * xhat)   float32 [G,C]
+ * cg3d_bn_bwd_apply:  dx = gamma*invstd*(dz - (dbeta + xhat*dgamma)/n[g])  (batch statistics;
+ *                 use_batch_stats == 0: dx = gamma*invstd*dz), dres (may be NULL) = dz;  group_n float32 [G]
  * ---------------------------------------------------------------------------------------- */
-int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, double *sums,
-                  cg3d_stream_t stream);
+int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off, int32_t G,
+                  int32_t c, float *ws, float *mean, float *var, cg3d_stream_t stream);
 int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
-                  const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t act,
+                  const float *mean, const float *var, float eps, const float *gamma, const float *beta, int32_t act,
                   float *Y, cg3d_stream_t stream);
 int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                       int32_t G, int32_t c, const float *mean, const float *invstd, int32_t act, double *sums,
-                       cg3d_stream_t stream);
+                       const int32_t *group_chunk_off, int32_t G, int32_t c, const float *mean, const float *var,
+                       float eps, int32_t act, float *ws, float *dbeta, float *dgamma, cg3d_stream_t stream);
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                      int32_t c, const float *mean, const float *invstd, const float *gamma, const double *sums,
-                      const float *group_n, int32_t G, int32_t act, int32_t use_batch_stats, float *dX, float *dRes,
-                      cg3d_stream_t stream);
+                      int32_t c, const float *mean, const float *var, float eps, const float *gamma,
+                      const float *dbeta, const float *dgamma, const float *group_n, int32_t act,
+                      int32_t use_batch_stats, float *dX, float *dRes, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * iou3d_nms (boxes are float32 [n,7] = x,y,z,dx,dy,dz,heading, contiguous).

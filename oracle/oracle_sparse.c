@@ -303,49 +303,8 @@ static inline float os_act_bwd(float y, int act) {
     if (act == 2) return y > 0.f ? 1.f : y + 1.f;
     return 1.f;
 }
-int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, double *sums,
-                  cg3d_stream_t s) {
-    (void)s;
-    const size_t ns = 2 * (size_t)G * c;
-    memset(sums, 0, sizeof(double) * ns);
-#pragma omp parallel
-    {
-        double *loc = (double *)calloc(ns, sizeof(double));
-#pragma omp for schedule(static)
-        for (int64_t k = 0; k < nchunk; k++) {
-            int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
-            for (int32_t r = r0; r < r0 + nr; r++)
-                for (int32_t a = 0; a < c; a++) {
-                    double v = X[(int64_t)r * c + a];
-                    loc[(int64_t)g * c + a] += v;
-                    loc[(int64_t)(G + g) * c + a] += v * v;
-                }
-        }
-#pragma omp critical
-        for (size_t i = 0; i < ns; i++) sums[i] += loc[i];
-        free(loc);
-    }
-    return CG3D_OK;
-}
-int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
-                  const float *invstd, const float *gamma, const float *beta, int32_t act, float *Y, cg3d_stream_t s) {
-    (void)s;
-#pragma omp parallel for schedule(static)
-    for (int64_t k = 0; k < nchunk; k++) {
-        int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
-        for (int32_t r = r0; r < r0 + nr; r++)
-            for (int32_t a = 0; a < c; a++) {
-                int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
-                float y = (X[o] - mean[p]) * invstd[p] * gamma[p] + beta[p];
-                if (R) y += R[o];
-                Y[o] = os_act_fwd(y, act);
-            }
-    }
-    return CG3D_OK;
-}
-int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G,
-                       int32_t c, const float *mean, const float *invstd, int32_t act, double *sums, cg3d_stream_t s) {
-    (void)s;
+static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                       int32_t G, int32_t c, const float *mean, const float *var, float eps, int32_t act, double *sums) {
     const size_t ns = 2 * (size_t)G * c;
     memset(sums, 0, sizeof(double) * ns);
 #pragma omp parallel
@@ -357,20 +316,71 @@ int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const in
             for (int32_t r = r0; r < r0 + nr; r++)
                 for (int32_t a = 0; a < c; a++) {
                     int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
-                    float d = dY[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
-                    loc[p] += d;
-                    loc[(int64_t)(G + g) * c + a] += (double)(d * (X[o] - mean[p]) * invstd[p]);
+                    if (!bwd) {
+                        double v = A[o];
+                        loc[p] += v;
+                        loc[(int64_t)(G + g) * c + a] += v * v;
+                    } else {
+                        float d = A[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
+                        loc[p] += d;
+                        loc[(int64_t)(G + g) * c + a] += (double)(d * (X[o] - mean[p]) * (1.0f / sqrtf(var[p] + eps)));
+                    }
                 }
         }
 #pragma omp critical
         for (size_t i = 0; i < ns; i++) sums[i] += loc[i];
         free(loc);
     }
+}
+int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *gco, int32_t G, int32_t c,
+                  float *ws, float *mean, float *var, cg3d_stream_t s) {
+    (void)s; (void)ws;
+    double *sums = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
+    os_bn_sums(0, X, NULL, NULL, chunks, nchunk, G, c, NULL, NULL, 0.f, 0, sums);
+    for (int32_t g = 0; g < G; g++) {
+        double n = 0;
+        for (int32_t k = gco[g]; k < gco[g + 1]; k++) n += chunks[k * 3 + 2];
+        if (n < 1) n = 1;
+        for (int32_t a = 0; a < c; a++) {
+            double m = sums[(int64_t)g * c + a] / n, v = sums[(int64_t)(G + g) * c + a] / n - m * m;
+            mean[(int64_t)g * c + a] = (float)m;
+            var[(int64_t)g * c + a] = (float)(v > 0 ? v : 0);
+        }
+    }
+    free(sums);
+    return CG3D_OK;
+}
+int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
+                  const float *var, float eps, const float *gamma, const float *beta, int32_t act, float *Y,
+                  cg3d_stream_t s) {
+    (void)s;
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nchunk; k++) {
+        int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
+        for (int32_t r = r0; r < r0 + nr; r++)
+            for (int32_t a = 0; a < c; a++) {
+                int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
+                float y = (X[o] - mean[p]) * (1.0f / sqrtf(var[p] + eps)) * gamma[p] + beta[p];
+                if (R) y += R[o];
+                Y[o] = os_act_fwd(y, act);
+            }
+    }
+    return CG3D_OK;
+}
+int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                       const int32_t *gco, int32_t G, int32_t c, const float *mean, const float *var, float eps,
+                       int32_t act, float *ws, float *dbeta, float *dgamma, cg3d_stream_t s) {
+    (void)s; (void)ws; (void)gco;
+    double *sums = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
+    os_bn_sums(1, dY, X, Y, chunks, nchunk, G, c, mean, var, eps, act, sums);
+    for (int64_t i = 0; i < (int64_t)G * c; i++) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[(int64_t)G * c + i]; }
+    free(sums);
     return CG3D_OK;
 }
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t c,
-                      const float *mean, const float *invstd, const float *gamma, const double *sums, const float *group_n,
-                      int32_t G, int32_t act, int32_t use_batch, float *dX, float *dR, cg3d_stream_t s) {
+                      const float *mean, const float *var, float eps, const float *gamma, const float *dbeta,
+                      const float *dgamma, const float *group_n, int32_t act, int32_t use_batch, float *dX, float *dR,
+                      cg3d_stream_t s) {
     (void)s;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < nchunk; k++) {
@@ -381,8 +391,9 @@ int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int
                 int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
                 float d = dY[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
                 if (dR) dR[o] = d;
-                float xh = (X[o] - mean[p]) * invstd[p];
-                dX[o] = gamma[p] * invstd[p] * (d - ((float)sums[p] + xh * (float)sums[(int64_t)(G + g) * c + a]) * inv_n);
+                float is = 1.0f / sqrtf(var[p] + eps);
+                float xh = (X[o] - mean[p]) * is;
+                dX[o] = gamma[p] * is * (d - (dbeta[p] + xh * dgamma[p]) * inv_n);
             }
     }
     return CG3D_OK;
