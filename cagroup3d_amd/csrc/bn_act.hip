@@ -78,32 +78,42 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
     }
 }
 
-// one thread per (group, channel): fp64 reduction over the group's chunks.
-// MODE 0: out0 = mean, out1 = biased variance (needs group row counts from the chunk table)
+// fp64 reduction over the group's chunks: a 256-thread block owns 16 channels of one group; its 16
+// chunk-lanes stride the group's chunks, then combine through LDS.
+// MODE 0: out0 = mean, out1 = biased variance (row count from the chunk table)
 // MODE 1: out0 = sum0 (dbeta), out1 = sum1 (dgamma)
 template <int MODE>
-__global__ void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
-                              const int32_t *__restrict__ gco, int32_t G, int32_t c, float *__restrict__ out0,
-                              float *__restrict__ out1) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G * c) return;
-    const int g = t / c, a = t % c;
+__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
+                                                     const int32_t *__restrict__ gco, int32_t G, int32_t c,
+                                                     float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ double r0[256], r1[256];
+    __shared__ long long rr[256];
+    const int cblocks = (c + 15) / 16;
+    const int g = blockIdx.x / cblocks, a = (blockIdx.x % cblocks) * 16 + (threadIdx.x & 15), lanek = threadIdx.x >> 4;
     double s0 = 0.0, s1 = 0.0;
-    int64_t rows = 0;
-    for (int k = gco[g]; k < gco[g + 1]; k++) {
-        s0 += (double)ws[(int64_t)k * 2 * c + a];
-        s1 += (double)ws[(int64_t)k * 2 * c + c + a];
-        if (MODE == 0) rows += chunks[k * 3 + 2];
+    long long rows = 0;
+    if (a < c) {
+        for (int k = gco[g] + lanek; k < gco[g + 1]; k += 16) {
+            s0 += (double)ws[(int64_t)k * 2 * c + a];
+            s1 += (double)ws[(int64_t)k * 2 * c + c + a];
+            if (MODE == 0) rows += chunks[k * 3 + 2];
+        }
     }
-    if (MODE == 0) {
-        const double n = rows > 0 ? (double)rows : 1.0;
-        const double m = s0 / n;
-        double v = s1 / n - m * m;
-        out0[t] = (float)m;
-        out1[t] = (float)(v > 0.0 ? v : 0.0);
-    } else {
-        out0[t] = (float)s0;
-        out1[t] = (float)s1;
+    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; rr[threadIdx.x] = rows;
+    __syncthreads();
+    if (lanek == 0 && a < c) {
+        for (int j = 1; j < 16; j++) { s0 += r0[j * 16 + threadIdx.x]; s1 += r1[j * 16 + threadIdx.x]; rows += rr[j * 16 + threadIdx.x]; }
+        const int64_t t = (int64_t)g * c + a;
+        if (MODE == 0) {
+            const double n = rows > 0 ? (double)rows : 1.0;
+            const double m = s0 / n;
+            double v = s1 / n - m * m;
+            out0[t] = (float)m;
+            out1[t] = (float)(v > 0.0 ? v : 0.0);
+        } else {
+            out0[t] = (float)s0;
+            out1[t] = (float)s1;
+        }
     }
 }
 
@@ -116,7 +126,7 @@ extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchu
     if (nchunk > 0)
         hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, c,
                            nullptr, nullptr, 0.f, 0, ws);
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)cg3d_divup((int64_t)G * c, 256)), dim3(256), 0, s, ws, chunks,
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
                        group_chunk_off, G, c, mean, var);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
@@ -130,7 +140,7 @@ extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *
     if (nchunk > 0)
         hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
                            act, ws);
-    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)cg3d_divup((int64_t)G * c, 256)), dim3(256), 0, s, ws, chunks,
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
                        group_chunk_off, G, c, dbeta, dgamma);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;

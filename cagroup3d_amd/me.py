@@ -478,19 +478,25 @@ _chunk_cache = {}
 
 
 def _bn_chunks(bounds, device):
-    """(chunks int32 [nchunk,3] = (group, first row, rows<=256), nchunk, group_chunk_off int32 [G+1],
-    group_n float32 [G]) for row groups `bounds` (host tuple of G+1 offsets); cached on the device."""
+    """Chunk tables for row groups `bounds` (host tuple of G+1 offsets), cached on the device:
+    reduce table (<=1024 chunks per group: few, long chunks for the statistics kernels + their group offsets),
+    apply table (128-row chunks: many workgroups for the streaming kernels), group_n float32 [G]."""
     ck = (bounds, str(device))
     hit = _chunk_cache.get(ck)
     if hit is None:
-        rows, gco = [], [0]
-        for g in range(len(bounds) - 1):
-            for r0 in range(bounds[g], bounds[g + 1], _BN_CHUNK):
-                rows.append((g, r0, min(_BN_CHUNK, bounds[g + 1] - r0)))
-            gco.append(len(rows))
-        tab = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3).to(device)
+        def table(step_of):
+            rows, gco = [], [0]
+            for g in range(len(bounds) - 1):
+                step = step_of(bounds[g + 1] - bounds[g])
+                for r0 in range(bounds[g], bounds[g + 1], step):
+                    rows.append((g, r0, min(step, bounds[g + 1] - r0)))
+                gco.append(len(rows))
+            tab = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3).to(device)
+            return tab, len(rows), torch.tensor(gco, dtype=torch.int32).to(device)
+        red, nred, gco = table(lambda ng: max(128, -(-ng // 1024)))
+        app, napp, _ = table(lambda ng: 128)
         gn = torch.tensor([max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)], dtype=torch.float32)
-        hit = (tab, len(rows), torch.tensor(gco, dtype=torch.int32).to(device), gn.to(device))
+        hit = (red, nred, gco, gn.to(device), app, napp)
         if len(_chunk_cache) > 512:
             _chunk_cache.clear()
         _chunk_cache[ck] = hit
@@ -507,7 +513,7 @@ class FusedBNActFunction(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         G = len(bounds) - 1
-        chunks, nchunk, gco, group_n = _bn_chunks(bounds, x.device)
+        chunks, nchunk, gco, group_n, achunks, nachunk = _bn_chunks(bounds, x.device)
         gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
         res = residual.contiguous() if residual is not None else None
         lib.check(x, gamma, beta, res, chunks)
@@ -520,17 +526,17 @@ class FusedBNActFunction(torch.autograd.Function):
         else:
             mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
         y = torch.empty_like(x)
-        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean), ptr(var),
+        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean), ptr(var),
                  c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), lib.stream())
-        ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n)
-        ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps))
+        ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n, achunks)
+        ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps), nachunk)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        x, y, mean, var, gamma, chunks, gco, group_n = ctx.saved_tensors
-        nchunk, G, C, act, use_batch, has_res, eps = ctx.meta
+        x, y, mean, var, gamma, chunks, gco, group_n, achunks = ctx.saved_tensors
+        nchunk, G, C, act, use_batch, has_res, eps, nachunk = ctx.meta
         lib = _lib.get()
         dy = dy.contiguous()
         ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
@@ -540,7 +546,7 @@ class FusedBNActFunction(torch.autograd.Function):
                  c_int32(C), ptr(mean), ptr(var), c_float(eps), c_int32(act), ptr(ws), ptr(dbeta), ptr(dgamma), lib.stream())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(C), ptr(mean),
+        lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean),
                  ptr(var), c_float(eps), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
                  c_int32(1 if use_batch else 0), ptr(dx), ptr(dres), lib.stream())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
