@@ -32,6 +32,7 @@ from cagroup3d_amd import _lib, build_model, me  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 
 def parse():
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--config", default="S50k")
     ap.add_argument("--dataset", default="scannet")
     ap.add_argument("--natural", action="store_true", help="untrained-net selection instead of forced GT selection")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="MFMA operand type of the sparse-conv forward/data-gradient (BASELINE.json configs[1]: bf16 backbone); "
+                         "accumulation, storage and the weight gradient are fp32 in both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="S50k:1", help="config:scenes timed on the CPU oracle")
     return ap.parse_args()
@@ -83,6 +87,7 @@ def cpu_baseline(args, forced):
     nsc = int(nsc)
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    prec, me.PRECISION = me.PRECISION, 0      # the CPU port computes in fp32 (bf16 emulation would only slow it down)
     with _lib.use_library(_lib.bind(oracle_so)):
         model, cfg = make_model(args.dataset, forced, "cpu")
         model.train()
@@ -91,6 +96,7 @@ def cpu_baseline(args, forced):
         t0 = time.time()
         train_step(model, opt, batch, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
         dt = time.time() - t0
+    me.PRECISION = prec
     return {"value": nsc / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
             "sample": "%d scene(s) of %s, one fwd+bwd+AdamW step of the full detector on the CPU oracle "
                       "(OpenMP + torch CPU threads), %.1f s" % (nsc, cfgname, dt)}
@@ -107,6 +113,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl")   # RCCL on ROCm
     forced = not args.natural
+    me.PRECISION = 1 if args.precision == "bf16" else 0
 
     model, cfg = make_model(args.dataset, forced, dev)
     model.train()
@@ -143,22 +150,32 @@ def main():
 
     if rank == 0:
         prof = me.KernelProfile.summary()
-        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
-        roof = {"kernel": "k_spconv_pairs (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)",
-                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
-                "algorithmic_gbytes_per_s": prof["bytes"] / (prof["ms"] * 1e-3) / 1e9 if prof["ms"] > 0 else 0.0,
-                "kernel_time_share": prof["ms"] * 1e-3 / dt}
+        secs = prof["ms"] * 1e-3
+        tf = prof["flops"] / secs / 1e12 if secs > 0 else 0.0
+        gbs = prof["bytes"] / secs / 1e9 if secs > 0 else 0.0
+        kname = "k_spconv_pairs_%s (sparse conv fwd + dgrad: gather -> %s MFMA -> atomic scatter)" % (
+            ("bf16", "bf16") if me.PRECISION == 1 else ("lds", "fp32"))
+        if me.PRECISION == 1:
+            # bf16 MFMA runs at 16x the fp32 rate: the kernel is bound by the row gather + atomic row scatter
+            roof = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "achieved_tflops": tf,
+                    "frac_of_bf16_mfma_peak": tf / BF16_MFMA_PEAK_TFLOPS}
+        else:
+            roof = {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_gbytes_per_s": gbs}
+        roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
+                    kernel_time_share=secs / dt)
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if me.PRECISION == 1 else "f32", "data": "synthetic",
                "config": {"workload": "ScanNetV2 CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
                    args.batch, args.config, "forced GT selection + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
                           "voxel_size_m": 0.02, "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
+                          "precision": ("bf16 MFMA operands in conv fwd/dgrad, fp32 accumulate/storage/wgrad"
+                                        if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
                           "last_loss": tb.get("loss_all")},
                "roofline": roof}
         if not args.no_cpu_baseline and world == 1:

@@ -352,6 +352,138 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_lds(const float *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand path (precision == 1): v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 in HBM.
+// Activations are rounded to bf16 (RNE) while they are staged into LDS; the weights arrive already
+// rounded and transposed to [slot][cout][cin] (cg3d_spconv_prep_weights_bf16) so that both MFMA
+// operands are 16-byte ds_read_b128 fragments (8 consecutive k per lane).  At 16x the fp32 MFMA rate
+// the kernel is bound by the row gather and the atomic scatter, not by the matrix pipe.
+// ---------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ static inline uint32_t f2bf(float f) {        // round-to-nearest-even, as the oracle's os_bf16
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ static inline uint2 pack4bf(float4 v) {
+    return make_uint2(f2bf(v.x) | (f2bf(v.y) << 16), f2bf(v.z) | (f2bf(v.w) << 16));
+}
+
+__global__ void k_prep_weights_bf16(const float *__restrict__ W, uint16_t *__restrict__ Wb, int64_t slots, int32_t cin,
+                                    int32_t cout) {
+    // Wb[s][co][ci] = bf16(W[s][ci][co]); thread per output element, reads strided (weights are small)
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)cin * cout;
+    if (t >= slots * per) return;
+    const int64_t s = t / per;
+    const int co = (int)((t % per) / cin), ci = (int)(t % cin);
+    Wb[t] = (uint16_t)f2bf(W[s * per + (int64_t)ci * cout + co]);
+}
+extern "C" int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout,
+                                             cg3d_stream_t stream) {
+    if (slots < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    const int64_t total = slots * cin * cout;
+    if (total == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_prep_weights_bf16, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream), W, Wb,
+                       slots, cin, cout);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__restrict__ X, const uint16_t *__restrict__ Wb,
+                                                              const int32_t *__restrict__ pin,
+                                                              const int32_t *__restrict__ pout,
+                                                              const int32_t *__restrict__ seg, float *__restrict__ Y,
+                                                              int32_t cin, int32_t cout) {
+    constexpr int CT = NT * 32;
+    constexpr int KC = 64;                 // input channels per chunk
+    constexpr int LP = KC + 8;             // padded LDS row (bf16 elements): 144 B, conflict-free b128 reads
+    __shared__ uint16_t As[128 * LP];
+    __shared__ uint16_t Ws[CT * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int n0 = blockIdx.y * CT;
+    const int local = wave * 32 + r;
+    const bool valid = local < count;
+    const int32_t irow = valid ? pin[start + local] : -1;
+    const int32_t orow = valid ? pout[start + local] : -1;
+    const bool wave_active = wave * 32 < count;
+    const uint16_t *wk = Wb + (int64_t)k * cin * cout;     // [cout][cin]
+    uint16_t *Aw = &As[wave * 32 * LP];
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    int32_t grow[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) grow[i] = __shfl(irow, 4 * i + (lane >> 4));
+    const int gcol = (lane & 15) * 4;
+
+    float4 areg[8];
+    uint4 wreg[NT];
+    auto issue_loads = [&](int32_t c0) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) {                  // W tile: CT cols x 64 ch bf16 = CT*8 pieces of 16 B
+            const int idx = tid + i * 256;
+            const int col = idx >> 3, piece = idx & 7;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n0 + col < cout && c0 + piece * 8 < cin)
+                v = *reinterpret_cast<const uint4 *>(wk + (int64_t)(n0 + col) * cin + c0 + piece * 8);
+            wreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow[i] >= 0 && c0 + gcol < cin)
+                v = *reinterpret_cast<const float4 *>(X + (int64_t)grow[i] * cin + c0 + gcol);
+            areg[i] = v;
+        }
+    };
+    issue_loads(0);
+    for (int32_t c0 = 0; c0 < cin; c0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<uint4 *>(&Ws[(idx >> 3) * LP + (idx & 7) * 8]) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(areg[i]);
+        __syncthreads();
+        if (c0 + KC < cin) issue_loads(c0 + KC);
+        if (wave_active) {
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(nt * 32 + r) * LP + ks * 16 + kg * 8]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int rowl = (e & 3) + 8 * (e >> 2) + 4 * kg;
+        const int32_t orow_e = __shfl(orow, rowl);
+        if (orow_e < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int col = n0 + nt * 32 + r;
+            if (col < cout) unsafeAtomicAdd(&Y[(int64_t)orow_e * cout + col], acc[nt][e]);
+        }
+    }
+}
+
 // Generic path (any cin / alignment; also the 3-channel input layer with KH = 2): per-lane fragment
 // gather straight to registers, W tile through LDS.
 template <int NT, int KH, bool VEC4>
@@ -435,15 +567,26 @@ extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32
                                      int32_t cin, int32_t cout, int32_t precision, int32_t accumulate,
                                      cg3d_stream_t stream) {
     if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0) return CG3D_ERR_ARG;
+    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (n_out == 0) return CG3D_OK;
     const int64_t total = n_out * cout;
+    if (precision == 1 && (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))) return CG3D_ERR_ARG;
     if (!accumulate) {
         if (bias) hipLaunchKernelGGL(k_init_rows, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, Y, bias, total, cout);
         else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     }
     if (nseg == 0) return CG3D_OK;
+    if (precision == 1) {     // W is the prepared bf16 [slot][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
+        const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
+#define LAUNCH_BF(NT)                                                                                              \
+    hipLaunchKernelGGL((k_spconv_pairs_bf16<NT>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, \
+                       X, Wb, pair_in, pair_out, seg, Y, cin, cout)
+        if (cout > 64) LAUNCH_BF(4); else if (cout > 32) LAUNCH_BF(2); else LAUNCH_BF(1);
+#undef LAUNCH_BF
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     const bool aligned = (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
     const char *dbg = getenv("CG3D_DBG_STORE");
     const int d = dbg ? atoi(dbg) : 0;
@@ -567,6 +710,97 @@ __global__ __launch_bounds__(256) void k_spconv_pairs_wgrad(const float *__restr
     }
 }
 
+// Wide-channel weight gradient (cin, cout >= 128): one workgroup owns a 128 x 128 (ci x co) tile; its four
+// waves are the four 64 x 64 quadrants and all consume the SAME pairs, which are staged once per workgroup
+// in LDS (32 pairs x 128 channels of X and of dY per stage, coalesced 512-byte row reads, register
+// prefetch of the next stage).  The 64 x 64 kernel above re-reads every gathered row once per tile of the
+// other operand: that traffic (2 KB per pair on a 128 x 128 layer), not the MFMA pipe, bounded it.
+#define WT_S 32            // pairs per stage
+#define WT_LD 132          // padded LDS row (floats)
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_t128(const float *__restrict__ X,
+                                                                    const float *__restrict__ dY,
+                                                                    const int32_t *__restrict__ pin,
+                                                                    const int32_t *__restrict__ pout,
+                                                                    const int32_t *__restrict__ seg,
+                                                                    float *__restrict__ dW, int32_t cin, int32_t cout,
+                                                                    int32_t co_tiles) {
+    __shared__ float Xs[2][WT_S * WT_LD];
+    __shared__ float Ds[2][WT_S * WT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int ci0 = (blockIdx.y / co_tiles) * 128, co0 = (blockIdx.y % co_tiles) * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // staging: thread owns float4 #(tid + 256*i) of the 32 x 128 tile: pair = idx >> 5, column = (idx & 31) * 4
+    const int c4 = (tid & 31) * 4;
+    const bool xin = ci0 + c4 < cin, din = co0 + c4 < cout;       // cin, cout are multiples of 4 here
+    float4 xr[4], dr[4];
+    auto issue = [&](int32_t p0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pr = (tid >> 5) + 8 * i;
+            const int32_t p = p0 + pr;
+            // clamped, unconditional addresses (masked below) keep the loads countable for vmcnt
+            const int32_t pp = p < count ? p : count - 1;
+            const int32_t ii = pin[start + pp], oo = pout[start + pp];
+            float4 a = *reinterpret_cast<const float4 *>(X + (int64_t)ii * cin + (xin ? ci0 + c4 : 0));
+            float4 b = *reinterpret_cast<const float4 *>(dY + (int64_t)oo * cout + (din ? co0 + c4 : 0));
+            const bool ok = p < count;
+            xr[i] = (ok && xin) ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+            dr[i] = (ok && din) ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pr = (tid >> 5) + 8 * i;
+            *reinterpret_cast<float4 *>(&Xs[buf][pr * WT_LD + c4]) = xr[i];
+            *reinterpret_cast<float4 *>(&Ds[buf][pr * WT_LD + c4]) = dr[i];
+        }
+    };
+    const int nstage = (count + WT_S - 1) / WT_S;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int st = 0; st < nstage; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) issue((st + 1) * WT_S);            // in flight during the MFMAs
+        const float *xa = &Xs[buf][h * WT_LD + wi * 64 + r];
+        const float *db = &Ds[buf][h * WT_LD + wj * 64 + r];
+#pragma unroll
+        for (int t = 0; t < WT_S / 2; t++) {
+            const float a0 = xa[2 * t * WT_LD], a1 = xa[2 * t * WT_LD + 32];
+            const float b0 = db[2 * t * WT_LD], b1 = db[2 * t * WT_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (st + 1 < nstage) commit(buf ^ 1);                   // the other buffer was last read two stages ago
+        __syncthreads();
+    }
+    float *dst = dW + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ci = ci0 + wi * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = co0 + wj * 64 + j * 32 + r;
+                if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+            }
+}
+
 extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in,
                                        const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
                                        int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
@@ -575,6 +809,14 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (nseg == 0) return CG3D_OK;
+    if (cin >= 128 && cout >= 128 && cin % 4 == 0 && cout % 4 == 0 && !(((uintptr_t)X | (uintptr_t)dY) & 15) &&
+        !getenv("CG3D_WGRAD64")) {
+        const int32_t ct = (cin + 127) / 128, ot = (cout + 127) / 128;
+        hipLaunchKernelGGL(k_spconv_pairs_wgrad_t128, dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, X, dY,
+                           pair_in, pair_out, seg, dW, cin, cout, ot);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     const int32_t ci_tiles = (cin + 63) / 64, co_tiles = (cout + 63) / 64;
     if ((int64_t)ci_tiles * co_tiles > 65535) return CG3D_ERR_ARG;
     hipLaunchKernelGGL(k_spconv_pairs_wgrad, dim3((unsigned)nseg, (unsigned)(ci_tiles * co_tiles)), dim3(256), 0, s, X,

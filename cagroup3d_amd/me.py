@@ -248,6 +248,16 @@ def _conv_fwd_raw(x, w3, nbr, bias, n_out):
 
 FWD_SEG = 128  # pairs per workgroup of cg3d_spconv_pairs_fwd
 
+# Operand precision of the sparse convolutions' forward / data-gradient MFMAs:
+#   0 = fp32 operands (v_mfma_f32_32x32x2_f32, exact products) -- the parity configuration;
+#   1 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[1] "bf16 backbone".
+# Features, weights, gradients and the weight-gradient kernel stay fp32 in both modes.
+PRECISION = 0
+
+
+def _use_bf16(cin):
+    return PRECISION == 1 and cin % 8 == 0 and cin >= 16
+
 
 def _seg_len_fwd():
     return FWD_SEG if _lib.get().is_device else (1 << 30)
@@ -271,7 +281,8 @@ class KernelProfile:
                 "bytes": float(sum(r[3] for r in cls.records))}
 
 
-def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0):
+def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=None):
+    """Y[pout] += X[pin] @ w3[slot].  `w_bf16_t` (optional): the weights already as bf16 [slots, cout, cin]."""
     lib = _lib.get()
     K, cin, cout = w3.shape
     lib.check(x, w3, pin, pout, seg, bias)
@@ -280,26 +291,36 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0):
         y = torch.zeros((n_out, cout), dtype=torch.float32, device=x.device)
     else:
         y = bias.view(1, -1).expand(n_out, cout).contiguous()
+    prec = 1 if _use_bf16(cin) else 0
+    wptr = w3
+    if prec == 1:
+        if w_bf16_t is None:
+            w_bf16_t = torch.empty((K, cout, cin), dtype=torch.int16, device=x.device)
+            lib.call("cg3d_spconv_prep_weights_bf16", ptr(w3), ptr(w_bf16_t), c_int64(K), c_int32(cin), c_int32(cout),
+                     lib.stream())
+        wptr = w_bf16_t
     prof = KernelProfile.enabled and lib.is_device
     if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(w3), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(None), ptr(y),
-             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(0), c_int32(1), lib.stream())
+    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(wptr), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(None), ptr(y),
+             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(prec), c_int32(1), lib.stream())
     if prof:
         ev1.record()
         # algorithmic work of one launch: 2*P*cin*cout flops; bytes = gathered rows + atomically added rows
         # (read-modify-write) + the weights once + the two pair lists
+        wb = 2.0 if prec == 1 else 4.0
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout + K * cin * cout) + 8.0 * n_pairs,
-                                      ("pairs", K, cin, cout, n_pairs, n_out, nseg)))
+                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout) + wb * K * cin * cout + 8.0 * n_pairs,
+                                      ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg)))
     return y
 
 
 def _wgrad_seg_len(P, cin, cout):
     if not _lib.get().is_device:
         return 1 << 30
-    tiles = ((cin + 63) // 64) * ((cout + 63) // 64)
+    t = 128 if (cin >= 128 and cout >= 128) else 64          # tile edge of the kernel the library will pick
+    tiles = ((cin + t - 1) // t) * ((cout + t - 1) // t)
     per = -(-P * tiles // 2048)             # aim at >= 2048 workgroups
     return max(256, -(-per // 256) * 256)
 
@@ -329,9 +350,15 @@ class SparseConvFunction(torch.autograd.Function):
         pin, pout, _, P = kmap.pairs(rb)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = w3.transpose(1, 2).contiguous()
             seg, nseg = kmap.segments(_seg_len_fwd(), rb)
-            dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
+            if _use_bf16(w3.shape[2]):
+                # the swapped problem's bf16 [slots, cout'=cin, cin'=cout] weights are W itself, cast
+                wt = w3.new_empty((w3.shape[0], w3.shape[2], w3.shape[1]))  # shape carrier only
+                dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
+                                 w_bf16_t=w3.to(torch.bfloat16).view(torch.int16))
+            else:
+                wt = w3.transpose(1, 2).contiguous()
+                dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
             KK, cin, cout = w3.shape
             dw = torch.empty_like(w3)

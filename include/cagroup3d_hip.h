@@ -123,7 +123,12 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
  *   The data gradient is the same call with the two pair lists swapped and W^T.
  * cg3d_spconv_pairs_wgrad: dW[k] = sum_p X[pair_in[p]]^T (outer) dY[pair_out[p]] over the
  *   segments (any count); dW [K,cin,cout] is overwritten.
+ *   precision == 1 (bf16 operands, fp32 accumulate): X stays float32 (rounded to bf16 on the fly), and `W`
+ *   must point to the buffer written by cg3d_spconv_prep_weights_bf16: uint16 [slots, cout, cin] =
+ *   bf16(W[slot, ci, co]) transposed per slot; cin % 8 == 0.
  * ---------------------------------------------------------------------------------------- */
+int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout,
+                                  cg3d_stream_t stream);
 int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
 int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
                      void *ws, int32_t *pair_off, cg3d_stream_t stream);

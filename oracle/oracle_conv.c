@@ -95,6 +95,19 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
 }
 
 
+int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout, cg3d_stream_t s) {
+    (void)s;
+    for (int64_t t = 0; t < slots; t++)
+        for (int32_t co = 0; co < cout; co++)
+            for (int32_t ci = 0; ci < cin; ci++) {
+                float v = os_bf16(W[(t * cin + ci) * cout + co]);
+                uint32_t u; memcpy(&u, &v, 4);
+                Wb[(t * cout + co) * cin + ci] = (uint16_t)(u >> 16);
+            }
+    return CG3D_OK;
+}
+static inline float os_bf16_bits(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
 /* Pair-list form (ME's in/out kernel maps): per offset k, Y[out] += X[in] W[k]. */
 int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, const int32_t *pout, const int32_t *seg,
                           int64_t nseg, const float *bias, float *Y, int64_t n_out, int32_t cin, int32_t cout,
@@ -109,15 +122,23 @@ int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, co
     for (int64_t g = 0; g < nseg; g++) {
         int32_t k = seg[g * 3], start = seg[g * 3 + 1], count = seg[g * 3 + 2];
         const float *w = W + (int64_t)k * cin * cout;
+        const uint16_t *wb = (const uint16_t *)W + (int64_t)k * cin * cout;   /* precision 1: prepared [cout][cin] bf16 */
 #pragma omp parallel for schedule(static)
         for (int32_t p = start; p < start + count; p++) {
             const float *x = X + (int64_t)pin[p] * cin;
             float *y = Y + (int64_t)pout[p] * cout;
-            for (int32_t a = 0; a < cin; a++) {
-                float xa = precision == 1 ? os_bf16(x[a]) : x[a];
-                const float *wr = w + (int64_t)a * cout;
-                if (precision == 1) { for (int32_t c = 0; c < cout; c++) y[c] += xa * os_bf16(wr[c]); }
-                else { for (int32_t c = 0; c < cout; c++) y[c] += xa * wr[c]; }
+            if (precision == 1) {
+                for (int32_t c = 0; c < cout; c++) {
+                    float acc = 0.f;
+                    for (int32_t a = 0; a < cin; a++) acc += os_bf16(x[a]) * os_bf16_bits(wb[(int64_t)c * cin + a]);
+                    y[c] += acc;
+                }
+            } else {
+                for (int32_t a = 0; a < cin; a++) {
+                    float xa = x[a];
+                    const float *wr = w + (int64_t)a * cout;
+                    for (int32_t c = 0; c < cout; c++) y[c] += xa * wr[c];
+                }
             }
         }
     }

@@ -142,6 +142,30 @@ def test_spconv_fwd_bwd_matches_oracle(oracle, hip, cin, cout, ks, stride, n, fo
             raise AssertionError("%s mismatch (cin=%d cout=%d ks=%d): %s" % (nm, cin, cout, ks, e))
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride,n", [(64, 64, 3, 1, 9000), (64, 128, 3, 2, 6000), (128, 128, 3, 1, 4000),
+                                                  (256, 256, 3, 1, 1500), (128, 64, 3, 1, 3000), (64, 192, 3, 1, 1000), (16, 24, 3, 1, 130)])
+def test_spconv_bf16_operands_match_oracle_emulation(oracle, hip, cin, cout, ks, stride, n):
+    """precision 1: bf16 (RNE) operands, fp32 accumulate -- against the oracle's bit-level emulation of the
+    same rounding, so only the fp32 summation order differs."""
+    torch.manual_seed(cin + cout)
+    coords = surface_coords(n, batch=2, extent=max(8, int(n ** 0.5) // 3), seed=n + ks)
+    feats = torch.randn(coords.shape[0], cin)
+    w = torch.randn(ks ** 3, cin, cout) / (cin * 27) ** 0.5
+    dy = torch.randn(coords.shape[0], cout)
+    me.PRECISION = 1
+    try:
+        ref, out = both(oracle, hip, _conv_case, coords, feats, w, None, dy, ks, stride)
+    finally:
+        me.PRECISION = 0
+    ref32, _ = both(oracle, None, _conv_case, coords, feats, w, None, dy, ks, stride) if hip is None else (ref, None)
+    for nm, r, o in zip(["y", "dx", "dw"], ref, out):
+        close(r, o, float(r.abs().max()))
+    # and the bf16 result is a bf16-accurate approximation of the fp32 one
+    with _lib.use_library(oracle):
+        full = _conv_case(coords, feats, w, None, dy, ks, stride)
+    assert (ref[0] - full[0]).abs().max() <= 2e-2 * float(full[0].abs().max())
+
+
 def test_spconv_empty_and_tiny(oracle, hip):
     for n in (1, 2, 33):
         coords = rand_coords(n, batch=1, extent=2, seed=n, dup=0.0)

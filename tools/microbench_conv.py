@@ -19,6 +19,7 @@ def timeit(fn, iters=10, warm=3):
 
 
 def main():
+    me.PRECISION = int(os.environ.get('PREC', '0'))
     bs = int(os.environ.get("BS", "4"))
     batch = synthetic.make_batch("S50k", bs)
     pts = torch.from_numpy(batch["points"]).cuda()
