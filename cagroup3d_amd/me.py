@@ -32,6 +32,16 @@ from . import _lib
 from ._lib import ptr
 
 
+def h2d(data, dtype, device):
+    """Small host table -> device WITHOUT stalling the stream: pinned staging + non_blocking copy
+    (a pageable-memory copy blocks the host until every kernel queued before it has finished)."""
+    t = torch.as_tensor(data, dtype=dtype) if not torch.is_tensor(data) else data.to(dtype)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 # ----------------------------------------------------------------------------- coordinate maps
 class CoordinateMapKey:
     def __init__(self, tensor_stride, uid):
@@ -102,7 +112,7 @@ class KernelMap:
             dev = self.nbr.device
             total = self.K * self.n_out
             G = 1 if row_bounds is None else len(row_bounds) - 1
-            rb = None if row_bounds is None else torch.tensor(row_bounds, dtype=torch.int32).to(dev)
+            rb = None if row_bounds is None else h2d(row_bounds, torch.int32, dev)
             ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
             off = torch.zeros(self.K * G + 1, dtype=torch.int32, device=dev)
             lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
@@ -138,7 +148,7 @@ class KernelMap:
             cnt = np.minimum(maxlen, off[slot + 1] - start)
             widx = (slot % G) * self.K + slot // G
             tab = np.stack([widx, start, cnt], 1).astype(np.int32)
-            seg = (torch.from_numpy(tab).to(pin.device).contiguous(), int(tab.shape[0]))
+            seg = (h2d(torch.from_numpy(tab), torch.int32, pin.device), int(tab.shape[0]))
             self._segs[ck] = seg
         return seg
 
@@ -163,11 +173,21 @@ def _build_map(coords_i32, qstride):
     return out_coords[:m], keys, vals, cap, uniq[:m], inv[:n]
 
 
+_offset_cache = {}
+
+
 def _offsets(kernel_size, spacing, device):
+    ck = (int(kernel_size), int(spacing), str(device))
+    if ck not in _offset_cache:
+        _offset_cache[ck] = _make_offsets(kernel_size, spacing, device)
+    return _offset_cache[ck]
+
+
+def _make_offsets(kernel_size, spacing, device):
     ks = int(kernel_size)
     rng = range(-(ks // 2), ks // 2 + 1) if ks % 2 == 1 else range(0, ks)
     offs = [(x * spacing, y * spacing, z * spacing) for x, y, z in itertools.product(rng, rng, rng)]
-    return torch.tensor(offs, dtype=torch.int32, device=device).contiguous()
+    return h2d(offs, torch.int32, device).contiguous()
 
 
 class CoordinateManager:
@@ -518,12 +538,13 @@ def _bn_chunks(bounds, device):
                 for r0 in range(bounds[g], bounds[g + 1], step):
                     rows.append((g, r0, min(step, bounds[g + 1] - r0)))
                 gco.append(len(rows))
-            tab = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3).to(device)
-            return tab, len(rows), torch.tensor(gco, dtype=torch.int32).to(device)
+            tab = h2d(rows if rows else [(0, 0, 0)], torch.int32, device).view(-1, 3)
+            return tab, len(rows), h2d(gco, torch.int32, device)
         red, nred, gco = table(lambda ng: max(128, -(-ng // 1024)))
         app, napp, _ = table(lambda ng: 128)
-        gn = torch.tensor([max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)], dtype=torch.float32)
-        hit = (red, nred, gco, gn.to(device), app, napp)
+        ns = [max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)]
+        unb = h2d([n / max(n - 1, 1) for n in ns], torch.float32, device).view(-1, 1)   # biased -> unbiased variance
+        hit = (red, nred, gco, h2d(ns, torch.float32, device), app, napp, unb)
         if len(_chunk_cache) > 512:
             _chunk_cache.clear()
         _chunk_cache[ck] = hit
@@ -540,7 +561,7 @@ class FusedBNActFunction(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         G = len(bounds) - 1
-        chunks, nchunk, gco, group_n, achunks, nachunk = _bn_chunks(bounds, x.device)
+        chunks, nchunk, gco, group_n, achunks, nachunk, _ = _bn_chunks(bounds, x.device)
         gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
         res = residual.contiguous() if residual is not None else None
         lib.check(x, gamma, beta, res, chunks)
@@ -605,8 +626,7 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     if b0.training and b0.track_running_stats:
         with torch.no_grad():
             m = b0.momentum
-            ns = [max(bounds[g + 1] - bounds[g], 1) for g in range(G)]
-            unb = var * var.new_tensor([n / max(n - 1, 1) for n in ns]).view(G, 1)
+            unb = var * _bn_chunks(tuple(bounds), feats.device)[6]
             rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
             torch._foreach_mul_(rms, 1 - m)
             torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)

@@ -97,7 +97,8 @@ def nms_batched_sorted(boxes_sorted, seg_off_cpu, thresh, rotated):
     moff = torch.zeros(nseg + 1, dtype=torch.int64)
     moff[1:] = torch.cumsum(words, 0)
     dev = boxes_sorted.device
-    seg_d, moff_d = seg.to(dev), moff[:-1].contiguous().to(dev)
+    from ..me import h2d
+    seg_d, moff_d = h2d(seg, torch.int64, dev), h2d(moff[:-1].contiguous(), torch.int64, dev)
     mask = torch.empty(max(int(moff[-1].item()), 1), dtype=torch.int64, device=dev)
     keep = torch.empty(max(boxes_sorted.shape[0], 1), dtype=torch.int64, device=dev)
     num = torch.zeros(max(nseg, 1), dtype=torch.int32, device=dev)

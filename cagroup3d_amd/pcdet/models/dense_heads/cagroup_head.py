@@ -140,6 +140,13 @@ class CAGroup3DHead(nn.Module):
                 out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
         return out_dict
 
+    def _vs_table(self, device):
+        """Per-class voxel sizes [C,3] on `device` (cached: building it from a Python list is a blocking copy)."""
+        key = str(device)
+        if getattr(self, "_vs_cache", None) is None or self._vs_cache[0] != key:
+            self._vs_cache = (key, ME.h2d(self.voxel_size_list, torch.float32, device))
+        return self._vs_cache[1]
+
     def _forced_selection(self, input_dict, out, ori_xyz):
         """bool [N, n_classes]: voxel lies inside a GT box of that class."""
         gt = input_dict["gt_boxes"]
@@ -232,7 +239,7 @@ class CAGroup3DHead(nn.Module):
             xyz_tab = torch.cat([voted.reshape(-1, 3), ori_xyz], dim=0)
             fuse_xyz = xyz_tab[src]
             bprime = row_cls.float() * B + batch_col[src_vox, 0]
-            vs_tab = fuse_xyz.new_tensor(self.voxel_size_list)
+            vs_tab = self._vs_table(fuse_xyz.device)
             vs = vs_tab[row_cls]
             fine = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / vs)], dim=1)
             coarse = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / (vs * self.expand)) * self.expand], dim=1)
@@ -471,7 +478,7 @@ class CAGroup3DHead(nn.Module):
         dev = m["points"].device
         scores = m["cls_score"].detach().sigmoid() * m["centerness"].detach().sigmoid()
         seg = m["seg"]                                                     # c*B + b, non-decreasing
-        per = torch.tensor(m["per_scene"], device=dev)
+        per = ME.h2d(m["per_scene"], torch.long, dev)
         pre = int(self.nms_cfg.NMS_PRE)
         if pre > 0:
             order = self._sort_seg_desc(seg, scores.max(dim=1)[0])
@@ -504,10 +511,10 @@ class CAGroup3DHead(nn.Module):
         off = seg_off.numpy()
         idx = np.concatenate([np.arange(off[g], off[g] + num[g]) for g in range(B * C)] + [np.zeros(0, np.int64)])
         gof = np.repeat(np.arange(B * C), num)
-        idx_d = torch.from_numpy(idx).to(dev)
-        sel = keep[idx_d] + torch.from_numpy(off[gof]).to(dev)
+        idx_d = ME.h2d(torch.from_numpy(idx), torch.long, dev)
+        sel = keep[idx_d] + ME.h2d(torch.from_numpy(off[gof]), torch.long, dev)
         out_boxes, out_scores = e_boxes[sel], e_score[sel]
-        out_labels = torch.from_numpy(gof % C).to(dev)
+        out_labels = ME.h2d(torch.from_numpy(gof % C), torch.long, dev)
         per_scene = num.reshape(B, C).sum(1).tolist()
         return list(zip(torch.split(out_boxes, per_scene), torch.split(out_scores, per_scene),
                         torch.split(out_labels, per_scene)))

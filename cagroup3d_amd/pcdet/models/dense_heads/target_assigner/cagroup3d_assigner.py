@@ -34,7 +34,7 @@ def find_points_in_boxes(points, gt_bboxes, expanded_volumes=None):
 
 def compute_centerness(bbox_targets):
     """sqrt of the product over axes of min/max face distance (:39-46)."""
-    x, y, z = bbox_targets[..., [0, 1]], bbox_targets[..., [2, 3]], bbox_targets[..., [4, 5]]
+    x, y, z = bbox_targets[..., 0:2], bbox_targets[..., 2:4], bbox_targets[..., 4:6]
     c = x.min(dim=-1)[0] / x.max(dim=-1)[0] * y.min(dim=-1)[0] / y.max(dim=-1)[0] * z.min(dim=-1)[0] / z.max(dim=-1)[0]
     return torch.sqrt(c)
 
@@ -91,15 +91,16 @@ class CAGroup3DAssigner(object):
         if m == 0:
             return (torch.zeros(n, device=dev), torch.zeros((n, 7), device=dev),
                     torch.full((n,), -1, dtype=torch.long, device=dev))
-        pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev),
-                                         torch.tensor(n_per, device=dev))
+        from ..... import me
+        n_per_d = me.h2d(n_per, torch.long, dev)
+        pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev), n_per_d, output_size=n)
         gt = gt_bboxes_ori.to(dev)
         gt_labels = gt_labels_ori.to(dev).long()
         targets = _face_distances(points, gt)                                   # (n, m, 7)
         inside = (targets[..., :6].min(-1)[0] > 0) & (pt_cls.unsqueeze(1) == gt_labels.unsqueeze(0))
         cness = compute_centerness(targets)
         cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
-        n_cls = torch.tensor(n_per, device=dev)[gt_labels.clamp(max=len(n_per) - 1)]   # points on the box's class map
+        n_cls = n_per_d[gt_labels.clamp(max=len(n_per) - 1)]   # points on the box's class map
         k = torch.clamp(n_cls, max=self.topk + 1).clamp(min=1)
         kth = torch.sort(cness, dim=0, descending=True)[0].gather(0, (k - 1).unsqueeze(0)).squeeze(0)
         in_top = cness > kth.unsqueeze(0)

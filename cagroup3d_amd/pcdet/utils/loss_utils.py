@@ -80,12 +80,12 @@ def axis_aligned_bbox_overlaps_3d(bboxes1, bboxes2, mode="iou", is_aligned=False
     lt, rb = torch.max(p1[..., :3], p2[..., :3]), torch.min(p1[..., 3:], p2[..., 3:])
     wh = (rb - lt).clamp(min=0)
     overlap = wh[..., 0] * wh[..., 1] * wh[..., 2]
-    union = torch.max(union_base - overlap, union_base.new_tensor([eps]))
+    union = torch.clamp(union_base - overlap, min=eps)
     ious = overlap / union
     if mode == "iou":
         return ious
     ewh = (torch.max(p1[..., 3:], p2[..., 3:]) - torch.min(p1[..., :3], p2[..., :3])).clamp(min=0)
-    earea = torch.max(ewh[..., 0] * ewh[..., 1] * ewh[..., 2], union.new_tensor([eps]))
+    earea = torch.clamp(ewh[..., 0] * ewh[..., 1] * ewh[..., 2], min=eps)
     return ious - (earea - union) / earea
 
 
