@@ -700,11 +700,16 @@ class SparseTensor:
 
     @property
     def decomposition_permutations(self):
+        """Per-scene row index lists (ascending), one stable sort + ONE host read for all scenes."""
         m = self._map
         if m._perms is None:
-            b = m.coords[:, 0]
-            nb = int(b.max().item()) + 1 if m.n > 0 else 0
-            m._perms = [torch.nonzero(b == i).squeeze(1) for i in range(nb)]
+            if m.n == 0:
+                m._perms = []
+            else:
+                b = m.coords[:, 0].long()
+                order = torch.sort(b, stable=True)[1]
+                counts = torch.bincount(b).cpu().numpy()
+                m._perms = list(torch.split(order, counts.tolist()))
         return m._perms
 
     @property

@@ -89,17 +89,17 @@ def nms_batched_sorted(boxes_sorted, seg_off_cpu, thresh, rotated):
     at the segment's offset, num_keep int32 [nseg]) -- both on the device, no host sync."""
     lib = _lib.get()
     lib.check(boxes_sorted)
-    seg = torch.as_tensor(seg_off_cpu, dtype=torch.int64)
-    nseg = seg.numel() - 1
-    sizes = seg[1:] - seg[:-1]
-    max_seg = int(sizes.max().item()) if nseg > 0 else 0
-    words = sizes * ((sizes + 63) // 64)
-    moff = torch.zeros(nseg + 1, dtype=torch.int64)
-    moff[1:] = torch.cumsum(words, 0)
-    dev = boxes_sorted.device
+    import numpy as np
     from ..me import h2d
-    seg_d, moff_d = h2d(seg, torch.int64, dev), h2d(moff[:-1].contiguous(), torch.int64, dev)
-    mask = torch.empty(max(int(moff[-1].item()), 1), dtype=torch.int64, device=dev)
+    seg = np.asarray(seg_off_cpu, dtype=np.int64)
+    nseg = seg.shape[0] - 1
+    sizes = seg[1:] - seg[:-1]
+    max_seg = int(sizes.max()) if nseg > 0 else 0
+    moff = np.zeros(nseg + 1, dtype=np.int64)
+    moff[1:] = np.cumsum(sizes * ((sizes + 63) // 64))
+    dev = boxes_sorted.device
+    seg_d, moff_d = h2d(torch.from_numpy(seg), torch.int64, dev), h2d(torch.from_numpy(moff[:-1].copy()), torch.int64, dev)
+    mask = torch.empty(max(int(moff[-1]), 1), dtype=torch.int64, device=dev)
     keep = torch.empty(max(boxes_sorted.shape[0], 1), dtype=torch.int64, device=dev)
     num = torch.zeros(max(nseg, 1), dtype=torch.int32, device=dev)
     lib.call("cg3d_nms_batched", ptr(boxes_sorted), ptr(seg_d), ptr(moff_d), c_int32(nseg), c_int64(max_seg),

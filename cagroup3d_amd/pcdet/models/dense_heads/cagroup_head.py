@@ -253,9 +253,9 @@ class CAGroup3DHead(nn.Module):
         with torch.no_grad():                                             # ONE host read for all group sizes
             fb, cb = fine_C[:, 0].long(), cls_exp.C[:, 0].long()
             sizes = torch.cat([torch.bincount(fb // B, minlength=C), torch.bincount(cb // B, minlength=C),
-                               torch.bincount(fb, minlength=C * B)]).cpu()
-        fine_bounds = (0,) + tuple(torch.cumsum(sizes[:C], 0).tolist())
-        coarse_bounds = (0,) + tuple(torch.cumsum(sizes[C:2 * C], 0).tolist())
+                               torch.bincount(fb, minlength=C * B)]).cpu().numpy()
+        fine_bounds = (0,) + tuple(np.cumsum(sizes[:C]).tolist())
+        coarse_bounds = (0,) + tuple(np.cumsum(sizes[C:2 * C]).tolist())
         per_scene = sizes[2 * C:].tolist()
 
         def stacked(mods, pick):
@@ -498,9 +498,9 @@ class CAGroup3DHead(nn.Module):
         e_score = c_scores[j, i]
         o = self._sort_seg_desc(e_seg, e_score)
         j, i, e_seg, e_score = j[o], i[o], e_seg[o], e_score[o]
-        counts = torch.bincount(e_seg, minlength=B * C).cpu()                          # host read 2
-        seg_off = torch.zeros(B * C + 1, dtype=torch.int64)
-        seg_off[1:] = torch.cumsum(counts, 0)
+        counts = torch.bincount(e_seg, minlength=B * C).cpu().numpy()                  # host read 2
+        seg_off = np.zeros(B * C + 1, dtype=np.int64)
+        seg_off[1:] = np.cumsum(counts)
         e_boxes = boxes[j].contiguous()
         nms_boxes = e_boxes
         if yaw_flag:
@@ -508,7 +508,7 @@ class CAGroup3DHead(nn.Module):
             nms_boxes[:, 6] *= -1                                                      # heading sign fix (:770)
         keep, num = nms_batched_sorted(nms_boxes, seg_off, float(self.nms_cfg.IOU_THR), yaw_flag)
         num = num.cpu().numpy().astype(np.int64)                                       # host read 3
-        off = seg_off.numpy()
+        off = seg_off
         idx = np.concatenate([np.arange(off[g], off[g] + num[g]) for g in range(B * C)] + [np.zeros(0, np.int64)])
         gof = np.repeat(np.arange(B * C), num)
         idx_d = ME.h2d(torch.from_numpy(idx), torch.long, dev)
