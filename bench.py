@@ -19,6 +19,8 @@ times the CPU oracle (oracle/liboracle.so, the checker -- never the product) on 
 import argparse
 import json
 import os
+
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # cpu_baseline leg: the oracle stops scaling beyond this
 import sys
 import time
 
@@ -85,7 +87,7 @@ def cpu_baseline(args, forced):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     cfgname, nsc = args.cpu_sample.split(":")
     nsc = int(nsc)
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     torch.set_num_threads(cores)
     prec, me.PRECISION = me.PRECISION, 0      # the CPU port computes in fp32 (bf16 emulation would only slow it down)
     with _lib.use_library(_lib.bind(oracle_so)):
@@ -100,6 +102,22 @@ def cpu_baseline(args, forced):
     return {"value": nsc / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
             "sample": "%d scene(s) of %s, one fwd+bwd+AdamW step of the full detector on the CPU oracle "
                       "(OpenMP + torch CPU threads), %.1f s" % (nsc, cfgname, dt)}
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv; separate runs, as the profiling guide prescribes).
+    gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
+    import csv
+    try:
+        tot = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_%s.csv" % c)))
+                    if kernel_substr in r["Kernel_Name"]]
+            tot[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / max(len(rows), 1)
+        return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+    except Exception:
+        return None
 
 
 def main():
@@ -164,7 +182,10 @@ def main():
             roof = {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_gbytes_per_s": gbs}
         roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
-                    kernel_time_share=secs / dt)
+                    kernel_time_share=secs / dt,
+                    algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1))
+        if me.PRECISION == 1:
+            roof["traffic"] = pmc_traffic("k_spconv_pairs_bf16")   # bytes per launch, from profiles/ (separate --pmc runs)
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -327,11 +327,12 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
              c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(prec), c_int32(1), lib.stream())
     if prof:
         ev1.record()
-        # algorithmic work of one launch: 2*P*cin*cout flops; bytes = gathered rows + atomically added rows
-        # (read-modify-write) + the weights once + the two pair lists
+        # algorithmic work of one launch: 2*P*cin*cout flops; bytes = every gathered input row and every
+        # scattered output row once (the PMC passes in profiles/ count the atomic payload once as well)
+        # + the weights once + the two pair lists
         wb = 2.0 if prec == 1 else 4.0
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      4.0 * (n_pairs * cin + 2 * n_pairs * cout) + wb * K * cin * cout + 8.0 * n_pairs,
+                                      4.0 * n_pairs * (cin + cout) + wb * K * cin * cout + 8.0 * n_pairs,
                                       ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg)))
     return y
 
