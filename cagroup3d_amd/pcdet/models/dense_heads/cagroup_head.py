@@ -325,6 +325,9 @@ class CAGroup3DHead(nn.Module):
         nb = len(img_metas)
         if pts_semantic_mask is None:
             pts_semantic_mask = pts_instance_mask = [None] * nb
+        if self.batched and self._merged is not None and all(len(g) > 0 for g in gt_bboxes):
+            return self._loss_batched(semantic_scores, voxel_offset, gt_bboxes, gt_labels, scene_points,
+                                      pts_semantic_mask, pts_instance_mask)
         assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == nb \
             == len(gt_bboxes) == len(gt_labels) == len(pts_instance_mask) == len(pts_semantic_mask) == len(scene_points)
         sem_perms = semantic_scores.decomposition_permutations
@@ -346,6 +349,103 @@ class CAGroup3DHead(nn.Module):
         vals = torch.stack(means + [loss]).detach().cpu().tolist()      # ONE device->host copy for the log
         tb_dict = dict(zip(names + ("one_stage_loss",), vals))
         return loss, tb_dict
+
+    def _loss_batched(self, semantic_scores, voxel_offset, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks):
+        """All scenes of the batch in one pass: the same five loss terms as `_loss_single` averaged over scenes
+        (cagroup_head.py:322-396,399-555), with per-row normalisers instead of a Python loop over scenes and
+        ONE all-reduce for every scene's three cross-rank means."""
+        m = self._merged
+        B = len(gt_bboxes)
+        dev = m["points"].device
+        vs = self.voxel_size
+        n_gt = [len(g) for g in gt_bboxes]
+        gt = torch.cat([g.to(dev) for g in gt_bboxes])
+        gl = torch.cat([l.to(dev).long() for l in gt_labels])
+        gt_scene = torch.repeat_interleave(torch.arange(B, device=dev), ME.h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
+        with torch.no_grad():
+            # ---- semantic labels of every backbone voxel (assigner.assign_semantic)
+            vox_scene = semantic_scores.C[:, 0].long()
+            vox_xyz = semantic_scores.C[:, 1:] * vs
+            inside = find_points_in_boxes(vox_xyz, gt) & (vox_scene.view(-1, 1) == gt_scene.view(1, -1))
+            from .target_assigner.cagroup3d_assigner import FLOAT_MAX, volume
+            vols = torch.where(inside, volume(gt).view(1, -1).expand(inside.shape), torch.full((1, 1), FLOAT_MAX, device=dev))
+            min_vol, min_ind = vols.min(dim=1)
+            semantic_labels = torch.where(min_vol == FLOAT_MAX, torch.full_like(min_ind, -1), gl[min_ind])
+            # ---- FCOS-style assignment of the class-map voxels (assigner.assign_all_classes, + same-scene mask)
+            seg = m["seg"]
+            pt_cls, pt_scene = seg // B, seg % B
+            per = ME.h2d(m["per_scene"], torch.long, dev)                      # points of map (class c, scene b) at c*B+b
+            centerness_targets, bbox_targets, labels = self.assigner.assign_all_classes(
+                [m["points"]], gt, gl, pt_cls=pt_cls, same=pt_scene.view(-1, 1) == gt_scene.view(1, -1),
+                n_map=per[gl.clamp(max=self.n_classes - 1) * B + gt_scene])
+            # ---- vote targets (per scene: the raw point sets differ in size)
+            perms = voxel_offset.decomposition_permutations
+            off_t = torch.zeros((voxel_offset.F.shape[0], 3 * (self.gt_per_seed if self.with_yaw else 1)), device=dev)
+            off_m = torch.zeros(voxel_offset.F.shape[0], device=dev)
+            n_vox = torch.zeros(voxel_offset.F.shape[0], device=dev)
+            if not self.with_yaw:
+                n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1  # one host read for all scenes
+            for b in range(B):
+                op = voxel_offset.C[perms[b], 1:] * vs
+                if self.with_yaw:
+                    t, mk = self._vote_targets_yaw(op, gt_bboxes[b], gt_labels[b])
+                else:
+                    t, mk = self._vote_targets_masks(op, gt_bboxes[b], scene_points[b], sem_masks[b], ins_masks[b], int(n_ins[b]))
+                off_t[perms[b]] = t
+                off_m[perms[b]] = mk.float()
+                n_vox[perms[b]] = float(len(perms[b]))
+            vox_scene_off = voxel_offset.C[:, 0].long()
+            # ---- per-scene normalisers, one all-reduce (the reference: 3 per scene, cagroup_head.py:523,530,538)
+            pos = labels >= 0
+            stats = torch.zeros((B, 3), device=dev)
+            stats[:, 0].index_add_(0, vox_scene, (semantic_labels >= 0).float())
+            stats[:, 1].index_add_(0, pt_scene, pos.float())
+            stats[:, 2].index_add_(0, pt_scene, torch.where(pos, centerness_targets, torch.zeros_like(centerness_targets)))
+            stats = reduce_mean(stats)
+            sem_n_pos, n_pos = stats[:, 0].clamp(min=1.), stats[:, 1].clamp(min=1.)
+            ctr_denorm = stats[:, 2].clamp(min=1e-6)
+
+        from ...utils.loss_utils import py_sigmoid_focal_loss
+        C = self.n_classes
+
+        def focal(pred, lab, row_w, loss_mod):
+            tgt = torch.where(lab < 0, torch.full_like(lab, C), lab)
+            onehot = torch.nn.functional.one_hot(tgt, C + 1)[:, :C]
+            el = py_sigmoid_focal_loss(pred, onehot, None, gamma=loss_mod.gamma, alpha=loss_mod.alpha, reduction="none")
+            return loss_mod.loss_weight * (el * row_w.view(-1, 1)).sum()
+        loss_sem = focal(semantic_scores.F, semantic_labels, 1.0 / (sem_n_pos[vox_scene] * B), self.loss_sem)
+        loss_cls = focal(m["cls_score"], labels, 1.0 / (n_pos[pt_scene] * B), self.loss_cls)
+        # vote loss: smooth-L1 'sum' per scene, then mean over scenes
+        if self.with_yaw:
+            msum = torch.zeros(B, device=dev).index_add_(0, vox_scene_off, off_m)
+            w = (off_m / (msum[vox_scene_off] + 1e-6)).unsqueeze(1)
+            base = (voxel_offset.C[:, 1:] * vs).repeat(1, self.gt_per_seed)
+            pred_v, tgt_v = base + voxel_offset.F, base + off_t
+        else:
+            w = (off_m / n_vox + 1e-6).unsqueeze(1)         # the reference's precedence quirk (:518): +1e-6 on every weight
+            pred_v, tgt_v = voxel_offset.F, off_t
+        d = torch.abs(pred_v - tgt_v)
+        beta = self.loss_offset.beta
+        el = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+        loss_vote = self.loss_offset.loss_weight * (el * w).sum() / B
+        # centerness + box losses over the positives
+        pos_inds = torch.nonzero(pos).squeeze(1)
+        ps = pt_scene[pos_inds]
+        pc, pb = m["centerness"][pos_inds], m["bbox_pred"][pos_inds]
+        ct = centerness_targets[pos_inds].unsqueeze(1)
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(pc, ct, reduction="none")
+        eps = torch.finfo(torch.float32).eps
+        loss_centerness = self.loss_centerness.loss_weight * (bce.squeeze(1) / ((n_pos[ps] + eps) * B)).sum()
+        boxes = self._bbox_pred_to_bbox(m["points"][pos_inds], pb)
+        # IoU3DLoss returns pred.sum()*weight.sum() (== 0) for a scene whose weights are all zero (iou3d_loss.py:31);
+        # with positives the weights (centerness targets) are > 0, so the plain weighted form is identical
+        iou_el = self.loss_bbox.loss_function(boxes, bbox_targets[pos_inds], None, reduction="none")
+        loss_bbox = self.loss_bbox.loss_weight * (iou_el * ct.squeeze(1) / (ctr_denorm[ps] * B)).sum()
+        losses = [loss_centerness, loss_bbox, loss_cls, loss_sem, loss_vote]
+        loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
+        names = ("loss_centerness", "loss_bbox", "loss_cls", "loss_sem", "loss_vote")
+        vals = torch.stack(losses + [loss]).detach().cpu().tolist()
+        return loss, dict(zip(names + ("one_stage_loss",), vals))
 
     def _vote_targets_yaw(self, original_points, gt_bboxes, gt_labels):
         """SUN RGB-D: up to gt_per_seed box-centre votes per voxel (cagroup_head.py:418-452)."""
@@ -369,13 +469,14 @@ class CAGroup3DHead(nn.Module):
             vote_idx[ind] = torch.clamp(vote_idx[ind] + 1, max=2)
         return vote_targets, vote_masks
 
-    def _vote_targets_masks(self, original_points, gt_bboxes, scene_points, sem_mask, ins_mask):
+    def _vote_targets_masks(self, original_points, gt_bboxes, scene_points, sem_mask, ins_mask, n_ins=None):
         """ScanNet: nearest raw point (kNN k=1) gives each voxel its instance; the target is the offset to
         the centre of the GT box nearest to that instance's bbox centre (cagroup_head.py:454-498).
         Instance statistics are segment reductions (the reference loops over torch.unique with a host
         sync per instance)."""
         dev = scene_points.device
-        n_ins = int(ins_mask.max()) + 1
+        if n_ins is None:
+            n_ins = int(ins_mask.max()) + 1
         xyz = scene_points[:, :3]
         # dense masked reductions over the few instances (atomic scatter_reduce contends on ~20 slots)
         member = ins_mask.view(-1, 1) == torch.arange(n_ins, device=dev).view(1, -1)            # (n_pts, n_ins)

@@ -80,28 +80,33 @@ class CAGroup3DAssigner(object):
             lab_all.append(labels)
         return torch.cat(ctr_all), torch.cat(box_all), torch.cat(lab_all)
 
-    def assign_all_classes(self, points_list, gt_bboxes_ori, gt_labels_ori):
-        """`assign` for all classes in one pass (no per-class launches): a point of class map c only
-        competes for GT boxes of class c.  Same positives / targets as `assign` for every labelled point;
-        rows with label -1 carry unspecified (unused) box / centerness values."""
-        n_per = [len(p) for p in points_list]
+    def assign_all_classes(self, points_list, gt_bboxes_ori, gt_labels_ori, pt_cls=None, same=None, n_map=None):
+        """`assign` for all classes (and, with `same`, all scenes) in one pass: a point of class map c only
+        competes for GT boxes of class c (and of its own scene).  Same positives / targets as `assign` for every
+        labelled point; rows with label -1 carry unspecified (unused) box / centerness values.
+          pt_cls : class of every point (default: list position);  same : bool [n, m] extra pair mask;
+          n_map  : [m] number of points on the map each GT box competes on (default: its class's point count)."""
         points = torch.cat(points_list)
         dev = points.device
         n, m = len(points), len(gt_bboxes_ori)
         if m == 0:
             return (torch.zeros(n, device=dev), torch.zeros((n, 7), device=dev),
                     torch.full((n,), -1, dtype=torch.long, device=dev))
-        from ..... import me
-        n_per_d = me.h2d(n_per, torch.long, dev)
-        pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev), n_per_d, output_size=n)
         gt = gt_bboxes_ori.to(dev)
         gt_labels = gt_labels_ori.to(dev).long()
+        if pt_cls is None:
+            from ..... import me
+            n_per = [len(p) for p in points_list]
+            n_per_d = me.h2d(n_per, torch.long, dev)
+            pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev), n_per_d, output_size=n)
+            n_map = n_per_d[gt_labels.clamp(max=len(n_per) - 1)]
         targets = _face_distances(points, gt)                                   # (n, m, 7)
         inside = (targets[..., :6].min(-1)[0] > 0) & (pt_cls.unsqueeze(1) == gt_labels.unsqueeze(0))
+        if same is not None:
+            inside = inside & same
         cness = compute_centerness(targets)
         cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
-        n_cls = n_per_d[gt_labels.clamp(max=len(n_per) - 1)]   # points on the box's class map
-        k = torch.clamp(n_cls, max=self.topk + 1).clamp(min=1)
+        k = torch.clamp(n_map, max=self.topk + 1).clamp(min=1)
         kth = torch.sort(cness, dim=0, descending=True)[0].gather(0, (k - 1).unsqueeze(0)).squeeze(0)
         in_top = cness > kth.unsqueeze(0)
         vols = volume(gt).unsqueeze(0).expand(n, m)
