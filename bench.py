@@ -128,7 +128,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CG3D_FORCE_DDP") == "1"      # the env knob exercises the DDP path on one GPU
+    if use_dist:
         dist.init_process_group(backend="nccl")   # RCCL on ROCm
     forced = not args.natural
     me.PRECISION = 1 if args.precision == "bf16" else 0
@@ -136,7 +137,7 @@ def main():
     model, cfg = make_model(args.dataset, forced, dev)
     model.train()
     net = model
-    if world > 1:
+    if use_dist:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
@@ -148,7 +149,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -161,7 +162,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     me.KernelProfile.enabled = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -206,7 +207,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
