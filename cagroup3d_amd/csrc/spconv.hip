@@ -93,31 +93,6 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(const float *__restrict__ X,
     }
 }
 
-extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
-                               int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-                               int32_t precision, cg3d_stream_t stream) {
-    (void)n_in;
-    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0) return CG3D_ERR_ARG;  // bf16 operand path: next round
-    if (n_out == 0) return CG3D_OK;
-    hipStream_t s = cg3d_hs(stream);
-    const unsigned gx = (unsigned)cg3d_divup(n_out, 128);
-    const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0);
-#define LAUNCH(NT, KH, V)                                                                                        \
-    hipLaunchKernelGGL((k_spconv_fwd<NT, KH, V>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, \
-                       W, nbr, bias, Y, n_out, K, cin, cout)
-    if (cin <= 4) {
-        if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
-    } else if (vec4) {
-        if (cout > 64) LAUNCH(4, 32, true); else if (cout > 32) LAUNCH(2, 32, true); else LAUNCH(1, 32, true);
-    } else {
-        if (cout > 64) LAUNCH(4, 32, false); else if (cout > 32) LAUNCH(2, 32, false); else LAUNCH(1, 32, false);
-    }
-#undef LAUNCH
-    CG3D_CHECK_LAUNCH();
-    return CG3D_OK;
-}
-
 // ---------------------------------------------------------------- weight gradient
 // dW[k][ci][co] = sum_o X[nbr[k][o]][ci] * dY[o][co]
 // grid: x = row chunk, y = offset k, z = (ci tile, co tile) of 64x64.  Each wave walks its share of
@@ -484,6 +459,107 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output-stationary bf16 form: one workgroup owns 128 output rows x CT channels for ALL offsets and
+// keeps the accumulators in registers; every output row is written once with a plain coalesced store
+// (no atomics, no zero-fill, deterministic).  With bf16 MFMA the padding work on absent neighbours is
+// free (the matrix pipe idles anyway) while the atomic scatter of the pair form was its biggest cost
+// at the neighbourhood occupancies of the tensor-stride >= 4 maps.  Only present neighbours are
+// gathered (absent rows stage zeros without a load).  Software pipeline: the index column of offset
+// k+1 and the global loads of the next (offset, chunk) step are in flight during the current MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__restrict__ X,
+                                                                 const uint16_t *__restrict__ Wb,
+                                                                 const int32_t *__restrict__ nbr,
+                                                                 const float *__restrict__ bias, float *__restrict__ Y,
+                                                                 int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+    constexpr int CT = NT * 32;
+    constexpr int KC = 64;
+    constexpr int LP = KC + 8;
+    __shared__ uint16_t As[128 * LP];
+    __shared__ uint16_t Ws[CT * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.y * CT;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+    const bool row_ok = row < n_out;
+    uint16_t *Aw = &As[wave * 32 * LP];
+    const int gcol = (lane & 15) * 4;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    float4 areg[8];
+    uint4 wreg[NT];
+    auto issue_loads = [&](int32_t k, int32_t c0, int32_t idx) {
+        const uint16_t *wk = Wb + (int64_t)k * cin * cout;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const int col = j >> 3, piece = j & 7;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n0 + col < cout && c0 + piece * 8 < cin)
+                v = *reinterpret_cast<const uint4 *>(wk + (int64_t)(n0 + col) * cin + c0 + piece * 8);
+            wreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && c0 + gcol < cin) v = *reinterpret_cast<const float4 *>(X + (int64_t)g * cin + c0 + gcol);
+            areg[i] = v;
+        }
+    };
+    int32_t idx_next = row_ok ? nbr[row] : -1;
+    issue_loads(0, 0, idx_next);
+    for (int32_t k = 0; k < K; k++) {
+        const int32_t idx_cur = idx_next;
+        if (k + 1 < K) idx_next = row_ok ? nbr[(int64_t)(k + 1) * n_out + row] : -1;   // prefetched one offset ahead
+        const bool wave_any = __any(idx_cur >= 0);
+        for (int32_t c0 = 0; c0 < cin; c0 += KC) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int j = tid + i * 256;
+                *reinterpret_cast<uint4 *>(&Ws[(j >> 3) * LP + (j & 7) * 8]) = wreg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(areg[i]);
+            __syncthreads();
+            if (c0 + KC < cin) issue_loads(k, c0 + KC, idx_cur);
+            else if (k + 1 < K) issue_loads(k + 1, 0, idx_next);
+            if (wave_any) {
+#pragma unroll
+                for (int ks = 0; ks < KC / 16; ks++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(nt * 32 + r) * LP + ks * 16 + kg * 8]);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = n0 + nt * 32 + r;
+        if (col >= cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int64_t orow = row_base + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (orow < n_out) Y[orow * cout + col] = acc[nt][e] + bv;
+        }
+    }
+}
+
 // Generic path (any cin / alignment; also the 3-channel input layer with KH = 2): per-lane fragment
 // gather straight to registers, W tile through LDS.
 template <int NT, int KH, bool VEC4>
@@ -824,3 +900,41 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ---------------------------------------------------------------- dense-map (output-stationary) entry point
+extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
+                               int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                               int32_t precision, cg3d_stream_t stream) {
+    (void)n_in;
+    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
+    if (n_out == 0) return CG3D_OK;
+    hipStream_t s = cg3d_hs(stream);
+    const unsigned gx = (unsigned)cg3d_divup(n_out, 128);
+    if (precision == 1) {   // W is the prepared bf16 [K][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
+        if (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15)) return CG3D_ERR_ARG;
+        const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
+#define LAUNCH_IB(NT)                                                                                           \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, Wb, \
+                       nbr, bias, Y, n_out, K, cin, cout)
+        if (cout > 64) LAUNCH_IB(4); else if (cout > 32) LAUNCH_IB(2); else LAUNCH_IB(1);
+#undef LAUNCH_IB
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
+    const bool vec4 = (cin % 4 == 0) && (((uintptr_t)X & 15) == 0);
+#define LAUNCH(NT, KH, V)                                                                                        \
+    hipLaunchKernelGGL((k_spconv_fwd<NT, KH, V>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, \
+                       W, nbr, bias, Y, n_out, K, cin, cout)
+    if (cin <= 4) {
+        if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
+    } else if (vec4) {
+        if (cout > 64) LAUNCH(4, 32, true); else if (cout > 32) LAUNCH(2, 32, true); else LAUNCH(1, 32, true);
+    } else {
+        if (cout > 64) LAUNCH(4, 32, false); else if (cout > 32) LAUNCH(2, 32, false); else LAUNCH(1, 32, false);
+    }
+#undef LAUNCH
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+

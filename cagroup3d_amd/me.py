@@ -279,6 +279,40 @@ def _use_bf16(cin):
     return PRECISION == 1 and cin % 8 == 0 and cin >= 16
 
 
+# bf16 mode: maps whose neighbourhood occupancy P / (K * n_out) is at least this run the output-stationary
+# kernel (no atomics, one plain store per output row); sparser maps keep the pair form
+IMPLICIT_MIN_OCCUPANCY = float(__import__("os").environ.get("CG3D_IMPLICIT_THR", "0.1"))
+
+
+def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
+    """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] with bf16 operands; w_bf16_t: int16 view of bf16 [K, cout, cin]."""
+    lib = _lib.get()
+    K = nbr.shape[0]
+    lib.check(x, w_bf16_t, nbr, bias)
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    prof = KernelProfile.enabled and lib.is_device
+    if prof:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    lib.call("cg3d_spconv_fwd", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(bias), ptr(y), c_int64(x.shape[0]), c_int64(n_out),
+             c_int32(K), c_int32(cin), c_int32(cout), c_int32(1), lib.stream())
+    if prof:
+        ev1.record()
+        KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
+                                      4.0 * (n_pairs * cin + n_out * cout) + 2.0 * K * cin * cout + 4.0 * K * n_out,
+                                      ("implicit_bf16", K, cin, cout, n_pairs, n_out, 0)))
+    return y
+
+
+def _prep_bf16_t(w3):
+    """fp32 [K, cin, cout] -> int16 view of bf16 [K, cout, cin] (cg3d_spconv_prep_weights_bf16)."""
+    lib = _lib.get()
+    K, cin, cout = w3.shape
+    out = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
+    lib.call("cg3d_spconv_prep_weights_bf16", ptr(w3), ptr(out), c_int64(K), c_int32(cin), c_int32(cout), lib.stream())
+    return out
+
+
 def _seg_len_fwd():
     return FWD_SEG if _lib.get().is_device else (1 << 30)
 
@@ -353,14 +387,22 @@ class SparseConvFunction(torch.autograd.Function):
     their own weights: weight is [G*K, cin, cout] and group g uses weight[g*K + k]."""
 
     @staticmethod
+    def _implicit(kmap, P, cin, row_bounds):
+        return (row_bounds is None and _use_bf16(cin) and kmap.K > 1
+                and P >= IMPLICIT_MIN_OCCUPANCY * kmap.K * max(min(kmap.n_out, kmap.n_in), 1))
+
+    @staticmethod
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
         x = x.contiguous()
         w3 = weight.contiguous()
         ctx.save_for_backward(x, w3)
         ctx.kmap, ctx.has_bias, ctx.row_bounds = kmap, bias is not None, row_bounds
         pin, pout, _, P = kmap.pairs(row_bounds)
+        b = bias.contiguous() if bias is not None else None
+        if SparseConvFunction._implicit(kmap, P, w3.shape[1], row_bounds):
+            return _conv_implicit_bf16(x, _prep_bf16_t(w3), kmap.nbr, b, kmap.n_out, w3.shape[1], w3.shape[2], P)
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
-        return _conv_pairs(x, w3, pin, pout, seg, nseg, bias.contiguous() if bias is not None else None, kmap.n_out, P)
+        return _conv_pairs(x, w3, pin, pout, seg, nseg, b, kmap.n_out, P)
 
     @staticmethod
     def backward(ctx, dy):
@@ -371,15 +413,19 @@ class SparseConvFunction(torch.autograd.Function):
         pin, pout, _, P = kmap.pairs(rb)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            seg, nseg = kmap.segments(_seg_len_fwd(), rb)
-            if _use_bf16(w3.shape[2]):
-                # the swapped problem's bf16 [slots, cout'=cin, cin'=cout] weights are W itself, cast
-                wt = w3.new_empty((w3.shape[0], w3.shape[2], w3.shape[1]))  # shape carrier only
-                dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
-                                 w_bf16_t=w3.to(torch.bfloat16).view(torch.int16))
+            if SparseConvFunction._implicit(kmap, P, w3.shape[2], rb):
+                # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
+                dx = _conv_implicit_bf16(dy, w3.to(torch.bfloat16).view(torch.int16), kmap.nbrT, None, kmap.n_in,
+                                         w3.shape[2], w3.shape[1], P)
             else:
-                wt = w3.transpose(1, 2).contiguous()
-                dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
+                seg, nseg = kmap.segments(_seg_len_fwd(), rb)
+                if _use_bf16(w3.shape[2]):
+                    wt = w3.new_empty((w3.shape[0], w3.shape[2], w3.shape[1]))  # shape carrier only
+                    dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
+                                     w_bf16_t=w3.to(torch.bfloat16).view(torch.int16))
+                else:
+                    wt = w3.transpose(1, 2).contiguous()
+                    dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
             KK, cin, cout = w3.shape
             dw = torch.empty_like(w3)

@@ -91,7 +91,9 @@ int cg3d_kernel_map(const int32_t *q_coords, int64_t nq, const int32_t *offsets,
  *   Y[o, :] = bias + sum_k  X[nbr[k, o], :] @ W[k]         (rows with nbr < 0 contribute 0)
  *   X float32 [n_in, cin], W float32 [K, cin, cout], nbr int32 [K, n_out], Y float32 [n_out, cout]
  *   precision: 0 = fp32 operands (v_mfma_f32_32x32x2_f32, exact fp32 products),
- *              1 = bf16 operands (RNE-rounded on the fly), fp32 accumulate.
+ *              1 = bf16 operands, fp32 accumulate: X is RNE-rounded on the fly and `W` must point to the
+ *                  buffer written by cg3d_spconv_prep_weights_bf16 (uint16 [K, cout, cin]); cin % 8 == 0,
+ *                  16-byte aligned X.  No atomics: every output row is stored once (deterministic).
  *   The data gradient is the same call with (dY, W^T[k] as [K,cout,cin], transposed map).
  * cg3d_spconv_wgrad:  dW[k] = sum_o X[nbr[k,o], :]^T (outer) dY[o, :]   -> float32 [K,cin,cout]
  *   dW is overwritten (the callee zero-fills it when it accumulates with atomics).

@@ -32,8 +32,16 @@ int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const fl
     float *Wq = NULL;
     if (precision == 1) {
         int64_t nw = (int64_t)K * cin * cout;
+        /* precision 1: W is the prepared bf16 [K][cout][cin] buffer; widen it back to fp32 [K][cin][cout] */
+        const uint16_t *wb = (const uint16_t *)W;
         Wq = (float *)malloc((size_t)nw * sizeof(float));
-        for (int64_t i = 0; i < nw; i++) Wq[i] = os_bf16(W[i]);
+        for (int32_t k = 0; k < K; k++)
+            for (int32_t c = 0; c < cout; c++)
+                for (int32_t a = 0; a < cin; a++) {
+                    union { uint32_t u; float f; } v;
+                    v.u = (uint32_t)wb[((int64_t)k * cout + c) * cin + a] << 16;
+                    Wq[((int64_t)k * cin + a) * cout + c] = v.f;
+                }
         W = Wq;
     }
 #pragma omp parallel

@@ -166,6 +166,29 @@ def test_spconv_bf16_operands_match_oracle_emulation(oracle, hip, cin, cout, ks,
     assert (ref[0] - full[0]).abs().max() <= 2e-2 * float(full[0].abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 4000), (128, 128, 4000), (128, 256, 2500), (256, 128, 2500), (64, 32, 900)])
+def test_spconv_output_stationary_bf16_matches_pair_form_oracle(oracle, hip, cin, cout, n):
+    """bf16 mode picks the atomic-free output-stationary kernel on dense-enough maps: same operator."""
+    torch.manual_seed(cin * 3 + cout)
+    coords = rand_coords(n, batch=1, extent=6, seed=n, dup=0.0)      # compact blob: ~50 % neighbourhood occupancy
+    feats = torch.randn(coords.shape[0], cin)
+    w = torch.randn(27, cin, cout) / (cin * 27) ** 0.5
+    bias = torch.randn(cout)
+    dy = torch.randn(coords.shape[0], cout)
+    me.PRECISION = 1
+    old = me.IMPLICIT_MIN_OCCUPANCY
+    try:
+        me.IMPLICIT_MIN_OCCUPANCY = 0.0          # force the output-stationary kernel on the device
+        ref, out = both(oracle, hip, _conv_case, coords, feats, w, bias, dy, 3, 1)
+        me.IMPLICIT_MIN_OCCUPANCY = 2.0          # and the pair form
+        _, out_pairs = both(oracle, hip, _conv_case, coords, feats, w, bias, dy, 3, 1)
+    finally:
+        me.PRECISION, me.IMPLICIT_MIN_OCCUPANCY = 0, old
+    for r, o, q in zip(ref, out, out_pairs):
+        close(r, o, float(r.abs().max()))
+        close(q, o, float(r.abs().max()))
+
+
 def test_spconv_empty_and_tiny(oracle, hip):
     for n in (1, 2, 33):
         coords = rand_coords(n, batch=1, extent=2, seed=n, dup=0.0)
