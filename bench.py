@@ -168,14 +168,22 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        prof = me.KernelProfile.summary()
+        kinds = me.KernelProfile.summary()
+        kind = max(kinds, key=lambda k: kinds[k]["ms"])          # the dominant conv kernel of this run
+        prof = kinds[kind]
         secs = prof["ms"] * 1e-3
         tf = prof["flops"] / secs / 1e12 if secs > 0 else 0.0
         gbs = prof["bytes"] / secs / 1e9 if secs > 0 else 0.0
-        kname = "k_spconv_pairs_%s (sparse conv fwd + dgrad: gather -> %s MFMA -> atomic scatter)" % (
-            ("bf16", "bf16") if me.PRECISION == 1 else ("lds", "fp32"))
+        kname, ksym = {
+            "implicit_bf16": ("k_spconv_implicit_bf16 (sparse conv fwd + dgrad, output-stationary: row gather -> LDS -> "
+                              "bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
+            "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)",
+                           "k_spconv_pairs_bf16"),
+            "pairs": ("k_spconv_pairs_lds (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)",
+                      "k_spconv_pairs_lds"),
+        }[kind]
         if me.PRECISION == 1:
-            # bf16 MFMA runs at 16x the fp32 rate: the kernel is bound by the row gather + atomic row scatter
+            # bf16 MFMA runs at 16x the fp32 rate: the kernel is bound by the row gather (+ row scatter)
             roof = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "achieved_tflops": tf,
                     "frac_of_bf16_mfma_peak": tf / BF16_MFMA_PEAK_TFLOPS}
@@ -184,9 +192,10 @@ def main():
                     "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_gbytes_per_s": gbs}
         roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
                     kernel_time_share=secs / dt,
-                    algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1))
-        if me.PRECISION == 1:
-            roof["traffic"] = pmc_traffic("k_spconv_pairs_bf16")   # bytes per launch, from profiles/ (separate --pmc runs)
+                    algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1),
+                    other_conv_kernels={k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps}
+                                        for k, v in kinds.items() if k != kind})
+        roof["traffic"] = pmc_traffic(ksym)   # bytes per launch, from profiles/ (separate --pmc runs)
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

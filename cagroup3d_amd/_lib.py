@@ -45,7 +45,7 @@ _SIGNATURES = {
     "cg3d_pool_map": (c_int32, [P, c_int64, c_int32, c_int32, P, P, c_int64, P, P]),
     "cg3d_scatter_mean_fwd": (c_int32, [P, P, c_int32, P, P, c_int64, c_int64, c_int32, P]),
     "cg3d_scatter_mean_bwd": (c_int32, [P, P, P, c_int32, P, c_int64, c_int64, c_int32, P]),
-    "cg3d_bn_stats": (c_int32, [P, P, c_int64, P, c_int32, c_int32, P, P, P, P]),
+    "cg3d_bn_stats": (c_int32, [P, P, c_int64, P, c_int32, c_int32, P, P, P, P, P, P, c_float, P]),
     "cg3d_bn_apply": (c_int32, [P, P, P, c_int64, c_int32, P, P, c_float, P, P, c_int32, P, P]),
     "cg3d_bn_bwd_reduce": (c_int32, [P, P, P, P, c_int64, P, c_int32, c_int32, P, P, c_float, c_int32, P, P, P, P]),
     "cg3d_bn_bwd_apply": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, c_float, P, P, P, P, c_int32, c_int32, P, P, P]),
@@ -86,8 +86,9 @@ class Library:
             raise CG3DError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
 
     def stream(self):
+        """Raw handle of torch's current stream on the current device (hipStream_t)."""
         if self.is_device:
-            return c_void_p(torch.cuda.current_stream().cuda_stream)
+            return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
         return c_void_p(0)
 
     def check(self, *tensors):

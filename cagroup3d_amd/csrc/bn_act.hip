@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
                                                      const int32_t *__restrict__ gco, int32_t G, int32_t c,
-                                                     float *__restrict__ out0, float *__restrict__ out1) {
+                                                     float *__restrict__ out0, float *__restrict__ out1,
+                                                     float *__restrict__ run0, float *__restrict__ run1,
+                                                     long long *__restrict__ nbt, float momentum) {
     __shared__ double r0[256], r1[256];
     __shared__ long long rr[256];
     const int cblocks = (c + 15) / 16;
@@ -110,6 +112,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
             double v = s1 / n - m * m;
             out0[t] = (float)m;
             out1[t] = (float)(v > 0.0 ? v : 0.0);
+            if (run0 && run1) {     // running statistics, as nn.BatchNorm1d updates them (unbiased variance)
+                const float unb = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
+                run0[t] = (1.f - momentum) * run0[t] + momentum * (float)m;
+                run1[t] = (1.f - momentum) * run1[t] + momentum * ((float)(v > 0.0 ? v : 0.0) * unb);
+            }
+            if (nbt && a == 0) nbt[g] += 1;
         } else {
             out0[t] = (float)s0;
             out1[t] = (float)s1;
@@ -120,14 +128,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
 static bool bad(const void *p) { return ((uintptr_t)p & 15) != 0; }
 
 extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off,
-                             int32_t G, int32_t c, float *ws, float *mean, float *var, cg3d_stream_t stream) {
+                             int32_t G, int32_t c, float *ws, float *mean, float *var, float *running_mean,
+                             float *running_var, int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream) {
     if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(ws)) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (nchunk > 0)
         hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, c,
                            nullptr, nullptr, 0.f, 0, ws);
     hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
-                       group_chunk_off, G, c, mean, var);
+                       group_chunk_off, G, c, mean, var, running_mean, running_var,
+                       reinterpret_cast<long long *>(num_batches_tracked), momentum);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
@@ -141,7 +151,7 @@ extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *
         hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
                            act, ws);
     hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
-                       group_chunk_off, G, c, dbeta, dgamma);
+                       group_chunk_off, G, c, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

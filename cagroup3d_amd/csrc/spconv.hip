@@ -341,9 +341,15 @@ __device__ static inline uint32_t f2bf(float f) {        // round-to-nearest-eve
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ static inline uint2 pack4bf(float4 v) {
-    return make_uint2(f2bf(v.x) | (f2bf(v.y) << 16), f2bf(v.z) | (f2bf(v.w) << 16));
+// four fp32 -> four bf16 (RNE) with the gfx950 packed convert (v_cvt_pk_bf16_f32)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ static inline uint32_t pack2bf(float a, float b) {
+    const f32x2_t v = {a, b};
+    const bf16x2_t o = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, o);
 }
+__device__ static inline uint2 pack4bf(float4 v) { return make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
 
 __global__ void k_prep_weights_bf16(const float *__restrict__ W, uint16_t *__restrict__ Wb, int64_t slots, int32_t cin,
                                     int32_t cout) {
@@ -477,15 +483,16 @@ __global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__
     constexpr int CT = NT * 32;
     constexpr int KC = 64;
     constexpr int LP = KC + 8;
-    __shared__ uint16_t As[128 * LP];
-    __shared__ uint16_t Ws[CT * LP];
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][128 * LP];
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[2][CT * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kg = lane >> 5;
     const int n0 = blockIdx.y * CT;
     const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + r;
     const bool row_ok = row < n_out;
-    uint16_t *Aw = &As[wave * 32 * LP];
     const int gcol = (lane & 15) * 4;
+    const int nchunk = (cin + KC - 1) / KC;
+    const int nstep = K * nchunk;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -493,58 +500,88 @@ __global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
+    // All loads are unconditional (clamped addresses, 32-bit element offsets from the kernel-argument
+    // bases); absent neighbours and channel tails are zeroed on the way into LDS.  A wave whose 32 rows
+    // have no neighbour at an offset skips its gather and its MFMAs for that offset (wave-uniform).
     float4 areg[8];
     uint4 wreg[NT];
-    auto issue_loads = [&](int32_t k, int32_t c0, int32_t idx) {
+    uint32_t amask = 0, wmask = 0;
+    bool a_live = false;
+    auto issue_loads = [&](int32_t k, int32_t c0, int32_t idx, bool live) {
         const uint16_t *wk = Wb + (int64_t)k * cin * cout;
+        wmask = 0;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int j = tid + i * 256;
-            const int col = j >> 3, piece = j & 7;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (n0 + col < cout && c0 + piece * 8 < cin)
-                v = *reinterpret_cast<const uint4 *>(wk + (int64_t)(n0 + col) * cin + c0 + piece * 8);
-            wreg[i] = v;
+            const int col = n0 + (j >> 3), cc = c0 + (j & 7) * 8;
+            const bool ok = col < cout && cc < cin;
+            const uint32_t off = ok ? (uint32_t)col * (uint32_t)cin + (uint32_t)cc : 0u;
+            wreg[i] = *reinterpret_cast<const uint4 *>(wk + off);
+            wmask |= ok ? (1u << i) : 0u;
         }
+        a_live = live;
+        if (live) {
+            amask = 0;
+            const bool cok = c0 + gcol < cin;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g >= 0 && c0 + gcol < cin) v = *reinterpret_cast<const float4 *>(X + (int64_t)g * cin + c0 + gcol);
-            areg[i] = v;
+            for (int i = 0; i < 8; i++) {
+                const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
+                const bool ok = g >= 0 && cok;
+                const uint32_t off = ok ? (uint32_t)g * (uint32_t)cin + (uint32_t)(c0 + gcol) : 0u;
+                areg[i] = *reinterpret_cast<const float4 *>(X + off);
+                amask |= ok ? (1u << i) : 0u;
+            }
         }
     };
-    int32_t idx_next = row_ok ? nbr[row] : -1;
-    issue_loads(0, 0, idx_next);
-    for (int32_t k = 0; k < K; k++) {
-        const int32_t idx_cur = idx_next;
-        if (k + 1 < K) idx_next = row_ok ? nbr[(int64_t)(k + 1) * n_out + row] : -1;   // prefetched one offset ahead
-        const bool wave_any = __any(idx_cur >= 0);
-        for (int32_t c0 = 0; c0 < cin; c0 += KC) {
-            __syncthreads();
+    auto commit = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int j = tid + i * 256;
-                *reinterpret_cast<uint4 *>(&Ws[(j >> 3) * LP + (j & 7) * 8]) = wreg[i];
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const uint4 v = (wmask >> i) & 1u ? wreg[i] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(&Ws[buf][(j >> 3) * LP + (j & 7) * 8]) = v;
+        }
+        if (a_live) {
+            uint16_t *Aw = &As[buf][wave * 32 * LP];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 v = (amask >> i) & 1u ? areg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(v);
             }
+        }
+    };
+    int32_t idx_cur = row_ok ? nbr[row] : -1;
+    int32_t idx_next = (K > 1 && row_ok) ? nbr[n_out + row] : -1;
+    bool live_cur = __any(idx_cur >= 0);
+    issue_loads(0, 0, idx_cur, live_cur);
+    commit(0);
+    int32_t k = 0, c0 = 0;
+    for (int st = 0; st < nstep; st++) {
+        const int buf = st & 1;
+        const bool live = live_cur;
+        // the step after this one: same offset, next channel chunk -- or the first chunk of the next offset
+        int32_t kn = k, cn = c0 + KC;
+        if (cn >= cin) {
+            kn = k + 1; cn = 0;
+            idx_cur = idx_next;
+            live_cur = __any(idx_cur >= 0);
+            if (kn + 1 < K) idx_next = row_ok ? nbr[(int64_t)(kn + 1) * n_out + row] : -1;   // one offset ahead
+        }
+        if (st + 1 < nstep) issue_loads(kn, cn, idx_cur, live_cur);     // in flight during the MFMAs
+        __syncthreads();
+        if (live) {
+            const uint16_t *Aw = &As[buf][wave * 32 * LP];
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(areg[i]);
-            __syncthreads();
-            if (c0 + KC < cin) issue_loads(k, c0 + KC, idx_cur);
-            else if (k + 1 < K) issue_loads(k + 1, 0, idx_next);
-            if (wave_any) {
+            for (int ks = 0; ks < KC / 16; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
 #pragma unroll
-                for (int ks = 0; ks < KC / 16; ks++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[(nt * 32 + r) * LP + ks * 16 + kg * 8]);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NT; nt++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[buf][(nt * 32 + r) * LP + ks * 16 + kg * 8]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
                 }
             }
         }
+        if (st + 1 < nstep) commit(buf ^ 1);          // that buffer was last read before this step's barrier
+        k = kn; c0 = cn;
     }
     const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
 #pragma unroll
@@ -877,14 +914,149 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_t128(const float 
             }
 }
 
+// bf16-operand weight gradient (precision 1): the same (segment x channel-tile) decomposition as the fp32 kernels,
+// 64 pairs per stage.  The contraction runs over pairs, which is the strided dimension of the row-major
+// operands, so each thread transposes a 4 pair x 4 channel block in registers on the way into LDS
+// ([channel][pair] bf16, 16-byte granules XOR-swizzled by channel>>4 so that the transposing 8-byte writes
+// spread over the banks); the MFMA fragments are then single 16-byte LDS reads.
+#define WB_S 64            // pairs per stage
+#define WB_LD 72           // padded LDS row (bf16): 144 B
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float *__restrict__ X,
+                                                                    const float *__restrict__ dY,
+                                                                    const int32_t *__restrict__ pin,
+                                                                    const int32_t *__restrict__ pout,
+                                                                    const int32_t *__restrict__ seg,
+                                                                    float *__restrict__ dW, int32_t cin, int32_t cout,
+                                                                    int32_t co_tiles) {
+    __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
+    constexpr int XT = TM / 4, DT = TN / 4;              // threads per gathered row
+    constexpr int XP = 16 / (256 / XT), DP = 16 / (256 / DT);   // passes over the 16 pair quads of a stage
+    constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 tiles per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int ci0 = (blockIdx.y / co_tiles) * TM, co0 = (blockIdx.y % co_tiles) * TN;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const int xc4 = (tid % XT) * 4, dc4 = (tid % DT) * 4;
+    const bool xin = ci0 + xc4 < cin, din = co0 + dc4 < cout;       // cin, cout are multiples of 4 here
+    const float *xbase = X + (xin ? ci0 + xc4 : 0);
+    const float *dbase = dY + (din ? co0 + dc4 : 0);
+    float4 xr[XP][4], dr[DP][4];
+    auto issue = [&](int32_t p0) {
+#pragma unroll
+        for (int ps = 0; ps < XP; ps++) {
+            const int q = ps * (256 / XT) + tid / XT;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int32_t p = p0 + 4 * q + i;
+                const int32_t pp = p < count ? p : count - 1;      // clamped, unconditional (masked below)
+                const float4 a = *reinterpret_cast<const float4 *>(xbase + (int64_t)pin[start + pp] * cin);
+                xr[ps][i] = (p < count && xin) ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < DP; ps++) {
+            const int q = ps * (256 / DT) + tid / DT;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int32_t p = p0 + 4 * q + i;
+                const int32_t pp = p < count ? p : count - 1;
+                const float4 b = *reinterpret_cast<const float4 *>(dbase + (int64_t)pout[start + pp] * cout);
+                dr[ps][i] = (p < count && din) ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    // 4 pairs x 4 channels -> four 8-byte rows [channel][4 pairs]
+    auto put = [&](uint16_t *T, int c4, int q, const float4 *v) {
+        const int col = (((q >> 1) ^ ((c4 >> 4) & 7)) << 3) + ((q & 1) << 2);
+        *reinterpret_cast<uint2 *>(&T[(c4 + 0) * WB_LD + col]) = pack4bf(make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+        *reinterpret_cast<uint2 *>(&T[(c4 + 1) * WB_LD + col]) = pack4bf(make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+        *reinterpret_cast<uint2 *>(&T[(c4 + 2) * WB_LD + col]) = pack4bf(make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+        *reinterpret_cast<uint2 *>(&T[(c4 + 3) * WB_LD + col]) = pack4bf(make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < XP; ps++) put(Xs[buf], xc4, ps * (256 / XT) + tid / XT, xr[ps]);
+#pragma unroll
+        for (int ps = 0; ps < DP; ps++) put(Ds[buf], dc4, ps * (256 / DT) + tid / DT, dr[ps]);
+    };
+    const int nstage = (count + WB_S - 1) / WB_S;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int st = 0; st < nstage; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) issue((st + 1) * WB_S);            // in flight during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < WB_S / 16; kk++) {
+            bf16x8 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                const int row = wi * (TM / 2) + i * 32 + r;
+                a[i] = *reinterpret_cast<const bf16x8 *>(&Xs[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int row = wj * (TN / 2) + j * 32 + r;
+                b[j] = *reinterpret_cast<const bf16x8 *>(&Ds[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nstage) commit(buf ^ 1);                   // the other buffer was last read two stages ago
+        __syncthreads();
+    }
+    float *dst = dW + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = co0 + wj * (TN / 2) + j * 32 + r;
+                if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+            }
+}
+
 extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in,
                                        const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
                                        int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
     if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0) return CG3D_ERR_ARG;
+    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (nseg == 0) return CG3D_OK;
+    if (precision == 1) {   // bf16 operands (both rounded on the fly), fp32 accumulate
+        if (cin % 4 != 0 || cout % 4 != 0 || (((uintptr_t)X | (uintptr_t)dY) & 15)) return CG3D_ERR_ARG;
+        const bool m128 = cin > 64, n128 = cout > 64;
+        const int32_t ct = cg3d_divup(cin, m128 ? 128 : 64), ot = cg3d_divup(cout, n128 ? 128 : 64);
+        if ((int64_t)ct * ot > 65535) return CG3D_ERR_ARG;
+#define LAUNCH_WB(TM, TN)                                                                                          \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_bf16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, X, \
+                       dY, pair_in, pair_out, seg, dW, cin, cout, ot)
+        if (m128 && n128) LAUNCH_WB(128, 128);
+        else if (m128) LAUNCH_WB(128, 64);
+        else if (n128) LAUNCH_WB(64, 128);
+        else LAUNCH_WB(64, 64);
+#undef LAUNCH_WB
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     if (cin >= 128 && cout >= 128 && cin % 4 == 0 && cout % 4 == 0 && !(((uintptr_t)X | (uintptr_t)dY) & 15) &&
         !getenv("CG3D_WGRAD64")) {
         const int32_t ct = (cin + 127) / 128, ot = (cout + 127) / 128;

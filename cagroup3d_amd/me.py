@@ -330,9 +330,15 @@ class KernelProfile:
 
     @classmethod
     def summary(cls):
-        ms = sum(r[0].elapsed_time(r[1]) for r in cls.records)
-        return {"launches": len(cls.records), "ms": ms, "flops": float(sum(r[2] for r in cls.records)),
-                "bytes": float(sum(r[3] for r in cls.records))}
+        """Per kernel kind: launches, total ms, algorithmic flops and bytes."""
+        out = {}
+        for ev0, ev1, flops, nbytes, meta in cls.records:
+            d = out.setdefault(meta[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += ev0.elapsed_time(ev1)
+            d["flops"] += float(flops)
+            d["bytes"] += float(nbytes)
+        return out
 
 
 def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=None):
@@ -371,9 +377,17 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
     return y
 
 
-def _wgrad_seg_len(P, cin, cout):
+_WGRAD_BF16_WGS = int(__import__("os").environ.get("CG3D_WGRAD_BF16_WGS", "2048"))
+_WGRAD_BF16_MIN = int(__import__("os").environ.get("CG3D_WGRAD_BF16_MIN", "256"))
+
+
+def _wgrad_seg_len(P, cin, cout, precision=0):
     if not _lib.get().is_device:
         return 1 << 30
+    if precision == 1:
+        tiles = (-(-cin // (128 if cin > 64 else 64))) * (-(-cout // (128 if cout > 64 else 64)))
+        per = -(-P * tiles // _WGRAD_BF16_WGS)
+        return max(_WGRAD_BF16_MIN, -(-per // 64) * 64)
     t = 128 if (cin >= 128 and cout >= 128) else 64          # tile edge of the kernel the library will pick
     tiles = ((cin + t - 1) // t) * ((cout + t - 1) // t)
     per = -(-P * tiles // 2048)             # aim at >= 2048 workgroups
@@ -429,18 +443,19 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             KK, cin, cout = w3.shape
             dw = torch.empty_like(w3)
-            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout), rb)
+            wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, wprec), rb)
             lib.check(x, dy, pin, pout, seg)
             prof = KernelProfile.enabled and KernelProfile.wgrad and lib.is_device
             if prof:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             lib.call("cg3d_spconv_pairs_wgrad", ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
-                     c_int32(KK), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
+                     c_int32(KK), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
             if prof:
                 ev1.record()
                 KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout, 4.0 * (P * cin + P * cout + KK * cin * cout),
-                                              ("wgrad", KK, cin, cout, P, kmap.n_out, nseg)))
+                                              ("wgrad_bf16" if wprec else "wgrad", KK, cin, cout, P, kmap.n_out, nseg)))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None
@@ -603,7 +618,8 @@ class FusedBNActFunction(torch.autograd.Function):
     Returns (y, batch_mean [G,C], batch_var_biased [G,C])."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps):
+    def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps, running=None):
+        # running: None or (running_mean [G*C], running_var, num_batches_tracked, momentum), updated in the statistics launch
         lib = _lib.get()
         x = x.contiguous()
         N, C = x.shape
@@ -616,8 +632,10 @@ class FusedBNActFunction(torch.autograd.Function):
             ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
             mean = torch.empty((G, C), dtype=torch.float32, device=x.device)
             var = torch.empty((G, C), dtype=torch.float32, device=x.device)
+            rm, rv, nbt, mom = running if running is not None else (None, None, None, 0.0)
+            lib.check(rm, rv, nbt)
             lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G), c_int32(C), ptr(ws),
-                     ptr(mean), ptr(var), lib.stream())
+                     ptr(mean), ptr(var), ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
         else:
             mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
         y = torch.empty_like(x)
@@ -644,7 +662,7 @@ class FusedBNActFunction(torch.autograd.Function):
         lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean),
                  ptr(var), c_float(eps), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
                  c_int32(1 if use_batch else 0), ptr(dx), ptr(dres), lib.stream())
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
@@ -669,8 +687,13 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     if not use_batch:
         mean_in = torch.stack([b.running_mean for b in bns]) if G > 1 else b0.running_mean.view(1, C)
         var_in = torch.stack([b.running_var for b in bns]) if G > 1 else b0.running_var.view(1, C)
-    y, mean, var = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in, b0.eps)
-    if b0.training and b0.track_running_stats:
+    track = b0.training and b0.track_running_stats
+    running = None
+    if track and G == 1 and b0.momentum is not None:
+        running = (b0.running_mean, b0.running_var, b0.num_batches_tracked, float(b0.momentum))
+    y, mean, var = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in,
+                                            b0.eps, running)
+    if track and running is None:
         with torch.no_grad():
             m = b0.momentum
             unb = var * _bn_chunks(tuple(bounds), feats.device)[6]
@@ -679,8 +702,7 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
             torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)
             torch._foreach_mul_(rvs, 1 - m)
             torch._foreach_add_(rvs, list(unb.unbind(0)), alpha=m)
-            for b in bns:
-                b.num_batches_tracked += 1
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
     return y
 
 

@@ -202,7 +202,10 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  *   `group_chunk_off` int32 [G+1]: chunks of group g are [group_chunk_off[g], group_chunk_off[g+1]).
  *   `ws` float32 [nchunk*2*C] scratch for per-chunk partial sums (no atomics; the per-group reduction over
  *   chunks runs in fp64 inside the finalise kernel).
- * cg3d_bn_stats:  mean, var (biased) float32 [G,C] of every group.
+ * cg3d_bn_stats:  mean, var (biased) float32 [G,C] of every group.  When `running_mean`/`running_var`
+ *                 (float32 [G,C]) are not NULL they are updated in the same launch like nn.BatchNorm1d does:
+ *                 r = (1-momentum)*r + momentum*stat, the variance unbiased (n/(n-1)); `num_batches_tracked`
+ *                 (int64 [G], may be NULL) is incremented.
  * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL)
  * cg3d_bn_bwd_reduce: with dz = dy * act'(y), xhat = (x-mean)*rsqrt(var+eps):
  *                 dbeta = sum(dz), dgamma = sum(dz * xhat)   float32 [G,C]
@@ -210,7 +213,8 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  *                 use_batch_stats == 0: dx = gamma*invstd*dz), dres (may be NULL) = dz;  group_n float32 [G]
  * ---------------------------------------------------------------------------------------- */
 int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off, int32_t G,
-                  int32_t c, float *ws, float *mean, float *var, cg3d_stream_t stream);
+                  int32_t c, float *ws, float *mean, float *var, float *running_mean, float *running_var,
+                  int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream);
 int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
                   const float *mean, const float *var, float eps, const float *gamma, const float *beta, int32_t act,
                   float *Y, cg3d_stream_t stream);

@@ -333,7 +333,8 @@ static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, 
     }
 }
 int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *gco, int32_t G, int32_t c,
-                  float *ws, float *mean, float *var, cg3d_stream_t s) {
+                  float *ws, float *mean, float *var, float *running_mean, float *running_var,
+                  int64_t *num_batches_tracked, float momentum, cg3d_stream_t s) {
     (void)s; (void)ws;
     double *sums = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
     os_bn_sums(0, X, NULL, NULL, chunks, nchunk, G, c, NULL, NULL, 0.f, 0, sums);
@@ -345,7 +346,14 @@ int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const i
             double m = sums[(int64_t)g * c + a] / n, v = sums[(int64_t)(G + g) * c + a] / n - m * m;
             mean[(int64_t)g * c + a] = (float)m;
             var[(int64_t)g * c + a] = (float)(v > 0 ? v : 0);
+            if (running_mean && running_var) {   /* nn.BatchNorm1d: unbiased variance into the running buffer */
+                float unb = (float)(n / (n > 1 ? n - 1 : 1));
+                float *rm = running_mean + (int64_t)g * c + a, *rv = running_var + (int64_t)g * c + a;
+                *rm = (1.f - momentum) * *rm + momentum * (float)m;
+                *rv = (1.f - momentum) * *rv + momentum * ((float)(v > 0 ? v : 0) * unb);
+            }
         }
+        if (num_batches_tracked) num_batches_tracked[g] += 1;
     }
     free(sums);
     return CG3D_OK;

@@ -292,6 +292,31 @@ def test_fused_bn_act_matches_oracle(oracle, hip, act, c, bounds):
         close(r, o, float(r.abs().max()))
 
 
+@pytest.mark.parametrize("G", [1, 3])
+def test_fused_bn_running_statistics_match_torch_batchnorm(oracle, hip, G):
+    """The statistics launch also updates running_mean / running_var / num_batches_tracked (G == 1) exactly as
+    nn.BatchNorm1d does; grouped calls go through the foreach path -- same contract."""
+    torch.manual_seed(G)
+    c, bounds = 64, tuple(range(0, 700 * G + 1, 700))
+    x = torch.randn(bounds[-1], c) * 3 + 1
+
+    def fn(x):
+        bns = [torch.nn.BatchNorm1d(c).to(x.device) for _ in range(G)]
+        refs = [torch.nn.BatchNorm1d(c).to(x.device) for _ in range(G)]
+        for _ in range(2):
+            y = me.fused_bn_act(x, bns, bounds, me.ACT_RELU)
+            yr = torch.cat([torch.relu(refs[g](x[bounds[g]:bounds[g + 1]])) for g in range(G)])
+        assert (y - yr).abs().max() < 1e-4
+        for b, r in zip(bns, refs):
+            assert (b.running_mean - r.running_mean).abs().max() < 1e-5
+            assert (b.running_var - r.running_var).abs().max() < 1e-4
+            assert int(b.num_batches_tracked) == int(r.num_batches_tracked) == 2
+        return torch.stack([b.running_mean for b in bns]), torch.stack([b.running_var for b in bns])
+    ref, out = both(oracle, hip, fn, x)
+    for r, o in zip(ref, out):
+        close(r, o, 1.0)
+
+
 # ------------------------------------------------------------------ iou3d_nms
 @pytest.mark.parametrize("na,nb", [(0, 5), (1, 1), (17, 33), (300, 257)])
 def test_boxes_overlap_and_iou_bit_exact(oracle, hip, na, nb):

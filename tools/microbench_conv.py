@@ -25,6 +25,22 @@ def main():
     pts = torch.from_numpy(batch["points"]).cuda()
     coords = pts[:, :4].clone()
     coords[:, 1:] /= 0.02
+    if os.environ.get("SORT"):
+        c = coords.floor().long()
+        if os.environ["SORT"] == "morton":
+            def spread(v):
+                v = v & 0x1FFFFF
+                v = (v | (v << 32)) & 0x1F00000000FFFF
+                v = (v | (v << 16)) & 0x1F0000FF0000FF
+                v = (v | (v << 8)) & 0x100F00F00F00F00F
+                v = (v | (v << 4)) & 0x10C30C30C30C30C3
+                v = (v | (v << 2)) & 0x1249249249249249
+                return v
+            key = (c[:, 0] << 60) | (spread(c[:, 1] + 2048) << 2) | (spread(c[:, 2] + 2048) << 1) | spread(c[:, 3] + 2048)
+        else:
+            key = ((c[:, 0] * 4096 + c[:, 1] + 2048) * 4096 + c[:, 2] + 2048) * 4096 + c[:, 3] + 2048
+        order = key.argsort()
+        coords, pts = coords[order].contiguous(), pts[order].contiguous()
     t0 = time.time()
     x = me.SparseTensor(coordinates=coords, features=pts[:, 4:] / 255.)
     torch.cuda.synchronize()
@@ -70,11 +86,20 @@ def main():
             lib.call("cg3d_spconv_pairs_wgrad", _lib.ptr(xin), _lib.ptr(dy), _lib.ptr(pin), _lib.ptr(pout), _lib.ptr(wseg),
                      c_int64(nwseg), _lib.ptr(dw), c_int32(ks ** 3), c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
         tw = timeit(wgp)
+        ti_b = tw_b = float("nan")
+        if me.PRECISION == 1 and cin % 8 == 0:
+            wb = me._prep_bf16_t(w)
+            ti_b = timeit(lambda: me._conv_implicit_bf16(xin, wb, km.nbr, None, km.n_out, cin, cout, P))
+            bseg, nbseg = km.segments(me._wgrad_seg_len(P, cin, cout, 1))
+            def wgb():
+                lib.call("cg3d_spconv_pairs_wgrad", _lib.ptr(xin), _lib.ptr(dy), _lib.ptr(pin), _lib.ptr(pout), _lib.ptr(bseg),
+                         c_int64(nbseg), _lib.ptr(dw), c_int32(ks ** 3), c_int32(cin), c_int32(cout), c_int32(1), lib.stream())
+            tw_b = timeit(wgb)
         gf = 2.0 * P * cin * cout / 1e9
         gfd = 2.0 * km.n_out * ks ** 3 * cin * cout / 1e9
         tot += tf + td + tw
-        print("ts %2d->%2d %4d->%4d k%d rows %7d pairs %8d (occ %.1f/%d) eff %7.2f GF dense %7.2f GF | map %5.1f+%4.1f ms | pairs: fwd %7.3f ms (%6.1f TF eff) dgrad %7.3f wgrad %7.3f | implicit: fwd %7.3f wgrad %7.3f"
-              % (tin, tout, cin, cout, ks, km.n_out, P, P / max(km.n_out, 1), ks ** 3, gf, gfd, tmap, tpairs, tf, gf / tf, td, tw, tf_i, tw_i))
+        print("ts %2d->%2d %4d->%4d k%d rows %7d pairs %8d (occ %.1f/%d) eff %7.2f GF dense %7.2f GF | map %5.1f+%4.1f ms | pairs: fwd %7.3f ms (%6.1f TF eff) dgrad %7.3f wgrad %7.3f | implicit: fwd %7.3f wgrad %7.3f | implicit bf16 fwd %7.3f bf16 wgrad %7.3f"
+              % (tin, tout, cin, cout, ks, km.n_out, P, P / max(km.n_out, 1), ks ** 3, gf, gfd, tmap, tpairs, tf, gf / tf, td, tw, tf_i, tw_i, ti_b, tw_b))
     print("sum fwd+dgrad+wgrad of listed layers: %.2f ms" % tot)
 
 
