@@ -461,6 +461,70 @@ class SparseConvFunction(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+_ident_cache = {}
+
+
+def _identity_pairs(n, seglen, device):
+    """arange pair list + (0, start, count) segment table for an n-row dense weight gradient (cached)."""
+    ck = (n, seglen, str(device))
+    hit = _ident_cache.get(ck)
+    if hit is None:
+        ar = None
+        for (n2, _, d2), v in _ident_cache.items():
+            if n2 == n and d2 == str(device):
+                ar = v[0]
+        if ar is None:
+            ar = torch.arange(n, dtype=torch.int32, device=device)
+        starts = np.arange(0, n, seglen, dtype=np.int64)
+        tab = np.stack([np.zeros_like(starts), starts, np.minimum(seglen, n - starts)], 1).astype(np.int32)
+        hit = (ar, h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
+        if len(_ident_cache) > 256:
+            _ident_cache.clear()
+        _ident_cache[ck] = hit
+    return hit
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = x @ w (+ bias) for the 1x1x1 convolutions.  Forward and data gradient are plain library GEMMs;
+    the weight gradient x^T @ dy has a tiny output and a contraction over every row of the sparse tensor, which
+    the library runs on a handful of workgroups -- it goes through the split-over-rows wgrad kernel instead
+    (cg3d_spconv_pairs_wgrad on the identity pair list)."""
+    MIN_ROWS = 8192
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, w) if bias is not None else x @ w
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w.t()
+        if ctx.needs_input_grad[1]:
+            n, (cin, cout) = x.shape[0], w.shape
+            lib = _lib.get()
+            if n < LinearFunction.MIN_ROWS or not lib.is_device:
+                dw = x.t() @ dy
+            else:
+                xc, dyc = x.contiguous(), dy.contiguous()
+                wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+                ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, wprec), x.device)
+                dw = torch.empty_like(w)
+                lib.check(xc, dyc, ar, seg, dw)
+                lib.call("cg3d_spconv_pairs_wgrad", ptr(xc), ptr(dyc), ptr(ar), ptr(ar), ptr(seg), c_int64(nseg), ptr(dw),
+                         c_int32(1), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def linear(x, w, bias=None):
+    return LinearFunction.apply(x, w, bias)
+
+
 class GatherRowsFunction(torch.autograd.Function):
     """out = F[idx] with a scatter-add backward (atomics) instead of torch's sort-based index_put."""
 
@@ -870,9 +934,7 @@ class MinkowskiConvolution(_ConvBase):
             out_key = x.coordinate_map_key
         bias = self.bias.view(-1) if self.bias is not None else None
         if self.kernel_volume == 1 and coordinates is None and self.stride == 1:
-            out = x.F @ self.kernel  # plain GEMM (rocBLAS): a 1x1x1 convolution has no neighbourhood
-            if bias is not None:
-                out = out + bias
+            out = linear(x.F, self.kernel, bias)    # a 1x1x1 convolution has no neighbourhood
         else:
             km = mgr.kernel_map(x.coordinate_map_key, out_key, self.kernel_size, self.dilation, False)
             out = SparseConvFunction.apply(x.F, self._w3(), bias, km)

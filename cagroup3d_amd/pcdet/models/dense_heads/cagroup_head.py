@@ -282,11 +282,11 @@ class CAGroup3DHead(nn.Module):
 
         with torch.no_grad():
             rc = fb // B                                                   # class of every fine row
-        centerness = f @ self.centerness_conv.kernel
-        cls_score = f @ self.cls_conv.kernel + self.cls_conv.bias.view(1, -1)
+        centerness = ME.linear(f, self.centerness_conv.kernel)
+        cls_score = ME.linear(f, self.cls_conv.kernel, self.cls_conv.bias.view(-1))
         if self.force_class_logit_boost:
             cls_score = cls_score + torch.nn.functional.one_hot(rc, C).float() * self.force_class_logit_boost
-        reg = f @ self.reg_conv.kernel
+        reg = ME.linear(f, self.reg_conv.kernel)
         scale_vec = torch.stack([sc.scale for sc in self.scales])
         bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
         points = fine_C[:, 1:].float() * vs_tab[rc]

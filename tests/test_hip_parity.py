@@ -189,6 +189,32 @@ def test_spconv_output_stationary_bf16_matches_pair_form_oracle(oracle, hip, cin
         close(q, o, float(r.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,prec", [(64, 64, 0), (64, 3, 0), (128, 18, 0), (64, 64, 1), (256, 128, 1)])
+def test_linear_split_row_weight_gradient(oracle, hip, cin, cout, prec):
+    """1x1x1 convolutions: library GEMMs forward, the split-over-rows wgrad kernel backward == x^T @ dy."""
+    torch.manual_seed(cin + cout)
+    n = 20000
+    x, w, b, dy = torch.randn(n, cin), torch.randn(cin, cout) / cin ** 0.5, torch.randn(cout), torch.randn(n, cout)
+
+    def fn(x, w, b, dy):
+        x, w, b = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        me.PRECISION = prec
+        try:
+            y = me.linear(x, w, b)
+            (y * dy).sum().backward()
+        finally:
+            me.PRECISION = 0
+        return y.detach(), x.grad, w.grad, b.grad
+    ref, out = both(oracle, hip, fn, x, w, b, dy)
+    exact = (x.t().double() @ dy.double()).float()
+    for i, (r, o) in enumerate(zip(ref, out)):
+        if i == 2 and prec:
+            continue            # bf16 operands on the device only (the oracle side of this op is the fp32 GEMM)
+        close(r, o, float(r.abs().max()))
+    tol = (2e-2 if prec else 2e-4) * float(exact.abs().max())
+    assert (out[2].cpu() - exact).abs().max() <= tol
+
+
 def test_spconv_empty_and_tiny(oracle, hip):
     for n in (1, 2, 33):
         coords = rand_coords(n, batch=1, extent=2, seed=n, dup=0.0)
