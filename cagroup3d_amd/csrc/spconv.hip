@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
 // gathered (absent rows stage zeros without a load).  Software pipeline: the index column of offset
 // k+1 and the global loads of the next (offset, chunk) step are in flight during the current MFMAs.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__restrict__ X,
                                                                  const uint16_t *__restrict__ Wb,
                                                                  const int32_t *__restrict__ nbr,
@@ -500,75 +500,102 @@ __global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
-    // All loads are unconditional (clamped addresses, 32-bit element offsets from the kernel-argument
-    // bases); absent neighbours and channel tails are zeroed on the way into LDS.  A wave whose 32 rows
-    // have no neighbour at an offset skips its gather and its MFMAs for that offset (wave-uniform).
-    float4 areg[8];
-    uint4 wreg[NT];
-    uint32_t amask = 0, wmask = 0;
-    bool a_live = false;
-    auto issue_loads = [&](int32_t k, int32_t c0, int32_t idx, bool live) {
+    // Three-deep software pipeline over the (offset, 64-channel chunk) steps: while step s runs on the matrix
+    // pipe, the tiles of step s+1 move registers -> LDS and the global loads of step s+2 are in flight (two
+    // register sets), the index column of the offset after that is being fetched.  All loads are unconditional
+    // (clamped addresses, 32-bit element offsets) so that the waits are exact counts; absent neighbours and
+    // channel tails are zeroed on the way into LDS.  A wave whose 32 rows have no neighbour at an offset skips
+    // its LDS staging and its MFMAs for that offset (wave-uniform).
+    struct Regs {
+        float4 a[8];
+        uint4 w[NT];
+        uint32_t amask, wmask;
+    };
+    Regs set0, set1;
+    // element offsets (row * cin + this lane's column) of the 8 rows this lane stages, for the offset being issued;
+    // refreshed once per offset (8 cross-lane reads), reused by all of its channel chunks
+    uint32_t goff[8];
+    uint32_t gmask = 0;
+    auto set_rows = [&](int32_t idx) {
+        gmask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
+            goff[i] = g >= 0 ? (uint32_t)g * (uint32_t)cin + (uint32_t)gcol : 0u;
+            gmask |= g >= 0 ? (1u << i) : 0u;
+        }
+    };
+    auto issue_loads = [&](Regs &R, int32_t k, int32_t c0) {
         const uint16_t *wk = Wb + (int64_t)k * cin * cout;
-        wmask = 0;
+        R.wmask = 0;
+        const bool cok = c0 + gcol < cin;
+        R.amask = cok ? gmask : 0u;
+        const uint32_t cadd = cok ? (uint32_t)c0 : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) R.a[i] = *reinterpret_cast<const float4 *>(X + ((DBG & 4) ? 0u : goff[i] + cadd));
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int j = tid + i * 256;
             const int col = n0 + (j >> 3), cc = c0 + (j & 7) * 8;
             const bool ok = col < cout && cc < cin;
             const uint32_t off = ok ? (uint32_t)col * (uint32_t)cin + (uint32_t)cc : 0u;
-            wreg[i] = *reinterpret_cast<const uint4 *>(wk + off);
-            wmask |= ok ? (1u << i) : 0u;
-        }
-        a_live = live;
-        if (live) {
-            amask = 0;
-            const bool cok = c0 + gcol < cin;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
-                const bool ok = g >= 0 && cok;
-                const uint32_t off = ok ? (uint32_t)g * (uint32_t)cin + (uint32_t)(c0 + gcol) : 0u;
-                areg[i] = *reinterpret_cast<const float4 *>(X + off);
-                amask |= ok ? (1u << i) : 0u;
-            }
+            R.w[i] = *reinterpret_cast<const uint4 *>(wk + ((DBG & 8) ? 0u : off));
+            R.wmask |= ok ? (1u << i) : 0u;
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](const Regs &R, int buf, bool live) {
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int j = tid + i * 256;
-            const uint4 v = (wmask >> i) & 1u ? wreg[i] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 v = (R.wmask >> i) & 1u ? R.w[i] : make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4 *>(&Ws[buf][(j >> 3) * LP + (j & 7) * 8]) = v;
         }
-        if (a_live) {
+        if (live) {
             uint16_t *Aw = &As[buf][wave * 32 * LP];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float4 v = (amask >> i) & 1u ? areg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v = (R.amask >> i) & 1u ? R.a[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(v);
             }
         }
     };
-    int32_t idx_cur = row_ok ? nbr[row] : -1;
-    int32_t idx_next = (K > 1 && row_ok) ? nbr[n_out + row] : -1;
-    bool live_cur = __any(idx_cur >= 0);
-    issue_loads(0, 0, idx_cur, live_cur);
-    commit(0);
-    int32_t k = 0, c0 = 0;
-    for (int st = 0; st < nstep; st++) {
+    // index column of offset k for this lane's output row: unconditional load (clamped), masked at use
+    const int64_t row_c = row_ok ? row : n_out - 1;
+    auto load_idx = [&](int32_t k) -> int32_t { return nbr[(int64_t)(k < K ? k : K - 1) * n_out + row_c]; };
+    auto masked = [&](int32_t v) -> int32_t { return row_ok ? v : -1; };
+
+    // step t = (offset k, chunk c); (k2, c2) is the step being issued, (k3, c3) the one whose index column is fetched
+    int32_t idx_issue = masked(load_idx(0));
+    bool live0 = __any(idx_issue >= 0);                    // liveness of steps s, s+1, s+2
+    set_rows(idx_issue);
+    issue_loads(set0, 0, 0);
+    int32_t k2 = 0, c2 = 1;
+    if (c2 == nchunk) { c2 = 0; k2 = 1; }
+    idx_issue = masked(load_idx(k2));
+    bool live1 = __any(idx_issue >= 0);
+    int32_t k2n = k2, c2n = c2 + 1;                        // step 2
+    if (c2n == nchunk) { c2n = 0; k2n++; }
+    // same order of loads as the steady state (index column first, then the tile loads) so that the wait at the
+    // loop head is an exact count on both the entry and the back edge
+    int32_t idx_pre = load_idx(k2n);                       // column of step 2's offset
+    if (c2 == 0) set_rows(idx_issue);
+    issue_loads(set1, k2 < K ? k2 : K - 1, c2 * KC);
+    commit(set0, 0, live0);
+    k2 = k2n; c2 = c2n;
+    int32_t k3 = k2, c3 = c2 + 1;                          // step 3
+    if (c3 == nchunk) { c3 = 0; k3++; }
+    bool live2 = false;
+
+    auto iteration = [&](int st, Regs &Rissue, const Regs &Rcommit) {
         const int buf = st & 1;
-        const bool live = live_cur;
-        // the step after this one: same offset, next channel chunk -- or the first chunk of the next offset
-        int32_t kn = k, cn = c0 + KC;
-        if (cn >= cin) {
-            kn = k + 1; cn = 0;
-            idx_cur = idx_next;
-            live_cur = __any(idx_cur >= 0);
-            if (kn + 1 < K) idx_next = row_ok ? nbr[(int64_t)(kn + 1) * n_out + row] : -1;   // one offset ahead
-        }
-        if (st + 1 < nstep) issue_loads(kn, cn, idx_cur, live_cur);     // in flight during the MFMAs
+        idx_issue = masked(idx_pre);                       // column of step st+2's offset, fetched last iteration
+        idx_pre = load_idx(k3);                            // column of step st+3's offset
+        live2 = __any(idx_issue >= 0);
+        if (c2 == 0) set_rows(idx_issue);                  // step st+2 starts an offset
+        issue_loads(Rissue, k2 < K ? k2 : K - 1, c2 * KC);  // past the end: harmless re-read, never used
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (live) {
+        if (live0 && !(DBG & 1)) {
             const uint16_t *Aw = &As[buf][wave * 32 * LP];
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ks++) {
@@ -580,8 +607,189 @@ __global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__
                 }
             }
         }
-        if (st + 1 < nstep) commit(buf ^ 1);          // that buffer was last read before this step's barrier
-        k = kn; c0 = cn;
+        if (!(DBG & 2)) commit(Rcommit, buf ^ 1, live1);   // loaded one iteration ago (past the end: unused)
+        else if (st == 1000000) commit(Rcommit, buf ^ 1, live1);
+        live0 = live1; live1 = live2;
+        c2 = c3; k2 = k3;
+        c3++;
+        if (c3 == nchunk) { c3 = 0; k3++; }
+    };
+    for (int st = 0; st < nstep; st += 2) {
+        iteration(st, set0, set1);
+        if (st + 1 < nstep) iteration(st + 1, set1, set0);
+    }
+    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = n0 + nt * 32 + r;
+        if (col >= cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int64_t orow = row_base + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (orow < n_out) Y[orow * cout + col] = acc[nt][e] + bv;
+        }
+    }
+}
+
+// Wave-specialised form of the kernel above (512 threads): waves 4-7 only gather rows (global -> registers ->
+// bf16 -> LDS), waves 0-3 run the matrix pipe and move the (L2-resident, already bf16) weight tile.  In the
+// single-role kernel every wave walks through load-issue, LDS staging and MFMA phases one after the other and
+// with <= 2 waves per SIMD nothing overlaps them (measured: the phases add up); here the gather/convert/stage
+// work of step s+1 runs on other waves while step s is on the matrix pipe; one barrier per step.
+//   gather waves, step s:  stage the rows of step s+1 (gathered two steps ago; two register sets for the
+//                          long-latency gather), issue the gather of step s+3.
+//   matrix waves, step s:  issue the weight loads of step s+1, MFMAs of step s, stage those weights.
+template <int NT>
+__global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const float *__restrict__ X,
+                                                                    const uint16_t *__restrict__ Wb,
+                                                                    const int32_t *__restrict__ nbr,
+                                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                                    int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+    constexpr int CT = NT * 32;
+    constexpr int KC = 64;
+    constexpr int LP = KC + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][128 * LP];
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[2][CT * LP];
+    __shared__ int32_t live_s[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.y * CT;
+    const int nchunk = (cin + KC - 1) / KC;
+    const int nstep = K * nchunk;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ gather waves
+        const int pw = wave - 4;
+        const int64_t row = (int64_t)blockIdx.x * 128 + pw * 32 + r;
+        const bool row_ok = row < n_out;
+        const int64_t row_c = row_ok ? row : n_out - 1;
+        const int gcol = (lane & 15) * 4;
+        struct ASet { float4 a[8]; uint32_t amask; };
+        ASet s0, s1;
+        uint32_t gmask = 0;
+        uint32_t goff[8];
+        auto set_rows = [&](int32_t idx) {
+            gmask = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
+                goff[i] = g >= 0 ? (uint32_t)g * (uint32_t)cin + (uint32_t)gcol : 0u;
+                gmask |= g >= 0 ? (1u << i) : 0u;
+            }
+        };
+        auto issue_a = [&](ASet &S, int32_t c0) {
+            const bool cok = c0 + gcol < cin;
+            S.amask = cok ? gmask : 0u;
+            const uint32_t cadd = cok ? (uint32_t)c0 : 0u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) S.a[i] = *reinterpret_cast<const float4 *>(X + (goff[i] + cadd));
+        };
+        auto commit = [&](const ASet &S, int buf, bool live) {
+            if (lane == 0) live_s[buf][pw] = live ? 1 : 0;
+            if (live) {
+                uint16_t *Aw = &As[buf][pw * 32 * LP];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 v = (S.amask >> i) & 1u ? S.a[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(v);
+                }
+            }
+        };
+        auto load_idx = [&](int32_t k) -> int32_t { return nbr[(int64_t)(k < K ? k : K - 1) * n_out + row_c]; };
+        auto masked = [&](int32_t v) -> int32_t { return row_ok ? v : -1; };
+        int32_t kq = 0, cq = 0;                       // (kq, cq): the step gathered next
+        auto advance = [&]() { cq++; if (cq == nchunk) { cq = 0; kq++; } };
+
+        // prologue: step 0 staged; rows of steps 1 and 2 in flight
+        int32_t idx = masked(load_idx(0));
+        bool lg = __any(idx >= 0);
+        set_rows(idx);
+        issue_a(s0, 0);
+        const bool L0 = lg;
+        advance();                                    // step 1
+        if (cq == 0) { idx = masked(load_idx(kq)); lg = __any(idx >= 0); set_rows(idx); }
+        issue_a(s1, cq * KC);
+        bool La = lg;                                 // liveness of the step staged next
+        commit(s0, 0, L0);
+        advance();                                    // step 2
+        if (cq == 0) { idx = masked(load_idx(kq)); lg = __any(idx >= 0); set_rows(idx); }
+        issue_a(s0, cq * KC);
+        bool Lb = lg, Lc = lg;
+        advance();                                    // step 3
+        int32_t idx_pre = load_idx(kq);
+        __syncthreads();
+
+        auto iteration = [&](int st, ASet &S) {
+            // the matrix waves are on step st; S holds the rows of step st+1
+            commit(S, (st + 1) & 1, La);
+            if (cq == 0) { idx = masked(idx_pre); lg = __any(idx >= 0); set_rows(idx); }
+            issue_a(S, cq * KC);                      // rows of step st+3 (past the end: clamped, unused)
+            Lc = lg;
+            advance();
+            idx_pre = load_idx(kq);                   // index column of the offset of step st+4
+            La = Lb; Lb = Lc;
+            __syncthreads();
+        };
+        for (int st = 0; st < nstep; st += 2) {
+            iteration(st, s1);
+            if (st + 1 < nstep) iteration(st + 1, s0);
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- matrix waves
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+    uint4 w[NT];
+    uint32_t wmask = 0;
+    auto issue_w = [&](int32_t k, int32_t c0) {
+        const uint16_t *wk = Wb + (int64_t)(k < K ? k : K - 1) * cin * cout;   // past the end: unused re-read
+        wmask = 0;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const int col = n0 + (j >> 3), cc = c0 + (j & 7) * 8;
+            const bool ok = col < cout && cc < cin;
+            const uint32_t off = ok ? (uint32_t)col * (uint32_t)cin + (uint32_t)cc : 0u;
+            w[i] = *reinterpret_cast<const uint4 *>(wk + off);
+            wmask |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto commit_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const uint4 v = (wmask >> i) & 1u ? w[i] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(&Ws[buf][(j >> 3) * LP + (j & 7) * 8]) = v;
+        }
+    };
+    int32_t kw = 0, cw = 0;
+    issue_w(0, 0);
+    commit_w(0);
+    __syncthreads();                                               // step 0 staged
+    for (int st = 0; st < nstep; st++) {
+        const int buf = st & 1;
+        cw++;
+        if (cw == nchunk) { cw = 0; kw++; }
+        issue_w(kw, cw * KC);                                      // weights of step st+1, in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (live_s[buf][wave]) {
+            const uint16_t *Aw = &As[buf][wave * 32 * LP];
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ks++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[buf][(nt * 32 + r) * LP + ks * 16 + kg * 8]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        commit_w(buf ^ 1);
+        __syncthreads();
     }
     const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
 #pragma unroll
@@ -1089,6 +1297,28 @@ extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nb
 #define LAUNCH_IB(NT)                                                                                           \
     hipLaunchKernelGGL((k_spconv_implicit_bf16<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, Wb, \
                        nbr, bias, Y, n_out, K, cin, cout)
+        static const int dbg = getenv("CG3D_DBG_IMPL") ? atoi(getenv("CG3D_DBG_IMPL")) : 0;
+        if (dbg && cout > 64) {
+#define LAUNCH_IBD(D)                                                                                            \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16<4, D>), dim3(gx, (unsigned)cg3d_divup(cout, 128)), dim3(256), 0, s, X, Wb, \
+                       nbr, bias, Y, n_out, K, cin, cout)
+            if (dbg == 1) LAUNCH_IBD(1); else if (dbg == 2) LAUNCH_IBD(2); else if (dbg == 3) LAUNCH_IBD(3);
+            else if (dbg == 4) LAUNCH_IBD(4); else if (dbg == 8) LAUNCH_IBD(8); else if (dbg == 12) LAUNCH_IBD(12);
+            else LAUNCH_IBD(15);
+#undef LAUNCH_IBD
+            CG3D_CHECK_LAUNCH();
+            return CG3D_OK;
+        }
+        static const int ws_form = getenv("CG3D_IMPL_WS") ? atoi(getenv("CG3D_IMPL_WS")) : 1;
+        if (ws_form) {
+#define LAUNCH_WS(NT)                                                                                           \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(512), 0, s, X, \
+                       Wb, nbr, bias, Y, n_out, K, cin, cout)
+            if (cout > 64) LAUNCH_WS(4); else if (cout > 32) LAUNCH_WS(2); else LAUNCH_WS(1);
+#undef LAUNCH_WS
+            CG3D_CHECK_LAUNCH();
+            return CG3D_OK;
+        }
         if (cout > 64) LAUNCH_IB(4); else if (cout > 32) LAUNCH_IB(2); else LAUNCH_IB(1);
 #undef LAUNCH_IB
         CG3D_CHECK_LAUNCH();
