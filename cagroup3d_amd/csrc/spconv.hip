@@ -351,6 +351,51 @@ __device__ static inline uint32_t pack2bf(float a, float b) {
 }
 __device__ static inline uint2 pack4bf(float4 v) { return make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
 
+// Four consecutive channels of a gathered row, as they travel global -> registers -> LDS (bf16):
+// fp32 rows (precision 1: 16-byte load, rounded on the way into LDS) or rows already stored as bf16
+// (precision 2: 8-byte load, no conversion -- half the gather traffic).
+template <typename XT> struct Row4;
+template <> struct Row4<float> {
+    typedef float4 T;
+    __device__ static inline uint2 bf(const T &v) { return pack4bf(v); }
+    __device__ static inline T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct Row4<uint16_t> {
+    typedef uint2 T;
+    __device__ static inline uint2 bf(const T &v) { return v; }
+    __device__ static inline T zero() { return make_uint2(0u, 0u); }
+};
+
+// How a gather wave of the output-stationary kernel fetches its 32 rows x 64 channels per step: fp32 rows as
+// 8 loads of 16 B (16 lanes per 256-byte row chunk), bf16 rows as 4 loads of 16 B (8 lanes per 128-byte chunk) --
+// the gather is bound by the number of outstanding requests, so the bf16 rows halve its cost.
+template <typename XT> struct Gather;
+template <> struct Gather<float> {
+    typedef float4 T;
+    static constexpr int NL = 8, ROWS = 4, LPR = 16, CH = 4;       // loads, rows per load, lanes per row, channels per lane
+    __device__ static inline void stage(uint16_t *dst, const T &v) { *reinterpret_cast<uint2 *>(dst) = pack4bf(v); }
+    __device__ static inline T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct Gather<uint16_t> {
+    typedef uint4 T;
+    static constexpr int NL = 4, ROWS = 8, LPR = 8, CH = 8;
+    __device__ static inline void stage(uint16_t *dst, const T &v) { *reinterpret_cast<uint4 *>(dst) = v; }
+    __device__ static inline T zero() { return make_uint4(0u, 0u, 0u, 0u); }
+};
+
+__global__ void k_to_bf16(const float4 *__restrict__ X, uint2 *__restrict__ Xb, int64_t n4) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < n4) Xb[t] = pack4bf(X[t]);
+}
+extern "C" int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t stream) {
+    if (n < 0 || (n & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Xb & 7)) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)cg3d_divup(n / 4, 256)), dim3(256), 0, cg3d_hs(stream),
+                       reinterpret_cast<const float4 *>(X), reinterpret_cast<uint2 *>(Xb), n / 4);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
 __global__ void k_prep_weights_bf16(const float *__restrict__ W, uint16_t *__restrict__ Wb, int64_t slots, int32_t cin,
                                     int32_t cout) {
     // Wb[s][co][ci] = bf16(W[s][ci][co]); thread per output element, reads strided (weights are small)
@@ -372,8 +417,8 @@ extern "C" int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64
     return CG3D_OK;
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__restrict__ X, const uint16_t *__restrict__ Wb,
+template <int NT, typename XT>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const XT *__restrict__ X, const uint16_t *__restrict__ Wb,
                                                               const int32_t *__restrict__ pin,
                                                               const int32_t *__restrict__ pout,
                                                               const int32_t *__restrict__ seg, float *__restrict__ Y,
@@ -406,7 +451,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
     for (int i = 0; i < 8; i++) grow[i] = __shfl(irow, 4 * i + (lane >> 4));
     const int gcol = (lane & 15) * 4;
 
-    float4 areg[8];
+    typedef typename Row4<XT>::T RowT;
+    RowT areg[8];
     uint4 wreg[NT];
     auto issue_loads = [&](int32_t c0) {
 #pragma unroll
@@ -420,9 +466,9 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            RowT v = Row4<XT>::zero();
             if (grow[i] >= 0 && c0 + gcol < cin)
-                v = *reinterpret_cast<const float4 *>(X + (int64_t)grow[i] * cin + c0 + gcol);
+                v = *reinterpret_cast<const RowT *>(X + (int64_t)grow[i] * cin + c0 + gcol);
             areg[i] = v;
         }
     };
@@ -436,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(areg[i]);
+            *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = Row4<XT>::bf(areg[i]);
         __syncthreads();
         if (c0 + KC < cin) issue_loads(c0 + KC);
         if (wave_active) {
@@ -470,178 +516,18 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const float *__res
 // keeps the accumulators in registers; every output row is written once with a plain coalesced store
 // (no atomics, no zero-fill, deterministic).  With bf16 MFMA the padding work on absent neighbours is
 // free (the matrix pipe idles anyway) while the atomic scatter of the pair form was its biggest cost
-// at the neighbourhood occupancies of the tensor-stride >= 4 maps.  Only present neighbours are
-// gathered (absent rows stage zeros without a load).  Software pipeline: the index column of offset
-// k+1 and the global loads of the next (offset, chunk) step are in flight during the current MFMAs.
+// at the neighbourhood occupancies of the tensor-stride >= 4 maps.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_spconv_implicit_bf16(const float *__restrict__ X,
-                                                                 const uint16_t *__restrict__ Wb,
-                                                                 const int32_t *__restrict__ nbr,
-                                                                 const float *__restrict__ bias, float *__restrict__ Y,
-                                                                 int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
-    constexpr int CT = NT * 32;
-    constexpr int KC = 64;
-    constexpr int LP = KC + 8;
-    __shared__ __attribute__((aligned(16))) uint16_t As[2][128 * LP];
-    __shared__ __attribute__((aligned(16))) uint16_t Ws[2][CT * LP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, kg = lane >> 5;
-    const int n0 = blockIdx.y * CT;
-    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + r;
-    const bool row_ok = row < n_out;
-    const int gcol = (lane & 15) * 4;
-    const int nchunk = (cin + KC - 1) / KC;
-    const int nstep = K * nchunk;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
-
-    // Three-deep software pipeline over the (offset, 64-channel chunk) steps: while step s runs on the matrix
-    // pipe, the tiles of step s+1 move registers -> LDS and the global loads of step s+2 are in flight (two
-    // register sets), the index column of the offset after that is being fetched.  All loads are unconditional
-    // (clamped addresses, 32-bit element offsets) so that the waits are exact counts; absent neighbours and
-    // channel tails are zeroed on the way into LDS.  A wave whose 32 rows have no neighbour at an offset skips
-    // its LDS staging and its MFMAs for that offset (wave-uniform).
-    struct Regs {
-        float4 a[8];
-        uint4 w[NT];
-        uint32_t amask, wmask;
-    };
-    Regs set0, set1;
-    // element offsets (row * cin + this lane's column) of the 8 rows this lane stages, for the offset being issued;
-    // refreshed once per offset (8 cross-lane reads), reused by all of its channel chunks
-    uint32_t goff[8];
-    uint32_t gmask = 0;
-    auto set_rows = [&](int32_t idx) {
-        gmask = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
-            goff[i] = g >= 0 ? (uint32_t)g * (uint32_t)cin + (uint32_t)gcol : 0u;
-            gmask |= g >= 0 ? (1u << i) : 0u;
-        }
-    };
-    auto issue_loads = [&](Regs &R, int32_t k, int32_t c0) {
-        const uint16_t *wk = Wb + (int64_t)k * cin * cout;
-        R.wmask = 0;
-        const bool cok = c0 + gcol < cin;
-        R.amask = cok ? gmask : 0u;
-        const uint32_t cadd = cok ? (uint32_t)c0 : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; i++) R.a[i] = *reinterpret_cast<const float4 *>(X + ((DBG & 4) ? 0u : goff[i] + cadd));
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const int j = tid + i * 256;
-            const int col = n0 + (j >> 3), cc = c0 + (j & 7) * 8;
-            const bool ok = col < cout && cc < cin;
-            const uint32_t off = ok ? (uint32_t)col * (uint32_t)cin + (uint32_t)cc : 0u;
-            R.w[i] = *reinterpret_cast<const uint4 *>(wk + ((DBG & 8) ? 0u : off));
-            R.wmask |= ok ? (1u << i) : 0u;
-        }
-    };
-    auto commit = [&](const Regs &R, int buf, bool live) {
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const int j = tid + i * 256;
-            const uint4 v = (R.wmask >> i) & 1u ? R.w[i] : make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4 *>(&Ws[buf][(j >> 3) * LP + (j & 7) * 8]) = v;
-        }
-        if (live) {
-            uint16_t *Aw = &As[buf][wave * 32 * LP];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float4 v = (R.amask >> i) & 1u ? R.a[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(v);
-            }
-        }
-    };
-    // index column of offset k for this lane's output row: unconditional load (clamped), masked at use
-    const int64_t row_c = row_ok ? row : n_out - 1;
-    auto load_idx = [&](int32_t k) -> int32_t { return nbr[(int64_t)(k < K ? k : K - 1) * n_out + row_c]; };
-    auto masked = [&](int32_t v) -> int32_t { return row_ok ? v : -1; };
-
-    // step t = (offset k, chunk c); (k2, c2) is the step being issued, (k3, c3) the one whose index column is fetched
-    int32_t idx_issue = masked(load_idx(0));
-    bool live0 = __any(idx_issue >= 0);                    // liveness of steps s, s+1, s+2
-    set_rows(idx_issue);
-    issue_loads(set0, 0, 0);
-    int32_t k2 = 0, c2 = 1;
-    if (c2 == nchunk) { c2 = 0; k2 = 1; }
-    idx_issue = masked(load_idx(k2));
-    bool live1 = __any(idx_issue >= 0);
-    int32_t k2n = k2, c2n = c2 + 1;                        // step 2
-    if (c2n == nchunk) { c2n = 0; k2n++; }
-    // same order of loads as the steady state (index column first, then the tile loads) so that the wait at the
-    // loop head is an exact count on both the entry and the back edge
-    int32_t idx_pre = load_idx(k2n);                       // column of step 2's offset
-    if (c2 == 0) set_rows(idx_issue);
-    issue_loads(set1, k2 < K ? k2 : K - 1, c2 * KC);
-    commit(set0, 0, live0);
-    k2 = k2n; c2 = c2n;
-    int32_t k3 = k2, c3 = c2 + 1;                          // step 3
-    if (c3 == nchunk) { c3 = 0; k3++; }
-    bool live2 = false;
-
-    auto iteration = [&](int st, Regs &Rissue, const Regs &Rcommit) {
-        const int buf = st & 1;
-        idx_issue = masked(idx_pre);                       // column of step st+2's offset, fetched last iteration
-        idx_pre = load_idx(k3);                            // column of step st+3's offset
-        live2 = __any(idx_issue >= 0);
-        if (c2 == 0) set_rows(idx_issue);                  // step st+2 starts an offset
-        issue_loads(Rissue, k2 < K ? k2 : K - 1, c2 * KC);  // past the end: harmless re-read, never used
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (live0 && !(DBG & 1)) {
-            const uint16_t *Aw = &As[buf][wave * 32 * LP];
-#pragma unroll
-            for (int ks = 0; ks < KC / 16; ks++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Aw[r * LP + ks * 16 + kg * 8]);
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[buf][(nt * 32 + r) * LP + ks * 16 + kg * 8]);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
-                }
-            }
-        }
-        if (!(DBG & 2)) commit(Rcommit, buf ^ 1, live1);   // loaded one iteration ago (past the end: unused)
-        else if (st == 1000000) commit(Rcommit, buf ^ 1, live1);
-        live0 = live1; live1 = live2;
-        c2 = c3; k2 = k3;
-        c3++;
-        if (c3 == nchunk) { c3 = 0; k3++; }
-    };
-    for (int st = 0; st < nstep; st += 2) {
-        iteration(st, set0, set1);
-        if (st + 1 < nstep) iteration(st + 1, set1, set0);
-    }
-    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int col = n0 + nt * 32 + r;
-        if (col >= cout) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int64_t orow = row_base + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (orow < n_out) Y[orow * cout + col] = acc[nt][e] + bv;
-        }
-    }
-}
-
-// Wave-specialised form of the kernel above (512 threads): waves 4-7 only gather rows (global -> registers ->
+// Wave-specialised (512 threads): waves 4-7 only gather rows (global -> registers ->
 // bf16 -> LDS), waves 0-3 run the matrix pipe and move the (L2-resident, already bf16) weight tile.  In the
-// single-role kernel every wave walks through load-issue, LDS staging and MFMA phases one after the other and
-// with <= 2 waves per SIMD nothing overlaps them (measured: the phases add up); here the gather/convert/stage
+// first, single-role version of this kernel every wave walked through load-issue, LDS staging and MFMA phases one after the other and
+// with <= 2 waves per SIMD nothing overlapped them (measured: the phases added up); here the gather/convert/stage
 // work of step s+1 runs on other waves while step s is on the matrix pipe; one barrier per step.
 //   gather waves, step s:  stage the rows of step s+1 (gathered two steps ago; two register sets for the
 //                          long-latency gather), issue the gather of step s+3.
 //   matrix waves, step s:  issue the weight loads of step s+1, MFMAs of step s, stage those weights.
-template <int NT>
-__global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const float *__restrict__ X,
+template <int NT, typename XT>
+__global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__restrict__ X,
                                                                     const uint16_t *__restrict__ Wb,
                                                                     const int32_t *__restrict__ nbr,
                                                                     const float *__restrict__ bias, float *__restrict__ Y,
@@ -664,16 +550,18 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const float 
         const int64_t row = (int64_t)blockIdx.x * 128 + pw * 32 + r;
         const bool row_ok = row < n_out;
         const int64_t row_c = row_ok ? row : n_out - 1;
-        const int gcol = (lane & 15) * 4;
-        struct ASet { float4 a[8]; uint32_t amask; };
+        typedef Gather<XT> G;
+        typedef typename G::T RowT;
+        const int gcol = (lane % G::LPR) * G::CH, grow = lane / G::LPR;
+        struct ASet { RowT a[G::NL]; uint32_t amask; };
         ASet s0, s1;
         uint32_t gmask = 0;
-        uint32_t goff[8];
+        uint32_t goff[G::NL];
         auto set_rows = [&](int32_t idx) {
             gmask = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int32_t g = __shfl(idx, 4 * i + (lane >> 4));
+            for (int i = 0; i < G::NL; i++) {
+                const int32_t g = __shfl(idx, G::ROWS * i + grow);
                 goff[i] = g >= 0 ? (uint32_t)g * (uint32_t)cin + (uint32_t)gcol : 0u;
                 gmask |= g >= 0 ? (1u << i) : 0u;
             }
@@ -683,16 +571,16 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const float 
             S.amask = cok ? gmask : 0u;
             const uint32_t cadd = cok ? (uint32_t)c0 : 0u;
 #pragma unroll
-            for (int i = 0; i < 8; i++) S.a[i] = *reinterpret_cast<const float4 *>(X + (goff[i] + cadd));
+            for (int i = 0; i < G::NL; i++) S.a[i] = *reinterpret_cast<const RowT *>(X + (goff[i] + cadd));
         };
         auto commit = [&](const ASet &S, int buf, bool live) {
             if (lane == 0) live_s[buf][pw] = live ? 1 : 0;
             if (live) {
                 uint16_t *Aw = &As[buf][pw * 32 * LP];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 v = (S.amask >> i) & 1u ? S.a[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<uint2 *>(&Aw[(4 * i + (lane >> 4)) * LP + gcol]) = pack4bf(v);
+                for (int i = 0; i < G::NL; i++) {
+                    const RowT v = (S.amask >> i) & 1u ? S.a[i] : G::zero();
+                    G::stage(&Aw[(G::ROWS * i + grow) * LP + gcol], v);
                 }
             }
         };
@@ -888,22 +776,26 @@ extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32
                                      int32_t cin, int32_t cout, int32_t precision, int32_t accumulate,
                                      cg3d_stream_t stream) {
     if (n_out < 0 || nseg < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
+    if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (n_out == 0) return CG3D_OK;
     const int64_t total = n_out * cout;
-    if (precision == 1 && (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))) return CG3D_ERR_ARG;
+    if (precision >= 1 && (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))) return CG3D_ERR_ARG;
     if (!accumulate) {
         if (bias) hipLaunchKernelGGL(k_init_rows, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, Y, bias, total, cout);
         else if (hipMemsetAsync(Y, 0, total * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     }
     if (nseg == 0) return CG3D_OK;
-    if (precision == 1) {     // W is the prepared bf16 [slot][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
+    if (precision >= 1) {     // W is the prepared bf16 [slot][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
         const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
-#define LAUNCH_BF(NT)                                                                                              \
-    hipLaunchKernelGGL((k_spconv_pairs_bf16<NT>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, \
-                       X, Wb, pair_in, pair_out, seg, Y, cin, cout)
-        if (cout > 64) LAUNCH_BF(4); else if (cout > 32) LAUNCH_BF(2); else LAUNCH_BF(1);
+#define LAUNCH_BF(NT, XT)                                                                                          \
+    hipLaunchKernelGGL((k_spconv_pairs_bf16<NT, XT>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, \
+                       s, reinterpret_cast<const XT *>(X), Wb, pair_in, pair_out, seg, Y, cin, cout)
+        if (precision == 1) {
+            if (cout > 64) LAUNCH_BF(4, float); else if (cout > 32) LAUNCH_BF(2, float); else LAUNCH_BF(1, float);
+        } else {              // X is bf16 [n_in][cin] (cg3d_to_bf16)
+            if (cout > 64) LAUNCH_BF(4, uint16_t); else if (cout > 32) LAUNCH_BF(2, uint16_t); else LAUNCH_BF(1, uint16_t);
+        }
 #undef LAUNCH_BF
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;
@@ -1129,9 +1021,24 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_t128(const float 
 // spread over the banks); the MFMA fragments are then single 16-byte LDS reads.
 #define WB_S 64            // pairs per stage
 #define WB_LD 72           // padded LDS row (bf16): 144 B
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float *__restrict__ X,
-                                                                    const float *__restrict__ dY,
+// 4 pairs x 4 channels -> four [channel][4 pairs] bf16 rows (8 bytes each)
+__device__ static inline void transpose4x4bf(const float4 *v, uint2 *o) {
+    o[0] = pack4bf(make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    o[1] = pack4bf(make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+    o[2] = pack4bf(make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+    o[3] = pack4bf(make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+}
+__device__ static inline void transpose4x4bf(const uint2 *v, uint2 *o) {   // rows already bf16: byte permutes only
+    constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;                // (low halves of b, a), (high halves of b, a)
+    o[0] = make_uint2(__builtin_amdgcn_perm(v[1].x, v[0].x, LO), __builtin_amdgcn_perm(v[3].x, v[2].x, LO));
+    o[1] = make_uint2(__builtin_amdgcn_perm(v[1].x, v[0].x, HI), __builtin_amdgcn_perm(v[3].x, v[2].x, HI));
+    o[2] = make_uint2(__builtin_amdgcn_perm(v[1].y, v[0].y, LO), __builtin_amdgcn_perm(v[3].y, v[2].y, LO));
+    o[3] = make_uint2(__builtin_amdgcn_perm(v[1].y, v[0].y, HI), __builtin_amdgcn_perm(v[3].y, v[2].y, HI));
+}
+
+template <int TM, int TN, typename ST, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__restrict__ X,
+                                                                    const ST *__restrict__ dY,
                                                                     const int32_t *__restrict__ pin,
                                                                     const int32_t *__restrict__ pout,
                                                                     const int32_t *__restrict__ seg,
@@ -1139,6 +1046,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
                                                                     int32_t co_tiles) {
     __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
+    typedef typename Row4<ST>::T RowT;
     constexpr int XT = TM / 4, DT = TN / 4;              // threads per gathered row
     constexpr int XP = 16 / (256 / XT), DP = 16 / (256 / DT);   // passes over the 16 pair quads of a stage
     constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 tiles per wave
@@ -1158,9 +1066,9 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
 
     const int xc4 = (tid % XT) * 4, dc4 = (tid % DT) * 4;
     const bool xin = ci0 + xc4 < cin, din = co0 + dc4 < cout;       // cin, cout are multiples of 4 here
-    const float *xbase = X + (xin ? ci0 + xc4 : 0);
-    const float *dbase = dY + (din ? co0 + dc4 : 0);
-    float4 xr[XP][4], dr[DP][4];
+    const ST *xbase = X + (xin ? ci0 + xc4 : 0);
+    const ST *dbase = dY + (din ? co0 + dc4 : 0);
+    RowT xr[XP][4], dr[DP][4];
     auto issue = [&](int32_t p0) {
 #pragma unroll
         for (int ps = 0; ps < XP; ps++) {
@@ -1169,8 +1077,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
             for (int i = 0; i < 4; i++) {
                 const int32_t p = p0 + 4 * q + i;
                 const int32_t pp = p < count ? p : count - 1;      // clamped, unconditional (masked below)
-                const float4 a = *reinterpret_cast<const float4 *>(xbase + (int64_t)pin[start + pp] * cin);
-                xr[ps][i] = (p < count && xin) ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+                const RowT a = *reinterpret_cast<const RowT *>(xbase + ((DBG & 4) ? 0 : (int64_t)pin[start + pp] * cin));
+                xr[ps][i] = (p < count && xin) ? a : Row4<ST>::zero();
             }
         }
 #pragma unroll
@@ -1180,18 +1088,17 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
             for (int i = 0; i < 4; i++) {
                 const int32_t p = p0 + 4 * q + i;
                 const int32_t pp = p < count ? p : count - 1;
-                const float4 b = *reinterpret_cast<const float4 *>(dbase + (int64_t)pout[start + pp] * cout);
-                dr[ps][i] = (p < count && din) ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+                const RowT b = *reinterpret_cast<const RowT *>(dbase + ((DBG & 4) ? 0 : (int64_t)pout[start + pp] * cout));
+                dr[ps][i] = (p < count && din) ? b : Row4<ST>::zero();
             }
         }
     };
-    // 4 pairs x 4 channels -> four 8-byte rows [channel][4 pairs]
-    auto put = [&](uint16_t *T, int c4, int q, const float4 *v) {
+    auto put = [&](uint16_t *T, int c4, int q, const RowT *v) {
         const int col = (((q >> 1) ^ ((c4 >> 4) & 7)) << 3) + ((q & 1) << 2);
-        *reinterpret_cast<uint2 *>(&T[(c4 + 0) * WB_LD + col]) = pack4bf(make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
-        *reinterpret_cast<uint2 *>(&T[(c4 + 1) * WB_LD + col]) = pack4bf(make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
-        *reinterpret_cast<uint2 *>(&T[(c4 + 2) * WB_LD + col]) = pack4bf(make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
-        *reinterpret_cast<uint2 *>(&T[(c4 + 3) * WB_LD + col]) = pack4bf(make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+        uint2 o[4];
+        transpose4x4bf(v, o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<uint2 *>(&T[(c4 + j) * WB_LD + col]) = o[j];
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -1206,6 +1113,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
     for (int st = 0; st < nstage; st++) {
         const int buf = st & 1;
         if (st + 1 < nstage) issue((st + 1) * WB_S);            // in flight during the MFMAs
+        if (!(DBG & 1))
 #pragma unroll
         for (int kk = 0; kk < WB_S / 16; kk++) {
             bf16x8 a[MI], b[NJ];
@@ -1225,7 +1133,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
                 for (int j = 0; j < NJ; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (st + 1 < nstage) commit(buf ^ 1);                   // the other buffer was last read two stages ago
+        if (st + 1 < nstage && (!(DBG & 2) || st == 1000000)) commit(buf ^ 1);   // the other buffer was last read two stages ago
         __syncthreads();
     }
     float *dst = dW + (int64_t)k * cin * cout;
@@ -1237,7 +1145,151 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
             for (int e = 0; e < 16; e++) {
                 const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int co = co0 + wj * (TN / 2) + j * 32 + r;
-                if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+                if (ci < cin && co < cout && (!(DBG & 8) || acc[i][j][e] == 12345.f)) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+            }
+}
+
+// Weight gradient over rows stored as bf16 (precision 2).  The gather of this kernel is bound by the NUMBER of
+// outstanding row requests, not by bytes (measured: halving the bytes per request changed nothing, removing the
+// address scatter made it 3x faster), so every lane fetches 16 bytes = 8 channels here and a stage needs half
+// the requests of the fp32-row kernel; the next TWO stages are kept in flight.  A thread transposes
+// PQ pairs x 8 channels (PQ = 4 for a 128-channel operand tile, 2 for a 64-channel one) into the [channel][pair]
+// LDS layout of k_spconv_pairs_wgrad_bf16; the MFMA phase is the same.
+template <int T> struct WRows {
+    static constexpr int TPR = T / 8;              // threads per gathered row
+    static constexpr int PQ = TPR / 4;             // pairs per thread per stage (64 pairs / (256 / TPR) threads)
+    uint4 v[PQ];
+};
+template <int TM, int TN, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint16_t *__restrict__ X,
+                                                                      const uint16_t *__restrict__ dY,
+                                                                      const int32_t *__restrict__ pin,
+                                                                      const int32_t *__restrict__ pout,
+                                                                      const int32_t *__restrict__ seg,
+                                                                      float *__restrict__ dW, int32_t cin, int32_t cout,
+                                                                      int32_t co_tiles) {
+    __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
+    constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 tiles per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    const int ci0 = (blockIdx.y / co_tiles) * TM, co0 = (blockIdx.y % co_tiles) * TN;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    constexpr int XTPR = WRows<TM>::TPR, XPQ = WRows<TM>::PQ, DTPR = WRows<TN>::TPR, DPQ = WRows<TN>::PQ;
+    const int xc8 = (tid % XTPR) * 8, xp0 = (tid / XTPR) * XPQ;
+    const int dc8 = (tid % DTPR) * 8, dp0 = (tid / DTPR) * DPQ;
+    const bool xin = ci0 + xc8 < cin, din = co0 + dc8 < cout;       // cin, cout are multiples of 8 here
+    const uint16_t *xbase = X + (xin ? ci0 + xc8 : 0);
+    const uint16_t *dbase = dY + (din ? co0 + dc8 : 0);
+    auto issue = [&](WRows<TM> &xr, WRows<TN> &dr, int32_t p0) {
+#pragma unroll
+        for (int i = 0; i < XPQ; i++) {
+            const int32_t p = p0 + xp0 + i;
+            const int32_t pp = p < count ? p : count - 1;           // clamped, unconditional (masked below)
+            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + ((DBG & 4) ? 0 : (int64_t)pin[start + pp] * cin));
+            xr.v[i] = (p < count && xin) ? a : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < DPQ; i++) {
+            const int32_t p = p0 + dp0 + i;
+            const int32_t pp = p < count ? p : count - 1;
+            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + ((DBG & 4) ? 0 : (int64_t)pout[start + pp] * cout));
+            dr.v[i] = (p < count && din) ? b : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    // PQ pairs x 8 channels -> eight [channel][PQ pairs] rows
+    constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;
+    auto put4 = [&](uint16_t *Tl, int c8, int p0, const uint4 *v) {
+        const int col = (((p0 >> 3) ^ ((c8 >> 4) & 7)) << 3) + (p0 & 7);
+        const uint32_t w0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, w1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+        const uint32_t w2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, w3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            *reinterpret_cast<uint2 *>(&Tl[(c8 + 2 * q) * WB_LD + col]) =
+                make_uint2(__builtin_amdgcn_perm(w1[q], w0[q], LO), __builtin_amdgcn_perm(w3[q], w2[q], LO));
+            *reinterpret_cast<uint2 *>(&Tl[(c8 + 2 * q + 1) * WB_LD + col]) =
+                make_uint2(__builtin_amdgcn_perm(w1[q], w0[q], HI), __builtin_amdgcn_perm(w3[q], w2[q], HI));
+        }
+    };
+    auto put2 = [&](uint16_t *Tl, int c8, int p0, const uint4 *v) {
+        const int col = (((p0 >> 3) ^ ((c8 >> 4) & 7)) << 3) + (p0 & 7);
+        const uint32_t w0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, w1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            *reinterpret_cast<uint32_t *>(&Tl[(c8 + 2 * q) * WB_LD + col]) = __builtin_amdgcn_perm(w1[q], w0[q], LO);
+            *reinterpret_cast<uint32_t *>(&Tl[(c8 + 2 * q + 1) * WB_LD + col]) = __builtin_amdgcn_perm(w1[q], w0[q], HI);
+        }
+    };
+    auto commit = [&](const WRows<TM> &xr, const WRows<TN> &dr, int buf) {
+        if (DBG & 2) return;
+        if (XPQ == 4) put4(Xs[buf], xc8, xp0, xr.v); else put2(Xs[buf], xc8, xp0, xr.v);
+        if (DPQ == 4) put4(Ds[buf], dc8, dp0, dr.v); else put2(Ds[buf], dc8, dp0, dr.v);
+    };
+    auto mfma_stage = [&](int buf) {
+        if (DBG & 1) return;
+#pragma unroll
+        for (int kk = 0; kk < WB_S / 16; kk++) {
+            bf16x8 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                const int row = wi * (TM / 2) + i * 32 + r;
+                a[i] = *reinterpret_cast<const bf16x8 *>(&Xs[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int row = wj * (TN / 2) + j * 32 + r;
+                b[j] = *reinterpret_cast<const bf16x8 *>(&Ds[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // stage st lives in LDS buffer st&1; register set A holds stage st+1, set B stage st+2 (roles swap every stage)
+    const int nstage = (count + WB_S - 1) / WB_S;
+    WRows<TM> xa, xb;
+    WRows<TN> da, db;
+    issue(xa, da, 0);
+    issue(xb, db, WB_S);                     // past the end: clamped rows, masked to zero, never used
+    commit(xa, da, 0);
+    issue(xa, da, 2 * WB_S);
+    __syncthreads();
+    for (int st = 0; st < nstage; st += 2) {
+        // even stage: xb/db hold stage st+1, xa/da stage st+2
+        mfma_stage(0);
+        commit(xb, db, 1);
+        issue(xb, db, (st + 3) * WB_S);
+        __syncthreads();
+        if (st + 1 < nstage) {
+            mfma_stage(1);
+            commit(xa, da, 0);
+            issue(xa, da, (st + 4) * WB_S);
+            __syncthreads();
+        }
+    }
+    float *dst = dW + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = co0 + wj * (TN / 2) + j * 32 + r;
+                if (ci < cin && co < cout && (!(DBG & 8) || acc[i][j][e] == 12345.f))
+                    unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
             }
 }
 
@@ -1245,22 +1297,53 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
                                        const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
                                        int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
     if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
+    if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (nseg == 0) return CG3D_OK;
-    if (precision == 1) {   // bf16 operands (both rounded on the fly), fp32 accumulate
+    if (precision >= 1) {   // bf16 operands: fp32 rows rounded on the fly (1) or rows stored as bf16 (2); fp32 accumulate
         if (cin % 4 != 0 || cout % 4 != 0 || (((uintptr_t)X | (uintptr_t)dY) & 15)) return CG3D_ERR_ARG;
         const bool m128 = cin > 64, n128 = cout > 64;
         const int32_t ct = cg3d_divup(cin, m128 ? 128 : 64), ot = cg3d_divup(cout, n128 ? 128 : 64);
         if ((int64_t)ct * ot > 65535) return CG3D_ERR_ARG;
-#define LAUNCH_WB(TM, TN)                                                                                          \
-    hipLaunchKernelGGL((k_spconv_pairs_wgrad_bf16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, X, \
-                       dY, pair_in, pair_out, seg, dW, cin, cout, ot)
-        if (m128 && n128) LAUNCH_WB(128, 128);
-        else if (m128) LAUNCH_WB(128, 64);
-        else if (n128) LAUNCH_WB(64, 128);
-        else LAUNCH_WB(64, 64);
+#define LAUNCH_WB(TM, TN, ST)                                                                                      \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_bf16<TM, TN, ST>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s,   \
+                       reinterpret_cast<const ST *>(X), reinterpret_cast<const ST *>(dY), pair_in, pair_out, seg, dW, cin,  \
+                       cout, ot)
+#define LAUNCH_WB_ALL(ST)                                                                                          \
+    do {                                                                                                           \
+        if (m128 && n128) LAUNCH_WB(128, 128, ST);                                                                 \
+        else if (m128) LAUNCH_WB(128, 64, ST);                                                                     \
+        else if (n128) LAUNCH_WB(64, 128, ST);                                                                     \
+        else LAUNCH_WB(64, 64, ST);                                                                                \
+    } while (0)
+        static const int wdbg = getenv("CG3D_DBG_WGRAD") ? atoi(getenv("CG3D_DBG_WGRAD")) : 0;
+        if (wdbg && m128 && n128 && precision == 2) {
+#define LAUNCH_WBD(D)                                                                                              \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<128, 128, D>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256),        \
+                       0, s, reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, \
+                       seg, dW, cin, cout, ot)
+            if (wdbg == 1) LAUNCH_WBD(1); else if (wdbg == 2) LAUNCH_WBD(2); else if (wdbg == 4) LAUNCH_WBD(4);
+            else if (wdbg == 8) LAUNCH_WBD(8); else if (wdbg == 3) LAUNCH_WBD(3); else LAUNCH_WBD(15);
+#undef LAUNCH_WBD
+            CG3D_CHECK_LAUNCH();
+            return CG3D_OK;
+        }
+        if (precision == 2 && cin % 8 == 0 && cout % 8 == 0 && !getenv("CG3D_WGRAD_NARROW")) {
+#define LAUNCH_WR(TM, TN)                                                                                          \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s,    \
+                       reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg, \
+                       dW, cin, cout, ot)
+            if (m128 && n128) LAUNCH_WR(128, 128);
+            else if (m128) LAUNCH_WR(128, 64);
+            else if (n128) LAUNCH_WR(64, 128);
+            else LAUNCH_WR(64, 64);
+#undef LAUNCH_WR
+            CG3D_CHECK_LAUNCH();
+            return CG3D_OK;
+        }
+        if (precision == 1) LAUNCH_WB_ALL(float); else LAUNCH_WB_ALL(uint16_t);
+#undef LAUNCH_WB_ALL
 #undef LAUNCH_WB
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;
@@ -1285,42 +1368,25 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
 extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
                                int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
                                int32_t precision, cg3d_stream_t stream) {
-    (void)n_in;
-    if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    if (precision != 0 && precision != 1) return CG3D_ERR_ARG;
+    if (n_out < 0 || n_in < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
     if (n_out == 0) return CG3D_OK;
     hipStream_t s = cg3d_hs(stream);
     const unsigned gx = (unsigned)cg3d_divup(n_out, 128);
-    if (precision == 1) {   // W is the prepared bf16 [K][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
+    if (precision >= 1) {   // W is the prepared bf16 [K][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
+        // 32-bit element offsets inside the kernel: rows * cin and the weight tensor must stay below 2^31 elements
         if (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15)) return CG3D_ERR_ARG;
+        if (n_in * (int64_t)cin >= (1ll << 31) || (int64_t)cin * cout >= (1ll << 31)) return CG3D_ERR_RANGE;
         const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
-#define LAUNCH_IB(NT)                                                                                           \
-    hipLaunchKernelGGL((k_spconv_implicit_bf16<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), 0, s, X, Wb, \
-                       nbr, bias, Y, n_out, K, cin, cout)
-        static const int dbg = getenv("CG3D_DBG_IMPL") ? atoi(getenv("CG3D_DBG_IMPL")) : 0;
-        if (dbg && cout > 64) {
-#define LAUNCH_IBD(D)                                                                                            \
-    hipLaunchKernelGGL((k_spconv_implicit_bf16<4, D>), dim3(gx, (unsigned)cg3d_divup(cout, 128)), dim3(256), 0, s, X, Wb, \
-                       nbr, bias, Y, n_out, K, cin, cout)
-            if (dbg == 1) LAUNCH_IBD(1); else if (dbg == 2) LAUNCH_IBD(2); else if (dbg == 3) LAUNCH_IBD(3);
-            else if (dbg == 4) LAUNCH_IBD(4); else if (dbg == 8) LAUNCH_IBD(8); else if (dbg == 12) LAUNCH_IBD(12);
-            else LAUNCH_IBD(15);
-#undef LAUNCH_IBD
-            CG3D_CHECK_LAUNCH();
-            return CG3D_OK;
+#define LAUNCH_WS(NT, XT)                                                                                       \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT, XT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(512), 0, s, \
+                       reinterpret_cast<const XT *>(X), Wb, nbr, bias, Y, n_out, K, cin, cout)
+        if (precision == 1) {
+            if (cout > 64) LAUNCH_WS(4, float); else if (cout > 32) LAUNCH_WS(2, float); else LAUNCH_WS(1, float);
+        } else {            // X is bf16 [n_in][cin] (cg3d_to_bf16)
+            if (cout > 64) LAUNCH_WS(4, uint16_t); else if (cout > 32) LAUNCH_WS(2, uint16_t); else LAUNCH_WS(1, uint16_t);
         }
-        static const int ws_form = getenv("CG3D_IMPL_WS") ? atoi(getenv("CG3D_IMPL_WS")) : 1;
-        if (ws_form) {
-#define LAUNCH_WS(NT)                                                                                           \
-    hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(512), 0, s, X, \
-                       Wb, nbr, bias, Y, n_out, K, cin, cout)
-            if (cout > 64) LAUNCH_WS(4); else if (cout > 32) LAUNCH_WS(2); else LAUNCH_WS(1);
 #undef LAUNCH_WS
-            CG3D_CHECK_LAUNCH();
-            return CG3D_OK;
-        }
-        if (cout > 64) LAUNCH_IB(4); else if (cout > 32) LAUNCH_IB(2); else LAUNCH_IB(1);
-#undef LAUNCH_IB
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;
     }

@@ -285,7 +285,8 @@ IMPLICIT_MIN_OCCUPANCY = float(__import__("os").environ.get("CG3D_IMPLICIT_THR",
 
 
 def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
-    """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] with bf16 operands; w_bf16_t: int16 view of bf16 [K, cout, cin]."""
+    """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] with bf16 operands; w_bf16_t: int16 view of bf16 [K, cout, cin];
+    x: fp32 rows (rounded in the kernel) or their int16/bf16 copy from _to_bf16."""
     lib = _lib.get()
     K = nbr.shape[0]
     lib.check(x, w_bf16_t, nbr, bias)
@@ -294,14 +295,27 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
     if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    rows16 = x.dtype == torch.int16
     lib.call("cg3d_spconv_fwd", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(bias), ptr(y), c_int64(x.shape[0]), c_int64(n_out),
-             c_int32(K), c_int32(cin), c_int32(cout), c_int32(1), lib.stream())
+             c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1), lib.stream())
     if prof:
         ev1.record()
+        xb = 2.0 if rows16 else 4.0     # bytes per gathered element
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      4.0 * (n_pairs * cin + n_out * cout) + 2.0 * K * cin * cout + 4.0 * K * n_out,
+                                      xb * n_pairs * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out,
                                       ("implicit_bf16", K, cin, cout, n_pairs, n_out, 0)))
     return y
+
+
+BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 mode: gather from bf16 row copies
+
+
+def _to_bf16(x):
+    """fp32 [N, C] -> int16 view of the bf16 rows (cg3d_to_bf16; one streaming pass, halves every later gather)."""
+    lib = _lib.get()
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    lib.call("cg3d_to_bf16", ptr(x), ptr(out), c_int64(x.numel()), lib.stream())
+    return out
 
 
 def _prep_bf16_t(w3):
@@ -363,8 +377,9 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
     if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    rows16 = x.dtype == torch.int16
     lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(wptr), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(None), ptr(y),
-             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(prec), c_int32(1), lib.stream())
+             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else prec), c_int32(1), lib.stream())
     if prof:
         ev1.record()
         # algorithmic work of one launch: 2*P*cin*cout flops; bytes = every gathered input row and every
@@ -372,7 +387,8 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
         # + the weights once + the two pair lists
         wb = 2.0 if prec == 1 else 4.0
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      4.0 * n_pairs * (cin + cout) + wb * K * cin * cout + 8.0 * n_pairs,
+                                      n_pairs * ((2.0 if rows16 else 4.0) * cin + 4.0 * cout) + wb * K * cin * cout
+                                      + 8.0 * n_pairs,
                                       ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg)))
     return y
 
@@ -381,12 +397,18 @@ _WGRAD_BF16_WGS = int(__import__("os").environ.get("CG3D_WGRAD_BF16_WGS", "2048"
 _WGRAD_BF16_MIN = int(__import__("os").environ.get("CG3D_WGRAD_BF16_MIN", "256"))
 
 
-def _wgrad_seg_len(P, cin, cout, precision=0):
+def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
     if not _lib.get().is_device:
         return 1 << 30
     if precision == 1:
         tiles = (-(-cin // (128 if cin > 64 else 64))) * (-(-cout // (128 if cout > 64 else 64)))
-        per = -(-P * tiles // _WGRAD_BF16_WGS)
+        # The kernel runs 2 workgroups per CU = 512 slots on MI355X; a launch of 1.3 x 512 workgroups costs two full
+        # rounds, so the segment length is chosen to land just under a whole number of rounds (every offset adds one
+        # short tail segment).  Measured optimum: ~4 rounds when several channel tiles share the gathered rows
+        # through L2, 1-2 rounds (fewer 64 KB atomic epilogues) when a single tile covers the layer.
+        rounds = 4 if tiles > 1 else (2 if max(cin, cout) <= 64 else 1)
+        slots = max(512 * rounds * _WGRAD_BF16_WGS // 2048 - K * tiles, 64)
+        per = -(-P * tiles // slots)
         return max(_WGRAD_BF16_MIN, -(-per // 64) * 64)
     t = 128 if (cin >= 128 and cout >= 128) else 64          # tile edge of the kernel the library will pick
     tiles = ((cin + t - 1) // t) * ((cout + t - 1) // t)
@@ -409,52 +431,61 @@ class SparseConvFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
         x = x.contiguous()
         w3 = weight.contiguous()
-        ctx.save_for_backward(x, w3)
         ctx.kmap, ctx.has_bias, ctx.row_bounds = kmap, bias is not None, row_bounds
         pin, pout, _, P = kmap.pairs(row_bounds)
         b = bias.contiguous() if bias is not None else None
-        if SparseConvFunction._implicit(kmap, P, w3.shape[1], row_bounds):
-            return _conv_implicit_bf16(x, _prep_bf16_t(w3), kmap.nbr, b, kmap.n_out, w3.shape[1], w3.shape[2], P)
+        cin, cout = w3.shape[1], w3.shape[2]
+        # bf16 mode: one streaming conversion of the input rows, then every gather of this layer (forward and
+        # weight gradient) moves half the bytes
+        xg = _to_bf16(x) if (BF16_ROWS and _use_bf16(cin)) else x
+        ctx.save_for_backward(x, w3, xg if xg is not x else None)
+        if SparseConvFunction._implicit(kmap, P, cin, row_bounds):
+            return _conv_implicit_bf16(xg, _prep_bf16_t(w3), kmap.nbr, b, kmap.n_out, cin, cout, P)
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
-        return _conv_pairs(x, w3, pin, pout, seg, nseg, b, kmap.n_out, P)
+        return _conv_pairs(xg, w3, pin, pout, seg, nseg, b, kmap.n_out, P)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w3 = ctx.saved_tensors
+        x, w3, xb = ctx.saved_tensors
         kmap, rb = ctx.kmap, ctx.row_bounds
         dy = dy.contiguous()
         lib = _lib.get()
         pin, pout, _, P = kmap.pairs(rb)
+        KK, cin, cout = w3.shape
         dx = dw = db = None
+        dyg = _to_bf16(dy) if (BF16_ROWS and _use_bf16(cout)) else dy     # shared by dgrad and wgrad
         if ctx.needs_input_grad[0]:
-            if SparseConvFunction._implicit(kmap, P, w3.shape[2], rb):
+            if SparseConvFunction._implicit(kmap, P, cout, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
-                dx = _conv_implicit_bf16(dy, w3.to(torch.bfloat16).view(torch.int16), kmap.nbrT, None, kmap.n_in,
-                                         w3.shape[2], w3.shape[1], P)
+                dx = _conv_implicit_bf16(dyg, w3.to(torch.bfloat16).view(torch.int16), kmap.nbrT, None, kmap.n_in,
+                                         cout, cin, P)
             else:
                 seg, nseg = kmap.segments(_seg_len_fwd(), rb)
-                if _use_bf16(w3.shape[2]):
-                    wt = w3.new_empty((w3.shape[0], w3.shape[2], w3.shape[1]))  # shape carrier only
-                    dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
+                if _use_bf16(cout):
+                    wt = w3.new_empty((KK, cout, cin))  # shape carrier only
+                    dx = _conv_pairs(dyg, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
                                      w_bf16_t=w3.to(torch.bfloat16).view(torch.int16))
                 else:
                     wt = w3.transpose(1, 2).contiguous()
                     dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
-            KK, cin, cout = w3.shape
             dw = torch.empty_like(w3)
             wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
-            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, wprec), rb)
-            lib.check(x, dy, pin, pout, seg)
+            xw, dyw = x, dy
+            if wprec and xb is not None and cout % 8 == 0:
+                xw, dyw, wprec = xb, (dyg if dyg is not dy else _to_bf16(dy)), 2
+            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, KK), rb)
+            lib.check(xw, dyw, pin, pout, seg)
             prof = KernelProfile.enabled and KernelProfile.wgrad and lib.is_device
             if prof:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            lib.call("cg3d_spconv_pairs_wgrad", ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
+            lib.call("cg3d_spconv_pairs_wgrad", ptr(xw), ptr(dyw), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
                      c_int32(KK), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
             if prof:
                 ev1.record()
-                KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout, 4.0 * (P * cin + P * cout + KK * cin * cout),
+                eb = 2.0 if wprec == 2 else 4.0
+                KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout, eb * P * (cin + cout) + 4.0 * KK * cin * cout,
                                               ("wgrad_bf16" if wprec else "wgrad", KK, cin, cout, P, kmap.n_out, nseg)))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
@@ -511,7 +542,7 @@ class LinearFunction(torch.autograd.Function):
             else:
                 xc, dyc = x.contiguous(), dy.contiguous()
                 wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
-                ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, wprec), x.device)
+                ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, wprec, 1), x.device)
                 dw = torch.empty_like(w)
                 lib.check(xc, dyc, ar, seg, dw)
                 lib.call("cg3d_spconv_pairs_wgrad", ptr(xc), ptr(dyc), ptr(ar), ptr(ar), ptr(seg), c_int64(nseg), ptr(dw),

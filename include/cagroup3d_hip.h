@@ -94,10 +94,16 @@ int cg3d_kernel_map(const int32_t *q_coords, int64_t nq, const int32_t *offsets,
  *              1 = bf16 operands, fp32 accumulate: X is RNE-rounded on the fly and `W` must point to the
  *                  buffer written by cg3d_spconv_prep_weights_bf16 (uint16 [K, cout, cin]); cin % 8 == 0,
  *                  16-byte aligned X.  No atomics: every output row is stored once (deterministic).
+ *              2 = as 1, but X already holds bf16 rows (uint16 [n_in, cin], written by cg3d_to_bf16): half the
+ *                  gather traffic, bit-identical results (the same round-to-nearest-even, done once up front).
+ *                  The same value selects bf16-stored rows in cg3d_spconv_pairs_fwd (X) and
+ *                  cg3d_spconv_pairs_wgrad (X and dY).
+ * cg3d_to_bf16: Xb[i] = bf16(X[i]) (RNE) for n elements (n % 4 == 0).
  *   The data gradient is the same call with (dY, W^T[k] as [K,cout,cin], transposed map).
  * cg3d_spconv_wgrad:  dW[k] = sum_o X[nbr[k,o], :]^T (outer) dY[o, :]   -> float32 [K,cin,cout]
  *   dW is overwritten (the callee zero-fills it when it accumulates with atomics).
  * ---------------------------------------------------------------------------------------- */
+int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t stream);
 int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias,
                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
                     int32_t precision, cg3d_stream_t stream);

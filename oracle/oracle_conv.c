@@ -24,13 +24,33 @@ static inline float os_bf16(float v) {
     return r;
 }
 
+static inline float os_bf16_bits(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+/* element a of a gathered row: fp32 storage (precision 0: as is, 1: rounded to bf16) or bf16 storage (2) */
+static inline float os_row(const void *base, int64_t i, int32_t precision) {
+    if (precision == 2) return os_bf16_bits(((const uint16_t *)base)[i]);
+    float v = ((const float *)base)[i];
+    return precision == 1 ? os_bf16(v) : v;
+}
+
+int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t s) {
+    (void)s;
+    if (n < 0 || (n & 3)) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float v = os_bf16(X[i]);
+        uint32_t u; memcpy(&u, &v, 4);
+        Xb[i] = (uint16_t)(u >> 16);
+    }
+    return CG3D_OK;
+}
+
 int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
                     int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
                     cg3d_stream_t s) {
     (void)s; (void)n_in;
     if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
     float *Wq = NULL;
-    if (precision == 1) {
+    if (precision >= 1) {
         int64_t nw = (int64_t)K * cin * cout;
         /* precision 1: W is the prepared bf16 [K][cout][cin] buffer; widen it back to fp32 [K][cin][cout] */
         const uint16_t *wb = (const uint16_t *)W;
@@ -54,8 +74,8 @@ int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const fl
             for (int32_t k = 0; k < K; k++) {
                 int32_t i = nbr[(int64_t)k * n_out + o];
                 if (i < 0) continue;
-                const float *x = X + (int64_t)i * cin;
-                if (precision == 1) { for (int32_t a = 0; a < cin; a++) xq[a] = os_bf16(x[a]); x = xq; }
+                for (int32_t a = 0; a < cin; a++) xq[a] = os_row(X, (int64_t)i * cin + a, precision);
+                const float *x = xq;
                 const float *w = W + (int64_t)k * cin * cout;
                 for (int32_t a = 0; a < cin; a++) {
                     float xa = x[a];
@@ -114,7 +134,6 @@ int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, i
             }
     return CG3D_OK;
 }
-static inline float os_bf16_bits(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 /* Pair-list form (ME's in/out kernel maps): per offset k, Y[out] += X[in] W[k]. */
 int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, const int32_t *pout, const int32_t *seg,
@@ -135,10 +154,11 @@ int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pin, co
         for (int32_t p = start; p < start + count; p++) {
             const float *x = X + (int64_t)pin[p] * cin;
             float *y = Y + (int64_t)pout[p] * cout;
-            if (precision == 1) {
+            if (precision >= 1) {
                 for (int32_t c = 0; c < cout; c++) {
                     float acc = 0.f;
-                    for (int32_t a = 0; a < cin; a++) acc += os_bf16(x[a]) * os_bf16_bits(wb[(int64_t)c * cin + a]);
+                    for (int32_t a = 0; a < cin; a++)
+                        acc += os_row(X, (int64_t)pin[p] * cin + a, precision) * os_bf16_bits(wb[(int64_t)c * cin + a]);
                     y[c] += acc;
                 }
             } else {
@@ -167,13 +187,13 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pin,
             int32_t k = seg[g * 3], start = seg[g * 3 + 1], count = seg[g * 3 + 2];
             float *w = dW + (int64_t)k * cin * cout;
             for (int32_t p = start; p < start + count; p++) {
-                const float *x = X + (int64_t)pin[p] * cin;
                 const float *d = dY + (int64_t)pout[p] * cout;
                 for (int32_t a = a0; a < a1; a++) {
-                    float xa = precision == 1 ? os_bf16(x[a]) : x[a];
+                    float xa = os_row(X, (int64_t)pin[p] * cin + a, precision);
                     float *wr = w + (int64_t)a * cout;
-                    if (precision == 1) { for (int32_t c = 0; c < cout; c++) wr[c] += xa * os_bf16(d[c]); }
-                    else { for (int32_t c = 0; c < cout; c++) wr[c] += xa * d[c]; }
+                    if (precision >= 1) {
+                        for (int32_t c = 0; c < cout; c++) wr[c] += xa * os_row(dY, (int64_t)pout[p] * cout + c, precision);
+                    } else { for (int32_t c = 0; c < cout; c++) wr[c] += xa * d[c]; }
                 }
             }
         }

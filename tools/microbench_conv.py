@@ -89,12 +89,20 @@ def main():
         ti_b = tw_b = float("nan")
         if me.PRECISION == 1 and cin % 8 == 0:
             wb = me._prep_bf16_t(w)
-            ti_b = timeit(lambda: me._conv_implicit_bf16(xin, wb, km.nbr, None, km.n_out, cin, cout, P))
+            rows16 = os.environ.get("ROWS16", "1") == "1"
+            xg = me._to_bf16(xin) if rows16 else xin
+            dg = me._to_bf16(dy) if (rows16 and cout % 8 == 0) else dy
+            tcv = timeit(lambda: me._to_bf16(xin))
+            ti_b = timeit(lambda: me._conv_implicit_bf16(xg, wb, km.nbr, None, km.n_out, cin, cout, P))
+            tf = timeit(lambda: me._conv_pairs(xg, w, pin, pout, seg, nseg, None, km.n_out))
             bseg, nbseg = km.segments(me._wgrad_seg_len(P, cin, cout, 1))
+            wp = 2 if (rows16 and dg is not dy) else 1
+            xw, dw_ = (xg, dg) if wp == 2 else (xin, dy)
             def wgb():
-                lib.call("cg3d_spconv_pairs_wgrad", _lib.ptr(xin), _lib.ptr(dy), _lib.ptr(pin), _lib.ptr(pout), _lib.ptr(bseg),
-                         c_int64(nbseg), _lib.ptr(dw), c_int32(ks ** 3), c_int32(cin), c_int32(cout), c_int32(1), lib.stream())
+                lib.call("cg3d_spconv_pairs_wgrad", _lib.ptr(xw), _lib.ptr(dw_), _lib.ptr(pin), _lib.ptr(pout), _lib.ptr(bseg),
+                         c_int64(nbseg), _lib.ptr(dw), c_int32(ks ** 3), c_int32(cin), c_int32(cout), c_int32(wp), lib.stream())
             tw_b = timeit(wgb)
+            print("   rows16=%s  to_bf16 %.3f ms" % (rows16, tcv))
         gf = 2.0 * P * cin * cout / 1e9
         gfd = 2.0 * km.n_out * ks ** 3 * cin * cout / 1e9
         tot += tf + td + tw
