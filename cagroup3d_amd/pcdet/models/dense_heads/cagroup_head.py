@@ -148,17 +148,16 @@ class CAGroup3DHead(nn.Module):
         return self._vs_cache[1]
 
     def _forced_selection(self, input_dict, out, ori_xyz):
-        """bool [N, n_classes]: voxel lies inside a GT box of that class."""
-        gt = input_dict["gt_boxes"]
-        mask = torch.zeros((ori_xyz.shape[0], self.n_classes), dtype=torch.bool, device=ori_xyz.device)
-        for b, perm in enumerate(out.decomposition_permutations):
-            g = gt[b][~(gt[b] == 0).all(dim=-1)]
-            if len(g) == 0:
-                continue
-            inside = find_points_in_boxes(ori_xyz[perm], g[:, :7])                     # (n, G)
-            onehot = torch.nn.functional.one_hot(g[:, 7].long(), self.n_classes).bool()   # (G, C)
-            mask[perm] = (inside.unsqueeze(2) & onehot.unsqueeze(0)).any(dim=1)
-        return mask
+        """bool [N, n_classes]: voxel lies inside a GT box of that class (all scenes in one pass)."""
+        gt = input_dict["gt_boxes"]                                    # [B, Gmax, 8], zero-padded
+        B, Gmax = gt.shape[0], gt.shape[1]
+        flat = gt.reshape(B * Gmax, -1)
+        real = ~(flat == 0).all(dim=-1)
+        box_scene = torch.arange(B, device=gt.device).repeat_interleave(Gmax)
+        inside = find_points_in_boxes(ori_xyz, flat[:, :7])            # (N, B*Gmax); padded rows are zero-size boxes
+        inside = inside & (out.C[:, 0].long().view(-1, 1) == box_scene.view(1, -1)) & real.view(1, -1)
+        onehot = torch.nn.functional.one_hot(flat[:, 7].long().clamp(0, self.n_classes - 1), self.n_classes).float()
+        return (inside.float() @ onehot) > 0
 
     def _class_branches_loop(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
                              batch_size):
@@ -383,18 +382,26 @@ class CAGroup3DHead(nn.Module):
             off_t = torch.zeros((voxel_offset.F.shape[0], 3 * (self.gt_per_seed if self.with_yaw else 1)), device=dev)
             off_m = torch.zeros(voxel_offset.F.shape[0], device=dev)
             n_vox = torch.zeros(voxel_offset.F.shape[0], device=dev)
+            vox_scene_off = voxel_offset.C[:, 0].long()
+            equal_pts = len({sp.shape[0] for sp in scene_points}) == 1
             if not self.with_yaw:
                 n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1  # one host read for all scenes
-            for b in range(B):
-                op = voxel_offset.C[perms[b], 1:] * vs
-                if self.with_yaw:
-                    t, mk = self._vote_targets_yaw(op, gt_bboxes[b], gt_labels[b])
-                else:
-                    t, mk = self._vote_targets_masks(op, gt_bboxes[b], scene_points[b], sem_masks[b], ins_masks[b], int(n_ins[b]))
-                off_t[perms[b]] = t
-                off_m[perms[b]] = mk.float()
-                n_vox[perms[b]] = float(len(perms[b]))
-            vox_scene_off = voxel_offset.C[:, 0].long()
+            if not self.with_yaw and equal_pts:
+                t, mk = self._vote_targets_masks_batched(voxel_offset.C[:, 1:] * vs, vox_scene_off, perms, gt_bboxes,
+                                                         scene_points, sem_masks, ins_masks, n_ins)
+                off_t, off_m = t, mk.float()
+                n_vox = torch.bincount(vox_scene_off, minlength=B).float()[vox_scene_off]
+            else:
+                for b in range(B):
+                    op = voxel_offset.C[perms[b], 1:] * vs
+                    if self.with_yaw:
+                        t, mk = self._vote_targets_yaw(op, gt_bboxes[b], gt_labels[b])
+                    else:
+                        t, mk = self._vote_targets_masks(op, gt_bboxes[b], scene_points[b], sem_masks[b], ins_masks[b],
+                                                         int(n_ins[b]))
+                    off_t[perms[b]] = t
+                    off_m[perms[b]] = mk.float()
+                    n_vox[perms[b]] = float(len(perms[b]))
             # ---- per-scene normalisers, one all-reduce (the reference: 3 per scene, cagroup_head.py:523,530,538)
             pos = labels >= 0
             stats = torch.zeros((B, 3), device=dev)
@@ -507,6 +514,46 @@ class CAGroup3DHead(nn.Module):
         offset_m = torch.where(offset_t < -100., torch.zeros_like(offset_t), torch.ones_like(offset_t)).all(1)
         offset_t = torch.where(offset_t < -100., torch.zeros_like(offset_t), offset_t)
         return offset_t, offset_m * valid
+
+    def _vote_targets_masks_batched(self, vox_xyz, vox_scene, perms, gt_bboxes, scene_points, sem_masks, ins_masks, n_ins):
+        """`_vote_targets_masks` for all scenes of the batch in one pass (scenes with equal raw point counts; the
+        kNN stays one launch per scene -- the raw point sets are separate search spaces).  Returns
+        (offset_t [N,3], offset_m [N]) in voxel row order."""
+        dev = vox_xyz.device
+        B, P = len(scene_points), scene_points[0].shape[0]
+        xyz = torch.stack([sp[:, :3] for sp in scene_points])                          # [B, P, 3]
+        ins, sem = torch.stack(list(ins_masks)), torch.stack(list(sem_masks))          # [B, P]
+        I = int(n_ins.max())
+        member = ins.unsqueeze(2) == torch.arange(I, device=dev).view(1, 1, -1)        # [B, P, I]
+        big = torch.full((1, 1, 1, 1), float("inf"), device=dev)
+        lo = torch.where(member.unsqueeze(3), xyz.unsqueeze(2), big).amin(1)           # [B, I, 3]
+        hi = torch.where(member.unsqueeze(3), xyz.unsqueeze(2), -big).amax(1)
+        ar = torch.arange(P, device=dev).view(1, -1, 1)
+        first = torch.where(member, ar, torch.full_like(ar, P)).amin(1)                # [B, I]
+        present = first < P
+        sem_first = sem.gather(1, first.clamp(max=P - 1))
+        is_obj = present & (sem_first < self.n_classes)
+        center = 0.5 * (lo + hi)
+        center = torch.where(is_obj.unsqueeze(2), center, torch.zeros_like(center))
+        n_gt = [len(g) for g in gt_bboxes]
+        G = max(n_gt)
+        gt_ctr = torch.zeros((B, G, 3), device=dev)
+        for b, g in enumerate(gt_bboxes):
+            gt_ctr[b, :n_gt[b]] = g[:, :3].to(dev)
+        gt_ok = torch.arange(G, device=dev).view(1, -1) < ME.h2d(n_gt, torch.long, dev).view(-1, 1)
+        d = torch.where(gt_ok.unsqueeze(1), torch.cdist(center, gt_ctr), torch.full((1, 1, 1), float("inf"), device=dev))
+        match = torch.argmin(d, dim=2)                                                  # [B, I]
+        instance_center = torch.where(is_obj.unsqueeze(2), gt_ctr.gather(1, match.unsqueeze(2).expand(-1, -1, 3)),
+                                      torch.where(present.unsqueeze(2), torch.full_like(center, -10000.),
+                                                  torch.zeros_like(center)))
+        nearest = torch.empty(vox_xyz.shape[0], dtype=torch.long, device=dev)
+        for b in range(B):
+            nearest[perms[b]] = knn(1, xyz[b:b + 1], vox_xyz[perms[b]][None].contiguous())[0, 0].long()
+        major = ins.view(-1)[vox_scene * P + nearest]
+        offset_t = instance_center.view(-1, 3)[vox_scene * I + major] - vox_xyz
+        offset_m = torch.where(offset_t < -100., torch.zeros_like(offset_t), torch.ones_like(offset_t)).all(1)
+        offset_t = torch.where(offset_t < -100., torch.zeros_like(offset_t), offset_t)
+        return offset_t, offset_m
 
     def _loss_single(self, centernesses, bbox_preds, cls_scores, points, voxel_offset_preds, original_points,
                      semantic_scores, semantic_points, img_meta, gt_bboxes, gt_labels, scene_points,

@@ -31,6 +31,37 @@ class ProposalTargetLayer(nn.Module):
                 "rcnn_cls_labels": cls_labels}
 
     def sample_rois_for_rcnn(self, batch_dict):
+        """All scenes at once: one pairwise-IoU launch (same-scene, same-class masked), ONE device->host read of
+        the per-RoI best overlaps, the fg/bg draw on the host with the reference's RNG call sequence, one gather."""
+        bs = batch_dict["batch_size"]
+        rois, roi_scores, roi_labels = batch_dict["rois"], batch_dict["roi_scores"], batch_dict["roi_labels"]
+        gt_boxes, gt_labels = batch_dict["gt_bboxes_3d"], batch_dict["gt_labels_3d"]
+        if any(len(g) == 0 for g in gt_boxes):
+            return self._sample_rois_per_scene(batch_dict)
+        from .....me import h2d
+        dev, R, Rin = rois.device, self.roi_per_image, rois.shape[1]
+        n_gt = [len(g) for g in gt_boxes]
+        gt_all = torch.cat([g for g in gt_boxes]).clone()
+        gt_all[..., 6] *= -1                                      # mmdet3d heading -> pcdet heading (:97)
+        gl_all = torch.cat([l for l in gt_labels])
+        gt_scene = torch.repeat_interleave(torch.arange(bs, device=dev), h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
+        gt_first = h2d(np.cumsum([0] + n_gt[:-1]), torch.long, dev)
+        roi_scene = torch.arange(bs, device=dev).repeat_interleave(Rin)
+        flat_rois, flat_labels = rois.reshape(bs * Rin, -1), roi_labels.reshape(-1)
+        iou = boxes_iou3d_gpu(flat_rois[:, :7].contiguous(), gt_all[:, 0:7].contiguous())          # (B*Rin, sum G)
+        same = (flat_labels.view(-1, 1) == gl_all.long().view(1, -1)) & (roi_scene.view(-1, 1) == gt_scene.view(1, -1))
+        best, arg = torch.max(torch.where(same, iou, torch.full_like(iou, -1.0)), dim=1)
+        has = best >= 0
+        max_ov = torch.where(has, best, torch.zeros_like(best))
+        assign = torch.where(has, arg, gt_first[roi_scene])        # no GT of the RoI's class: the scene's first box (:204-238)
+        ov_host = max_ov.view(bs, Rin).cpu()                       # the only host read
+        keep = torch.stack([self.subsample_rois(ov_host[i]) for i in range(bs)])            # host, reference RNG order
+        flat_keep = (h2d(keep, torch.long, dev) + torch.arange(bs, device=dev).view(-1, 1) * Rin).view(-1)
+        a = assign[flat_keep]
+        return (flat_rois[flat_keep].view(bs, R, -1), gt_all[a].view(bs, R, -1), gl_all[a].view(bs, R).to(rois.dtype),
+                max_ov[flat_keep].view(bs, R), roi_scores.reshape(-1)[flat_keep].view(bs, R), flat_labels[flat_keep].view(bs, R))
+
+    def _sample_rois_per_scene(self, batch_dict):
         bs = batch_dict["batch_size"]
         rois, roi_scores, roi_labels = batch_dict["rois"], batch_dict["roi_scores"], batch_dict["roi_labels"]
         gt_boxes, gt_labels = batch_dict["gt_bboxes_3d"], batch_dict["gt_labels_3d"]

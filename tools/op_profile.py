@@ -17,12 +17,14 @@ torch.cuda.synchronize()
 
 
 def phase(name, fn):
-    with profile(activities=[ProfilerActivity.CPU]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         out = fn()
-    ka = prof.key_averages()
+        torch.cuda.synchronize()
+    nk = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+    ka = [e for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CPU]
     tot = sum(e.self_cpu_time_total for e in ka) / 1e3
     n = sum(e.count for e in ka)
-    print("== %-10s host %7.2f ms, %5d ops" % (name, tot, n))
+    print("== %-10s host %7.2f ms, %5d ops, %5d device activities (kernels + copies)" % (name, tot, n, nk))
     for e in sorted(ka, key=lambda e: -e.self_cpu_time_total)[:14]:
         print("     %-42s %6d %8.2f ms" % (e.key[:42], e.count, e.self_cpu_time_total / 1e3))
     return out
