@@ -120,7 +120,9 @@ def pmc_traffic(kernel_substr):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_%s.csv" % c)))
                     if kernel_substr in r["Kernel_Name"]]
-            tot[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / max(len(rows), 1)
+            if not rows:
+                return None
+            tot[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / len(rows)
         return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
     except Exception:
         return None

@@ -217,7 +217,7 @@ extern "C" int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t 
 //     re-fetched every line up to 8x once the 4 waves' 32 KB of in-flight lines overflowed the L1;
 //   * the next chunk's global loads (W tile + rows) are issued into registers BEFORE the current
 //     chunk's MFMAs and written to LDS after them, so HBM/L2 latency hides under the matrix pipe;
-template <int NT, int DBG = 0>
+template <int NT>
 __global__ __launch_bounds__(256, 2) void k_spconv_pairs_lds(const float *__restrict__ X, const float *__restrict__ W,
                                                           const int32_t *__restrict__ pin,
                                                           const int32_t *__restrict__ pout,
@@ -319,10 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_lds(const float *__rest
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int col = n0 + nt * 32 + r;
-            if (col < cout) {
-                if (DBG == 2) { if (acc[nt][e] == 12345.f) Y[0] = 1.f; }   // timing experiment only
-                else unsafeAtomicAdd(&Y[(int64_t)orow_e * cout + col], acc[nt][e]);
-            }
+            if (col < cout) unsafeAtomicAdd(&Y[(int64_t)orow_e * cout + col], acc[nt][e]);
         }
     }
 }
@@ -801,19 +798,16 @@ extern "C" int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32
         return CG3D_OK;
     }
     const bool aligned = (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0);
-    const char *dbg = getenv("CG3D_DBG_STORE");
-    const int d = dbg ? atoi(dbg) : 0;
-#define LAUNCH_LDS(NT, D)                                                                                          \
-    hipLaunchKernelGGL((k_spconv_pairs_lds<NT, D>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256), \
+#define LAUNCH_LDS(NT)                                                                                             \
+    hipLaunchKernelGGL((k_spconv_pairs_lds<NT>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)), dim3(256),    \
                        0, s, X, W, pair_in, pair_out, seg, Y, cin, cout)
 #define LAUNCH(NT, KH, V)                                                                                     \
     hipLaunchKernelGGL((k_spconv_pairs<NT, KH, V>), dim3((unsigned)nseg, (unsigned)cg3d_divup(cout, NT * 32)),   \
                        dim3(256), 0, s, X, W, pair_in, pair_out, seg, Y, cin, cout)
-    if (cin % 4 == 0 && cin >= 16 && aligned && d != 3) {
-        if (d == 2) { if (cout > 64) LAUNCH_LDS(4, 2); else LAUNCH_LDS(2, 2); }
-        else if (cout > 64) LAUNCH_LDS(4, 0);
-        else if (cout > 32) LAUNCH_LDS(2, 0);
-        else LAUNCH_LDS(1, 0);
+    if (cin % 4 == 0 && cin >= 16 && aligned) {
+        if (cout > 64) LAUNCH_LDS(4);
+        else if (cout > 32) LAUNCH_LDS(2);
+        else LAUNCH_LDS(1);
     } else if (cin <= 4) {
         if (cout > 64) LAUNCH(4, 2, false); else LAUNCH(2, 2, false);
     } else if (cin % 4 == 0 && aligned) {
@@ -1028,17 +1022,10 @@ __device__ static inline void transpose4x4bf(const float4 *v, uint2 *o) {
     o[2] = pack4bf(make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
     o[3] = pack4bf(make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
 }
-__device__ static inline void transpose4x4bf(const uint2 *v, uint2 *o) {   // rows already bf16: byte permutes only
-    constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;                // (low halves of b, a), (high halves of b, a)
-    o[0] = make_uint2(__builtin_amdgcn_perm(v[1].x, v[0].x, LO), __builtin_amdgcn_perm(v[3].x, v[2].x, LO));
-    o[1] = make_uint2(__builtin_amdgcn_perm(v[1].x, v[0].x, HI), __builtin_amdgcn_perm(v[3].x, v[2].x, HI));
-    o[2] = make_uint2(__builtin_amdgcn_perm(v[1].y, v[0].y, LO), __builtin_amdgcn_perm(v[3].y, v[2].y, LO));
-    o[3] = make_uint2(__builtin_amdgcn_perm(v[1].y, v[0].y, HI), __builtin_amdgcn_perm(v[3].y, v[2].y, HI));
-}
 
-template <int TM, int TN, typename ST, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__restrict__ X,
-                                                                    const ST *__restrict__ dY,
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float *__restrict__ X,
+                                                                    const float *__restrict__ dY,
                                                                     const int32_t *__restrict__ pin,
                                                                     const int32_t *__restrict__ pout,
                                                                     const int32_t *__restrict__ seg,
@@ -1046,7 +1033,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
                                                                     int32_t co_tiles) {
     __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
-    typedef typename Row4<ST>::T RowT;
+    typedef float ST;
+    typedef Row4<float>::T RowT;
     constexpr int XT = TM / 4, DT = TN / 4;              // threads per gathered row
     constexpr int XP = 16 / (256 / XT), DP = 16 / (256 / DT);   // passes over the 16 pair quads of a stage
     constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 tiles per wave
@@ -1077,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
             for (int i = 0; i < 4; i++) {
                 const int32_t p = p0 + 4 * q + i;
                 const int32_t pp = p < count ? p : count - 1;      // clamped, unconditional (masked below)
-                const RowT a = *reinterpret_cast<const RowT *>(xbase + ((DBG & 4) ? 0 : (int64_t)pin[start + pp] * cin));
+                const RowT a = *reinterpret_cast<const RowT *>(xbase + (int64_t)pin[start + pp] * cin);
                 xr[ps][i] = (p < count && xin) ? a : Row4<ST>::zero();
             }
         }
@@ -1088,7 +1076,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
             for (int i = 0; i < 4; i++) {
                 const int32_t p = p0 + 4 * q + i;
                 const int32_t pp = p < count ? p : count - 1;
-                const RowT b = *reinterpret_cast<const RowT *>(dbase + ((DBG & 4) ? 0 : (int64_t)pout[start + pp] * cout));
+                const RowT b = *reinterpret_cast<const RowT *>(dbase + (int64_t)pout[start + pp] * cout);
                 dr[ps][i] = (p < count && din) ? b : Row4<ST>::zero();
             }
         }
@@ -1113,7 +1101,6 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
     for (int st = 0; st < nstage; st++) {
         const int buf = st & 1;
         if (st + 1 < nstage) issue((st + 1) * WB_S);            // in flight during the MFMAs
-        if (!(DBG & 1))
 #pragma unroll
         for (int kk = 0; kk < WB_S / 16; kk++) {
             bf16x8 a[MI], b[NJ];
@@ -1133,7 +1120,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
                 for (int j = 0; j < NJ; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (st + 1 < nstage && (!(DBG & 2) || st == 1000000)) commit(buf ^ 1);   // the other buffer was last read two stages ago
+        if (st + 1 < nstage) commit(buf ^ 1);                   // the other buffer was last read two stages ago
         __syncthreads();
     }
     float *dst = dW + (int64_t)k * cin * cout;
@@ -1145,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const ST *__
             for (int e = 0; e < 16; e++) {
                 const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int co = co0 + wj * (TN / 2) + j * 32 + r;
-                if (ci < cin && co < cout && (!(DBG & 8) || acc[i][j][e] == 12345.f)) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+                if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
             }
 }
 
@@ -1160,7 +1147,7 @@ template <int T> struct WRows {
     static constexpr int PQ = TPR / 4;             // pairs per thread per stage (64 pairs / (256 / TPR) threads)
     uint4 v[PQ];
 };
-template <int TM, int TN, int DBG = 0>
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint16_t *__restrict__ X,
                                                                       const uint16_t *__restrict__ dY,
                                                                       const int32_t *__restrict__ pin,
@@ -1196,14 +1183,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
         for (int i = 0; i < XPQ; i++) {
             const int32_t p = p0 + xp0 + i;
             const int32_t pp = p < count ? p : count - 1;           // clamped, unconditional (masked below)
-            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + ((DBG & 4) ? 0 : (int64_t)pin[start + pp] * cin));
+            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + (int64_t)pin[start + pp] * cin);
             xr.v[i] = (p < count && xin) ? a : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < DPQ; i++) {
             const int32_t p = p0 + dp0 + i;
             const int32_t pp = p < count ? p : count - 1;
-            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + ((DBG & 4) ? 0 : (int64_t)pout[start + pp] * cout));
+            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + (int64_t)pout[start + pp] * cout);
             dr.v[i] = (p < count && din) ? b : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -1231,12 +1218,10 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
         }
     };
     auto commit = [&](const WRows<TM> &xr, const WRows<TN> &dr, int buf) {
-        if (DBG & 2) return;
         if (XPQ == 4) put4(Xs[buf], xc8, xp0, xr.v); else put2(Xs[buf], xc8, xp0, xr.v);
         if (DPQ == 4) put4(Ds[buf], dc8, dp0, dr.v); else put2(Ds[buf], dc8, dp0, dr.v);
     };
     auto mfma_stage = [&](int buf) {
-        if (DBG & 1) return;
 #pragma unroll
         for (int kk = 0; kk < WB_S / 16; kk++) {
             bf16x8 a[MI], b[NJ];
@@ -1288,8 +1273,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
             for (int e = 0; e < 16; e++) {
                 const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int co = co0 + wj * (TN / 2) + j * 32 + r;
-                if (ci < cin && co < cout && (!(DBG & 8) || acc[i][j][e] == 12345.f))
-                    unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+                if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
             }
 }
 
@@ -1307,9 +1291,8 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
         const int32_t ct = cg3d_divup(cin, m128 ? 128 : 64), ot = cg3d_divup(cout, n128 ? 128 : 64);
         if ((int64_t)ct * ot > 65535) return CG3D_ERR_ARG;
 #define LAUNCH_WB(TM, TN, ST)                                                                                      \
-    hipLaunchKernelGGL((k_spconv_pairs_wgrad_bf16<TM, TN, ST>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s,   \
-                       reinterpret_cast<const ST *>(X), reinterpret_cast<const ST *>(dY), pair_in, pair_out, seg, dW, cin,  \
-                       cout, ot)
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_bf16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, X, dY, \
+                       pair_in, pair_out, seg, dW, cin, cout, ot)
 #define LAUNCH_WB_ALL(ST)                                                                                          \
     do {                                                                                                           \
         if (m128 && n128) LAUNCH_WB(128, 128, ST);                                                                 \
@@ -1317,19 +1300,8 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
         else if (n128) LAUNCH_WB(64, 128, ST);                                                                     \
         else LAUNCH_WB(64, 64, ST);                                                                                \
     } while (0)
-        static const int wdbg = getenv("CG3D_DBG_WGRAD") ? atoi(getenv("CG3D_DBG_WGRAD")) : 0;
-        if (wdbg && m128 && n128 && precision == 2) {
-#define LAUNCH_WBD(D)                                                                                              \
-    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<128, 128, D>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256),        \
-                       0, s, reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, \
-                       seg, dW, cin, cout, ot)
-            if (wdbg == 1) LAUNCH_WBD(1); else if (wdbg == 2) LAUNCH_WBD(2); else if (wdbg == 4) LAUNCH_WBD(4);
-            else if (wdbg == 8) LAUNCH_WBD(8); else if (wdbg == 3) LAUNCH_WBD(3); else LAUNCH_WBD(15);
-#undef LAUNCH_WBD
-            CG3D_CHECK_LAUNCH();
-            return CG3D_OK;
-        }
-        if (precision == 2 && cin % 8 == 0 && cout % 8 == 0 && !getenv("CG3D_WGRAD_NARROW")) {
+        if (precision == 2) {   // rows stored as bf16: 16-byte gathers need 8-channel multiples
+            if (cin % 8 != 0 || cout % 8 != 0) return CG3D_ERR_ARG;
 #define LAUNCH_WR(TM, TN)                                                                                          \
     hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s,    \
                        reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg, \
@@ -1342,14 +1314,13 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
             CG3D_CHECK_LAUNCH();
             return CG3D_OK;
         }
-        if (precision == 1) LAUNCH_WB_ALL(float); else LAUNCH_WB_ALL(uint16_t);
+        LAUNCH_WB_ALL(float);
 #undef LAUNCH_WB_ALL
 #undef LAUNCH_WB
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;
     }
-    if (cin >= 128 && cout >= 128 && cin % 4 == 0 && cout % 4 == 0 && !(((uintptr_t)X | (uintptr_t)dY) & 15) &&
-        !getenv("CG3D_WGRAD64")) {
+    if (cin >= 128 && cout >= 128 && cin % 4 == 0 && cout % 4 == 0 && !(((uintptr_t)X | (uintptr_t)dY) & 15)) {
         const int32_t ct = (cin + 127) / 128, ot = (cout + 127) / 128;
         hipLaunchKernelGGL(k_spconv_pairs_wgrad_t128, dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, X, dY,
                            pair_in, pair_out, seg, dW, cin, cout, ot);

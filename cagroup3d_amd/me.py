@@ -282,6 +282,7 @@ def _use_bf16(cin):
 # bf16 mode: maps whose neighbourhood occupancy P / (K * n_out) is at least this run the output-stationary
 # kernel (no atomics, one plain store per output row); sparser maps keep the pair form
 IMPLICIT_MIN_OCCUPANCY = float(__import__("os").environ.get("CG3D_IMPLICIT_THR", "0.1"))
+IMPLICIT_MIN_TILES = int(__import__("os").environ.get("CG3D_IMPLICIT_TILES", "96"))
 
 
 def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
@@ -423,9 +424,12 @@ class SparseConvFunction(torch.autograd.Function):
     their own weights: weight is [G*K, cin, cout] and group g uses weight[g*K + k]."""
 
     @staticmethod
-    def _implicit(kmap, P, cin, row_bounds):
+    def _implicit(kmap, P, cin, cout, n_rows, row_bounds):
+        """Output-stationary kernel (no atomics) or pair form?  bf16 mode, ungrouped maps with >= 10 % neighbourhood
+        occupancy and enough output tiles (128 rows x 128 channels each) to give the chip ~100 workgroups."""
         return (row_bounds is None and _use_bf16(cin) and kmap.K > 1
-                and P >= IMPLICIT_MIN_OCCUPANCY * kmap.K * max(min(kmap.n_out, kmap.n_in), 1))
+                and P >= IMPLICIT_MIN_OCCUPANCY * kmap.K * max(min(kmap.n_out, kmap.n_in), 1)
+                and -(-n_rows // 128) * -(-cout // 128) >= IMPLICIT_MIN_TILES)
 
     @staticmethod
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
@@ -439,7 +443,7 @@ class SparseConvFunction(torch.autograd.Function):
         # weight gradient) moves half the bytes
         xg = _to_bf16(x) if (BF16_ROWS and _use_bf16(cin)) else x
         ctx.save_for_backward(x, w3, xg if xg is not x else None)
-        if SparseConvFunction._implicit(kmap, P, cin, row_bounds):
+        if SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
             return _conv_implicit_bf16(xg, _prep_bf16_t(w3), kmap.nbr, b, kmap.n_out, cin, cout, P)
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
         return _conv_pairs(xg, w3, pin, pout, seg, nseg, b, kmap.n_out, P)
@@ -455,7 +459,7 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dw = db = None
         dyg = _to_bf16(dy) if (BF16_ROWS and _use_bf16(cout)) else dy     # shared by dgrad and wgrad
         if ctx.needs_input_grad[0]:
-            if SparseConvFunction._implicit(kmap, P, cout, rb):
+            if SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
                 dx = _conv_implicit_bf16(dyg, w3.to(torch.bfloat16).view(torch.int16), kmap.nbrT, None, kmap.n_in,
                                          cout, cin, P)

@@ -176,14 +176,15 @@ def test_spconv_output_stationary_bf16_matches_pair_form_oracle(oracle, hip, cin
     bias = torch.randn(cout)
     dy = torch.randn(coords.shape[0], cout)
     me.PRECISION = 1
-    old = me.IMPLICIT_MIN_OCCUPANCY
+    old, old_t = me.IMPLICIT_MIN_OCCUPANCY, me.IMPLICIT_MIN_TILES
+    me.IMPLICIT_MIN_TILES = 0
     try:
         me.IMPLICIT_MIN_OCCUPANCY = 0.0          # force the output-stationary kernel on the device
         ref, out = both(oracle, hip, _conv_case, coords, feats, w, bias, dy, 3, 1)
         me.IMPLICIT_MIN_OCCUPANCY = 2.0          # and the pair form
         _, out_pairs = both(oracle, hip, _conv_case, coords, feats, w, bias, dy, 3, 1)
     finally:
-        me.PRECISION, me.IMPLICIT_MIN_OCCUPANCY = 0, old
+        me.PRECISION, me.IMPLICIT_MIN_OCCUPANCY, me.IMPLICIT_MIN_TILES = 0, old, old_t
     for r, o, q in zip(ref, out, out_pairs):
         close(r, o, float(r.abs().max()))
         close(q, o, float(r.abs().max()))
