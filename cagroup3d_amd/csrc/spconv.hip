@@ -393,25 +393,49 @@ extern "C" int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream
     return CG3D_OK;
 }
 
-__global__ void k_prep_weights_bf16(const float *__restrict__ W, uint16_t *__restrict__ Wb, int64_t slots, int32_t cin,
-                                    int32_t cout) {
-    // Wb[s][co][ci] = bf16(W[s][ci][co]); thread per output element, reads strided (weights are small)
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+// fp32 weights [slot][ci][co] -> bf16 copies, transposed [slot][co][ci] (the MFMA B operand of forward) and/or plain
+// [slot][ci][co] (the B operand of the data gradient), 64 x 64 tiles through LDS so both sides stay coalesced.
+// The slots may come from G separate tensors (one per class branch, `Ws` = device array of G pointers): the grouped
+// convolutions never materialise an fp32 stack of the per-class weights.
+__global__ __launch_bounds__(256) void k_prep_weights(const float *__restrict__ W0, const float *const *__restrict__ Ws,
+                                                      uint16_t *__restrict__ Wb_t, uint16_t *__restrict__ Wb,
+                                                      int64_t slots_per, int32_t cin, int32_t cout, int32_t co_tiles) {
+    __shared__ uint16_t T[64][66];
+    const int64_t slot = blockIdx.x;
     const int64_t per = (int64_t)cin * cout;
-    if (t >= slots * per) return;
-    const int64_t s = t / per;
-    const int co = (int)((t % per) / cin), ci = (int)(t % cin);
-    Wb[t] = (uint16_t)f2bf(W[s * per + (int64_t)ci * cout + co]);
+    const float *src = Ws ? Ws[slot / slots_per] + (slot % slots_per) * per : W0 + slot * per;
+    const int ci0 = (blockIdx.y / co_tiles) * 64, co0 = (blockIdx.y % co_tiles) * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;                       // r: input channel, c: output channel
+        const bool ok = ci0 + r < cin && co0 + c < cout;
+        const uint16_t b = ok ? (uint16_t)f2bf(src[(int64_t)(ci0 + r) * cout + co0 + c]) : (uint16_t)0;
+        T[r][c] = b;
+        if (Wb && ok) Wb[slot * per + (int64_t)(ci0 + r) * cout + co0 + c] = b;
+    }
+    __syncthreads();
+    if (!Wb_t) return;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;                       // r: output channel, c: input channel
+        if (co0 + r < cout && ci0 + c < cin) Wb_t[slot * per + (int64_t)(co0 + r) * cin + ci0 + c] = T[c][r];
+    }
+}
+extern "C" int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws, uint16_t *Wb_t, uint16_t *Wb,
+                                                   int32_t G, int64_t slots_per, int32_t cin, int32_t cout,
+                                                   cg3d_stream_t stream) {
+    if (G < 1 || slots_per < 0 || cin < 1 || cout < 1 || (!W0 && !Ws) || (!Wb_t && !Wb)) return CG3D_ERR_ARG;
+    const int64_t slots = (int64_t)G * slots_per;
+    if (slots == 0) return CG3D_OK;
+    const int32_t ct = cg3d_divup(cin, 64), ot = cg3d_divup(cout, 64);
+    if (slots > 0x7fffffffll || (int64_t)ct * ot > 65535) return CG3D_ERR_RANGE;
+    hipLaunchKernelGGL(k_prep_weights, dim3((unsigned)slots, (unsigned)(ct * ot)), dim3(256), 0, cg3d_hs(stream), W0, Ws,
+                       Wb_t, Wb, slots_per, cin, cout, ot);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
 }
 extern "C" int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout,
                                              cg3d_stream_t stream) {
-    if (slots < 0 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    const int64_t total = slots * cin * cout;
-    if (total == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_prep_weights_bf16, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream), W, Wb,
-                       slots, cin, cout);
-    CG3D_CHECK_LAUNCH();
-    return CG3D_OK;
+    if (slots < 0) return CG3D_ERR_ARG;
+    return cg3d_spconv_prep_weights_bf16_multi(W, nullptr, Wb, nullptr, 1, slots, cin, cout, stream);
 }
 
 template <int NT, typename XT>

@@ -328,6 +328,37 @@ def _prep_bf16_t(w3):
     return out
 
 
+def _prep_bf16_both(w3):
+    """One launch: (bf16 [K, cout, cin] for the forward, bf16 [K, cin, cout] for the data gradient)."""
+    lib = _lib.get()
+    K, cin, cout = w3.shape
+    wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
+    wp = torch.empty((K, cin, cout), dtype=torch.int16, device=w3.device)
+    lib.call("cg3d_spconv_prep_weights_bf16_multi", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K),
+             c_int32(cin), c_int32(cout), lib.stream())
+    return wt, wp
+
+
+_wptr_cache = {}
+
+
+def _prep_bf16_group(weights, transposed):
+    """Per-group weights (G tensors [K, cin, cout], never stacked in fp32) -> int16 view of the stacked bf16 buffer
+    [G*K, cout, cin] (transposed) or [G*K, cin, cout]."""
+    lib = _lib.get()
+    G, (K, cin, cout) = len(weights), weights[0].shape
+    key = tuple(w.data_ptr() for w in weights)
+    tab = _wptr_cache.get(key)
+    if tab is None:
+        if len(_wptr_cache) > 64:
+            _wptr_cache.clear()
+        tab = _wptr_cache[key] = h2d(list(key), torch.int64, weights[0].device) if lib.is_device else torch.tensor(key, dtype=torch.int64)
+    out = torch.empty((G * K, cout, cin) if transposed else (G * K, cin, cout), dtype=torch.int16, device=weights[0].device)
+    lib.call("cg3d_spconv_prep_weights_bf16_multi", ptr(None), ptr(tab), ptr(out if transposed else None),
+             ptr(None if transposed else out), c_int32(G), c_int64(K), c_int32(cin), c_int32(cout), lib.stream())
+    return out
+
+
 def _seg_len_fwd():
     return FWD_SEG if _lib.get().is_device else (1 << 30)
 
@@ -359,8 +390,12 @@ class KernelProfile:
 def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=None):
     """Y[pout] += X[pin] @ w3[slot].  `w_bf16_t` (optional): the weights already as bf16 [slots, cout, cin]."""
     lib = _lib.get()
-    K, cin, cout = w3.shape
-    lib.check(x, w3, pin, pout, seg, bias)
+    if isinstance(w3, tuple):                 # (slots, cin, cout): the weights only exist as the prepared bf16 buffer
+        K, cin, cout = w3
+        w3 = None
+    else:
+        K, cin, cout = w3.shape
+    lib.check(x, w3, pin, pout, seg, bias, w_bf16_t)
     # Y initialised here (torch fill / broadcast copy) so that the C call launches exactly one kernel
     if bias is None:
         y = torch.zeros((n_out, cout), dtype=torch.float32, device=x.device)
@@ -442,15 +477,19 @@ class SparseConvFunction(torch.autograd.Function):
         # bf16 mode: one streaming conversion of the input rows, then every gather of this layer (forward and
         # weight gradient) moves half the bytes
         xg = _to_bf16(x) if (BF16_ROWS and _use_bf16(cin)) else x
-        ctx.save_for_backward(x, w3, xg if xg is not x else None)
+        wt = wp = None
+        if _use_bf16(cin):
+            # both bf16 copies of the weights in one launch; the plain one is the data gradient's operand
+            wt, wp = _prep_bf16_both(w3) if _use_bf16(cout) else (_prep_bf16_t(w3), None)
+        ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
         if SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
-            return _conv_implicit_bf16(xg, _prep_bf16_t(w3), kmap.nbr, b, kmap.n_out, cin, cout, P)
+            return _conv_implicit_bf16(xg, wt, kmap.nbr, b, kmap.n_out, cin, cout, P)
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
-        return _conv_pairs(xg, w3, pin, pout, seg, nseg, b, kmap.n_out, P)
+        return _conv_pairs(xg, w3, pin, pout, seg, nseg, b, kmap.n_out, P, w_bf16_t=wt)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w3, xb = ctx.saved_tensors
+        x, w3, xb, wp = ctx.saved_tensors
         kmap, rb = ctx.kmap, ctx.row_bounds
         dy = dy.contiguous()
         lib = _lib.get()
@@ -461,14 +500,13 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
-                dx = _conv_implicit_bf16(dyg, w3.to(torch.bfloat16).view(torch.int16), kmap.nbrT, None, kmap.n_in,
-                                         cout, cin, P)
+                dx = _conv_implicit_bf16(dyg, wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16),
+                                         kmap.nbrT, None, kmap.n_in, cout, cin, P)
             else:
                 seg, nseg = kmap.segments(_seg_len_fwd(), rb)
                 if _use_bf16(cout):
-                    wt = w3.new_empty((KK, cout, cin))  # shape carrier only
-                    dx = _conv_pairs(dyg, wt, pout, pin, seg, nseg, None, kmap.n_in, P,
-                                     w_bf16_t=w3.to(torch.bfloat16).view(torch.int16))
+                    dx = _conv_pairs(dyg, (KK, cout, cin), pout, pin, seg, nseg, None, kmap.n_in, P,
+                                     w_bf16_t=wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16))
                 else:
                     wt = w3.transpose(1, 2).contiguous()
                     dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
@@ -494,6 +532,62 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None
+
+
+class GroupedConvFunction(torch.autograd.Function):
+    """SparseConvFunction for G row groups whose weights are G separate parameters (the class branches,
+    cagroup_head.py:183-188) in the bf16 mode: the per-class weights go straight into the stacked bf16 operand
+    buffers (no 215 MB fp32 stack per step for the 9^3 branch), the weight gradient is computed into one stacked
+    buffer and handed back as per-class views."""
+
+    @staticmethod
+    def forward(ctx, x, kmap, row_bounds, *weights):
+        x = x.contiguous()
+        G, (K, cin, cout) = len(weights), weights[0].shape
+        ctx.kmap, ctx.row_bounds, ctx.shape = kmap, row_bounds, (G, K, cin, cout)
+        pin, pout, _, P = kmap.pairs(row_bounds)
+        xg = _to_bf16(x) if BF16_ROWS else x
+        ctx.save_for_backward(x, xg if xg is not x else None, *weights)
+        seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
+        return _conv_pairs(xg, (G * K, cin, cout), pin, pout, seg, nseg, None, kmap.n_out, P,
+                           w_bf16_t=_prep_bf16_group(weights, True))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xb = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        kmap, rb = ctx.kmap, ctx.row_bounds
+        G, K, cin, cout = ctx.shape
+        lib = _lib.get()
+        dy = dy.contiguous()
+        pin, pout, _, P = kmap.pairs(rb)
+        dyg = _to_bf16(dy) if BF16_ROWS else dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            seg, nseg = kmap.segments(_seg_len_fwd(), rb)
+            dx = _conv_pairs(dyg, (G * K, cout, cin), pout, pin, seg, nseg, None, kmap.n_in, P,
+                             w_bf16_t=_prep_bf16_group(weights, False))
+        dws = [None] * G
+        if any(ctx.needs_input_grad[3:]):
+            dw = torch.empty((G * K, cin, cout), dtype=torch.float32, device=x.device)
+            wprec = 2 if (xb is not None and dyg is not dy) else 1
+            xw, dyw = (xb, dyg) if wprec == 2 else (x, dy)
+            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, 1, G * K), rb)
+            lib.check(xw, dyw, pin, pout, seg)
+            lib.call("cg3d_spconv_pairs_wgrad", ptr(xw), ptr(dyw), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
+                     c_int32(G * K), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
+            dws = [dw[g * K:(g + 1) * K] for g in range(G)]
+        return (dx, None, None) + tuple(dws)
+
+
+def grouped_conv(x, weights, kmap, row_bounds):
+    """Convolution of G contiguous row groups with their own weights ([K, cin, cout] each)."""
+    weights = [w.view(-1, w.shape[-2], w.shape[-1]) for w in weights]
+    cin, cout = weights[0].shape[1], weights[0].shape[2]
+    if _use_bf16(cin) and _use_bf16(cout) and _lib.get().is_device:
+        return GroupedConvFunction.apply(x, kmap, row_bounds, *weights)
+    w = torch.stack(weights, dim=0)
+    return SparseConvFunction.apply(x, w.view(-1, cin, cout), None, kmap, row_bounds)
 
 
 _ident_cache = {}
@@ -527,9 +621,23 @@ class LinearFunction(torch.autograd.Function):
     MIN_ROWS = 8192
 
     @staticmethod
+    def _skinny(n, a, b):
+        """Many rows x (few channels on one side): the library picks 16 x 256 tiles for these (0.25 ms for a
+        155 k x 64 x 3 product); the identity-map pair kernel streams the rows once instead."""
+        return n >= LinearFunction.MIN_ROWS and min(a, b) < 32 and _lib.get().is_device
+
+    @staticmethod
+    def _rows_gemm(x, w, bias):
+        n, (cin, cout) = x.shape[0], w.shape
+        ar, seg, nseg = _identity_pairs(n, 128, x.device)
+        return _conv_pairs(x.contiguous(), w.contiguous().view(1, cin, cout), ar, ar, seg, nseg, bias, n, n)
+
+    @staticmethod
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        if LinearFunction._skinny(x.shape[0], w.shape[0], w.shape[1]):
+            return LinearFunction._rows_gemm(x, w, bias.contiguous() if bias is not None else None)
         return torch.addmm(bias, x, w) if bias is not None else x @ w
 
     @staticmethod
@@ -537,7 +645,10 @@ class LinearFunction(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = dy @ w.t()
+            if LinearFunction._skinny(x.shape[0], w.shape[0], w.shape[1]):
+                dx = LinearFunction._rows_gemm(dy, w.t(), None)
+            else:
+                dx = dy @ w.t()
         if ctx.needs_input_grad[1]:
             n, (cin, cout) = x.shape[0], w.shape
             lib = _lib.get()

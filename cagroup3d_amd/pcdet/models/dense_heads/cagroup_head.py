@@ -257,26 +257,22 @@ class CAGroup3DHead(nn.Module):
         coarse_bounds = (0,) + tuple(np.cumsum(sizes[C:2 * C]).tolist())
         per_scene = sizes[2 * C:].tolist()
 
-        def stacked(mods, pick):
-            w = torch.stack([pick(m).kernel for m in mods], dim=0)
-            return w.view(-1, w.shape[-2], w.shape[-1])
         mgr = cls_map.coordinate_manager
         km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, self.cls_kernel, 1, False)
-        a = ME.SparseConvFunction.apply(cls_map.F, stacked(self.cls_individual_out, lambda m: m[0]), None, km9, fine_bounds)
+        a = ME.grouped_conv(cls_map.F, [m[0].kernel for m in self.cls_individual_out], km9, fine_bounds)
         a = self._grouped_bn_act(a, fine_bounds, [m[1] for m in self.cls_individual_out], elu)
 
         emgr = cls_exp.coordinate_manager
         km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
-        e = ME.SparseConvFunction.apply(cls_exp.F, stacked(self.cls_individual_expand_out, lambda m: m[0]), None, km5, coarse_bounds)
+        e = ME.grouped_conv(cls_exp.F, [m[0].kernel for m in self.cls_individual_expand_out], km5, coarse_bounds)
         e = self._grouped_bn_act(e, coarse_bounds, [m[1] for m in self.cls_individual_expand_out], elu)
         tgt_key, _, _ = emgr.insert(fine_C, 1)                             # generative transposed conv onto the fine voxels
         km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, self.expand, 1, True)
-        u = ME.SparseConvFunction.apply(e, stacked(self.cls_individual_up, lambda m: m[0]), None, km_up, fine_bounds)
+        u = ME.grouped_conv(e, [m[0].kernel for m in self.cls_individual_up], km_up, fine_bounds)
         u = self._grouped_bn_act(u, fine_bounds, [m[1][0] for m in self.cls_individual_up], elu)
 
         ident = ME.KernelMap.identity(fine_C.shape[0], dev)
-        f = ME.SparseConvFunction.apply(torch.cat([u, a], dim=1), stacked(self.cls_individual_fuse, lambda m: m[0]), None,
-                                        ident, fine_bounds)
+        f = ME.grouped_conv(torch.cat([u, a], dim=1), [m[0].kernel for m in self.cls_individual_fuse], ident, fine_bounds)
         f = self._grouped_bn_act(f, fine_bounds, [m[1] for m in self.cls_individual_fuse], elu)
 
         with torch.no_grad():

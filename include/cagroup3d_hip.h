@@ -137,6 +137,12 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
  * ---------------------------------------------------------------------------------------- */
 int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout,
                                   cg3d_stream_t stream);
+/* General form: the G*slots_per weight slots come from ONE tensor (W0, Ws == NULL) or from G tensors of slots_per
+ * slots each (Ws = device array of G pointers, e.g. the per-class weights of cagroup_head.py:183-188, never stacked
+ * in fp32); writes the transposed copy Wb_t [G*slots_per, cout, cin] and/or the plain copy Wb [G*slots_per, cin, cout]
+ * (either may be NULL).  The plain copy is the prepared buffer of the data gradient (the swapped problem). */
+int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws, uint16_t *Wb_t, uint16_t *Wb,
+                                        int32_t G, int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t stream);
 int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
 int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
                      void *ws, int32_t *pair_off, cg3d_stream_t stream);

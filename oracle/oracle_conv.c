@@ -24,6 +24,23 @@ static inline float os_bf16(float v) {
     return r;
 }
 
+int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws, uint16_t *Wb_t, uint16_t *Wb, int32_t G,
+                                        int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t s) {
+    (void)s;
+    if (G < 1 || slots_per < 0 || cin < 1 || cout < 1 || (!W0 && !Ws) || (!Wb_t && !Wb)) return CG3D_ERR_ARG;
+    int64_t per = (int64_t)cin * cout;
+    for (int64_t slot = 0; slot < (int64_t)G * slots_per; slot++) {
+        const float *src = Ws ? Ws[slot / slots_per] + (slot % slots_per) * per : W0 + slot * per;
+        for (int32_t ci = 0; ci < cin; ci++)
+            for (int32_t co = 0; co < cout; co++) {
+                float v = os_bf16(src[(int64_t)ci * cout + co]);
+                uint32_t u; memcpy(&u, &v, 4);
+                if (Wb) Wb[slot * per + (int64_t)ci * cout + co] = (uint16_t)(u >> 16);
+                if (Wb_t) Wb_t[slot * per + (int64_t)co * cin + ci] = (uint16_t)(u >> 16);
+            }
+    }
+    return CG3D_OK;
+}
 static inline float os_bf16_bits(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 /* element a of a gathered row: fp32 storage (precision 0: as is, 1: rounded to bf16) or bf16 storage (2) */
 static inline float os_row(const void *base, int64_t i, int32_t precision) {
