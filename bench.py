@@ -209,11 +209,11 @@ def main():
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if me.PRECISION == 1 else "f32", "data": "synthetic",
-               "config": {"workload": "ScanNetV2 CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
-                   args.batch, args.config, "forced GT selection + own-class logit boost (trained-like loads)" if forced
+               "config": {"workload": "%s CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
+                   {"scannet": "ScanNetV2", "sunrgbd": "SUN RGB-D"}.get(args.dataset, args.dataset), args.batch, args.config, "forced GT selection + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
-                          "voxel_size_m": 0.02, "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
+                          "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
                           "precision": ("bf16 MFMA operands in conv fwd/dgrad, fp32 accumulate/storage/wgrad"
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
                           "last_loss": tb.get("loss_all")},
