@@ -1,0 +1,182 @@
+"""Train / evaluate drivers for the CAGroup3D path: this build's counterparts of the reference's `tools/train.py`
+(:59-202), `tools/train_utils/train_utils.py` (train_one_epoch :12-90, train_model :111-196, checkpoint_state /
+save_checkpoint :199-228), `tools/train_utils/optimization/__init__.py` (build_optimizer :11-40, build_scheduler
+:43-65) and `tools/test.py` + `eval_utils.eval_one_epoch` (prediction dicts -> `indoor_eval`).  The data side is the
+committed synthetic scene generator (no datasets in this environment); the loop, the optimiser / step-decay
+schedule / gradient clipping, the semantic-threshold schedule input (`cur_epoch`), the checkpoint layout
+(`model_state`, `optimizer_state`, `epoch`, `it`) and the evaluation protocol follow the reference.
+
+    python -m cagroup3d_amd.train --dataset scannet --config S5k --scenes 8 --epochs 2 --ckpt /tmp/ck.pth --eval
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m cagroup3d_amd.train ...     # DDP over RCCL
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import build_model, synthetic
+from .pcdet.datasets.indoor_eval import indoor_eval
+from .pcdet.models import load_data_to_gpu, model_fn_decorator
+
+
+class SyntheticIndoorDataset:
+    """Scenes 0..n-1 of a synthetic configuration, sharded like DistributedSampler (scene i -> rank i mod W) and
+    collated into the reference's batch_dict (dataset.py:159-230)."""
+
+    def __init__(self, config, n_scenes, batch_size, rank=0, world=1, first_scene=0):
+        self.config, self.batch_size = config, batch_size
+        self.scene_ids = list(range(first_scene + rank, first_scene + n_scenes, world))
+
+    def __len__(self):
+        return (len(self.scene_ids) + self.batch_size - 1) // self.batch_size
+
+    def batches(self, epoch=0, shuffle=False):
+        ids = list(self.scene_ids)
+        if shuffle:
+            np.random.RandomState(epoch).shuffle(ids)           # epoch-seeded, like sampler.set_epoch
+        for i in range(0, len(ids), self.batch_size):
+            chunk = ids[i:i + self.batch_size]
+            scenes = [synthetic.make_scene(self.config, s) for s in chunk]
+            pts = np.concatenate([np.c_[np.full(len(s["points"]), j, np.float32), s["points"]] for j, s in enumerate(scenes)])
+            gmax = max(len(s["gt_boxes"]) for s in scenes)
+            gt = np.zeros((len(scenes), gmax, 8), np.float32)
+            for j, s in enumerate(scenes):
+                gt[j, :len(s["gt_boxes"])] = s["gt_boxes"]
+            yield {"points": pts.astype(np.float32), "gt_boxes": gt, "batch_size": len(scenes), "frame_id": np.array(chunk),
+                   "instance_mask": [s["instance_mask"] for s in scenes], "semantic_mask": [s["semantic_mask"] for s in scenes]}
+
+    @staticmethod
+    def gt_annos(batch):
+        """info['annos'] of the reference's info files: gt_num / gt_boxes_upright_depth / class (scannet_dataset.py:145)."""
+        out = []
+        for g in batch["gt_boxes"]:
+            g = np.asarray(g.cpu() if torch.is_tensor(g) else g)
+            g = g[~(g == 0).all(-1)]
+            out.append({"gt_num": len(g), "gt_boxes_upright_depth": g[:, :7].astype(np.float32), "class": g[:, 7].astype(np.int64)})
+        return out
+
+
+def build_optimizer(model, optim_cfg):
+    params = [p for p in model.parameters() if p.requires_grad]
+    name = optim_cfg.OPTIMIZER
+    if name == "adam":
+        return torch.optim.Adam(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY)
+    if name == "adamW":
+        return torch.optim.AdamW(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY,
+                                 fused=params[0].is_cuda)       # one multi-tensor launch set per step on the GPU
+    if name == "sgd":
+        return torch.optim.SGD(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY, momentum=optim_cfg.MOMENTUM)
+    raise NotImplementedError(name)       # adam_onecycle (fastai wrapper) is not used by the CAGroup3D configurations
+
+
+def build_scheduler(optimizer, iters_per_epoch, optim_cfg, last_it=-1):
+    """LR x LR_DECAY at every DECAY_STEP_LIST epoch boundary, stepped per ITERATION, floored at LR_CLIP."""
+    steps = [e * iters_per_epoch for e in optim_cfg.DECAY_STEP_LIST]
+    floor = optim_cfg.get("LR_CLIP", 0.0) / optim_cfg.LR
+
+    def factor(it):
+        f = 1.0
+        for s in steps:
+            if it >= s:
+                f *= optim_cfg.LR_DECAY
+        return max(f, floor)
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch=last_it)
+
+
+def checkpoint_state(model, optimizer, epoch, it):
+    m = model.module if hasattr(model, "module") else model
+    return {"epoch": epoch, "it": it, "model_state": {k: v.cpu() for k, v in m.state_dict().items()},
+            "optimizer_state": optimizer.state_dict() if optimizer is not None else None, "version": "cagroup3d_amd"}
+
+
+def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=0, log=print):
+    model.train()
+    model_func = model_fn_decorator()
+    params = [p for p in model.parameters() if p.requires_grad]
+    device = params[0].device
+    for batch in dataset.batches(epoch, shuffle=True):
+        batch["cur_epoch"] = epoch                               # drives the semantic threshold (cagroup3d.py:31)
+        load_data_to_gpu(batch, device)
+        optimizer.zero_grad(set_to_none=True)
+        loss, tb, disp = model_func(model, batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, clip)
+        optimizer.step()
+        scheduler.step()
+        it += 1
+        if rank == 0:
+            log("epoch %d it %d lr %.2e loss %.4f (%s)" % (epoch, it, optimizer.param_groups[0]["lr"], float(loss.detach()),
+                                                          ", ".join("%s %.3f" % (k, v) for k, v in sorted(tb.items()) if k.startswith("loss_"))))
+    return it
+
+
+@torch.no_grad()
+def eval_one_epoch(model, dataset, class_names, device, metric=(0.25, 0.5), log=print):
+    """Detections of every scene of this rank's shard -> indoor_eval (test.py / eval_utils.py / scannet_dataset.py:88-150)."""
+    model.eval()
+    det_annos, gt_annos = [], []
+    for batch in dataset.batches():
+        batch["cur_epoch"] = 0
+        gt_annos += SyntheticIndoorDataset.gt_annos(batch)
+        load_data_to_gpu(batch, device)
+        pred_dicts, _ = model(batch)
+        for p in pred_dicts:
+            det_annos.append({"boxes_3d": p["pred_boxes"].cpu().numpy(), "scores_3d": p["pred_scores"].cpu().numpy(),
+                              "labels_3d": p["pred_labels"].cpu().numpy().astype(np.int64)})
+    return indoor_eval(gt_annos, det_annos, list(metric), {i: c for i, c in enumerate(class_names)},
+                       logger=type("L", (), {"info": staticmethod(log)}))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", default="scannet")
+    ap.add_argument("--config", default="S50k")
+    ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--ckpt", default=None)
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--eval", action="store_true")
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32")
+    args = ap.parse_args(argv)
+    from . import me
+    me.PRECISION = 1 if args.precision == "bf16" else 0
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device(args.device, int(os.environ.get("LOCAL_RANK", "0"))) if args.device == "cuda" else torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(backend="nccl" if dev.type == "cuda" else "gloo")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    model, cfg = build_model.build_cagroup3d(args.dataset, seed=0)
+    model = model.to(dev)
+    oc = cfg.OPTIMIZATION
+    epochs = args.epochs if args.epochs is not None else oc.NUM_EPOCHS
+    ds = SyntheticIndoorDataset(args.config, args.scenes, args.batch or oc.BATCH_SIZE_PER_GPU, rank, world)
+    optimizer = build_optimizer(model, oc)
+    start_epoch, it = 0, 0
+    if args.resume:
+        it, start_epoch = model.load_params_with_optimizer(args.resume, to_cpu=dev.type == "cpu", optimizer=optimizer)
+    scheduler = build_scheduler(optimizer, len(ds), oc, last_it=it - 1 if it else -1)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if dev.type == "cuda" else None,
+                                                    gradient_as_bucket_view=True) if world > 1 else model
+    t0 = time.time()
+    for epoch in range(start_epoch, epochs):
+        it = train_one_epoch(net, optimizer, scheduler, ds, epoch, it, oc.GRAD_NORM_CLIP, rank)
+        if args.ckpt and rank == 0:
+            torch.save(checkpoint_state(net, optimizer, epoch + 1, it), args.ckpt)
+    if rank == 0:
+        print("trained %d iterations in %.1f s" % (it, time.time() - t0))
+    result = None
+    if args.eval and rank == 0:
+        result = eval_one_epoch(model, SyntheticIndoorDataset(args.config, args.scenes, ds.batch_size), cfg.CLASS_NAMES, dev)
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()
