@@ -53,3 +53,14 @@ def test_train_checkpoint_resume_eval(oracle, tmp_path):
         res = train.main(["--config", "S5k", "--scenes", "2", "--batch", "2", "--epochs", "2", "--resume", ck, "--device", "cpu",
                           "--eval"])
     assert set(k for k in res if k.startswith("m")) == {"mAP_0.25", "mAP_0.50", "mAR_0.25", "mAR_0.50"}
+
+
+@pytest.mark.gpu
+def test_train_and_eval_on_device(hip, tmp_path):
+    ck = str(tmp_path / "ck.pth")
+    with _lib.use_library(hip):
+        res = train.main(["--config", "S5k", "--scenes", "4", "--batch", "2", "--epochs", "1", "--ckpt", ck, "--eval",
+                          "--precision", "bf16"])
+    from cagroup3d_amd import me
+    me.PRECISION = 0
+    assert os.path.exists(ck) and "mAP_0.25" in res
