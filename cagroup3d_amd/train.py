@@ -59,6 +59,42 @@ class SyntheticIndoorDataset:
         return out
 
 
+class DiskIndoorDataset:
+    """The reference's processed ScanNet / SUN RGB-D folder behind the same `.batches()` interface: IndoorDataset +
+    torch DataLoader workers (per-worker numpy seeding like common_utils.worker_init_fn) + rank sharding."""
+
+    def __init__(self, kind, root, class_names, batch_size, training, rank=0, world=1, workers=4, seed=666):
+        import yaml
+        from .pcdet.datasets.indoor_dataset import IndoorDataset
+        cfg = yaml.safe_load(open(os.path.join(build_model.CFG_DIR, "dataset_configs", "%s_dataset.yaml" % kind)))
+        self.data = IndoorDataset(cfg, class_names, training=training, root_path=root, kind=kind)
+        self.batch_size, self.training, self.rank, self.world, self.workers, self.seed = batch_size, training, rank, world, workers, seed
+
+    def __len__(self):
+        return (len(range(self.rank, len(self.data), self.world)) + self.batch_size - 1) // self.batch_size
+
+    def gt_annos(self):
+        return [self.data.gt_annos()[i] for i in range(self.rank, len(self.data), self.world)]
+
+    def batches(self, epoch=0, shuffle=False):
+        ids = np.arange(len(self.data))
+        if shuffle:
+            np.random.RandomState(self.seed + epoch).shuffle(ids)
+        ids = ids[self.rank::self.world].tolist()
+        seed = self.seed
+
+        def init(worker_id):
+            np.random.seed(seed + epoch * 1000 + worker_id)
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(self.data, ids), batch_size=self.batch_size, shuffle=False,
+                                             num_workers=self.workers, collate_fn=self.data.collate_batch, worker_init_fn=init,
+                                             drop_last=False)
+        yield from loader
+
+    @staticmethod
+    def batch_gt_annos(batch):
+        return SyntheticIndoorDataset.gt_annos(batch)
+
+
 def build_optimizer(model, optim_cfg):
     params = [p for p in model.parameters() if p.requires_grad]
     name = optim_cfg.OPTIMIZER
@@ -135,6 +171,8 @@ def main(argv=None):
     ap.add_argument("--dataset", default="scannet")
     ap.add_argument("--config", default="S50k")
     ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--data-root", default=None, help="processed ScanNet / SUN RGB-D folder (default: synthetic scenes)")
+    ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--ckpt", default=None)
@@ -155,7 +193,11 @@ def main(argv=None):
     model = model.to(dev)
     oc = cfg.OPTIMIZATION
     epochs = args.epochs if args.epochs is not None else oc.NUM_EPOCHS
-    ds = SyntheticIndoorDataset(args.config, args.scenes, args.batch or oc.BATCH_SIZE_PER_GPU, rank, world)
+    bs = args.batch or oc.BATCH_SIZE_PER_GPU
+    if args.data_root:
+        ds = DiskIndoorDataset(args.dataset, args.data_root, cfg.CLASS_NAMES, bs, True, rank, world, args.workers)
+    else:
+        ds = SyntheticIndoorDataset(args.config, args.scenes, bs, rank, world)
     optimizer = build_optimizer(model, oc)
     start_epoch, it = 0, 0
     if args.resume:
@@ -172,7 +214,9 @@ def main(argv=None):
         print("trained %d iterations in %.1f s" % (it, time.time() - t0))
     result = None
     if args.eval and rank == 0:
-        result = eval_one_epoch(model, SyntheticIndoorDataset(args.config, args.scenes, ds.batch_size), cfg.CLASS_NAMES, dev)
+        val = (DiskIndoorDataset(args.dataset, args.data_root, cfg.CLASS_NAMES, bs, False, workers=args.workers) if args.data_root
+               else SyntheticIndoorDataset(args.config, args.scenes, bs))
+        result = eval_one_epoch(model, val, cfg.CLASS_NAMES, dev)
     if world > 1:
         dist.destroy_process_group()
     return result

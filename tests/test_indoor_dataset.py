@@ -123,3 +123,30 @@ def test_loader_batch_trains_the_detector(oracle, tmp_path):
         ret, tb, _ = model(batch)
         ret["loss"].backward()
     assert torch.isfinite(ret["loss"]) and tb["loss_vote"] > 0
+
+
+def test_train_driver_on_a_processed_folder(oracle, tmp_path):
+    from cagroup3d_amd import _lib, build_model, synthetic, train
+    names = build_model.load_cfg("scannet").CLASS_NAMES
+    inv = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 24, 28, 33, 34, 36, 39]
+    infos = []
+    for i in range(2):
+        s = synthetic.make_scene("S5k", i)
+        sem = np.array([inv[c] if c < 18 else 1 for c in s["semantic_mask"]], dtype=np.int64)
+        infos.append(ds.write_processed_scene(str(tmp_path), "scene%04d_00" % i, s["points"], s["gt_boxes"][:, :7],
+                                              [names[int(c)] for c in s["gt_boxes"][:, 7]], instance_mask=s["instance_mask"],
+                                              semantic_mask=sem, class_ids=s["gt_boxes"][:, 7], axis_align_matrix=np.eye(4, dtype=np.float32)))
+    for split in ("train", "val"):
+        pickle.dump(infos, open(os.path.join(str(tmp_path), "scannet_infos_%s.pkl" % split), "wb"))
+    d = train.DiskIndoorDataset("scannet", str(tmp_path), names, 2, True, workers=0)
+    d.data.infos = d.data.infos[:2]                          # REPEAT 10 -> one pass for the test
+    assert len(d) == 1
+    with _lib.use_library(oracle):
+        model, cfg = build_model.build_cagroup3d("scannet", seed=0)
+        opt = train.build_optimizer(model, cfg.OPTIMIZATION)
+        sched = train.build_scheduler(opt, len(d), cfg.OPTIMIZATION)
+        it = train.train_one_epoch(model, opt, sched, d, 0, 0, cfg.OPTIMIZATION.GRAD_NORM_CLIP, log=lambda *a: None)
+        assert it == 1
+        res = train.eval_one_epoch(model, train.DiskIndoorDataset("scannet", str(tmp_path), names, 2, False, workers=0), names,
+                                   "cpu", log=lambda *a: None)
+    assert "mAP_0.25" in res
