@@ -71,6 +71,8 @@ def make_model(dataset, forced, device):
 
 
 _PARAMS = {}
+_PREPARED = {}
+PREFETCH = os.environ.get("CG3D_PREFETCH", "1") != "0"
 
 
 def train_step(model, opt, batch, clip):
@@ -78,10 +80,18 @@ def train_step(model, opt, batch, clip):
     if params is None:                      # walking the module tree every step costs ~2 ms of host time
         params = _PARAMS[id(model)] = [p for p in model.parameters() if p.requires_grad]
     opt.zero_grad(set_to_none=True)
-    ret, tb, disp = model(fresh(batch))
+    b = fresh(batch)
+    core = model.module if hasattr(model, "module") else model
+    if PREFETCH and _PREPARED.get(id(core)) is not None:
+        b["prepared"] = _PREPARED.pop(id(core))
+    ret, tb, disp = model(b)
     ret["loss"].backward()
     torch.nn.utils.clip_grad_norm_(params, clip)
     opt.step()
+    if PREFETCH:
+        # the NEXT batch's coordinate structures (here: the same synthetic scenes again), on a side stream while the
+        # GPU still works through the backward just queued -- every step builds them anew, nothing is reused
+        _PREPARED[id(core)] = core.prefetch_coordinates(batch)
     return tb
 
 

@@ -311,6 +311,41 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
 BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 mode: gather from bf16 row copies
 
 
+# Coordinate-only dry run (CAGroup3D.prefetch_coordinates): modules build every coordinate / kernel map, pair list and
+# segment table they will need -- with their host reads -- but launch no feature kernel and return uninitialised
+# feature tensors of the right shape.  Run on a side stream for the NEXT batch while the GPU is still busy with the
+# current step's backward, it takes the data-dependent host syncs out of the timed forward pass.
+COORDS_ONLY = False
+
+
+def _fake(n, c, like):
+    return torch.empty((n, c), dtype=torch.float32, device=like.device)
+
+
+def release_to_stream(mgr, extra, stream):
+    """Every tensor the coordinate manager holds was allocated on the prefetch stream; tell the caching allocator that
+    `stream` uses them too (their blocks may only be recycled after that stream's pending work)."""
+    seen = []
+
+    def walk(o):
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                seen.append(o)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, _CoordMap):
+            walk([o.coords, o.keys, o.vals, o._perms])
+        elif isinstance(o, KernelMap):
+            walk([o.nbr, o._nbrT, o._pairs, o._segs])
+    walk([mgr._maps, mgr._kmaps, extra])
+    for t in seen:
+        t.record_stream(stream)
+
+
 def _to_bf16(x):
     """fp32 [N, C] -> int16 view of the bf16 rows (cg3d_to_bf16; one streaming pass, halves every later gather)."""
     lib = _lib.get()
@@ -465,6 +500,20 @@ class SparseConvFunction(torch.autograd.Function):
         return (row_bounds is None and _use_bf16(cin) and kmap.K > 1
                 and P >= IMPLICIT_MIN_OCCUPANCY * kmap.K * max(min(kmap.n_out, kmap.n_in), 1)
                 and -(-n_rows // 128) * -(-cout // 128) >= IMPLICIT_MIN_TILES)
+
+    @staticmethod
+    def warm(kmap, K, cin, cout, row_bounds=None, backward=True):
+        """Build (and cache on the map) everything forward / backward of this layer will read from the host."""
+        _, _, _, P = kmap.pairs(row_bounds)
+        if not SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
+            kmap.segments(_seg_len_fwd(), row_bounds)
+        if backward:
+            if SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, row_bounds):
+                _ = kmap.nbrT
+            else:
+                kmap.segments(_seg_len_fwd(), row_bounds)
+            wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+            kmap.segments(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), row_bounds)
 
     @staticmethod
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
@@ -878,6 +927,8 @@ class FusedBNActFunction(torch.autograd.Function):
 def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     """BatchNorm1d modules `bns` (one per contiguous row group of `bounds`) + residual + activation in
     two launches (statistics, apply); updates the modules' running statistics like nn.BatchNorm1d."""
+    if COORDS_ONLY:
+        return feats
     bns = list(bns)
     G, N, C = len(bns), feats.shape[0], feats.shape[1]
     if bounds is None:
@@ -1002,6 +1053,8 @@ class SparseTensor:
 
     def features_at_coordinates(self, query):
         """Trilinear interpolation of this tensor at continuous coordinates [nq,4] (b,x,y,z)."""
+        if COORDS_ONLY:
+            return _fake(query.shape[0], self.F.shape[1], self.F)
         lib = _lib.get()
         q = query.to(torch.float32).contiguous()
         m = self._map
@@ -1034,6 +1087,8 @@ class SparseTensor:
 def cat(*tensors):
     for t in tensors[1:]:
         tensors[0]._same_map(t)
+    if COORDS_ONLY:
+        return tensors[0]._like(_fake(tensors[0].F.shape[0], sum(t.F.shape[1] for t in tensors), tensors[0].F))
     return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
 
 
@@ -1080,10 +1135,14 @@ class MinkowskiConvolution(_ConvBase):
             out_key = x.coordinate_map_key
         bias = self.bias.view(-1) if self.bias is not None else None
         if self.kernel_volume == 1 and coordinates is None and self.stride == 1:
-            out = linear(x.F, self.kernel, bias)    # a 1x1x1 convolution has no neighbourhood
+            out = _fake(x.F.shape[0], self.out_channels, x.F) if COORDS_ONLY else linear(x.F, self.kernel, bias)
         else:
             km = mgr.kernel_map(x.coordinate_map_key, out_key, self.kernel_size, self.dilation, False)
-            out = SparseConvFunction.apply(x.F, self._w3(), bias, km)
+            if COORDS_ONLY:
+                SparseConvFunction.warm(km, self.kernel_volume, self.in_channels, self.out_channels, None, self.training)
+                out = _fake(km.n_out, self.out_channels, x.F)
+            else:
+                out = SparseConvFunction.apply(x.F, self._w3(), bias, km)
         return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
@@ -1103,6 +1162,9 @@ class MinkowskiConvolutionTranspose(_ConvBase):
             out_key = cands[0]
         km = mgr.kernel_map(x.coordinate_map_key, out_key, self.kernel_size, self.dilation, True)
         bias = self.bias.view(-1) if self.bias is not None else None
+        if COORDS_ONLY:
+            SparseConvFunction.warm(km, self.kernel_volume, self.in_channels, self.out_channels, None, self.training)
+            return SparseTensor(features=_fake(km.n_out, self.out_channels, x.F), coordinate_map_key=out_key, coordinate_manager=mgr)
         out = SparseConvFunction.apply(x.F, self._w3(), bias, km)
         return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
@@ -1135,7 +1197,7 @@ class MinkowskiAvgPooling(nn.Module):
                      c_int64(dst.cap), ptr(pmap), lib.stream())
             pmap = pmap[:, :src.n].contiguous() if src.n > 0 else pmap[:, :0]
             mgr._kmaps[ck] = pmap
-        out = ScatterMeanFunction.apply(x.F, pmap, dst.n)
+        out = _fake(dst.n, x.F.shape[1], x.F) if COORDS_ONLY else ScatterMeanFunction.apply(x.F, pmap, dst.n)
         return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
@@ -1151,7 +1213,7 @@ class MinkowskiBatchNorm(nn.Module):
 
 class _Pointwise(nn.Module):
     def forward(self, x):
-        return x._like(self.fn(x.F))
+        return x if COORDS_ONLY else x._like(self.fn(x.F))
 
 
 class MinkowskiReLU(_Pointwise):

@@ -57,6 +57,8 @@ class CAGroup3DHead(nn.Module):
         # batched = all class branches share one coordinate space (class folded into the batch index) and
         # run as grouped launches; False = the reference's 18-iteration loop (kept for the equivalence test)
         self.batched = True
+        self._data_targets = None        # data-only targets / forced mask handed over by CAGroup3D.prefetch_coordinates
+        self._forced_pre = None
 
         def sub(name, default):
             return cfg.get(name, AttrDict(default))
@@ -121,7 +123,11 @@ class CAGroup3DHead(nn.Module):
         batch_col = out.C[:, :1].float()
         offset_features = offset_features.view(offset_features.shape[0], n_vote, -1)
         sem_prob = semantic_scores.F.detach().sigmoid()
-        forced = self._forced_selection(input_dict, out, ori_xyz) if self.force_gt_selection else None
+        forced = None
+        if self.force_gt_selection:
+            forced, self._forced_pre = self._forced_pre, None
+            if forced is None or forced.shape[0] != ori_xyz.shape[0]:
+                forced = self._forced_selection(input_dict, out, ori_xyz)
 
         self._merged = None
         branch = self._class_branches_batched if self.batched else self._class_branches_loop
@@ -345,6 +351,51 @@ class CAGroup3DHead(nn.Module):
         tb_dict = dict(zip(names + ("one_stage_loss",), vals))
         return loss, tb_dict
 
+    @torch.no_grad()
+    def data_targets(self, vox_C, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks):
+        """The training targets that depend on the DATA only (stride-2 voxel coordinates, boxes, raw points and their
+        masks), not on the network: semantic label of every backbone voxel (assigner.assign_semantic,
+        cagroup3d_assigner.py:132-152) and the vote targets (cagroup_head.py:418-498).  `CAGroup3D.prefetch_coordinates`
+        computes them ahead of the step on its side stream; `_loss_batched` falls back to calling this itself."""
+        from .target_assigner.cagroup3d_assigner import FLOAT_MAX, volume
+        B, dev, vs = len(gt_bboxes), vox_C.device, self.voxel_size
+        n_gt = [len(g) for g in gt_bboxes]
+        gt = torch.cat([g.to(dev) for g in gt_bboxes])
+        gl = torch.cat([l.to(dev).long() for l in gt_labels])
+        gt_scene = torch.repeat_interleave(torch.arange(B, device=dev), ME.h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
+        vox_scene = vox_C[:, 0].long()
+        vox_xyz = vox_C[:, 1:] * vs
+        inside = find_points_in_boxes(vox_xyz, gt) & (vox_scene.view(-1, 1) == gt_scene.view(1, -1))
+        vols = torch.where(inside, volume(gt).view(1, -1).expand(inside.shape), torch.full((1, 1), FLOAT_MAX, device=dev))
+        min_vol, min_ind = vols.min(dim=1)
+        semantic_labels = torch.where(min_vol == FLOAT_MAX, torch.full_like(min_ind, -1), gl[min_ind])
+        # ---- vote targets
+        N = vox_C.shape[0]
+        equal_pts = len({sp.shape[0] for sp in scene_points}) == 1
+        if not self.with_yaw:
+            n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1      # one host read for all scenes
+        if not self.with_yaw and equal_pts:
+            order = torch.sort(vox_scene, stable=True)[1]
+            counts = torch.bincount(vox_scene, minlength=B)
+            perms = list(torch.split(order, counts.cpu().tolist()))
+            t, mk = self._vote_targets_masks_batched(vox_xyz, vox_scene, perms, gt_bboxes, scene_points, sem_masks, ins_masks, n_ins)
+            off_t, off_m = t, mk.float()
+            n_vox = counts.float()[vox_scene]
+        else:
+            off_t = torch.zeros((N, 3 * (self.gt_per_seed if self.with_yaw else 1)), device=dev)
+            off_m, n_vox = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+            for b in range(B):
+                rows = torch.nonzero(vox_scene == b).squeeze(1)
+                op = vox_xyz[rows]
+                if self.with_yaw:
+                    t, mk = self._vote_targets_yaw(op, gt_bboxes[b], gt_labels[b])
+                else:
+                    t, mk = self._vote_targets_masks(op, gt_bboxes[b], scene_points[b], sem_masks[b], ins_masks[b], int(n_ins[b]))
+                off_t[rows] = t
+                off_m[rows] = mk.float()
+                n_vox[rows] = float(len(rows))
+        return {"n": N, "semantic_labels": semantic_labels, "vox_scene": vox_scene, "off_t": off_t, "off_m": off_m, "n_vox": n_vox}
+
     def _loss_batched(self, semantic_scores, voxel_offset, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks):
         """All scenes of the batch in one pass: the same five loss terms as `_loss_single` averaged over scenes
         (cagroup_head.py:322-396,399-555), with per-row normalisers instead of a Python loop over scenes and
@@ -358,14 +409,12 @@ class CAGroup3DHead(nn.Module):
         gl = torch.cat([l.to(dev).long() for l in gt_labels])
         gt_scene = torch.repeat_interleave(torch.arange(B, device=dev), ME.h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
         with torch.no_grad():
-            # ---- semantic labels of every backbone voxel (assigner.assign_semantic)
-            vox_scene = semantic_scores.C[:, 0].long()
-            vox_xyz = semantic_scores.C[:, 1:] * vs
-            inside = find_points_in_boxes(vox_xyz, gt) & (vox_scene.view(-1, 1) == gt_scene.view(1, -1))
-            from .target_assigner.cagroup3d_assigner import FLOAT_MAX, volume
-            vols = torch.where(inside, volume(gt).view(1, -1).expand(inside.shape), torch.full((1, 1), FLOAT_MAX, device=dev))
-            min_vol, min_ind = vols.min(dim=1)
-            semantic_labels = torch.where(min_vol == FLOAT_MAX, torch.full_like(min_ind, -1), gl[min_ind])
+            pre = self._data_targets
+            self._data_targets = None
+            if pre is None or pre["n"] != semantic_scores.C.shape[0]:
+                pre = self.data_targets(semantic_scores.C, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks)
+            semantic_labels, vox_scene, off_t, off_m, n_vox = (pre[k] for k in ("semantic_labels", "vox_scene", "off_t", "off_m", "n_vox"))
+            vox_scene_off = vox_scene
             # ---- FCOS-style assignment of the class-map voxels (assigner.assign_all_classes, + same-scene mask)
             seg = m["seg"]
             pt_cls, pt_scene = seg // B, seg % B
@@ -373,31 +422,6 @@ class CAGroup3DHead(nn.Module):
             centerness_targets, bbox_targets, labels = self.assigner.assign_all_classes(
                 [m["points"]], gt, gl, pt_cls=pt_cls, same=pt_scene.view(-1, 1) == gt_scene.view(1, -1),
                 n_map=per[gl.clamp(max=self.n_classes - 1) * B + gt_scene])
-            # ---- vote targets (per scene: the raw point sets differ in size)
-            perms = voxel_offset.decomposition_permutations
-            off_t = torch.zeros((voxel_offset.F.shape[0], 3 * (self.gt_per_seed if self.with_yaw else 1)), device=dev)
-            off_m = torch.zeros(voxel_offset.F.shape[0], device=dev)
-            n_vox = torch.zeros(voxel_offset.F.shape[0], device=dev)
-            vox_scene_off = voxel_offset.C[:, 0].long()
-            equal_pts = len({sp.shape[0] for sp in scene_points}) == 1
-            if not self.with_yaw:
-                n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1  # one host read for all scenes
-            if not self.with_yaw and equal_pts:
-                t, mk = self._vote_targets_masks_batched(voxel_offset.C[:, 1:] * vs, vox_scene_off, perms, gt_bboxes,
-                                                         scene_points, sem_masks, ins_masks, n_ins)
-                off_t, off_m = t, mk.float()
-                n_vox = torch.bincount(vox_scene_off, minlength=B).float()[vox_scene_off]
-            else:
-                for b in range(B):
-                    op = voxel_offset.C[perms[b], 1:] * vs
-                    if self.with_yaw:
-                        t, mk = self._vote_targets_yaw(op, gt_bboxes[b], gt_labels[b])
-                    else:
-                        t, mk = self._vote_targets_masks(op, gt_bboxes[b], scene_points[b], sem_masks[b], ins_masks[b],
-                                                         int(n_ins[b]))
-                    off_t[perms[b]] = t
-                    off_m[perms[b]] = mk.float()
-                    n_vox[perms[b]] = float(len(perms[b]))
             # ---- per-scene normalisers, one all-reduce (the reference: 3 per scene, cagroup_head.py:523,530,538)
             pos = labels >= 0
             stats = torch.zeros((B, 3), device=dev)

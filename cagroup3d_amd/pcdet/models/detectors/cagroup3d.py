@@ -17,12 +17,60 @@ class CAGroup3D(Detector3DTemplate):
         self.semantic_iter_value = self.model_cfg.SEMANTIC_ITER_VALUE
         self.semantic_value = self.model_cfg.SEMANTIC_THR
 
-    def voxelization(self, points):
+    def voxelization(self, points, prepared=None):
         """points (N,7) = (b,x,y,z,r,g,b) -> sparse tensor on the 0.02 m grid; one (the first) point's
-        colour per voxel (cagroup3d.py:18-25)."""
+        colour per voxel (cagroup3d.py:18-25).  `prepared`: the coordinate side from `prefetch_coordinates`."""
+        if prepared is not None:
+            mgr, key, uniq, n_in, event, keep, targets = prepared
+            assert n_in == points.shape[0], "prefetched coordinates belong to another batch"
+            torch.cuda.current_stream().wait_event(event)
+            ME.release_to_stream(mgr, [keep, targets], torch.cuda.current_stream())
+            if targets is not None and self.training:
+                self.dense_head._data_targets, self.dense_head._forced_pre = targets.get("loss"), targets.get("forced")
+            feats = points[:, 4:] if uniq.shape[0] == n_in else points[:, 4:][uniq.long()]
+            return ME.SparseTensor(features=feats.clone(), coordinate_map_key=key, coordinate_manager=mgr)
         coordinates = points[:, :4].clone()
         coordinates[:, 1:] /= self.voxel_size
         return ME.SparseTensor(coordinates=coordinates, features=points[:, 4:].clone())
+
+    def prefetch_coordinates(self, batch_dict):
+        """Everything of a training / inference step that depends only on the point COORDINATES of a batch -- the
+        voxel hash, every strided map, kernel map, pair list and segment table of the backbone, the per-scene row
+        lists -- built on a side stream, with its data-dependent host reads, while the main stream is still busy (with
+        the previous step's backward).  Pass the result as batch_dict['prepared'] to the forward of THAT batch.  The
+        forward then has no host sync before the head, so the host runs ahead of the GPU through the backbone."""
+        points = batch_dict["points"]
+        if not points.is_cuda:
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=points.device, priority=-1)      # tiny kernels: jump the queue
+        side = self._side_stream
+        with torch.cuda.stream(side), torch.no_grad():
+            coordinates = points[:, :4].clone()
+            coordinates[:, 1:] /= self.voxel_size
+            ME.COORDS_ONLY = True
+            try:
+                sp = ME.SparseTensor(coordinates=coordinates, features=points[:, 4:])
+                out = self.backbone_3d({"sp_tensor": sp, "batch_size": batch_dict["batch_size"]})["sp_tensor"]
+                _ = out.decomposition_permutations            # the head's first host read
+            finally:
+                ME.COORDS_ONLY = False
+            targets = None
+            if self.training and "gt_boxes" in batch_dict and getattr(self.dense_head, "batched", False):
+                # training targets that depend on the data only (semantic labels, vote targets, the bench's forced mask)
+                head, dev, bs = self.dense_head, points.device, batch_dict["batch_size"]
+                gt_b, gt_l = split_gt_boxes(batch_dict["gt_boxes"], torch.long)
+                if all(len(g) > 0 for g in gt_b) and "instance_mask" in batch_dict:
+                    def masks(key):
+                        return [x.to(dev) if torch.is_tensor(x) else torch.from_numpy(x).to(dev) for x in batch_dict[key]]
+                    targets = {"loss": head.data_targets(out.C, gt_b, gt_l, self.convert2list(points, bs),
+                                                         masks("semantic_mask"), masks("instance_mask"))}
+                    if head.force_gt_selection:
+                        targets["forced"] = head._forced_selection(batch_dict, out, out.C[:, 1:].float() * head.voxel_size)
+            event = torch.cuda.Event()
+            event.record(side)
+        return (sp.coordinate_manager, sp.coordinate_map_key, sp.unique_index, points.shape[0], event,
+                [sp.unique_index, sp.inverse_mapping], targets)
 
     def forward(self, batch_dict):
         cur_epoch = batch_dict.get("cur_epoch", None)
@@ -30,7 +78,7 @@ class CAGroup3D(Detector3DTemplate):
         self.module_list[1].semantic_threshold = max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value,
                                                      self.semantic_min_threshold)
         batch_dict["points"][:, -3:] = batch_dict["points"][:, -3:] / 255.
-        batch_dict["sp_tensor"] = self.voxelization(batch_dict["points"])
+        batch_dict["sp_tensor"] = self.voxelization(batch_dict["points"], batch_dict.pop("prepared", None))
         for module in self.module_list:
             batch_dict.update(module(batch_dict))
         if self.training:

@@ -88,6 +88,36 @@ def test_bf16_mode_stays_within_stated_tolerance_of_fp32(hip):
     assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
 
 
+def test_prefetched_coordinates_give_the_same_step(hip):
+    """CAGroup3D.prefetch_coordinates (side stream, coordinate-only dry run of the backbone) must hand the forward
+    exactly the structures it would have built itself."""
+    res = []
+    for use_prefetch in (False, True):
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        model.dense_head.force_gt_selection = True
+        model = model.cuda().train()
+        torch.manual_seed(1)
+        np.random.seed(1)
+        batch = build_model.synthetic_batch("S5k", 2, device="cuda")
+        with _lib.use_library(hip):
+            if use_prefetch:
+                batch["prepared"] = model.prefetch_coordinates(batch)
+                assert batch["prepared"] is not None
+            ret, tb, _ = model(batch)
+            ret["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((batch["sp_tensor"].C.clone(), batch["one_stage_results"][1].F.detach().clone(), tb,
+                    {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (c0, f0, tb0, g0), (c1, f1, tb1, g1) = res
+    assert torch.equal(c0, c1)
+    torch.testing.assert_close(f1, f0, rtol=1e-4, atol=1e-5)
+    for k in tb0:
+        assert abs(tb0[k] - tb1[k]) <= 1e-3 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    assert (num / den) ** 0.5 < 2e-2
+
+
 def _s50k_tensor():
     batch = synthetic.make_batch("S50k", 4)
     pts = torch.from_numpy(batch["points"]).cuda()
