@@ -133,15 +133,31 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
     model_func = model_fn_decorator()
     params = [p for p in model.parameters() if p.requires_grad]
     device = params[0].device
-    for batch in dataset.batches(epoch, shuffle=True):
-        batch["cur_epoch"] = epoch                               # drives the semantic threshold (cagroup3d.py:31)
-        load_data_to_gpu(batch, device)
+    core = model.module if hasattr(model, "module") else model
+
+    def staged(it_batches):
+        """Look one batch ahead: the next batch is moved to the device and its coordinate structures / data-only
+        targets are built on the side stream right after the current step's backward has been queued."""
+        prev = None
+        for b in it_batches:
+            b["cur_epoch"] = epoch                               # drives the semantic threshold (cagroup3d.py:31)
+            load_data_to_gpu(b, device)
+            if prev is not None:
+                yield prev, b
+            prev = b
+        if prev is not None:
+            yield prev, None
+    prepared = None
+    for batch, nxt in staged(dataset.batches(epoch, shuffle=True)):
+        if prepared is not None:
+            batch["prepared"] = prepared
         optimizer.zero_grad(set_to_none=True)
         loss, tb, disp = model_func(model, batch)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, clip)
         optimizer.step()
         scheduler.step()
+        prepared = core.prefetch_coordinates(nxt) if (nxt is not None and device.type == "cuda") else None
         it += 1
         if rank == 0:
             log("epoch %d it %d lr %.2e loss %.4f (%s)" % (epoch, it, optimizer.param_groups[0]["lr"], float(loss.detach()),
