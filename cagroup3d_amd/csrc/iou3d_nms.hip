@@ -362,3 +362,45 @@ extern "C" int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, cons
     return nms_launch(boxes, seg_off, mask_off, nseg, max_seg, thresh, rotated, mask_ws, keep, num_keep,
                       cg3d_hs(stream));
 }
+
+
+// ---------------------------------------------------------------- points strictly inside (rotated) boxes
+// find_points_in_boxes (pcdet/models/dense_heads/target_assigner/cagroup3d_assigner.py:9-36): the point is moved into
+// the box frame (shift, rotate by -heading about z, add the centre back), the six face distances are formed in the
+// reference's operation order and the point is inside when the smallest is > 0.  One thread per (point, box); the
+// reference materialises [n, g, 7] fp32 temporaries through ~40 tensor launches (5.5 ms per step at 155 k x 80).
+// Optional segment ids restrict a point to the boxes of its own scene.
+__global__ void k_points_in_boxes(const float *__restrict__ pts, int64_t n, const float *__restrict__ boxes, int32_t g,
+                                  const int32_t *__restrict__ pseg, const int32_t *__restrict__ bseg,
+                                  uint8_t *__restrict__ out) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * g) return;
+    const int64_t i = t / g;
+    const int j = (int)(t % g);
+    const float *b = boxes + (int64_t)j * 7;
+    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    const float cx = b[0], cy = b[1], cz = b[2];
+    const float sx = px - cx, sy = py - cy, sz = pz - cz;
+    const float c = dg_cosf(-b[6]), s = dg_sinf(-b[6]);
+    const float rx = sx * c + sy * s, ry = sy * c - sx * s;           // rows of [[c,-s,0],[s,c,0],[0,0,1]] applied to (sx,sy,sz)
+    const float qx = cx + rx, qy = cy + ry, qz = cz + sz;
+    const float hx = b[3] / 2, hy = b[4] / 2, hz = b[5] / 2;
+    float m = qx - cx + hx;
+    m = fminf(m, cx + hx - qx);
+    m = fminf(m, qy - cy + hy);
+    m = fminf(m, cy + hy - qy);
+    m = fminf(m, qz - cz + hz);
+    m = fminf(m, cz + hz - qz);
+    bool in = m > 0.f;
+    if (pseg && bseg) in = in && pseg[i] == bseg[j];
+    out[t] = in ? 1 : 0;
+}
+extern "C" int cg3d_points_in_boxes(const float *points, int64_t n, const float *boxes, int32_t g, const int32_t *point_seg,
+                                    const int32_t *box_seg, uint8_t *inside, cg3d_stream_t stream) {
+    if (n < 0 || g < 0) return CG3D_ERR_ARG;
+    if (n == 0 || g == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_points_in_boxes, dim3((unsigned)cg3d_divup(n * g, 256)), dim3(256), 0, cg3d_hs(stream), points, n,
+                       boxes, g, point_seg, box_seg, inside);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -21,6 +21,20 @@ def _pair(name, boxes_a, boxes_b):
     return out
 
 
+def points_in_boxes(points, boxes, point_seg=None, box_seg=None):
+    """(n,3) x (g,7) -> bool (n,g): strictly inside the rotated box (find_points_in_boxes, cagroup3d_assigner.py:9-36);
+    with the two int32 segment vectors a point only counts for boxes of its own segment (scene)."""
+    lib = _lib.get()
+    p, b = points[:, :3].contiguous().float(), boxes[:, :7].contiguous().float()
+    ps = point_seg.to(torch.int32).contiguous() if point_seg is not None else None
+    bs = box_seg.to(torch.int32).contiguous() if box_seg is not None else None
+    lib.check(p, b, ps, bs)
+    out = torch.empty((p.shape[0], b.shape[0]), dtype=torch.uint8, device=p.device)
+    lib.call("cg3d_points_in_boxes", ptr(p), c_int64(p.shape[0]), ptr(b), c_int32(b.shape[0]), ptr(ps), ptr(bs), ptr(out),
+             lib.stream())
+    return out.bool()
+
+
 def boxes_overlap_bev(boxes_a, boxes_b):
     """(N,7),(M,7) -> (N,M) rotated BEV intersection area (iou3d_nms.cpp:49-66)."""
     return _pair("cg3d_boxes_overlap_bev", boxes_a, boxes_b)

@@ -160,8 +160,8 @@ class CAGroup3DHead(nn.Module):
         flat = gt.reshape(B * Gmax, -1)
         real = ~(flat == 0).all(dim=-1)
         box_scene = torch.arange(B, device=gt.device).repeat_interleave(Gmax)
-        inside = find_points_in_boxes(ori_xyz, flat[:, :7])            # (N, B*Gmax); padded rows are zero-size boxes
-        inside = inside & (out.C[:, 0].long().view(-1, 1) == box_scene.view(1, -1)) & real.view(1, -1)
+        inside = find_points_in_boxes(ori_xyz, flat[:, :7], point_seg=out.C[:, 0], box_seg=box_scene)   # padded rows: zero size
+        inside = inside & real.view(1, -1)
         onehot = torch.nn.functional.one_hot(flat[:, 7].long().clamp(0, self.n_classes - 1), self.n_classes).float()
         return (inside.float() @ onehot) > 0
 
@@ -365,7 +365,7 @@ class CAGroup3DHead(nn.Module):
         gt_scene = torch.repeat_interleave(torch.arange(B, device=dev), ME.h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
         vox_scene = vox_C[:, 0].long()
         vox_xyz = vox_C[:, 1:] * vs
-        inside = find_points_in_boxes(vox_xyz, gt) & (vox_scene.view(-1, 1) == gt_scene.view(1, -1))
+        inside = find_points_in_boxes(vox_xyz, gt, point_seg=vox_scene, box_seg=gt_scene)      # same-scene pairs only
         vols = torch.where(inside, volume(gt).view(1, -1).expand(inside.shape), torch.full((1, 1), FLOAT_MAX, device=dev))
         min_vol, min_ind = vols.min(dim=1)
         semantic_labels = torch.where(min_vol == FLOAT_MAX, torch.full_like(min_ind, -1), gl[min_ind])

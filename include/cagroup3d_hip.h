@@ -281,6 +281,16 @@ int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const
 int cg3d_sort_vertices(int32_t b, int32_t n, int32_t m, const float *vertices, const uint8_t *mask,
                        const int32_t *num_valid, int32_t *idx, cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Points strictly inside (rotated) boxes -- find_points_in_boxes of
+ * pcdet/models/dense_heads/target_assigner/cagroup3d_assigner.py:9-36 (used by assign_semantic :132-152, the vote
+ * targets cagroup_head.py:418-452 and the bench's forced selection).
+ *   points float32 [n,3], boxes float32 [g,7] (x,y,z,dx,dy,dz,heading) -> inside uint8 [n,g].
+ *   point_seg int32 [n] / box_seg int32 [g] (both or neither NULL): a point only counts for boxes of its segment (scene).
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_points_in_boxes(const float *points, int64_t n, const float *boxes, int32_t g, const int32_t *point_seg,
+                         const int32_t *box_seg, uint8_t *inside, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

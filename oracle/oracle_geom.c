@@ -372,3 +372,34 @@ int cg3d_sort_vertices(int32_t b, int32_t n, int32_t m, const float *vertices, c
     }
     return CG3D_OK;
 }
+
+
+/* find_points_in_boxes (cagroup3d_assigner.py:9-36): strictly inside the rotated box; same operation order as the
+ * reference's tensor expression (and as k_points_in_boxes). */
+int cg3d_points_in_boxes(const float *pts, int64_t n, const float *boxes, int32_t g, const int32_t *pseg, const int32_t *bseg,
+                         uint8_t *out, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || g < 0) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int32_t j = 0; j < g; j++) {
+            const float *b = boxes + (int64_t)j * 7;
+            float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+            float cx = b[0], cy = b[1], cz = b[2];
+            float sx = px - cx, sy = py - cy, sz = pz - cz;
+            float c = og_cosf(-b[6]), s = og_sinf(-b[6]);
+            float rx = sx * c + sy * s, ry = sy * c - sx * s;
+            float qx = cx + rx, qy = cy + ry, qz = cz + sz;
+            float hx = b[3] / 2, hy = b[4] / 2, hz = b[5] / 2;
+            float m = qx - cx + hx;
+            m = fminf(m, cx + hx - qx);
+            m = fminf(m, qy - cy + hy);
+            m = fminf(m, cy + hy - qy);
+            m = fminf(m, qz - cz + hz);
+            m = fminf(m, cz + hz - qz);
+            int in = m > 0.f;
+            if (pseg && bseg) in = in && pseg[i] == bseg[j];
+            out[i * g + j] = (uint8_t)in;
+        }
+    return CG3D_OK;
+}

@@ -41,24 +41,25 @@ def test_rotation_and_coder():
     assert abs(cu.bias_init_with_prob(0.01) - float(G["bias_init_001"])) < 1e-12
 
 
-def test_assigner_matches_reference():
-    gt, gl = t("assign_gt"), t("assign_gt_labels")
-    pts = [p for p in t("assign_points")]
-    a = asg.CAGroup3DAssigner(AttrDict(LIMIT=27, TOPK=18, N_SCALES=4))
-    ctr, boxes, labels = a.assign(pts, gt, gl)
-    assert torch.equal(labels, t("assign_labels"))
-    close(ctr, "assign_centerness")
-    close(boxes, "assign_boxes")
-    # the all-classes-at-once form: identical labels, identical targets on every labelled point
-    ctr2, boxes2, labels2 = a.assign_all_classes(pts, gt, gl)
-    assert torch.equal(labels2, t("assign_labels"))
-    pos = labels2 >= 0
-    assert pos.sum() > 20
-    torch.testing.assert_close(ctr2[pos], t("assign_centerness")[pos], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(boxes2[pos], t("assign_boxes")[pos])
-    sem, ins = asg.CAGroup3DAssigner.assign_semantic(torch.cat(pts), gt, gl, 4)
-    assert torch.equal(sem, t("assign_sem_labels")) and torch.equal(ins, t("assign_ins_labels"))
-    assert torch.equal(asg.find_points_in_boxes(torch.cat(pts), gt), t("assign_inside"))
+def test_assigner_matches_reference(oracle):
+    with _lib.use_library(oracle):        # find_points_in_boxes is one fused op of the bound library
+        gt, gl = t("assign_gt"), t("assign_gt_labels")
+        pts = [p for p in t("assign_points")]
+        a = asg.CAGroup3DAssigner(AttrDict(LIMIT=27, TOPK=18, N_SCALES=4))
+        ctr, boxes, labels = a.assign(pts, gt, gl)
+        assert torch.equal(labels, t("assign_labels"))
+        close(ctr, "assign_centerness")
+        close(boxes, "assign_boxes")
+        # the all-classes-at-once form: identical labels, identical targets on every labelled point
+        ctr2, boxes2, labels2 = a.assign_all_classes(pts, gt, gl)
+        assert torch.equal(labels2, t("assign_labels"))
+        pos = labels2 >= 0
+        assert pos.sum() > 20
+        torch.testing.assert_close(ctr2[pos], t("assign_centerness")[pos], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(boxes2[pos], t("assign_boxes")[pos])
+        sem, ins = asg.CAGroup3DAssigner.assign_semantic(torch.cat(pts), gt, gl, 4)
+        assert torch.equal(sem, t("assign_sem_labels")) and torch.equal(ins, t("assign_ins_labels"))
+        assert torch.equal(asg.find_points_in_boxes(torch.cat(pts), gt), t("assign_inside"))
 
 
 def test_losses_match_reference():

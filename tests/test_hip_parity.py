@@ -3,6 +3,7 @@ through the same C-ABI binding.  Integer / index / mask outputs must be BIT-EXAC
 feature outputs are compared with the tolerance SURVEY.md section 8(d) states:
 rtol 1e-4, atol 1e-5 (scaled by the magnitude of the accumulated sum).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -342,6 +343,26 @@ def test_fused_bn_running_statistics_match_torch_batchnorm(oracle, hip, G):
     ref, out = both(oracle, hip, fn, x)
     for r, o in zip(ref, out):
         close(r, o, 1.0)
+
+
+@pytest.mark.parametrize("n,g,seg", [(0, 4, False), (5, 0, False), (3000, 37, False), (20000, 64, True)])
+def test_points_in_boxes_bit_exact(oracle, hip, n, g, seg):
+    """find_points_in_boxes as one fused op: identical masks on both libraries, points placed ON faces included."""
+    from cagroup3d_amd.ops.iou3d_nms_utils import points_in_boxes
+    boxes = rand_boxes(g, seed=g + 1)
+    rs = np.random.RandomState(n + g)
+    pts = torch.from_numpy(rs.uniform(-6, 6, (n, 3)).astype(np.float32))
+    if n and g:
+        k = min(n, g)
+        pts[:k] = boxes[:k, :3]                                   # box centres: inside
+        pts[k:2 * k, :] = boxes[:k, :3][: max(0, min(k, n - k))]   # and points exactly on a face: not strictly inside
+        pts[k:2 * k, 2] += boxes[: max(0, min(k, n - k)), 5] / 2
+    ps = torch.from_numpy(rs.randint(0, 4, n).astype(np.int32)) if seg else None
+    bs = torch.from_numpy(rs.randint(0, 4, g).astype(np.int32)) if seg else None
+    ref, out = both(oracle, hip, points_in_boxes, pts, boxes, ps, bs)
+    eq(ref, out)
+    if n and g and not seg:
+        assert bool(ref[0, 0]) and ref.shape == (n, g) and ref.dtype == torch.bool
 
 
 # ------------------------------------------------------------------ iou3d_nms
