@@ -8,8 +8,8 @@ from .. import _lib
 from .._lib import ptr
 
 
-def _scratch(lib, b, m, k, device):
-    nbytes = int(lib.raw("cg3d_knn_ws_bytes")(b, m, k))
+def _scratch(lib, b, n, m, k, device):
+    nbytes = int(lib.raw("cg3d_knn_ws_bytes")(b, n, m, k))
     return torch.empty(nbytes // 8, dtype=torch.int64, device=device) if nbytes > 0 else None
 
 
@@ -33,7 +33,7 @@ class KNN(Function):
         idx = torch.zeros((B, npoint, k), dtype=torch.int32, device=xyz.device)
         dist2 = torch.zeros((B, npoint, k), dtype=torch.float32, device=xyz.device)
         lib.call("cg3d_knn", c_int32(B), c_int32(N), c_int32(npoint), c_int32(k), ptr(xyz),
-                 ptr(center_xyz), ptr(idx), ptr(dist2), ptr(_scratch(lib, B, npoint, k, xyz.device)), lib.stream())
+                 ptr(center_xyz), ptr(idx), ptr(dist2), ptr(_scratch(lib, B, xyz.shape[1], npoint, k, xyz.device)), lib.stream())
         idx = idx.transpose(2, 1).contiguous()
         ctx.mark_non_differentiable(idx)
         return idx
@@ -55,5 +55,5 @@ def knn_with_dist(k, xyz, center_xyz):
     idx = torch.zeros((B, npoint, k), dtype=torch.int32, device=xyz.device)
     dist2 = torch.zeros((B, npoint, k), dtype=torch.float32, device=xyz.device)
     lib.call("cg3d_knn", c_int32(B), c_int32(xyz.shape[1]), c_int32(npoint), c_int32(k), ptr(xyz), ptr(center_xyz),
-             ptr(idx), ptr(dist2), ptr(_scratch(lib, B, npoint, k, xyz.device)), lib.stream())
+             ptr(idx), ptr(dist2), ptr(_scratch(lib, B, xyz.shape[1], npoint, k, xyz.device)), lib.stream())
     return idx, dist2

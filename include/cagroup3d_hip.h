@@ -266,10 +266,11 @@ int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *
  *   of xyz[b,n,:] by squared distance, ascending; a candidate replaces the current worst only
  *   if strictly closer (ties keep the lower index).  1 <= k <= 100.
  *   idx int32 [b,m,k], dist2 float32 [b,m,k].
- *   `ws`: cg3d_knn_ws_bytes(b, m, k) bytes of scratch (k == 1 merges partial winners of reference-point
+ *   `ws`: cg3d_knn_ws_bytes(b, n, m, k) bytes of scratch (k == 1: uniform-grid search, exact -- cell sort buffers;
+ *   small problems merge partial winners of reference-point
  *   splits through 64-bit atomicMin keys); may be NULL (single pass per query block).
  * ---------------------------------------------------------------------------------------- */
-int64_t cg3d_knn_ws_bytes(int32_t b, int32_t m, int32_t k);
+int64_t cg3d_knn_ws_bytes(int32_t b, int32_t n, int32_t m, int32_t k);
 int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const float *new_xyz,
              int32_t *idx, float *dist2, void *ws, cg3d_stream_t stream);
 

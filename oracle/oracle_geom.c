@@ -284,7 +284,7 @@ static void og_reheap(float *d, int *ix, int k) { /* knn_cuda.cu:25-40 */
         root = child; child = root * 2 + 1;
     }
 }
-int64_t cg3d_knn_ws_bytes(int32_t b, int32_t m, int32_t k) { (void)b; (void)m; (void)k; return 0; }
+int64_t cg3d_knn_ws_bytes(int32_t b, int32_t n, int32_t m, int32_t k) { (void)b; (void)n; (void)m; (void)k; return 0; }
 int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const float *new_xyz,
              int32_t *idx, float *dist2, void *ws, cg3d_stream_t s) {
     (void)s; (void)ws;

@@ -436,6 +436,25 @@ def test_knn_bit_exact(oracle, hip, b, n, m, k):
         assert int(out[0][0, 0, 0]) == 2
 
 
+@pytest.mark.parametrize("b,n,m,far", [(1, 6000, 2000, 0.0), (2, 9000, 5000, 0.2), (1, 20000, 30000, 1.0)])
+def test_knn1_uniform_grid_is_exact(oracle, hip, b, n, m, far):
+    """k = 1 on large problems goes through the cell grid: same indices and distances as the exhaustive scan, including
+    exact ties (lowest index), clustered points, and queries far from every point (redone exhaustively)."""
+    g = torch.Generator().manual_seed(n + m)
+    xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 6.0, 3.0])
+    xyz[:, : n // 4] = xyz[:, : n // 4] * 0.02 + 1.0                  # a dense cluster: many points per cell
+    xyz[:, 7] = xyz[:, 3]                                            # exact duplicates
+    q = xyz[:, torch.randint(0, n, (m,), generator=g)] + torch.randn(b, m, 3, generator=g) * 0.01
+    nfar = int(m * far)
+    if nfar:
+        q[:, :nfar] = torch.rand(b, nfar, 3, generator=g) * 40 - 20    # far outside the point cloud
+    q[:, -1] = xyz[:, 3]
+    ref, out = both(oracle, hip, lambda x, c: knn_mod.knn_with_dist(1, x, c), xyz, q)
+    eq(ref[0], out[0])
+    eq(ref[1], out[1])
+    assert int(out[0][0, -1, 0]) == 3
+
+
 def test_sort_vertices_bit_exact(oracle, hip):
     g = torch.Generator().manual_seed(0)
     v = torch.rand(2, 1500, 24, 2, generator=g)
