@@ -49,9 +49,9 @@ _SIGNATURES = {
     "cg3d_points_in_boxes": (c_int32, [P, c_int64, P, c_int32, P, P, P, P]),
     "cg3d_spconv_prep_weights_bf16_multi": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, P]),
     "cg3d_bn_stats": (c_int32, [P, P, c_int64, P, c_int32, c_int32, P, P, P, P, P, P, c_float, P]),
-    "cg3d_bn_apply": (c_int32, [P, P, P, c_int64, c_int32, P, P, c_float, P, P, c_int32, P, P]),
+    "cg3d_bn_apply": (c_int32, [P, P, P, c_int64, c_int32, P, P, c_float, P, P, c_int32, P, P, P]),
     "cg3d_bn_bwd_reduce": (c_int32, [P, P, P, P, c_int64, P, c_int32, c_int32, P, P, c_float, c_int32, P, P, P, P]),
-    "cg3d_bn_bwd_apply": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, c_float, P, P, P, P, c_int32, c_int32, P, P, P]),
+    "cg3d_bn_bwd_apply": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, c_float, P, P, P, P, c_int32, c_int32, P, P, P, P]),
     "cg3d_boxes_overlap_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
     "cg3d_boxes_iou_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
     "cg3d_nms": (c_int32, [P, c_int64, c_float, c_int32, P, P, P, P]),

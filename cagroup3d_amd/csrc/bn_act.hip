@@ -156,11 +156,20 @@ extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *
     return CG3D_OK;
 }
 
+// four fp32 -> four bf16, round-to-nearest-even (v_cvt_pk_bf16_f32): the copy the next convolution gathers from
+typedef float bn_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ static inline uint2 bn_pack4bf(float4 v) {
+    const bn_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bn_bf16x2)),
+                      __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bn_bf16x2)));
+}
+
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, const float *__restrict__ R,
                                                   const int32_t *__restrict__ chunks, int32_t c,
                                                   const float *__restrict__ mean, const float *__restrict__ var, float eps,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, int act,
-                                                  float *__restrict__ Y) {
+                                                  float *__restrict__ Y, uint2 *__restrict__ Y16) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
     const int64_t total = (int64_t)nr * cq;
@@ -181,15 +190,16 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
         }
         y.x = act_fwd(y.x, act); y.y = act_fwd(y.y, act); y.z = act_fwd(y.z, act); y.w = act_fwd(y.w, act);
         reinterpret_cast<float4 *>(Y)[off] = y;
+        if (Y16) Y16[off] = bn_pack4bf(y);
     }
 }
 extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
                              const float *mean, const float *var, float eps, const float *gamma, const float *beta,
-                             int32_t act, float *Y, cg3d_stream_t stream) {
-    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual)) return CG3D_ERR_ARG;
+                             int32_t act, float *Y, uint16_t *Y16, cg3d_stream_t stream) {
+    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual) || ((uintptr_t)Y16 & 7)) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean, var,
-                       eps, gamma, beta, act, Y);
+                       eps, gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16));
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                       const float *__restrict__ gamma, const float *__restrict__ dbeta,
                                                       const float *__restrict__ dgamma, const float *__restrict__ group_n,
                                                       int act, int use_batch, float *__restrict__ dX,
-                                                      float *__restrict__ dR) {
+                                                      uint2 *__restrict__ dX16, float *__restrict__ dR) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
     const int64_t total = (int64_t)nr * cq;
@@ -228,16 +238,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         o.z = ga.z * is.z * (d.z - (sb.z + (x.z - mu.z) * is.z * sg.z) * inv_n);
         o.w = ga.w * is.w * (d.w - (sb.w + (x.w - mu.w) * is.w * sg.w) * inv_n);
         reinterpret_cast<float4 *>(dX)[off] = o;
+        if (dX16) dX16[off] = bn_pack4bf(o);
     }
 }
 extern "C" int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
                                  int32_t c, const float *mean, const float *var, float eps, const float *gamma,
                                  const float *dbeta, const float *dgamma, const float *group_n, int32_t act,
-                                 int32_t use_batch_stats, float *dX, float *dRes, cg3d_stream_t stream) {
-    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes)) return CG3D_ERR_ARG;
+                                 int32_t use_batch_stats, float *dX, uint16_t *dX16, float *dRes, cg3d_stream_t stream) {
+    if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes) || ((uintptr_t)dX16 & 7))
+        return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var,
-                       eps, gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, dRes);
+                       eps, gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, reinterpret_cast<uint2 *>(dX16), dRes);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

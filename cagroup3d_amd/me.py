@@ -346,8 +346,23 @@ def release_to_stream(mgr, extra, stream):
         t.record_stream(stream)
 
 
-def _to_bf16(x):
-    """fp32 [N, C] -> int16 view of the bf16 rows (cg3d_to_bf16; one streaming pass, halves every later gather)."""
+# bf16 row copies written by the BatchNorm apply kernels, keyed by the address of the fp32 tensor they mirror.  The entry
+# holds the fp32 tensor itself, so its storage cannot be recycled while the entry exists; entries are consumed by the
+# convolution that gathers from them and the table is emptied at the start of every detector forward.
+_ROWS16 = {}
+
+
+def rows16_of(x, keep=False):
+    e = _ROWS16.get(x.data_ptr()) if keep else _ROWS16.pop(x.data_ptr(), None)
+    return e[1] if (e is not None and e[0].shape == x.shape and e[0].dtype == x.dtype) else None
+
+
+def _to_bf16(x, keep=False):
+    """fp32 [N, C] -> int16 view of the bf16 rows (cg3d_to_bf16; one streaming pass, halves every later gather).
+    keep: leave a BatchNorm-written copy registered (forward activations may feed several convolutions)."""
+    ready = rows16_of(x, keep)
+    if ready is not None:
+        return ready
     lib = _lib.get()
     out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
     lib.call("cg3d_to_bf16", ptr(x), ptr(out), c_int64(x.numel()), lib.stream())
@@ -525,7 +540,7 @@ class SparseConvFunction(torch.autograd.Function):
         cin, cout = w3.shape[1], w3.shape[2]
         # bf16 mode: one streaming conversion of the input rows, then every gather of this layer (forward and
         # weight gradient) moves half the bytes
-        xg = _to_bf16(x) if (BF16_ROWS and _use_bf16(cin)) else x
+        xg = _to_bf16(x, keep=True) if (BF16_ROWS and _use_bf16(cin)) else x
         wt = wp = None
         if _use_bf16(cin):
             # both bf16 copies of the weights in one launch; the plain one is the data gradient's operand
@@ -898,8 +913,15 @@ class FusedBNActFunction(torch.autograd.Function):
         else:
             mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
         y = torch.empty_like(x)
+        # bf16 mode: the apply kernels also write the bf16 row copy the neighbouring convolution gathers from
+        # (forward: y16 -> its input; backward: dx16 -> its output gradient), instead of separate cg3d_to_bf16 passes
+        want16 = BF16_ROWS and _use_bf16(C)
+        y16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want16 else None
         lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean), ptr(var),
-                 c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), lib.stream())
+                 c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), lib.stream())
+        ctx.want16 = want16
+        if want16:
+            _ROWS16[y.data_ptr()] = (y, y16)
         ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n, achunks)
         ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps), nachunk)
         ctx.mark_non_differentiable(mean, var)
@@ -918,9 +940,12 @@ class FusedBNActFunction(torch.autograd.Function):
                  c_int32(C), ptr(mean), ptr(var), c_float(eps), c_int32(act), ptr(ws), ptr(dbeta), ptr(dgamma), lib.stream())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
+        dx16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if ctx.want16 else None
         lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean),
                  ptr(var), c_float(eps), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
-                 c_int32(1 if use_batch else 0), ptr(dx), ptr(dres), lib.stream())
+                 c_int32(1 if use_batch else 0), ptr(dx), ptr(dx16), ptr(dres), lib.stream())
+        if dx16 is not None:
+            _ROWS16[dx.data_ptr()] = (dx, dx16)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 

@@ -75,6 +75,7 @@ class CAGroup3D(Detector3DTemplate):
     def forward(self, batch_dict):
         cur_epoch = batch_dict.get("cur_epoch", None)
         assert cur_epoch is not None
+        ME._ROWS16.clear()
         self.module_list[1].semantic_threshold = max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value,
                                                      self.semantic_min_threshold)
         batch_dict["points"][:, -3:] = batch_dict["points"][:, -3:] / 255.

@@ -218,7 +218,10 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  *                 (float32 [G,C]) are not NULL they are updated in the same launch like nn.BatchNorm1d does:
  *                 r = (1-momentum)*r + momentum*stat, the variance unbiased (n/(n-1)); `num_batches_tracked`
  *                 (int64 [G], may be NULL) is incremented.
- * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL)
+ * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL);
+ *                 Y16 / dX16 (may be NULL): the same rows again as bf16 (RNE) -- the copy the next convolution (forward:
+ *                 its input, backward: its output gradient) gathers from at precision 2, written while the fp32 values
+ *                 are in registers instead of by a separate cg3d_to_bf16 pass
  * cg3d_bn_bwd_reduce: with dz = dy * act'(y), xhat = (x-mean)*rsqrt(var+eps):
  *                 dbeta = sum(dz), dgamma = sum(dz * xhat)   float32 [G,C]
  * cg3d_bn_bwd_apply:  dx = gamma*invstd*(dz - (dbeta + xhat*dgamma)/n[g])  (batch statistics;
@@ -229,14 +232,14 @@ int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const i
                   int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream);
 int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
                   const float *mean, const float *var, float eps, const float *gamma, const float *beta, int32_t act,
-                  float *Y, cg3d_stream_t stream);
+                  float *Y, uint16_t *Y16, cg3d_stream_t stream);
 int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
                        const int32_t *group_chunk_off, int32_t G, int32_t c, const float *mean, const float *var,
                        float eps, int32_t act, float *ws, float *dbeta, float *dgamma, cg3d_stream_t stream);
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
                       int32_t c, const float *mean, const float *var, float eps, const float *gamma,
                       const float *dbeta, const float *dgamma, const float *group_n, int32_t act,
-                      int32_t use_batch_stats, float *dX, float *dRes, cg3d_stream_t stream);
+                      int32_t use_batch_stats, float *dX, uint16_t *dX16, float *dRes, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * iou3d_nms (boxes are float32 [n,7] = x,y,z,dx,dy,dz,heading, contiguous).

@@ -332,6 +332,12 @@ static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, 
         free(loc);
     }
 }
+/* fp32 -> bf16 bits, round-to-nearest-even (the copy the next convolution gathers from; cg3d_to_bf16's rounding) */
+static inline uint16_t os_bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *gco, int32_t G, int32_t c,
                   float *ws, float *mean, float *var, float *running_mean, float *running_var,
                   int64_t *num_batches_tracked, float momentum, cg3d_stream_t s) {
@@ -360,7 +366,7 @@ int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const i
 }
 int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
                   const float *var, float eps, const float *gamma, const float *beta, int32_t act, float *Y,
-                  cg3d_stream_t s) {
+                  uint16_t *Y16, cg3d_stream_t s) {
     (void)s;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < nchunk; k++) {
@@ -371,6 +377,7 @@ int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t
                 float y = (X[o] - mean[p]) * (1.0f / sqrtf(var[p] + eps)) * gamma[p] + beta[p];
                 if (R) y += R[o];
                 Y[o] = os_act_fwd(y, act);
+                if (Y16) Y16[o] = os_bf16_rne(Y[o]);
             }
     }
     return CG3D_OK;
@@ -387,8 +394,8 @@ int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const in
 }
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t c,
                       const float *mean, const float *var, float eps, const float *gamma, const float *dbeta,
-                      const float *dgamma, const float *group_n, int32_t act, int32_t use_batch, float *dX, float *dR,
-                      cg3d_stream_t s) {
+                      const float *dgamma, const float *group_n, int32_t act, int32_t use_batch, float *dX,
+                      uint16_t *dX16, float *dR, cg3d_stream_t s) {
     (void)s;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < nchunk; k++) {
@@ -402,6 +409,7 @@ int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int
                 float is = 1.0f / sqrtf(var[p] + eps);
                 float xh = (X[o] - mean[p]) * is;
                 dX[o] = gamma[p] * is * (d - (dbeta[p] + xh * dgamma[p]) * inv_n);
+                if (dX16) dX16[o] = os_bf16_rne(dX[o]);
             }
     }
     return CG3D_OK;
