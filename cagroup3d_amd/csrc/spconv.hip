@@ -552,7 +552,8 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
                                                                     const uint16_t *__restrict__ Wb,
                                                                     const int32_t *__restrict__ nbr,
                                                                     const float *__restrict__ bias, float *__restrict__ Y,
-                                                                    int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+                                                                    int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                                                                    const int32_t *__restrict__ tiles) {
     constexpr int CT = NT * 32;
     constexpr int KC = 64;
     constexpr int LP = KC + 8;
@@ -564,13 +565,22 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
     const int n0 = blockIdx.y * CT;
     const int nchunk = (cin + KC - 1) / KC;
     const int nstep = K * nchunk;
+    // the rows this workgroup owns: blockIdx.x * 128 .. +128, or -- grouped convolutions (one weight set per class
+    // branch) -- a tile (group, first row, row count <= 128) of the table, which never straddles two groups
+    int64_t tile_row0 = (int64_t)blockIdx.x * 128;
+    int tile_rows = (int)(n_out - tile_row0 < 128 ? n_out - tile_row0 : 128);
+    if (tiles) {
+        Wb += (int64_t)tiles[blockIdx.x * 3] * K * cin * cout;
+        tile_row0 = tiles[blockIdx.x * 3 + 1];
+        tile_rows = tiles[blockIdx.x * 3 + 2];
+    }
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ gather waves
         const int pw = wave - 4;
-        const int64_t row = (int64_t)blockIdx.x * 128 + pw * 32 + r;
-        const bool row_ok = row < n_out;
-        const int64_t row_c = row_ok ? row : n_out - 1;
+        const int64_t row = tile_row0 + pw * 32 + r;
+        const bool row_ok = pw * 32 + r < tile_rows;
+        const int64_t row_c = row_ok ? row : tile_row0;
         typedef Gather<XT> G;
         typedef typename G::T RowT;
         const int gcol = (lane % G::LPR) * G::CH, grow = lane / G::LPR;
@@ -700,7 +710,6 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
         commit_w(buf ^ 1);
         __syncthreads();
     }
-    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int col = n0 + nt * 32 + r;
@@ -708,8 +717,8 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const int64_t orow = row_base + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (orow < n_out) Y[orow * cout + col] = acc[nt][e] + bv;
+            const int lrow = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (lrow < tile_rows) Y[(tile_row0 + lrow) * cout + col] = acc[nt][e] + bv;
         }
     }
 }
@@ -1360,14 +1369,15 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
 }
 
 // ---------------------------------------------------------------- dense-map (output-stationary) entry point
-extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
-                               int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-                               int32_t precision, cg3d_stream_t stream) {
+extern "C" int cg3d_spconv_fwd_tiled(const float *X, const float *W, const int32_t *nbr, const int32_t *tiles,
+                                     int64_t ntile, const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K,
+                                     int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
     if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
-    if (n_out == 0) return CG3D_OK;
+    if (n_out == 0 || (tiles && ntile == 0)) return CG3D_OK;
+    if (tiles && (precision == 0 || ntile < 0)) return CG3D_ERR_ARG;     // row groups: bf16 forms only
     hipStream_t s = cg3d_hs(stream);
-    const unsigned gx = (unsigned)cg3d_divup(n_out, 128);
+    const unsigned gx = tiles ? (unsigned)ntile : (unsigned)cg3d_divup(n_out, 128);
     if (precision >= 1) {   // W is the prepared bf16 [K][cout][cin] buffer (cg3d_spconv_prep_weights_bf16)
         // 32-bit element offsets inside the kernel: rows * cin and the weight tensor must stay below 2^31 elements
         if (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15)) return CG3D_ERR_ARG;
@@ -1375,7 +1385,7 @@ extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nb
         const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
 #define LAUNCH_WS(NT, XT)                                                                                       \
     hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT, XT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(512), 0, s, \
-                       reinterpret_cast<const XT *>(X), Wb, nbr, bias, Y, n_out, K, cin, cout)
+                       reinterpret_cast<const XT *>(X), Wb, nbr, bias, Y, n_out, K, cin, cout, tiles)
         if (precision == 1) {
             if (cout > 64) LAUNCH_WS(4, float); else if (cout > 32) LAUNCH_WS(2, float); else LAUNCH_WS(1, float);
         } else {            // X is bf16 [n_in][cin] (cg3d_to_bf16)
@@ -1401,3 +1411,8 @@ extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nb
     return CG3D_OK;
 }
 
+extern "C" int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
+                               int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                               int32_t precision, cg3d_stream_t stream) {
+    return cg3d_spconv_fwd_tiled(X, W, nbr, nullptr, 0, bias, Y, n_in, n_out, K, cin, cout, precision, stream);
+}

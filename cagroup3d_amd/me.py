@@ -88,6 +88,7 @@ class KernelMap:
         self._nbrT, self._make_T = None, make_T
         self._pairs = None
         self._segs = {}
+        self.same_map = False
 
     @property
     def nbrT(self):
@@ -130,6 +131,17 @@ class KernelMap:
             hit = (pin, pout, off_h, P)
             self._pairs[row_bounds] = hit
         return hit
+
+    def tiles(self, row_bounds, rows=128):
+        """int32 [ntile,3] (group, first row, row count <= rows) covering the output rows group by group; cached."""
+        ck = ("tiles", row_bounds, rows)
+        t = self._segs.get(ck)
+        if t is None:
+            tab = [(g, r0, min(rows, row_bounds[g + 1] - r0)) for g in range(len(row_bounds) - 1)
+                   for r0 in range(row_bounds[g], row_bounds[g + 1], rows)]
+            t = (h2d(np.asarray(tab if tab else [(0, 0, 0)], dtype=np.int32), torch.int32, self.nbr.device), len(tab))
+            self._segs[ck] = t
+        return t
 
     def segments(self, maxlen, row_bounds=None):
         """int32 [nseg,3] (weight index, start, count<=maxlen) covering every pair; cached.
@@ -245,6 +257,7 @@ class CoordinateManager:
             nbr = self._lookup_map(dst.coords, src, fwd_off)
             km = KernelMap(nbr.contiguous(), offs.shape[0], src.n, dst.n,
                            lambda: self._lookup_map(src.coords, dst, bwd_off).contiguous())
+            km.same_map = in_key == out_key          # row groups of the output are row groups of the input
             self._kmaps[ck] = km
         return km
 
@@ -285,7 +298,7 @@ IMPLICIT_MIN_OCCUPANCY = float(__import__("os").environ.get("CG3D_IMPLICIT_THR",
 IMPLICIT_MIN_TILES = int(__import__("os").environ.get("CG3D_IMPLICIT_TILES", "96"))
 
 
-def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
+def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs, tiles=None):
     """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] with bf16 operands; w_bf16_t: int16 view of bf16 [K, cout, cin];
     x: fp32 rows (rounded in the kernel) or their int16/bf16 copy from _to_bf16."""
     lib = _lib.get()
@@ -297,8 +310,13 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rows16 = x.dtype == torch.int16
-    lib.call("cg3d_spconv_fwd", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(bias), ptr(y), c_int64(x.shape[0]), c_int64(n_out),
-             c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1), lib.stream())
+    if tiles is None:
+        lib.call("cg3d_spconv_fwd", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(bias), ptr(y), c_int64(x.shape[0]), c_int64(n_out),
+                 c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1), lib.stream())
+    else:       # row groups with their own weights: w_bf16_t stacks G sets of K slots
+        lib.call("cg3d_spconv_fwd_tiled", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(tiles[0]), c_int64(tiles[1]), ptr(bias), ptr(y),
+                 c_int64(x.shape[0]), c_int64(n_out), c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1),
+                 lib.stream())
     if prof:
         ev1.record()
         xb = 2.0 if rows16 else 4.0     # bytes per gathered element
@@ -602,19 +620,26 @@ class GroupedConvFunction(torch.autograd.Function):
     """SparseConvFunction for G row groups whose weights are G separate parameters (the class branches,
     cagroup_head.py:183-188) in the bf16 mode: the per-class weights go straight into the stacked bf16 operand
     buffers (no 215 MB fp32 stack per step for the 9^3 branch), the weight gradient is computed into one stacked
-    buffer and handed back as per-class views."""
+    buffer and handed back as per-class views.  Maps from a coordinate map onto itself with >= 10 % neighbourhood
+    occupancy (the 9^3 and 5^3 class convolutions) run the output-stationary kernel on group-aligned row tiles."""
 
     @staticmethod
-    def forward(ctx, x, kmap, row_bounds, *weights):
+    def _tiled(kmap, P, K, closed):
+        return closed and kmap.same_map and K > 1 and P >= IMPLICIT_MIN_OCCUPANCY * K * max(kmap.n_out, 1)
+
+    @staticmethod
+    def forward(ctx, x, kmap, row_bounds, closed, *weights):
         x = x.contiguous()
         G, (K, cin, cout) = len(weights), weights[0].shape
-        ctx.kmap, ctx.row_bounds, ctx.shape = kmap, row_bounds, (G, K, cin, cout)
+        ctx.kmap, ctx.row_bounds, ctx.shape, ctx.closed = kmap, row_bounds, (G, K, cin, cout), closed
         pin, pout, _, P = kmap.pairs(row_bounds)
-        xg = _to_bf16(x) if BF16_ROWS else x
+        xg = _to_bf16(x, keep=True) if BF16_ROWS else x
         ctx.save_for_backward(x, xg if xg is not x else None, *weights)
+        wt = _prep_bf16_group(weights, True)
+        if GroupedConvFunction._tiled(kmap, P, K, closed):
+            return _conv_implicit_bf16(xg, wt, kmap.nbr, None, kmap.n_out, cin, cout, P, kmap.tiles(row_bounds))
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
-        return _conv_pairs(xg, (G * K, cin, cout), pin, pout, seg, nseg, None, kmap.n_out, P,
-                           w_bf16_t=_prep_bf16_group(weights, True))
+        return _conv_pairs(xg, (G * K, cin, cout), pin, pout, seg, nseg, None, kmap.n_out, P, w_bf16_t=wt)
 
     @staticmethod
     def backward(ctx, dy):
@@ -628,11 +653,14 @@ class GroupedConvFunction(torch.autograd.Function):
         dyg = _to_bf16(dy) if BF16_ROWS else dy
         dx = None
         if ctx.needs_input_grad[0]:
-            seg, nseg = kmap.segments(_seg_len_fwd(), rb)
-            dx = _conv_pairs(dyg, (G * K, cout, cin), pout, pin, seg, nseg, None, kmap.n_in, P,
-                             w_bf16_t=_prep_bf16_group(weights, False))
+            wp = _prep_bf16_group(weights, False)
+            if GroupedConvFunction._tiled(kmap, P, K, ctx.closed):
+                dx = _conv_implicit_bf16(dyg, wp, kmap.nbrT, None, kmap.n_in, cout, cin, P, kmap.tiles(rb))
+            else:
+                seg, nseg = kmap.segments(_seg_len_fwd(), rb)
+                dx = _conv_pairs(dyg, (G * K, cout, cin), pout, pin, seg, nseg, None, kmap.n_in, P, w_bf16_t=wp)
         dws = [None] * G
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dw = torch.empty((G * K, cin, cout), dtype=torch.float32, device=x.device)
             wprec = 2 if (xb is not None and dyg is not dy) else 1
             xw, dyw = (xb, dyg) if wprec == 2 else (x, dy)
@@ -641,15 +669,18 @@ class GroupedConvFunction(torch.autograd.Function):
             lib.call("cg3d_spconv_pairs_wgrad", ptr(xw), ptr(dyw), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
                      c_int32(G * K), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
             dws = [dw[g * K:(g + 1) * K] for g in range(G)]
-        return (dx, None, None) + tuple(dws)
+        return (dx, None, None, None) + tuple(dws)
 
 
-def grouped_conv(x, weights, kmap, row_bounds):
-    """Convolution of G contiguous row groups with their own weights ([K, cin, cout] each)."""
+def grouped_conv(x, weights, kmap, row_bounds, closed=False):
+    """Convolution of G contiguous row groups with their own weights ([K, cin, cout] each); a pair (in, out) uses the
+    weights of the OUTPUT row's group.  closed=True promises that no pair crosses a group boundary (the class branches:
+    every group has its own batch index) -- then the data gradient may be tiled by input-row groups as well and the
+    atomic-free output-stationary kernel is used on dense enough maps."""
     weights = [w.view(-1, w.shape[-2], w.shape[-1]) for w in weights]
     cin, cout = weights[0].shape[1], weights[0].shape[2]
     if _use_bf16(cin) and _use_bf16(cout) and _lib.get().is_device:
-        return GroupedConvFunction.apply(x, kmap, row_bounds, *weights)
+        return GroupedConvFunction.apply(x, kmap, row_bounds, bool(closed), *weights)
     w = torch.stack(weights, dim=0)
     return SparseConvFunction.apply(x, w.view(-1, cin, cout), None, kmap, row_bounds)
 

@@ -265,12 +265,12 @@ class CAGroup3DHead(nn.Module):
 
         mgr = cls_map.coordinate_manager
         km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, self.cls_kernel, 1, False)
-        a = ME.grouped_conv(cls_map.F, [m[0].kernel for m in self.cls_individual_out], km9, fine_bounds)
+        a = ME.grouped_conv(cls_map.F, [m[0].kernel for m in self.cls_individual_out], km9, fine_bounds, closed=True)
         a = self._grouped_bn_act(a, fine_bounds, [m[1] for m in self.cls_individual_out], elu)
 
         emgr = cls_exp.coordinate_manager
         km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
-        e = ME.grouped_conv(cls_exp.F, [m[0].kernel for m in self.cls_individual_expand_out], km5, coarse_bounds)
+        e = ME.grouped_conv(cls_exp.F, [m[0].kernel for m in self.cls_individual_expand_out], km5, coarse_bounds, closed=True)
         e = self._grouped_bn_act(e, coarse_bounds, [m[1] for m in self.cls_individual_expand_out], elu)
         tgt_key, _, _ = emgr.insert(fine_C, 1)                             # generative transposed conv onto the fine voxels
         km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, self.expand, 1, True)

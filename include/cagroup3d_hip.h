@@ -107,6 +107,12 @@ int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t stream);
 int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias,
                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
                     int32_t precision, cg3d_stream_t stream);
+/* Row groups with their own weights (the 18 class branches): `tiles` int32 [ntile,3] = (group, first output row, row
+ * count <= 128), a tile never straddles two groups; W holds the G weight sets stacked ([G*K, ...], prepared bf16);
+ * precision 1 / 2 only.  tiles == NULL: cg3d_spconv_fwd. */
+int cg3d_spconv_fwd_tiled(const float *X, const float *W, const int32_t *nbr, const int32_t *tiles, int64_t ntile,
+                          const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                          int32_t precision, cg3d_stream_t stream);
 int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float *dW,
                       int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
                       int32_t precision, cg3d_stream_t stream);

@@ -61,14 +61,28 @@ int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t s) {
     return CG3D_OK;
 }
 
-int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
-                    int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
-                    cg3d_stream_t s) {
+/* `tiles` (may be NULL): int32 [ntile,3] = (group, first row, row count): the output rows of a tile use the weights of
+ * that group (W holds G stacked weight sets of K slots each); rows not covered by a tile are not written. */
+int cg3d_spconv_fwd_tiled(const float *X, const float *W, const int32_t *nbr, const int32_t *tiles, int64_t ntile,
+                          const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                          int32_t precision, cg3d_stream_t s) {
     (void)s; (void)n_in;
     if (n_out < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    if (tiles && (precision == 0 || ntile < 0)) return CG3D_ERR_ARG;
+    int32_t G = 1;
+    int32_t *grp = NULL;                       /* group of every output row, -1 = not covered */
+    if (tiles) {
+        grp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_out > 0 ? n_out : 1));
+        for (int64_t o = 0; o < n_out; o++) grp[o] = -1;
+        for (int64_t t = 0; t < ntile; t++) {
+            if (tiles[t * 3] + 1 > G) G = tiles[t * 3] + 1;
+            for (int32_t r = 0; r < tiles[t * 3 + 2]; r++) grp[tiles[t * 3 + 1] + r] = tiles[t * 3];
+        }
+    }
     float *Wq = NULL;
     if (precision >= 1) {
-        int64_t nw = (int64_t)K * cin * cout;
+        int64_t nw = (int64_t)G * K * cin * cout;
+        K = G * K;                              /* widen all G*K slots; restored below */
         /* precision 1: W is the prepared bf16 [K][cout][cin] buffer; widen it back to fp32 [K][cin][cout] */
         const uint16_t *wb = (const uint16_t *)W;
         Wq = (float *)malloc((size_t)nw * sizeof(float));
@@ -80,12 +94,15 @@ int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const fl
                     Wq[((int64_t)k * cin + a) * cout + c] = v.f;
                 }
         W = Wq;
+        K = K / G;
     }
 #pragma omp parallel
     {
         float *xq = (float *)malloc((size_t)cin * sizeof(float));
 #pragma omp for schedule(dynamic, 64)
         for (int64_t o = 0; o < n_out; o++) {
+            if (grp && grp[o] < 0) continue;
+            const int64_t slot0 = grp ? (int64_t)grp[o] * K : 0;
             float *y = Y + o * cout;
             for (int32_t c = 0; c < cout; c++) y[c] = bias ? bias[c] : 0.f;
             for (int32_t k = 0; k < K; k++) {
@@ -93,7 +110,7 @@ int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const fl
                 if (i < 0) continue;
                 for (int32_t a = 0; a < cin; a++) xq[a] = os_row(X, (int64_t)i * cin + a, precision);
                 const float *x = xq;
-                const float *w = W + (int64_t)k * cin * cout;
+                const float *w = W + (slot0 + k) * cin * cout;
                 for (int32_t a = 0; a < cin; a++) {
                     float xa = x[a];
                     const float *wr = w + (int64_t)a * cout;
@@ -104,7 +121,13 @@ int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const fl
         free(xq);
     }
     free(Wq);
+    free(grp);
     return CG3D_OK;
+}
+int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias, float *Y,
+                    int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t precision,
+                    cg3d_stream_t s) {
+    return cg3d_spconv_fwd_tiled(X, W, nbr, NULL, 0, bias, Y, n_in, n_out, K, cin, cout, precision, s);
 }
 
 int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float *dW, int64_t n_in,

@@ -217,6 +217,38 @@ def test_linear_split_row_weight_gradient(oracle, hip, cin, cout, prec):
     assert (out[2].cpu() - exact).abs().max() <= tol
 
 
+@pytest.mark.parametrize("ks,frac", [(3, (0, 0.2, 0.2, 0.6, 1.0)), (5, (0, 0.0005, 0.05, 1.0))])
+def test_grouped_conv_row_groups_with_their_own_weights(oracle, hip, ks, frac):
+    """me.grouped_conv (the class branches): every row group convolves with its own weights; bf16 mode runs the
+    group-tiled output-stationary kernel on the device, the oracle side the stacked pair form -- same operator,
+    per-group weight gradients come back as separate tensors."""
+    cin, cout, G = 64, 64, len(frac) - 1
+    coords = torch.unique(rand_coords(4000, batch=1, extent=7, seed=ks, dup=0.0), dim=0)     # ~60 % of the cells: dense map
+    n = coords.shape[0]
+    bounds = tuple(int(round(f * n)) for f in frac)           # includes an empty group and a 1-2 row group
+    for g in range(G):                                        # every group its own batch index: no pair crosses groups
+        coords[bounds[g]:bounds[g + 1], 0] = g
+    torch.manual_seed(ks)
+    feats, dy = torch.randn(n, cin), torch.randn(n, cout)
+    ws = [torch.randn(ks ** 3, cin, cout) / (cin * ks ** 3) ** 0.5 for _ in range(G)]
+
+    def fn(coords, feats, dy, *ws):
+        x = me.SparseTensor(coordinates=coords.float(), features=feats)
+        km = x.coordinate_manager.kernel_map(x.coordinate_map_key, x.coordinate_map_key, ks, 1, False)
+        f = x.F.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        me.PRECISION = 1
+        try:
+            y = me.grouped_conv(f, wl, km, bounds, closed=True)
+            (y * dy).sum().backward()
+        finally:
+            me.PRECISION = 0
+        return (y.detach(), f.grad) + tuple(w.grad for w in wl)
+    ref, out = both(oracle, hip, fn, coords, feats, dy, *ws)
+    for r, o in zip(ref, out):
+        close(r, o, float(r.abs().max()))
+
+
 def test_spconv_empty_and_tiny(oracle, hip):
     for n in (1, 2, 33):
         coords = rand_coords(n, batch=1, extent=2, seed=n, dup=0.0)
