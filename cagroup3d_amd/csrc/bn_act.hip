@@ -44,22 +44,39 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
             is = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
         }
         if (tr < rpb) {
-            for (int r = tr; r < nr; r += rpb) {
-                const int64_t off = (int64_t)(r0 + r) * cq + q;
-                if (!BWD) {
-                    float4 v = reinterpret_cast<const float4 *>(A)[off];
-                    s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-                    s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
-                } else {
-                    float4 d = reinterpret_cast<const float4 *>(A)[off];
-                    float4 x = reinterpret_cast<const float4 *>(X)[off];
-                    if (act) {
-                        float4 y = reinterpret_cast<const float4 *>(Yv)[off];
-                        d.x *= act_bwd(y.x, act); d.y *= act_bwd(y.y, act); d.z *= act_bwd(y.z, act); d.w *= act_bwd(y.w, act);
+            // four rows per trip, all loads issued before the first use: a thread walks only nr / rpb rows, so with
+            // one load in flight the kernel was bound by memory LATENCY, not bandwidth
+            for (int r = tr; r < nr; r += 4 * rpb) {
+                float4 a[4], x[4], y[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int rr = r + u * rpb;
+                    ok[u] = rr < nr;
+                    const int64_t off = (int64_t)(r0 + (ok[u] ? rr : r)) * cq + q;      // clamped, unconditional load
+                    a[u] = reinterpret_cast<const float4 *>(A)[off];
+                    if (BWD) {
+                        x[u] = reinterpret_cast<const float4 *>(X)[off];
+                        if (act) y[u] = reinterpret_cast<const float4 *>(Yv)[off];
                     }
-                    s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
-                    s1.x += d.x * (x.x - mu.x) * is.x; s1.y += d.y * (x.y - mu.y) * is.y;
-                    s1.z += d.z * (x.z - mu.z) * is.z; s1.w += d.w * (x.w - mu.w) * is.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!ok[u]) continue;
+                    if (!BWD) {
+                        const float4 v = a[u];
+                        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+                        s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
+                    } else {
+                        float4 d = a[u];
+                        if (act) {
+                            d.x *= act_bwd(y[u].x, act); d.y *= act_bwd(y[u].y, act);
+                            d.z *= act_bwd(y[u].z, act); d.w *= act_bwd(y[u].w, act);
+                        }
+                        s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
+                        s1.x += d.x * (x[u].x - mu.x) * is.x; s1.y += d.y * (x[u].y - mu.y) * is.y;
+                        s1.z += d.z * (x[u].z - mu.z) * is.z; s1.w += d.w * (x[u].w - mu.w) * is.w;
+                    }
                 }
             }
         }
@@ -172,25 +189,42 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
                                                   float *__restrict__ Y, uint2 *__restrict__ Y16) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
-    const int64_t total = (int64_t)nr * cq;
-    for (int64_t t = threadIdx.x; t < total; t += 256) {
-        const int q = (int)(t % cq);
-        const int64_t off = (int64_t)r0 * cq + t;
+    // thread = (channel quad tq, row lane tr): the per-channel constants are loaded and inverted ONCE per thread, rows
+    // are walked four at a time with all loads issued before the first use (memory-level parallelism)
+    const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
+    const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    if (tr >= rpb) return;
+    for (int q = tq; q < cq; q += tpr) {
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
         const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         const float4 be = reinterpret_cast<const float4 *>(beta + (int64_t)g * c)[q];
-        float4 x = reinterpret_cast<const float4 *>(X)[off];
-        float4 y;
-        y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * ga.x + be.x; y.y = (x.y - mu.y) * rsqrtf(vv.y + eps) * ga.y + be.y;
-        y.z = (x.z - mu.z) * rsqrtf(vv.z + eps) * ga.z + be.z; y.w = (x.w - mu.w) * rsqrtf(vv.w + eps) * ga.w + be.w;
-        if (R) {
-            float4 r = reinterpret_cast<const float4 *>(R)[off];
-            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        const float4 is = make_float4(rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps));
+        for (int r = tr; r < nr; r += 4 * rpb) {
+            float4 xv[4], rv[4];
+            int64_t off[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int rr = r + u * rpb;
+                ok[u] = rr < nr;
+                off[u] = (int64_t)(r0 + (ok[u] ? rr : r)) * cq + q;
+                xv[u] = reinterpret_cast<const float4 *>(X)[off[u]];
+                if (R) rv[u] = reinterpret_cast<const float4 *>(R)[off[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) continue;
+                const float4 x = xv[u];
+                float4 y;
+                y.x = (x.x - mu.x) * is.x * ga.x + be.x; y.y = (x.y - mu.y) * is.y * ga.y + be.y;
+                y.z = (x.z - mu.z) * is.z * ga.z + be.z; y.w = (x.w - mu.w) * is.w * ga.w + be.w;
+                if (R) { y.x += rv[u].x; y.y += rv[u].y; y.z += rv[u].z; y.w += rv[u].w; }
+                y.x = act_fwd(y.x, act); y.y = act_fwd(y.y, act); y.z = act_fwd(y.z, act); y.w = act_fwd(y.w, act);
+                reinterpret_cast<float4 *>(Y)[off[u]] = y;
+                if (Y16) Y16[off[u]] = bn_pack4bf(y);
+            }
         }
-        y.x = act_fwd(y.x, act); y.y = act_fwd(y.y, act); y.z = act_fwd(y.z, act); y.w = act_fwd(y.w, act);
-        reinterpret_cast<float4 *>(Y)[off] = y;
-        if (Y16) Y16[off] = bn_pack4bf(y);
     }
 }
 extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
@@ -214,31 +248,49 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                       uint2 *__restrict__ dX16, float *__restrict__ dR) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
-    const int64_t total = (int64_t)nr * cq;
     const float inv_n = use_batch ? 1.f / group_n[g] : 0.f;
-    for (int64_t t = threadIdx.x; t < total; t += 256) {
-        const int q = (int)(t % cq);
-        const int64_t off = (int64_t)r0 * cq + t;
+    const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
+    const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    if (tr >= rpb) return;
+    for (int q = tq; q < cq; q += tpr) {
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
         const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         const float4 sb = reinterpret_cast<const float4 *>(dbeta + (int64_t)g * c)[q];
         const float4 sg = reinterpret_cast<const float4 *>(dgamma + (int64_t)g * c)[q];
         const float4 is = make_float4(rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps));
-        float4 d = reinterpret_cast<const float4 *>(dY)[off];
-        float4 x = reinterpret_cast<const float4 *>(X)[off];
-        if (act) {
-            float4 y = reinterpret_cast<const float4 *>(Yv)[off];
-            d.x *= act_bwd(y.x, act); d.y *= act_bwd(y.y, act); d.z *= act_bwd(y.z, act); d.w *= act_bwd(y.w, act);
+        for (int r = tr; r < nr; r += 4 * rpb) {
+            float4 dv[4], xv[4], yv[4];
+            int64_t off[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int rr = r + u * rpb;
+                ok[u] = rr < nr;
+                off[u] = (int64_t)(r0 + (ok[u] ? rr : r)) * cq + q;
+                dv[u] = reinterpret_cast<const float4 *>(dY)[off[u]];
+                xv[u] = reinterpret_cast<const float4 *>(X)[off[u]];
+                if (act) yv[u] = reinterpret_cast<const float4 *>(Yv)[off[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) continue;
+                float4 d = dv[u];
+                const float4 x = xv[u];
+                if (act) {
+                    const float4 y = yv[u];
+                    d.x *= act_bwd(y.x, act); d.y *= act_bwd(y.y, act); d.z *= act_bwd(y.z, act); d.w *= act_bwd(y.w, act);
+                }
+                if (dR) reinterpret_cast<float4 *>(dR)[off[u]] = d;
+                float4 o;
+                o.x = ga.x * is.x * (d.x - (sb.x + (x.x - mu.x) * is.x * sg.x) * inv_n);
+                o.y = ga.y * is.y * (d.y - (sb.y + (x.y - mu.y) * is.y * sg.y) * inv_n);
+                o.z = ga.z * is.z * (d.z - (sb.z + (x.z - mu.z) * is.z * sg.z) * inv_n);
+                o.w = ga.w * is.w * (d.w - (sb.w + (x.w - mu.w) * is.w * sg.w) * inv_n);
+                reinterpret_cast<float4 *>(dX)[off[u]] = o;
+                if (dX16) dX16[off[u]] = bn_pack4bf(o);
+            }
         }
-        if (dR) reinterpret_cast<float4 *>(dR)[off] = d;
-        float4 o;
-        o.x = ga.x * is.x * (d.x - (sb.x + (x.x - mu.x) * is.x * sg.x) * inv_n);
-        o.y = ga.y * is.y * (d.y - (sb.y + (x.y - mu.y) * is.y * sg.y) * inv_n);
-        o.z = ga.z * is.z * (d.z - (sb.z + (x.z - mu.z) * is.z * sg.z) * inv_n);
-        o.w = ga.w * is.w * (d.w - (sb.w + (x.w - mu.w) * is.w * sg.w) * inv_n);
-        reinterpret_cast<float4 *>(dX)[off] = o;
-        if (dX16) dX16[off] = bn_pack4bf(o);
     }
 }
 extern "C" int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
