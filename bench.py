@@ -215,6 +215,12 @@ def main():
                     other_conv_kernels={k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps}
                                         for k, v in kinds.items() if k != kind})
         roof["traffic"] = pmc_traffic(ksym)   # bytes per launch, from profiles/ (separate --pmc runs)
+        # SURVEY 8(d) aggregate over every timed conv launch (forward + data gradient): sum of per-launch roofline
+        # bounds max(flops / MFMA peak, bytes / HBM peak) over the sum of measured times
+        mfma_peak = (BF16_MFMA_PEAK_TFLOPS if me.PRECISION == 1 else FP32_MFMA_PEAK_TFLOPS) * 1e12
+        bound_s = sum(max(r[2] / mfma_peak, r[3] / (HBM_PEAK_GBS * 1e9)) for r in me.KernelProfile.records)
+        meas_s = sum(v["ms"] for v in kinds.values()) * 1e-3
+        roof["conv_fwd_dgrad_bound_over_measured"] = bound_s / meas_s if meas_s > 0 else None
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
