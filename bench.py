@@ -86,6 +86,8 @@ def train_step(model, opt, batch, clip):
         b["prepared"] = _PREPARED.pop(id(core))
     ret, tb, disp = model(b)
     ret["loss"].backward()
+    if getattr(core, "grad_sync", None) is not None:
+        core.grad_sync.finish()                 # early/mid buckets were sent from the backward pass, late bucket here
     torch.nn.utils.clip_grad_norm_(params, clip)
     opt.step()
     if PREFETCH:
@@ -155,8 +157,11 @@ def main():
     model, cfg = make_model(args.dataset, forced, dev)
     model.train()
     net = model
-    if use_dist:
+    if use_dist and os.environ.get("CG3D_TORCH_DDP") == "1":      # A/B: torch DDP (per-parameter hooks + bucket copies)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    elif use_dist:
+        from cagroup3d_amd.grad_sync import TwoBucketGradSync
+        model.grad_sync = TwoBucketGradSync(model)   # flat buckets over RCCL, sent from inside the backward pass
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY,
                             fused=True)      # one multi-tensor launch set for the whole update
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP

@@ -1,0 +1,132 @@
+"""Data-parallel gradient exchange for the detector (one all-reduce of 126.5 M gradients per step).
+
+torch DDP costs this model ~14 ms per step on ONE GPU before any byte is exchanged (432 parameters: a Python-visible
+autograd hook and a bucket-copy launch each) -- a third of the 48 ms step.  The exchange here is two flat buckets over
+RCCL instead, split where the model splits:
+
+  early bucket  dense head + RoI head parameters (57 % of the bytes: the 18 class branches).  Their gradients are
+                complete when the backward pass reaches the backbone output; a hook on THAT tensor packs them with one
+                multi-tensor copy and starts an asynchronous all-reduce which runs under the whole backbone backward.
+  mid bucket    the backbone from layer3 on (the 256/512/1024-channel layers: nearly all of the backbone's bytes), sent
+                from a hook on layer2's output -- the backward pass still has the high-resolution stem in front of it.
+  late bucket   conv1 / layer1 / layer2 (a few MB), packed and reduced after backward: the only exposed communication.
+
+Both buckets are persistent flat buffers; after the exchange every `p.grad` is a view into its bucket, so clipping and
+the fused optimiser run on them unchanged.  ReduceOp.AVG does the 1/W."""
+import torch
+import torch.distributed as dist
+
+
+class TwoBucketGradSync:
+    def __init__(self, model, early_modules=("dense_head", "roi_head"), process_group=None,
+                 stem_modules=("conv1", "layer1", "layer2")):
+        self.group = process_group
+        early_ids = set()
+        for name in early_modules:
+            m = getattr(model, name, None)
+            if m is not None:
+                early_ids.update(id(p) for p in m.parameters())
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.early = [p for p in params if id(p) in early_ids]
+        stem_ids = set()
+        backbone = getattr(model, "backbone_3d", None)
+        for name in (stem_modules if backbone is not None else ()):
+            m = getattr(backbone, name, None)
+            if m is not None:
+                stem_ids.update(id(p) for p in m.parameters())
+        rest = [p for p in params if id(p) not in early_ids]
+        self.mid = [p for p in rest if id(p) not in stem_ids] if stem_ids else []
+        self.late = [p for p in rest if id(p) in stem_ids] if stem_ids else rest
+        self._mid_work, self._mid_sent = None, False
+        if backbone is not None and stem_ids:
+            backbone.grad_sync = self                 # BiResNet.forward hooks layer2's output
+        self._buf = {}
+        self._work = None
+        # RCCL/NCCL average in the collective; gloo (CPU tests) only sums
+        self._avg = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        self._world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        self._early_sent = False
+        # identical starting point on every rank (what DDP's constructor does)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for p in params:
+                dist.broadcast(p.data, src=0, group=self.group)
+            for b in model.buffers():
+                dist.broadcast(b.data, src=0, group=self.group)
+
+    def _bucket(self, key, plist):
+        hit = self._buf.get(key)
+        if hit is None:
+            n = sum(p.numel() for p in plist)
+            flat = torch.zeros(max(n, 1), dtype=plist[0].dtype if plist else torch.float32, device=plist[0].device if plist else "cpu")
+            views, off = [], 0
+            for p in plist:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            hit = self._buf[key] = (flat, views)
+        return hit
+
+    def _pack(self, key, plist):
+        flat, views = self._bucket(key, plist)
+        have = [(v, p.grad) for v, p in zip(views, plist) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, plist):
+            if p.grad is None:
+                v.zero_()
+        return flat, views
+
+    def _reduce(self, flat, async_op):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        return dist.all_reduce(flat, op=op, group=self.group, async_op=async_op)
+
+    # -- called from the detector's forward (training): hook the tensor where the head(s) attach to the backbone
+    def attach(self, tensor):
+        self._early_sent = False
+        self._work = None
+        if tensor.requires_grad:
+            tensor.register_hook(self._on_backbone_output_grad)
+
+    def attach_mid(self, tensor):
+        self._mid_sent = False
+        self._mid_work = None
+        if self.mid and tensor.requires_grad:
+            tensor.register_hook(self._on_stem_output_grad)
+
+    def _on_stem_output_grad(self, grad):
+        if all(p.grad is not None for p in self.mid):
+            flat, _ = self._pack("mid", self.mid)
+            self._mid_work = self._reduce(flat, True)
+            self._mid_sent = True
+        return grad
+
+    def _on_backbone_output_grad(self, grad):
+        if self.early and all(p.grad is not None for p in self.early):
+            flat, _ = self._pack("early", self.early)
+            self._work = self._reduce(flat, True)
+            self._early_sent = True
+        return grad
+
+    # -- called after loss.backward()
+    def finish(self):
+        if not self._early_sent and self.early:
+            flat, _ = self._pack("early", self.early)
+            self._work = self._reduce(flat, True)
+        if self.mid and not self._mid_sent:
+            flat, _ = self._pack("mid", self.mid)
+            self._mid_work = self._reduce(flat, True)
+        if self.late:
+            flat, _ = self._pack("late", self.late)
+            self._reduce(flat, False)
+        for w in (self._work, self._mid_work):
+            if w is not None:
+                w.wait()
+        self._work = self._mid_work = None
+        self._mid_sent = False
+        if not self._avg and self._world > 1:
+            for key in self._buf:
+                self._buf[key][0].div_(self._world)
+        for key, plist in (("early", self.early), ("mid", self.mid), ("late", self.late)):
+            if plist:
+                for v, p in zip(self._buf[key][1], plist):
+                    p.grad = v
+        self._early_sent = False

@@ -7,7 +7,7 @@ schedule / gradient clipping, the semantic-threshold schedule input (`cur_epoch`
 (`model_state`, `optimizer_state`, `epoch`, `it`) and the evaluation protocol follow the reference.
 
     python -m cagroup3d_amd.train --dataset scannet --config S5k --scenes 8 --epochs 2 --ckpt /tmp/ck.pth --eval
-    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m cagroup3d_amd.train ...     # DDP over RCCL
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m cagroup3d_amd.train ...     # data parallel over RCCL (grad_sync.py)
 """
 import argparse
 import os
@@ -154,6 +154,8 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
         optimizer.zero_grad(set_to_none=True)
         loss, tb, disp = model_func(model, batch)
         loss.backward()
+        if getattr(core, "grad_sync", None) is not None:
+            core.grad_sync.finish()                 # head/backbone buckets are already in flight; stem bucket here
         torch.nn.utils.clip_grad_norm_(params, clip)
         optimizer.step()
         scheduler.step()
@@ -219,8 +221,12 @@ def main(argv=None):
     if args.resume:
         it, start_epoch = model.load_params_with_optimizer(args.resume, to_cpu=dev.type == "cpu", optimizer=optimizer)
     scheduler = build_scheduler(optimizer, len(ds), oc, last_it=it - 1 if it else -1)
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if dev.type == "cuda" else None,
-                                                    gradient_as_bucket_view=True) if world > 1 else model
+    net = model
+    if world > 1:
+        # flat gradient buckets over RCCL sent from inside the backward pass (grad_sync.py; torch DDP's per-parameter
+        # hooks cost this 432-parameter model 8 ms/step on one MI355X before a byte moves)
+        from .grad_sync import TwoBucketGradSync
+        model.grad_sync = TwoBucketGradSync(model)
     t0 = time.time()
     for epoch in range(start_epoch, epochs):
         it = train_one_epoch(net, optimizer, scheduler, ds, epoch, it, oc.GRAD_NORM_CLIP, rank)
