@@ -1,7 +1,7 @@
 """Data-parallel gradient exchange for the detector (one all-reduce of 126.5 M gradients per step).
 
 torch DDP costs this model ~14 ms per step on ONE GPU before any byte is exchanged (432 parameters: a Python-visible
-autograd hook and a bucket-copy launch each) -- a third of the 48 ms step.  The exchange here is two flat buckets over
+autograd hook and a bucket-copy launch each) -- a third of the 48 ms step.  The exchange here is three flat buckets over
 RCCL instead, split where the model splits:
 
   early bucket  dense head + RoI head parameters (57 % of the bytes: the 18 class branches).  Their gradients are
@@ -11,7 +11,7 @@ RCCL instead, split where the model splits:
                 from a hook on layer2's output -- the backward pass still has the high-resolution stem in front of it.
   late bucket   conv1 / layer1 / layer2 (a few MB), packed and reduced after backward: the only exposed communication.
 
-Both buckets are persistent flat buffers; after the exchange every `p.grad` is a view into its bucket, so clipping and
+The buckets are persistent flat buffers; after the exchange every `p.grad` is a view into its bucket, so clipping and
 the fused optimiser run on them unchanged.  ReduceOp.AVG does the 1/W."""
 import torch
 import torch.distributed as dist
@@ -92,15 +92,17 @@ class TwoBucketGradSync:
         if self.mid and tensor.requires_grad:
             tensor.register_hook(self._on_stem_output_grad)
 
+    # Both hooks send unconditionally: whether a bucket leaves from its hook or from finish() must not depend on the data
+    # (a rank whose RoI head saw no proposal has no gradient for it -> zeros), or the ranks would issue their
+    # collectives in different orders.
     def _on_stem_output_grad(self, grad):
-        if all(p.grad is not None for p in self.mid):
-            flat, _ = self._pack("mid", self.mid)
-            self._mid_work = self._reduce(flat, True)
-            self._mid_sent = True
+        flat, _ = self._pack("mid", self.mid)
+        self._mid_work = self._reduce(flat, True)
+        self._mid_sent = True
         return grad
 
     def _on_backbone_output_grad(self, grad):
-        if self.early and all(p.grad is not None for p in self.early):
+        if self.early:
             flat, _ = self._pack("early", self.early)
             self._work = self._reduce(flat, True)
             self._early_sent = True
