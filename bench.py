@@ -199,8 +199,8 @@ def main():
         tf = prof["flops"] / secs / 1e12 if secs > 0 else 0.0
         gbs = prof["bytes"] / secs / 1e9 if secs > 0 else 0.0
         kname, ksym = {
-            "implicit_bf16": ("k_spconv_implicit_bf16 (sparse conv fwd + dgrad, output-stationary: row gather -> LDS -> "
-                              "bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
+            "implicit_bf16": ("k_spconv_implicit_bf16_ad (sparse conv fwd + dgrad, output-stationary: neighbour rows -> "
+                              "registers -> bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
             "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)",
                            "k_spconv_pairs_bf16"),
             "pairs": ("k_spconv_pairs_lds (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)",

@@ -112,7 +112,23 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
     double s0 = 0.0, s1 = 0.0;
     long long rows = 0;
     if (a < c) {
-        for (int k = gco[g] + lanek; k < gco[g + 1]; k += 16) {
+        // four chunks per trip, every load issued before the first add: with one dependent load per trip the whole
+        // kernel was a chain of ~40 L2 round trips (11 us for a few hundred KB)
+        int k = gco[g] + lanek;
+        const int kend = gco[g + 1];
+        for (; k + 48 < kend; k += 64) {
+            float p0[4], p1[4];
+            int pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                p0[u] = ws[(int64_t)(k + 16 * u) * 2 * c + a];
+                p1[u] = ws[(int64_t)(k + 16 * u) * 2 * c + c + a];
+                pr[u] = MODE == 0 ? chunks[(k + 16 * u) * 3 + 2] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { s0 += (double)p0[u]; s1 += (double)p1[u]; rows += pr[u]; }
+        }
+        for (; k < kend; k += 16) {
             s0 += (double)ws[(int64_t)k * 2 * c + a];
             s1 += (double)ws[(int64_t)k * 2 * c + c + a];
             if (MODE == 0) rows += chunks[k * 3 + 2];

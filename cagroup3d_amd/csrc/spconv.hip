@@ -564,6 +564,12 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
     const int r = lane & 31, kg = lane >> 5;
     const int n0 = blockIdx.y * CT;
     const int nchunk = (cin + KC - 1) / KC;
+    // gridDim.z > 1: the offsets are split over z (small layers: more, shorter workgroups); partial sums meet in Y
+    // through atomics, Y zero-filled by the launcher
+    const int32_t kz0 = (int32_t)((int64_t)K * blockIdx.z / gridDim.z), kz1 = (int32_t)((int64_t)K * (blockIdx.z + 1) / gridDim.z);
+    Wb += (int64_t)kz0 * cin * cout;
+    nbr += (int64_t)kz0 * n_out;
+    K = kz1 - kz0;
     const int nstep = K * nchunk;
     // the rows this workgroup owns: blockIdx.x * 128 .. +128, or -- grouped convolutions (one weight set per class
     // branch) -- a tile (group, first row, row count <= 128) of the table, which never straddles two groups
@@ -714,11 +720,171 @@ __global__ __launch_bounds__(512, 2) void k_spconv_implicit_bf16_ws(const XT *__
     for (int nt = 0; nt < NT; nt++) {
         const int col = n0 + nt * 32 + r;
         if (col >= cout) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const float bv = bias && blockIdx.z == 0 ? bias[col] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int lrow = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (lrow < tile_rows) Y[(tile_row0 + lrow) * cout + col] = acc[nt][e] + bv;
+            if (lrow >= tile_rows) continue;
+            if (gridDim.z == 1) Y[(tile_row0 + lrow) * cout + col] = acc[nt][e] + bv;
+            else unsafeAtomicAdd(&Y[(tile_row0 + lrow) * cout + col], acc[nt][e] + bv);
+        }
+    }
+}
+
+// Direct-operand form for bf16 rows (precision 2): a wave loads the MFMA A fragments of its 32 rows straight from the
+// row matrix into registers -- lane (r, kg) owns row r and the 32 channels [kg*32, kg*32+32) of the chunk as four 16-byte
+// pieces (the contraction order over channels is free, the weight fragments are read from LDS in the same order) --
+// three register sets deep, so there are no gather waves, no row staging through LDS and no liveness flags; only the
+// weight tile goes through LDS (double buffer, one barrier per step among 4 waves).  256 threads and 37 KB of LDS per
+// workgroup: three independent workgroups per CU instead of two barrier-coupled 8-wave ones.
+template <int NT>
+__global__ __launch_bounds__(256, 3) void k_spconv_implicit_bf16_ad(const uint16_t *__restrict__ X,
+                                                                    const uint16_t *__restrict__ Wb,
+                                                                    const int32_t *__restrict__ nbr,
+                                                                    const float *__restrict__ bias, float *__restrict__ Y,
+                                                                    int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+                                                                    const int32_t *__restrict__ tiles) {
+    constexpr int CT = NT * 32;
+    constexpr int KC = 64;
+    constexpr int LP = KC + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[2][CT * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.y * CT;
+    const int nchunk = (cin + KC - 1) / KC;
+    // gridDim.z > 1: the offsets are split over z (small layers: more, shorter workgroups); partial sums meet in Y
+    // through atomics, Y zero-filled by the launcher
+    const int32_t kz0 = (int32_t)((int64_t)K * blockIdx.z / gridDim.z), kz1 = (int32_t)((int64_t)K * (blockIdx.z + 1) / gridDim.z);
+    Wb += (int64_t)kz0 * cin * cout;
+    nbr += (int64_t)kz0 * n_out;
+    K = kz1 - kz0;
+    const int nstep = K * nchunk;
+    int64_t tile_row0 = (int64_t)blockIdx.x * 128;
+    int tile_rows = (int)(n_out - tile_row0 < 128 ? n_out - tile_row0 : 128);
+    if (tiles) {
+        Wb += (int64_t)tiles[blockIdx.x * 3] * K * cin * cout;
+        tile_row0 = tiles[blockIdx.x * 3 + 1];
+        tile_rows = tiles[blockIdx.x * 3 + 2];
+    }
+    const bool row_ok = wave * 32 + r < tile_rows;
+    const int64_t row_c = row_ok ? tile_row0 + wave * 32 + r : tile_row0;
+    const bool partial = (cin & (KC - 1)) != 0;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
+
+    // ---- rows: three register sets (step s on the matrix pipe, s+1 and s+2 in flight)
+    struct ASet { uint4 a[4]; uint32_t ok; bool live; };
+    ASet s0, s1, s2;
+    uint32_t goff = 0;                 // element offset of this lane's 32 channels inside the current neighbour row
+    bool gvalid = false, glive = false;
+    auto load_idx = [&](int32_t k) -> int32_t { return nbr[(int64_t)(k < K ? k : K - 1) * n_out + row_c]; };
+    auto set_row = [&](int32_t raw) {
+        const int32_t g = row_ok ? raw : -1;
+        gvalid = g >= 0;
+        goff = gvalid ? (uint32_t)g * (uint32_t)cin + (uint32_t)(kg * 32) : (uint32_t)(kg * 32);
+        glive = __any(gvalid);
+    };
+    auto issue_a = [&](ASet &S, int32_t c0) {
+        S.live = glive;
+        S.ok = gvalid ? 0xFu : 0u;
+        if (partial) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool cok = c0 + kg * 32 + i * 8 < cin;
+                if (!cok) S.ok &= ~(1u << i);
+                S.a[i] = *reinterpret_cast<const uint4 *>(X + (goff + (cok ? (uint32_t)(c0 + i * 8) : 0u)));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) S.a[i] = *reinterpret_cast<const uint4 *>(X + (goff + (uint32_t)(c0 + i * 8)));
+        }
+    };
+    int32_t kq = 0, cq = 0;                       // (kq, cq): the step whose rows are requested next
+    auto advance = [&]() { cq++; if (cq == nchunk) { cq = 0; kq++; } };
+
+    // ---- weight tile: L2 -> registers -> LDS, one step ahead
+    uint4 w[NT];
+    uint32_t wmask = 0;
+    auto issue_w = [&](int32_t k, int32_t c0) {
+        const uint16_t *wk = Wb + (int64_t)(k < K ? k : K - 1) * cin * cout;   // past the end: unused re-read
+        wmask = 0;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const int col = n0 + (j >> 3), cc = c0 + (j & 7) * 8;
+            const bool ok = col < cout && cc < cin;
+            const uint32_t off = ok ? (uint32_t)col * (uint32_t)cin + (uint32_t)cc : 0u;
+            w[i] = *reinterpret_cast<const uint4 *>(wk + off);
+            wmask |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto commit_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int j = tid + i * 256;
+            const uint4 v = (wmask >> i) & 1u ? w[i] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(&Ws[buf][(j >> 3) * LP + (j & 7) * 8]) = v;
+        }
+    };
+
+    // prologue: rows of steps 0 and 1 requested, weights of step 0 staged
+    int32_t idx_pre;
+    set_row(load_idx(0));
+    issue_a(s0, 0);
+    advance();                                    // step 1
+    if (cq == 0) set_row(load_idx(kq));
+    issue_a(s1, cq * KC);
+    advance();                                    // step 2
+    idx_pre = load_idx(kq);
+    int32_t kw = 0, cw = 0;
+    issue_w(0, 0);
+    commit_w(0);
+    __syncthreads();
+
+    auto step = [&](int st, const ASet &Cur, ASet &Far) {
+        const int buf = st & 1;
+        cw++;
+        if (cw == nchunk) { cw = 0; kw++; }
+        issue_w(kw, cw * KC);                     // weights of step st+1
+        if (cq == 0) set_row(idx_pre);
+        issue_a(Far, cq * KC);                    // rows of step st+2 (past the end: clamped, unused)
+        advance();
+        idx_pre = load_idx(kq);                   // index column of the offset of step st+3
+        if (Cur.live) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const uint4 av = (Cur.ok >> ks) & 1u ? Cur.a[ks] : make_uint4(0u, 0u, 0u, 0u);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Ws[buf][(nt * 32 + r) * LP + kg * 32 + ks * 8]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        commit_w(buf ^ 1);
+        __syncthreads();
+    };
+    for (int st = 0; st < nstep; st += 3) {
+        step(st, s0, s2);
+        if (st + 1 < nstep) step(st + 1, s1, s0);
+        if (st + 2 < nstep) step(st + 2, s2, s1);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = n0 + nt * 32 + r;
+        if (col >= cout) continue;
+        const float bv = bias && blockIdx.z == 0 ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int lrow = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (lrow >= tile_rows) continue;
+            if (gridDim.z == 1) Y[(tile_row0 + lrow) * cout + col] = acc[nt][e] + bv;
+            else unsafeAtomicAdd(&Y[(tile_row0 + lrow) * cout + col], acc[nt][e] + bv);
         }
     }
 }
@@ -1383,14 +1549,24 @@ extern "C" int cg3d_spconv_fwd_tiled(const float *X, const float *W, const int32
         if (cin % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15)) return CG3D_ERR_ARG;
         if (n_in * (int64_t)cin >= (1ll << 31) || (int64_t)cin * cout >= (1ll << 31)) return CG3D_ERR_RANGE;
         const uint16_t *Wb = reinterpret_cast<const uint16_t *>(W);
+        // small layers: fewer workgroups than the chip has slots -> split the offsets over gridDim.z
+        const int64_t nwg = (int64_t)gx * cg3d_divup(cout, cout > 64 ? 128 : (cout > 32 ? 64 : 32));
+        const int zmax = 4;
+        unsigned gz = 1;
+        while (!tiles && (int)gz < zmax && nwg * (gz + 1) <= 768 && (int)(gz + 1) * 4 <= K) gz++;
+        if (gz > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
 #define LAUNCH_WS(NT, XT)                                                                                       \
-    hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT, XT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32)), dim3(512), 0, s, \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16_ws<NT, XT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32), gz), dim3(512), 0, s, \
                        reinterpret_cast<const XT *>(X), Wb, nbr, bias, Y, n_out, K, cin, cout, tiles)
-        if (precision == 1) {
+#define LAUNCH_AD(NT)                                                                                            \
+    hipLaunchKernelGGL((k_spconv_implicit_bf16_ad<NT>), dim3(gx, (unsigned)cg3d_divup(cout, NT * 32), gz), dim3(256), 0, s, \
+                       reinterpret_cast<const uint16_t *>(X), Wb, nbr, bias, Y, n_out, K, cin, cout, tiles)
+        if (precision == 2) {   // X is bf16 [n_in][cin] (cg3d_to_bf16): fragments straight from the row matrix
+            if (cout > 64) LAUNCH_AD(4); else if (cout > 32) LAUNCH_AD(2); else LAUNCH_AD(1);
+        } else {                // fp32 rows, rounded to bf16 on the way into LDS by the gather waves
             if (cout > 64) LAUNCH_WS(4, float); else if (cout > 32) LAUNCH_WS(2, float); else LAUNCH_WS(1, float);
-        } else {            // X is bf16 [n_in][cin] (cg3d_to_bf16)
-            if (cout > 64) LAUNCH_WS(4, uint16_t); else if (cout > 32) LAUNCH_WS(2, uint16_t); else LAUNCH_WS(1, uint16_t);
         }
+#undef LAUNCH_AD
 #undef LAUNCH_WS
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;

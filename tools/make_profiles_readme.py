@@ -5,7 +5,7 @@ P = os.path.join(ROOT, "profiles")
 out = ["# profiles/ — round 1 (MI355X, 1 GPU, ROCm 7.2)\n\n",
        "Commands (on the GPU box, `cd /tmp && export TMPDIR=/tmp` first):\n\n",
        "```\nrocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o bench -- python bench.py --no-cpu-baseline [--precision fp32]\n"
-       "rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_spconv_(implicit_bf16_ws|pairs_bf16|pairs_wgrad_rows16)' --output-format csv ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline   # and a second pass with WRITE_SIZE\n"
+       "rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_spconv_(implicit_bf16|pairs_bf16|pairs_wgrad_rows16)' --output-format csv ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline   # and a second pass with WRITE_SIZE\n"
        "python bench.py            # r01_bench_bf16.json (incl. cpu_baseline)\npython tools/stream_bw.py  # r01_stream_bw.txt\n```\n\n"
        "All of it is `tools/refresh_profiles.sh` (one gpurun call).  Device copy rate on this box: " + open(os.path.join(P, "r01_stream_bw.txt")).read().strip().splitlines()[-1] + ".\n\n",
        "13 steps per run (3 warm-up + 10 timed), batch = 4 synthetic S50k scenes, full training step (fwd + bwd + clip + AdamW).\n"]

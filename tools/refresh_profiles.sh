@@ -13,7 +13,7 @@ for prec in bf16 fp32; do
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-include-regex "k_spconv_(implicit_bf16_ws|pairs_bf16|pairs_wgrad_rows16)" --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-include-regex "k_spconv_(implicit_bf16|pairs_bf16|pairs_wgrad_rows16)" --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   find /tmp/pmc_$c -name "*counter_collection.csv" -exec cp {} $O/r01_pmc_$c.csv \;
 done
 ls -la $O
