@@ -19,6 +19,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "sort_vertices.hip": ["-ffp-contract=off"],
     "bn_act.hip": [],
+    "loss.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -234,7 +234,8 @@ class CoordinateManager:
         return self._strided[ck]
 
     # -- kernel maps
-    def _lookup_map(self, q_coords, table, offsets):
+    @staticmethod
+    def _lookup_map(q_coords, table, offsets):
         lib = _lib.get()
         K, nq = offsets.shape[0], q_coords.shape[0]
         nbr = torch.empty((K, max(nq, 1)), dtype=torch.int32, device=q_coords.device)
@@ -255,8 +256,12 @@ class CoordinateManager:
                 offs = _offsets(kernel_size, dst.tensor_stride * dilation, src.coords.device)
                 fwd_off, bwd_off = (-offs).contiguous(), offs      # o - off = i   /   i + off = o
             nbr = self._lookup_map(dst.coords, src, fwd_off)
+            # the lazy transposed map must not close over `self`: manager -> _kmaps -> KernelMap -> closure -> manager
+            # is a reference cycle, and every step's coordinate structures (0.5 GB of device tensors at S50k x 4) then
+            # live until the cyclic collector's next gen-2 pass -- tens of GB of garbage in a long run
+            lookup = CoordinateManager._lookup_map
             km = KernelMap(nbr.contiguous(), offs.shape[0], src.n, dst.n,
-                           lambda: self._lookup_map(src.coords, dst, bwd_off).contiguous())
+                           lambda: lookup(src.coords, dst, bwd_off).contiguous())
             km.same_map = in_key == out_key          # row groups of the output are row groups of the input
             self._kmaps[ck] = km
         return km
@@ -340,26 +345,27 @@ def _fake(n, c, like):
     return torch.empty((n, c), dtype=torch.float32, device=like.device)
 
 
+def _walk_tensors(o, seen):
+    if torch.is_tensor(o):
+        if o.is_cuda:
+            seen.append(o)
+    elif isinstance(o, (list, tuple)):
+        for v in o:
+            _walk_tensors(v, seen)
+    elif isinstance(o, dict):
+        for v in o.values():
+            _walk_tensors(v, seen)
+    elif isinstance(o, _CoordMap):
+        _walk_tensors([o.coords, o.keys, o.vals, o._perms], seen)
+    elif isinstance(o, KernelMap):
+        _walk_tensors([o.nbr, o._nbrT, o._pairs, o._segs], seen)
+
+
 def release_to_stream(mgr, extra, stream):
     """Every tensor the coordinate manager holds was allocated on the prefetch stream; tell the caching allocator that
     `stream` uses them too (their blocks may only be recycled after that stream's pending work)."""
     seen = []
-
-    def walk(o):
-        if torch.is_tensor(o):
-            if o.is_cuda:
-                seen.append(o)
-        elif isinstance(o, (list, tuple)):
-            for v in o:
-                walk(v)
-        elif isinstance(o, dict):
-            for v in o.values():
-                walk(v)
-        elif isinstance(o, _CoordMap):
-            walk([o.coords, o.keys, o.vals, o._perms])
-        elif isinstance(o, KernelMap):
-            walk([o.nbr, o._nbrT, o._pairs, o._segs])
-    walk([mgr._maps, mgr._kmaps, extra])
+    _walk_tensors([mgr._maps, mgr._kmaps, extra], seen)
     for t in seen:
         t.record_stream(stream)
 

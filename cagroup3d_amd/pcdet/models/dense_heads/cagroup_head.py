@@ -432,14 +432,11 @@ class CAGroup3DHead(nn.Module):
             sem_n_pos, n_pos = stats[:, 0].clamp(min=1.), stats[:, 1].clamp(min=1.)
             ctr_denorm = stats[:, 2].clamp(min=1e-6)
 
-        from ...utils.loss_utils import py_sigmoid_focal_loss
+        from ....ops.focal_loss import sigmoid_focal_loss_rows
         C = self.n_classes
 
-        def focal(pred, lab, row_w, loss_mod):
-            tgt = torch.where(lab < 0, torch.full_like(lab, C), lab)
-            onehot = torch.nn.functional.one_hot(tgt, C + 1)[:, :C]
-            el = py_sigmoid_focal_loss(pred, onehot, None, gamma=loss_mod.gamma, alpha=loss_mod.alpha, reduction="none")
-            return loss_mod.loss_weight * (el * row_w.view(-1, 1)).sum()
+        def focal(pred, lab, row_w, loss_mod):      # FocalLoss + the per-scene avg_factor as a row weight, one pass
+            return loss_mod.loss_weight * sigmoid_focal_loss_rows(pred, lab, row_w, loss_mod.gamma, loss_mod.alpha)
         loss_sem = focal(semantic_scores.F, semantic_labels, 1.0 / (sem_n_pos[vox_scene] * B), self.loss_sem)
         loss_cls = focal(m["cls_score"], labels, 1.0 / (n_pos[pt_scene] * B), self.loss_cls)
         # vote loss: smooth-L1 'sum' per scene, then mean over scenes

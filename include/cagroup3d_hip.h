@@ -301,6 +301,21 @@ int cg3d_sort_vertices(int32_t b, int32_t n, int32_t m, const float *vertices, c
 int cg3d_points_in_boxes(const float *points, int64_t n, const float *boxes, int32_t g, const int32_t *point_seg,
                          const int32_t *box_seg, uint8_t *inside, cg3d_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Fused sigmoid focal loss with per-row weights.
+ * Replaces: py_sigmoid_focal_loss, pcdet/utils/loss_utils.py:903-961 (the element-wise torch chain FocalLoss :964-1040
+ *   runs for cagroup_head.py:520-531), including the -1 -> background rewrite of FocalLoss.forward :1024.
+ *   pred float32 [n,c] logits; label int32 [n] (class id in [0,c) = foreground, anything else = background row);
+ *   row_w float32 [n] (the avg_factor / per-scene normaliser folded into a row weight).
+ *   fwd: partial float32 [cg3d_focal_loss_nblocks(n,c)] per-block sums of row_w[i] * loss[i,a] -- the caller adds them.
+ *   bwd: dpred[i,a] = gscale[0] * row_w[i] * d loss[i,a] / d pred[i,a]; gscale = device pointer to the upstream scalar.
+ * ---------------------------------------------------------------------------------------- */
+int32_t cg3d_focal_loss_nblocks(int64_t n, int32_t c);
+int cg3d_focal_loss_fwd(const float *pred, const int32_t *label, const float *row_w, int64_t n, int32_t c, float gamma,
+                        float alpha, float *partial, cg3d_stream_t stream);
+int cg3d_focal_loss_bwd(const float *pred, const int32_t *label, const float *row_w, const float *gscale, int64_t n,
+                        int32_t c, float gamma, float alpha, float *dpred, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,53 @@
+/* oracle_loss.c -- CPU restatement of the fused focal loss (TEST INFRASTRUCTURE ONLY: tests/, smoke() and bench.py's
+ * cpu_baseline may load this; the product path is cagroup3d_amd/csrc/loss.hip).
+ * Follows py_sigmoid_focal_loss, reference pcdet/utils/loss_utils.py:903-961 (sigmoid; pt = (1-p)t + p(1-t);
+ * focal weight (alpha t + (1-alpha)(1-t)) pt^gamma; BCE-with-logits; weight broadcast over the class axis; sum),
+ * with the -1 -> background rewrite of FocalLoss.forward :1024.  Pinned by tests/test_losses_cpu.py against the
+ * torch expression and the golden vectors generated from the reference's loss_utils.py. */
+#include <math.h>
+#include <stdint.h>
+#include "../include/cagroup3d_hip.h"
+
+static void focal_terms(float x, float t, float gamma, float alpha, float *loss, float *grad) {
+    const float p = 1.f / (1.f + expf(-x));
+    const float pt = (1.f - p) * t + p * (1.f - t);
+    const float at = alpha * t + (1.f - alpha) * (1.f - t);
+    const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    const float ptg = powf(pt, gamma);
+    *loss = bce * at * ptg;
+    const float dptg = pt > 0.f ? gamma * powf(pt, gamma - 1.f) * (1.f - 2.f * t) * p * (1.f - p) : 0.f;
+    *grad = at * ((p - t) * ptg + bce * dptg);
+}
+
+int32_t cg3d_focal_loss_nblocks(int64_t n, int32_t c) {
+    (void)n; (void)c;
+    return 1;
+}
+int cg3d_focal_loss_fwd(const float *pred, const int32_t *label, const float *row_w, int64_t n, int32_t c, float gamma,
+                        float alpha, float *partial, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || c < 1) return CG3D_ERR_ARG;
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int a = 0; a < c; a++) {
+            float l, g;
+            focal_terms(pred[i * c + a], label[i] == a ? 1.f : 0.f, gamma, alpha, &l, &g);
+            s += (double)(l * row_w[i]);
+        }
+    partial[0] = (float)s;
+    return CG3D_OK;
+}
+int cg3d_focal_loss_bwd(const float *pred, const int32_t *label, const float *row_w, const float *gscale, int64_t n,
+                        int32_t c, float gamma, float alpha, float *dpred, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || c < 1) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int a = 0; a < c; a++) {
+            float l, g;
+            focal_terms(pred[i * c + a], label[i] == a ? 1.f : 0.f, gamma, alpha, &l, &g);
+            dpred[i * c + a] = g * row_w[i] * gscale[0];
+        }
+    return CG3D_OK;
+}

@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 def _build_oracle():
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_geom.c", "oracle_sparse.c", "oracle_conv.c")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_geom.c", "oracle_sparse.c", "oracle_conv.c", "oracle_loss.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return so
