@@ -231,7 +231,7 @@ def main():
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if me.PRECISION == 1 else "f32", "data": "synthetic",
                "config": {"workload": "%s CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
-                   {"scannet": "ScanNetV2", "sunrgbd": "SUN RGB-D"}.get(args.dataset, args.dataset), args.batch, args.config, "forced GT selection + own-class logit boost (trained-like loads); the net trains on the fixed batch, so the data-dependent sizes grow after ~30 optimizer steps (DESIGN.md section 5)" if forced
+                   {"scannet": "ScanNetV2", "sunrgbd": "SUN RGB-D"}.get(args.dataset, args.dataset), args.batch, args.config, "forced GT selection (replaces the net's own selection: sizes independent of the weights) + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",

@@ -173,7 +173,7 @@ class CAGroup3DHead(nn.Module):
             with torch.no_grad():
                 hit = sem_prob[:, cls_id] > self.semantic_threshold
                 if forced is not None:
-                    hit = hit | forced[:, cls_id]
+                    hit = forced[:, cls_id]          # the forced mode REPLACES the net's selection (sizes independent of the weights)
                 sel = torch.nonzero(hit).squeeze(1)
                 sel = torch.cat([sel, pad_id])
             b = batch_col[sel]
@@ -218,7 +218,7 @@ class CAGroup3DHead(nn.Module):
         with torch.no_grad():
             hit = sem_prob > self.semantic_threshold
             if forced is not None:
-                hit = hit | forced
+                hit = forced                         # the forced mode REPLACES the net's selection (sizes independent of the weights)
             sel_cls, sel_row = torch.nonzero(hit.t(), as_tuple=True)                 # class-major, rows ascending
             ar_c = torch.arange(C, device=dev)
             all_cls = torch.cat([sel_cls, ar_c.repeat_interleave(B)])

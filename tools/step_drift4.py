@@ -33,3 +33,15 @@ for k in range(0, 80, 10):
     print("steps %2d-%2d: %.1f ms/step | conv launches %.0f  pairs %.2f M  output rows %.2f M  conv time %.2f ms | loss %s" % (
         k, k + 9, sum(d[k:k + 10]) / len(d[k:k + 10]), sum(x[0] for x in p) / 10, sum(x[1] for x in p) / 1e7, sum(x[2] for x in p) / 1e7,
         sum(x[3] for x in p) / 10, "%.3f" % losses[k + 9] if losses[k + 9] is not None else None))
+import collections
+def agg(lo, hi):
+    a = collections.Counter()
+    prev = marks[lo - 1] if lo else 0
+    for r in recs[prev:marks[hi - 1]]:
+        m = r[4]
+        a[(m[0], m[1], m[2], m[3])] += m[4] / (hi - lo)
+    return a
+a0, a1 = agg(0, 10), agg(70, 80)
+print("conv pairs per step by (kind, K, cin, cout): early -> late")
+for k in sorted(set(a0) | set(a1), key=lambda k: -(a1[k] - a0[k]))[:12]:
+    print("  %-40s %10.2f M -> %10.2f M" % (k, a0[k] / 1e6, a1[k] / 1e6))

@@ -12,6 +12,11 @@ opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=Tr
 batch = build_model.synthetic_batch("S50k", 4, device="cuda")
 for _ in range(5):
     bench.train_step(model, opt, batch, 10)
+import gc
+if os.environ.get("GC_FREEZE") == "1":
+    gc.collect(); gc.freeze()
+if os.environ.get("GC_FREEZE") == "2":
+    gc.collect(); gc.freeze(); gc.disable()
 for rep in range(3):
     evs = []
     for i in range(41):
@@ -20,4 +25,5 @@ for rep in range(3):
     torch.cuda.synchronize()
     d = [evs[i].elapsed_time(evs[i + 1]) for i in range(40)]
     s = sorted(d)
+    print("gc", gc.get_count(), gc.get_stats()[2]["collections"], "reserved %.1f GB segments %d" % (torch.cuda.memory_reserved() / 2**30, torch.cuda.memory_stats()["segment.all.allocated"]))
     print("rep %d mean %.1f median %.1f min %.1f p90 %.1f max %.1f | %s" % (rep, sum(d) / 40, s[20], s[0], s[36], s[-1], " ".join("%.0f" % x for x in d)))
