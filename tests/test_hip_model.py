@@ -163,6 +163,30 @@ def test_full_size_conv_linearity_and_forms_agree(hip):
     torch.testing.assert_close(f(a), me.ImplicitConvFunction.apply(a, w, None, km), rtol=1e-4, atol=1e-4)
 
 
+def test_full_size_bf16_direct_operand_form_agrees_with_pair_form(hip):
+    """k_spconv_implicit_bf16_ad at a launch of > 768 workgroups (no offset split, three workgroups per CU) against the
+    atomic pair-list bf16 kernel on the same bf16 rows and weights: same products, fp32 sums in another order."""
+    x, _ = _s50k_tensor()
+    mgr = x.coordinate_manager
+    k2 = mgr.stride(x.coordinate_map_key, 2)
+    km = mgr.kernel_map(k2, k2, 3, 1, False)
+    assert km.n_out > 128 * 768
+    torch.manual_seed(1)
+    prec, me.PRECISION = me.PRECISION, 1
+    try:
+        for cin, cout in ((64, 64), (128, 128), (64, 128)):
+            xin = me._to_bf16(torch.randn(km.n_in, cin, device="cuda"))
+            w = torch.randn(27, cin, cout, device="cuda") * 0.05
+            P = int((km.nbr >= 0).sum())
+            y_ad = me._conv_implicit_bf16(xin, me._prep_bf16_t(w), km.nbr, None, km.n_out, cin, cout, P)
+            pin, pout, off, _ = km.pairs()
+            seg, nseg = km.segments(128)
+            y_pairs = me._conv_pairs(xin, w, pin, pout, seg, nseg, None, km.n_out, P)
+            torch.testing.assert_close(y_ad, y_pairs, rtol=1e-3, atol=1e-3)
+    finally:
+        me.PRECISION = prec
+
+
 def test_full_size_knn_self_query_and_nms_idempotence(hip):
     _, pts = _s50k_tensor()
     xyz = pts[pts[:, 0] == 0, 1:4].contiguous()[None]
