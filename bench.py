@@ -20,7 +20,11 @@ import argparse
 import json
 import os
 
-os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # cpu_baseline leg: the oracle stops scaling beyond this
+# One host thread for torch's CPU-side ops: every host tensor of a step is tiny, and with the default (one OpenMP
+# thread per core) a descheduled worker of some small parallel region stalled the launching thread for 50-200 ms a few
+# times per 100 steps -- mean step 54-57 ms vs 44.5 ms with one thread (tools/alloc_steady.py).  torchrun sets the same
+# default for its workers.  The cpu_baseline leg runs in its own process with all cores.
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 import sys
 import time
 
@@ -51,6 +55,7 @@ def parse():
                          "accumulation, storage and the weight gradient are fp32 in both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="S50k:1", help="config:scenes timed on the CPU oracle")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     return ap.parse_args()
 
 
@@ -140,8 +145,26 @@ def pmc_traffic(kernel_substr):
         return None
 
 
+def cpu_baseline_subprocess(args):
+    """The cpu_baseline leg in a child process with every core (this process runs torch's host ops on one thread)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(min(os.cpu_count() or 1, 64)))   # the oracle stops scaling beyond 64
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", args.cpu_sample,
+           "--dataset", args.dataset] + (["--natural"] if args.natural else [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError("cpu_baseline child failed: %s" % out.stderr[-400:])
+    return json.loads(lines[-1])
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args, not args.natural)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -241,7 +264,7 @@ def main():
                "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, forced)
+                out["cpu_baseline"] = cpu_baseline_subprocess(args)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

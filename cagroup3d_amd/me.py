@@ -32,6 +32,43 @@ from . import _lib
 from ._lib import ptr
 
 
+class _PinnedStage:
+    """Pinned staging memory for the many small host tables of a step (segment tables, tile tables, row counts).
+    `Tensor.pin_memory()` goes through the caching host allocator, and every table has another size: misses end in
+    hipHostMalloc, which was caught stalling the launching thread for 50-100 ms behind a busy device (tools/outliers.py).
+    Two fixed halves per (device, stream) instead: a half is reused only after the event recorded when it was left --
+    half a ring (tens of steps) earlier -- has completed."""
+    HALF = 16 << 20
+    _rings = {}
+
+    def __init__(self):
+        self.buf = torch.empty(2 * self.HALF, dtype=torch.uint8).pin_memory()
+        self.half, self.off = 0, 0
+        self.left = [None, None]          # event recorded when a half was left
+
+    @classmethod
+    def get(cls, stream):
+        key = (stream.device_index, stream.cuda_stream)
+        ring = cls._rings.get(key)
+        if ring is None:
+            ring = cls._rings[key] = cls()
+        return ring
+
+    def take(self, nbytes, stream):
+        nbytes = (nbytes + 63) & ~63
+        if self.off + nbytes > self.HALF:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.left[self.half] = ev
+            self.half ^= 1
+            self.off = 0
+            if self.left[self.half] is not None:
+                self.left[self.half].synchronize()      # recorded half a ring ago: complete long since
+        o = self.half * self.HALF + self.off
+        self.off += nbytes
+        return self.buf[o:o + nbytes]
+
+
 def h2d(data, dtype, device):
     """Small host table -> device WITHOUT stalling the stream: pinned staging + non_blocking copy
     (a pageable-memory copy blocks the host until every kernel queued before it has finished)."""
@@ -39,7 +76,14 @@ def h2d(data, dtype, device):
     dev = torch.device(device)
     if dev.type != "cuda":
         return t.to(dev)
-    return t.pin_memory().to(dev, non_blocking=True)
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0 or nbytes > _PinnedStage.HALF:
+        return t.pin_memory().to(dev, non_blocking=True)
+    stream = torch.cuda.current_stream(dev)
+    stage = _PinnedStage.get(stream).take(nbytes, stream)[:nbytes].view(dtype).view(t.shape)
+    stage.copy_(t)
+    return stage.to(dev, non_blocking=True)
 
 
 # ----------------------------------------------------------------------------- coordinate maps

@@ -13,9 +13,13 @@ import argparse
 import os
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# one host thread for torch's CPU-side ops: every host tensor of a step is tiny, and the default OpenMP teams only
+# add 50-200 ms stalls of the launching thread; torchrun sets the same default for its workers
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from . import build_model, synthetic
 from .pcdet.datasets.indoor_eval import indoor_eval
