@@ -508,3 +508,31 @@ def test_rotated_iou3d_pairs(oracle, hip):
     b[0, :100, :3] += 0.05
     ref, out = both(oracle, hip, rotated_iou.cal_iou_3d, a, b)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_pinned_staging_ring_survives_wraparound(hip):
+    """me.h2d stages small host tables in two fixed pinned halves; shrink them so that a few hundred copies wrap the
+    ring many times while the stream is busy, and check every table arrived intact."""
+    half = me._PinnedStage.HALF
+    me._PinnedStage.HALF = 4096
+    me._PinnedStage._rings.clear()
+    try:
+        busy = torch.randn(2048, 2048, device="cuda")
+        outs, refs = [], []
+        g = torch.Generator().manual_seed(0)
+        for i in range(300):
+            if i % 10 == 0:
+                busy = busy @ busy * 1e-3          # keep the stream behind the host
+            n = int(torch.randint(1, 700, (1,), generator=g))
+            t = torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32)
+            refs.append(t)
+            outs.append(me.h2d(t, torch.int32, "cuda"))
+        big = torch.arange(5000, dtype=torch.int32)                # larger than a half: the pin_memory() fallback
+        assert torch.equal(me.h2d(big, torch.int32, "cuda").cpu(), big)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, refs):
+            assert torch.equal(o.cpu(), r)
+    finally:
+        me._PinnedStage.HALF = half
+        me._PinnedStage._rings.clear()
