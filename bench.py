@@ -169,11 +169,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if os.environ.get("CG3D_SINGLE_DEVICE") == "1":      # test aid: every rank on cuda:0 (with CG3D_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("CG3D_FORCE_DDP") == "1"      # the env knob exercises the DDP path on one GPU
     if use_dist:
-        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get("CG3D_DIST_BACKEND", "nccl"))   # "nccl" = RCCL on ROCm
     forced = not args.natural
     me.PRECISION = 1 if args.precision == "bf16" else 0
 
