@@ -79,12 +79,14 @@ def _ddp_worker(rank, world, port, q):
         model.train()
         model.dense_head.force_gt_selection = True
         model.dense_head.force_class_logit_boost = 6.0
-        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        from cagroup3d_amd.grad_sync import TwoBucketGradSync
+        model.grad_sync = TwoBucketGradSync(model)       # the product's exchange (bench.py / train.py at WORLD_SIZE > 1)
         torch.manual_seed(1)
         np.random.seed(1)
         batch = bm.synthetic_batch("S5k", 1, first_scene=rank, device="cpu")     # scene i -> rank i mod W
-        ret, tb, _ = ddp(batch)
+        ret, tb, _ = model(batch)
         ret["loss"].backward()
+        model.grad_sync.finish()
         g = torch.cat([p.grad.flatten() for p in model.parameters()])
         q.put((rank, float(ret["loss"]), g[::997].clone().numpy(), float(g.abs().sum())))
     dist.destroy_process_group()
@@ -92,7 +94,7 @@ def _ddp_worker(rank, world, port, q):
 
 @pytest.mark.timeout(900)
 def test_data_parallel_two_ranks_gloo(oracle):
-    """One scene per rank, DDP gradient all-reduce + the fused reduce_mean all-reduce on gloo:
+    """One scene per rank, the bucketed gradient all-reduce (grad_sync.py) + the fused reduce_mean all-reduce on gloo:
     both ranks end with identical (averaged) gradients, different from a single-rank run."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
