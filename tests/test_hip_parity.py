@@ -167,7 +167,8 @@ def test_spconv_bf16_operands_match_oracle_emulation(oracle, hip, cin, cout, ks,
     assert (ref[0] - full[0]).abs().max() <= 2e-2 * float(full[0].abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,n", [(64, 64, 4000), (128, 128, 4000), (128, 256, 2500), (256, 128, 2500), (64, 32, 900)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 4000), (128, 128, 4000), (128, 256, 2500), (256, 128, 2500), (64, 32, 900),
+                                       (96, 64, 1500), (72, 48, 900), (192, 80, 1200)])     # partial 64-channel chunk / column tile
 def test_spconv_output_stationary_bf16_matches_pair_form_oracle(oracle, hip, cin, cout, n):
     """bf16 mode picks the atomic-free output-stationary kernel on dense-enough maps: same operator."""
     torch.manual_seed(cin * 3 + cout)
