@@ -432,6 +432,40 @@ extern "C" int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float 
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+// Table-driven form: ONE launch for the bf16 copies of every convolution weight of the model (a training step used to
+// spend 55 launches of 15 us on them).  Row b of the table describes the 64 x 64 tile block b converts:
+//   { address of the fp32 slot [cin][cout], address of its transposed bf16 copy or 0, address of its plain bf16 copy or
+//     0, cin, cout, tile index = ci_tile * ceil(cout / 64) + co_tile }
+__global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__restrict__ table) {
+    __shared__ uint16_t T[64][66];
+    const int64_t *row = table + (int64_t)blockIdx.x * 6;
+    const float *src = reinterpret_cast<const float *>(row[0]);
+    uint16_t *Wb_t = reinterpret_cast<uint16_t *>(row[1]);
+    uint16_t *Wb = reinterpret_cast<uint16_t *>(row[2]);
+    const int cin = (int)row[3], cout = (int)row[4], tile = (int)row[5];
+    const int co_tiles = (cout + 63) / 64;
+    const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;                       // r: input channel, c: output channel
+        const bool ok = ci0 + r < cin && co0 + c < cout;
+        const uint16_t b = ok ? (uint16_t)f2bf(src[(int64_t)(ci0 + r) * cout + co0 + c]) : (uint16_t)0;
+        T[r][c] = b;
+        if (Wb && ok) Wb[(int64_t)(ci0 + r) * cout + co0 + c] = b;
+    }
+    __syncthreads();
+    if (!Wb_t) return;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;                       // r: output channel, c: input channel
+        if (co0 + r < cout && ci0 + c < cin) Wb_t[(int64_t)(co0 + r) * cin + ci0 + c] = T[c][r];
+    }
+}
+extern "C" int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream) {
+    if (nrows < 0 || nrows > 0x7fffffffll || (nrows > 0 && !table)) return CG3D_ERR_ARG;
+    if (nrows == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_prep_weights_table, dim3((unsigned)nrows), dim3(256), 0, cg3d_hs(stream), table);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
 extern "C" int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout,
                                              cg3d_stream_t stream) {
     if (slots < 0) return CG3D_ERR_ARG;

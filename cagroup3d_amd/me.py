@@ -437,8 +437,132 @@ def _to_bf16(x, keep=False):
     return out
 
 
+class _WeightPlan:
+    """The bf16 weight copies of a whole step in ONE launch (cg3d_spconv_prep_weights_bf16_table).
+
+    Self-learning: the first time a weight (or a group of per-class weights) asks for its copies it is converted on the
+    spot and recorded; from then on `prepare_weights()` -- called by the detector at the start of every forward --
+    converts every recorded weight whose tensor version changed (i.e. after every optimizer step, never in inference)
+    into one persistent arena with a single launch, and the per-layer requests are answered from the arena."""
+    singles = {}        # data_ptr -> [w3, need_plain, version, wt_view, wp_view]
+    groups = {}         # (ptrs, transposed) -> [weights, versions, out_view]
+    table = None        # device int64 [nrows, 6]
+    nrows = 0
+    dirty = False
+    keep = None         # the arenas
+    live = False        # inside a detector forward that called prepare_weights(): arena answers are valid
+    pending = True      # the weights may have changed since the last conversion
+
+    @classmethod
+    def reset(cls):
+        cls.singles, cls.groups, cls.table, cls.nrows, cls.dirty, cls.keep = {}, {}, None, 0, False, None
+        cls.live, cls.pending = False, True
+
+    @classmethod
+    def _rebuild(cls, device):
+        import numpy as _np
+        n_t = sum(e[0].numel() for e in cls.singles.values()) + sum(sum(w.numel() for w in g[0]) for k, g in cls.groups.items() if k[1])
+        n_p = sum(e[0].numel() for e in cls.singles.values() if e[1]) + sum(sum(w.numel() for w in g[0]) for k, g in cls.groups.items() if not k[1])
+        arena_t = torch.empty(max(n_t, 1), dtype=torch.int16, device=device)
+        arena_p = torch.empty(max(n_p, 1), dtype=torch.int16, device=device)
+        rows, ot, op = [], 0, 0
+
+        def add(w, off_t, off_p):
+            K, cin, cout = w.shape
+            per = cin * cout
+            tiles = -(-cin // 64) * -(-cout // 64)
+            k = _np.repeat(_np.arange(K, dtype=_np.int64), tiles)
+            t = _np.tile(_np.arange(tiles, dtype=_np.int64), K)
+            r = _np.empty((K * tiles, 6), dtype=_np.int64)
+            r[:, 0] = w.data_ptr() + k * per * 4
+            r[:, 1] = 0 if off_t is None else arena_t.data_ptr() + (off_t + k * per) * 2
+            r[:, 2] = 0 if off_p is None else arena_p.data_ptr() + (off_p + k * per) * 2
+            r[:, 3], r[:, 4], r[:, 5] = cin, cout, t
+            rows.append(r)
+        for e in cls.singles.values():
+            w = e[0]
+            K, cin, cout = w.shape
+            add(w, ot, op if e[1] else None)
+            e[3] = arena_t[ot:ot + w.numel()].view(K, cout, cin)
+            ot += w.numel()
+            if e[1]:
+                e[4] = arena_p[op:op + w.numel()].view(K, cin, cout)
+                op += w.numel()
+            e[2] = -1
+        for (ptrs, transposed), g in cls.groups.items():
+            ws = g[0]
+            K, cin, cout = ws[0].shape
+            base = ot if transposed else op
+            for i, w in enumerate(ws):
+                add(w, base + i * w.numel() if transposed else None, None if transposed else base + i * w.numel())
+            tot = sum(w.numel() for w in ws)
+            if transposed:
+                g[2] = arena_t[ot:ot + tot].view(len(ws) * K, cout, cin)
+                ot += tot
+            else:
+                g[2] = arena_p[op:op + tot].view(len(ws) * K, cin, cout)
+                op += tot
+            g[1] = None
+        tab = _np.concatenate(rows) if rows else _np.zeros((0, 6), dtype=_np.int64)
+        cls.table, cls.nrows = h2d(torch.from_numpy(tab), torch.int64, device), int(tab.shape[0])
+        cls.keep, cls.dirty = (arena_t, arena_p), False
+
+
+def prepare_weights(training=True):
+    """Start of a detector forward: convert the recorded convolution weights -- one launch -- and let the per-layer
+    requests of THIS forward be answered from the arena (until `finish_weights()`).
+
+    Training forwards always convert: a fused optimizer step changes the weights WITHOUT bumping their tensor version
+    (checked: torch.optim.AdamW(fused=True) leaves `_version` at 0), so versions cannot tell.  Inference forwards
+    convert after a training forward, when a version changed (load_state_dict, in-place edits), and the first time.
+    No-op on a CPU library and in fp32 mode."""
+    lib = _lib.get()
+    P = _WeightPlan
+    P.live = False
+    if not lib.is_device or PRECISION != 1 or not (P.singles or P.groups):
+        return
+    if len(P.singles) + len(P.groups) > 512:
+        P.reset()
+        return
+    if P.dirty:
+        dev = next(iter(P.singles.values()))[0].device if P.singles else next(iter(P.groups.values()))[0][0].device
+        P._rebuild(dev)
+        P.pending = True
+    need = training or P.pending or any(e[2] != e[0]._version for e in P.singles.values()) or \
+        any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
+    if need:
+        lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
+        for e in P.singles.values():
+            e[2] = e[0]._version
+        for g in P.groups.values():
+            g[1] = tuple(w._version for w in g[0])
+    P.pending = bool(training)          # after a training forward the weights change behind our back
+    P.live = True
+
+
+def finish_weights():
+    """End of the detector forward: from here on the arena may be stale (an optimizer step may follow)."""
+    _WeightPlan.live = False
+
+
+def _planned_single(w3, need_plain):
+    P = _WeightPlan
+    e = P.singles.get(w3.data_ptr())
+    if e is not None and e[0].shape == w3.shape and (e[1] or not need_plain):
+        if P.live and e[3] is not None and e[2] == w3._version:
+            return e
+        return None
+    if _lib.get().is_device and w3.dim() == 3:
+        P.singles[w3.data_ptr()] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
+        P.dirty = True
+    return None
+
+
 def _prep_bf16_t(w3):
     """fp32 [K, cin, cout] -> int16 view of bf16 [K, cout, cin] (cg3d_spconv_prep_weights_bf16)."""
+    e = _planned_single(w3, False)
+    if e is not None:
+        return e[3]
     lib = _lib.get()
     K, cin, cout = w3.shape
     out = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
@@ -448,6 +572,9 @@ def _prep_bf16_t(w3):
 
 def _prep_bf16_both(w3):
     """One launch: (bf16 [K, cout, cin] for the forward, bf16 [K, cin, cout] for the data gradient)."""
+    e = _planned_single(w3, True)
+    if e is not None:
+        return e[3], e[4]
     lib = _lib.get()
     K, cin, cout = w3.shape
     wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
@@ -466,6 +593,13 @@ def _prep_bf16_group(weights, transposed):
     lib = _lib.get()
     G, (K, cin, cout) = len(weights), weights[0].shape
     key = tuple(w.data_ptr() for w in weights)
+    g = _WeightPlan.groups.get((key, transposed))
+    if g is not None:
+        if _WeightPlan.live and g[2] is not None and g[1] == tuple(w._version for w in weights):
+            return g[2]
+    elif lib.is_device:
+        _WeightPlan.groups[(key, transposed)] = [[w.detach() for w in weights], None, None]
+        _WeightPlan.dirty = True
     tab = _wptr_cache.get(key)
     if tab is None:
         if len(_wptr_cache) > 64:
@@ -686,6 +820,8 @@ class GroupedConvFunction(torch.autograd.Function):
         xg = _to_bf16(x, keep=True) if BF16_ROWS else x
         ctx.save_for_backward(x, xg if xg is not x else None, *weights)
         wt = _prep_bf16_group(weights, True)
+        # the data gradient's operand: free while the step's arena is live (backward runs after the forward closed it)
+        ctx.wp_plain = _prep_bf16_group(weights, False) if (_WeightPlan.live and ctx.needs_input_grad[0]) else None
         if GroupedConvFunction._tiled(kmap, P, K, closed):
             return _conv_implicit_bf16(xg, wt, kmap.nbr, None, kmap.n_out, cin, cout, P, kmap.tiles(row_bounds))
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
@@ -703,7 +839,7 @@ class GroupedConvFunction(torch.autograd.Function):
         dyg = _to_bf16(dy) if BF16_ROWS else dy
         dx = None
         if ctx.needs_input_grad[0]:
-            wp = _prep_bf16_group(weights, False)
+            wp = ctx.wp_plain if ctx.wp_plain is not None else _prep_bf16_group(weights, False)
             if GroupedConvFunction._tiled(kmap, P, K, ctx.closed):
                 dx = _conv_implicit_bf16(dyg, wp, kmap.nbrT, None, kmap.n_in, cout, cin, P, kmap.tiles(rb))
             else:

@@ -78,6 +78,14 @@ class CAGroup3D(Detector3DTemplate):
         cur_epoch = batch_dict.get("cur_epoch", None)
         assert cur_epoch is not None
         ME._ROWS16.clear()
+        # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
+        ME.prepare_weights(self.training)
+        try:
+            return self._forward(batch_dict, cur_epoch)
+        finally:
+            ME.finish_weights()
+
+    def _forward(self, batch_dict, cur_epoch):
         self.module_list[1].semantic_threshold = max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value,
                                                      self.semantic_min_threshold)
         batch_dict["points"][:, -3:] = batch_dict["points"][:, -3:] / 255.

@@ -149,6 +149,11 @@ int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, i
  * (either may be NULL).  The plain copy is the prepared buffer of the data gradient (the swapped problem). */
 int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws, uint16_t *Wb_t, uint16_t *Wb,
                                         int32_t G, int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t stream);
+/* Table form: the bf16 copies of ANY set of weight slots in one launch.  `table` = device int64 [nrows, 6], one row per
+ * 64 x 64 tile of one slot: { address of the float32 slot [cin][cout], address of its transposed bf16 copy [cout][cin]
+ * or 0, address of its plain bf16 copy [cin][cout] or 0, cin, cout, tile = ci_tile * ceil(cout / 64) + co_tile }.
+ * Same values as cg3d_spconv_prep_weights_bf16_multi writes. */
+int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream);
 int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
 int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
                      void *ws, int32_t *pair_off, cg3d_stream_t stream);

@@ -163,6 +163,29 @@ int cg3d_spconv_wgrad(const float *X, const float *dY, const int32_t *nbr, float
 }
 
 
+/* table form (include/cagroup3d_hip.h): one row per 64 x 64 tile of one slot */
+int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t s) {
+    (void)s;
+    if (nrows < 0 || (nrows > 0 && !table)) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nrows; b++) {
+        const int64_t *row = table + b * 6;
+        const float *src = (const float *)(uintptr_t)row[0];
+        uint16_t *wt = (uint16_t *)(uintptr_t)row[1], *wp = (uint16_t *)(uintptr_t)row[2];
+        const int cin = (int)row[3], cout = (int)row[4], tile = (int)row[5];
+        const int co_tiles = (cout + 63) / 64;
+        const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
+        for (int r = ci0; r < ci0 + 64 && r < cin; r++)
+            for (int c = co0; c < co0 + 64 && c < cout; c++) {
+                const float f = os_bf16(src[(int64_t)r * cout + c]);
+                uint32_t u; memcpy(&u, &f, 4);
+                const uint16_t v = (uint16_t)(u >> 16);
+                if (wp) wp[(int64_t)r * cout + c] = v;
+                if (wt) wt[(int64_t)c * cin + r] = v;
+            }
+    }
+    return CG3D_OK;
+}
 int cg3d_spconv_prep_weights_bf16(const float *W, uint16_t *Wb, int64_t slots, int32_t cin, int32_t cout, cg3d_stream_t s) {
     (void)s;
     for (int64_t t = 0; t < slots; t++)

@@ -537,3 +537,49 @@ def test_pinned_staging_ring_survives_wraparound(hip):
     finally:
         me._PinnedStage.HALF = half
         me._PinnedStage._rings.clear()
+
+
+@pytest.mark.gpu
+def test_weight_plan_single_launch_equals_per_layer_conversion(hip):
+    """me.prepare_weights(): every recorded conv weight converted by ONE table-driven launch into the arena -- the same
+    bits as the per-layer launches, refreshed exactly when a weight's version changes."""
+    me._WeightPlan.reset()
+    me.PRECISION = 1
+    try:
+        torch.manual_seed(0)
+        ws = [torch.randn(27, 64, 64, device="cuda"), torch.randn(8, 72, 48, device="cuda"), torch.randn(27, 128, 256, device="cuda")]
+        grp = [torch.randn(125, 64, 64, device="cuda") for _ in range(3)]
+        first = [me._prep_bf16_both(w) for w in ws[:2]] + [(me._prep_bf16_t(ws[2]), None)]        # per-layer launches; recorded
+        g_t, g_p = me._prep_bf16_group(grp, True), me._prep_bf16_group(grp, False)
+        assert me._WeightPlan.dirty and me._WeightPlan.table is None
+        me.prepare_weights()
+        assert me._WeightPlan.nrows == 27 + 8 * 2 + 27 * 2 * 4 + 2 * 3 * 125
+        again = [me._prep_bf16_both(w) for w in ws[:2]] + [(me._prep_bf16_t(ws[2]), None)]
+        for (a_t, a_p), (b_t, b_p), w in zip(first, again, ws):
+            assert b_t.data_ptr() != a_t.data_ptr() and torch.equal(a_t, b_t)                 # answered from the arena
+            assert (a_p is None and b_p is None) or torch.equal(a_p, b_p)
+        assert torch.equal(me._prep_bf16_group(grp, True), g_t) and torch.equal(me._prep_bf16_group(grp, False), g_p)
+        arena_ptr = again[0][0].data_ptr()
+        me.finish_weights()                                  # outside a detector forward the arena is never trusted
+        assert me._prep_bf16_both(ws[0])[0].data_ptr() != arena_ptr
+        # a fused optimizer step changes the weights WITHOUT bumping the version: a training forward converts always
+        ws[0].data.copy_(ws[0].data + 1.0)
+        with torch.no_grad():
+            expect = me._prep_bf16_both(ws[0])               # converted on the spot
+        me.prepare_weights(training=True)
+        fresh = me._prep_bf16_both(ws[0])
+        assert fresh[0].data_ptr() == arena_ptr and torch.equal(fresh[0], expect[0]) and torch.equal(fresh[1], expect[1])
+        assert not torch.equal(fresh[0], first[0][0])
+        me.finish_weights()
+        # inference: converts once after a training forward, then only when a version changes
+        me.prepare_weights(training=False)
+        n0 = me._WeightPlan.pending
+        assert n0 is False
+        ws[1].add_(1.0)
+        me.prepare_weights(training=False)
+        again2 = me._prep_bf16_both(ws[1])
+        me.finish_weights()
+        assert torch.equal(again2[0], me._prep_bf16_both(ws[1])[0])
+    finally:
+        me.PRECISION = 0
+        me._WeightPlan.reset()
