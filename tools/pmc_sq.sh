@@ -1,7 +1,7 @@
 # dev tool (GPU box): SQ occupancy / stall counters of the output-stationary conv kernel, per layer shape
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc_sq.txt; : > $O
-KREG=${KREG:-k_spconv_implicit_bf16_ws}
+KREG=${KREG:-k_spconv_implicit_bf16}
 for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/sq_$n
