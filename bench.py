@@ -35,6 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from cagroup3d_amd import _lib, build_model, me  # noqa: E402
+from cagroup3d_amd.hostpin import pin_host_threads  # noqa: E402
+
+_ALL_CPUS = None
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
@@ -153,7 +156,8 @@ def cpu_baseline_subprocess(args):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", args.cpu_sample,
            "--dataset", args.dataset] + (["--natural"] if args.natural else [])
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    every = (lambda: os.sched_setaffinity(0, _ALL_CPUS)) if _ALL_CPUS else None      # the child is not pinned
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, preexec_fn=every)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not lines:
         raise RuntimeError("cpu_baseline child failed: %s" % out.stderr[-400:])
@@ -168,6 +172,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    global _ALL_CPUS
+    _ALL_CPUS, _ = pin_host_threads(local_rank)        # before the runtime starts its helper threads
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if os.environ.get("CG3D_SINGLE_DEVICE") == "1":      # test aid: every rank on cuda:0 (with CG3D_DIST_BACKEND=gloo)
         local_rank = 0

@@ -207,6 +207,9 @@ def main(argv=None):
     me.PRECISION = 1 if args.precision == "bf16" else 0
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device(args.device, int(os.environ.get("LOCAL_RANK", "0"))) if args.device == "cuda" else torch.device("cpu")
+    if dev.type == "cuda":
+        from .hostpin import pin_host_threads
+        pin_host_threads(int(os.environ.get("LOCAL_RANK", "0")))     # the launching thread stays on a few cores
     if world > 1:
         dist.init_process_group(backend="nccl" if dev.type == "cuda" else "gloo")
     if dev.type == "cuda":
