@@ -27,9 +27,15 @@ def pin_host_threads(local_rank=0, width=4, stride=8):
         pick = sorted(want & set(allowed)) or allowed[:width]
     else:
         # blocks of `width` CPUs, `stride` apart, so that neighbouring ranks do not share a core complex
+        nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
         base = 8 if len(allowed) >= 64 else 0            # leave the first cores to the OS's own work
-        nblocks = max((len(allowed) - base - width) // stride + 1, 1)
-        start = base + (int(local_rank) % nblocks) * stride
+        for st in (stride, width):
+            nblocks = (len(allowed) - base - width) // st + 1
+            if nblocks >= nlocal:
+                break
+        else:
+            return set(allowed), set(allowed)            # not enough CPUs for a block per rank: leave the scheduler alone
+        start = base + (int(local_rank) % nblocks) * st
         pick = allowed[start:start + width]
     os.sched_setaffinity(0, set(pick))
     return set(allowed), set(pick)
