@@ -12,9 +12,10 @@ grad-norm clip, AdamW step; inputs are resident in HBM when the timed region sta
 one batch per rank (weak scaling); the only collectives are DDP's gradient all-reduce and the
 fused 3-scalar reduce_mean per scene, over RCCL.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_spconv_pairs: gather ->
-fp32 MFMA -> atomic scatter), timed live with HIP events on the launch stream; `cpu_baseline`
-times the CPU oracle (oracle/liboracle.so, the checker -- never the product) on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the conv kernel that accumulates the most time (bf16:
+k_spconv_implicit_bf16_ad, fp32: k_spconv_pairs_lds), every conv launch timed live with HIP events on the launch stream on
+up to six of the timed steps spread over the timed region (`roofline.timed_steps`); `cpu_baseline` times the CPU oracle
+(oracle/liboracle.so, the checker -- never the product) on a bounded sample, in a child process.
 """
 import argparse
 import json
@@ -208,11 +209,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # live HIP-event timing of every conv launch (the roofline figures) -- on at most ~6 of the timed steps, spread evenly
+    # over the timed region: two events per launch add up (20 k live events in a 100-step run slowed the run itself)
     me.KernelProfile.reset()
-    me.KernelProfile.enabled = True
+    stride = max(1, -(-args.steps // 6))
+    profiled_steps = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        me.KernelProfile.enabled = i % stride == 0
+        profiled_steps += int(me.KernelProfile.enabled)
         tb = train_step(net, opt, batch, clip)
     barrier()
     dt = time.perf_counter() - t0
@@ -246,9 +252,9 @@ def main():
             roof = {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_gbytes_per_s": gbs}
         roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
-                    kernel_time_share=secs / dt,
+                    kernel_time_share=secs / (dt * profiled_steps / args.steps), timed_steps=profiled_steps,
                     algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1),
-                    other_conv_kernels={k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps}
+                    other_conv_kernels={k: {"launches": v["launches"], "ms_per_step": v["ms"] / profiled_steps}
                                         for k, v in kinds.items() if k != kind})
         roof["traffic"] = pmc_traffic(ksym)   # bytes per launch, from profiles/ (separate --pmc runs)
         # SURVEY 8(d) aggregate over every timed conv launch (forward + data gradient): sum of per-launch roofline
