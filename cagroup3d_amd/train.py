@@ -132,6 +132,9 @@ def checkpoint_state(model, optimizer, epoch, it):
             "optimizer_state": optimizer.state_dict() if optimizer is not None else None, "version": "cagroup3d_amd"}
 
 
+_FROZEN = [False]
+
+
 def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=0, log=print):
     model.train()
     model_func = model_fn_decorator()
@@ -165,6 +168,13 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
         scheduler.step()
         prepared = core.prefetch_coordinates(nxt) if (nxt is not None and device.type == "cuda") else None
         it += 1
+        if not _FROZEN[0] and device.type == "cuda":
+            # the model, the optimizer state and the cached tables are permanent: out of the cyclic collector's
+            # generations after the first iteration, or every gen-2 pass walks them again (a 75 ms pause each)
+            import gc
+            gc.collect()
+            gc.freeze()
+            _FROZEN[0] = True
         if rank == 0:
             log("epoch %d it %d lr %.2e loss %.4f (%s)" % (epoch, it, optimizer.param_groups[0]["lr"], float(loss.detach()),
                                                           ", ".join("%s %.3f" % (k, v) for k, v in sorted(tb.items()) if k.startswith("loss_"))))
