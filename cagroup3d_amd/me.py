@@ -1142,12 +1142,15 @@ class FusedBNActFunction(torch.autograd.Function):
         ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n, achunks)
         ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps), nachunk)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)      # or autograd fills a zero gradient for `mean` and `var` on every backward
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         x, y, mean, var, gamma, chunks, gco, group_n, achunks = ctx.saved_tensors
         nchunk, G, C, act, use_batch, has_res, eps, nachunk = ctx.meta
+        if dy is None:
+            return (None,) * 11
         lib = _lib.get()
         dy = dy.contiguous()
         ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
