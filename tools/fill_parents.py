@@ -17,7 +17,8 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
     bench.train_step(model, opt, batch, 10)
     torch.cuda.synchronize()
-ev = [e for e in prof.events() if e.name in ("aten::fill_", "aten::zero_")]
+names = tuple(os.environ.get("OPS", "aten::fill_,aten::zero_").split(","))
+ev = [e for e in prof.events() if e.name in names]
 cnt = collections.Counter()
 for e in ev:
     p = e.cpu_parent
@@ -27,6 +28,6 @@ for e in ev:
         p = p.cpu_parent
     st = [s for s in (e.stack or []) if "cagroup3d_amd" in s or "bench.py" in s]
     cnt[(" <- ".join(chain), st[0].split("repo/")[-1] if st else "")] += 1
-print("fill_/zero_ ops in one step:", len(ev))
+print(names, "ops in one step:", len(ev))
 for k, v in cnt.most_common(30):
     print("%4d  %-70s %s" % (v, k[0][:70], k[1][:90]))
