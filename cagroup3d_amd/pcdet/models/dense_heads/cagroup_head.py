@@ -709,13 +709,16 @@ class CAGroup3DHead(nn.Module):
         """(dx-,dx+,dy-,dy+,dz-,dz+[, yaw params]) at a point -> (x,y,z,w,l,h[,alpha]) (cagroup_head.py:654-703)."""
         if bbox_pred.shape[0] == 0:
             return bbox_pred
+        if bbox_pred.shape[1] == 6:
+            # the same arithmetic on strided column slices (two views instead of twelve selects, each of which costs a
+            # zero-fill + copy in backward): centre = p + (d+ - d-) / 2, size = d- + d+
+            lo, hi = bbox_pred[:, 0:6:2], bbox_pred[:, 1:6:2]
+            return torch.cat([points[:, :3] + (hi - lo) / 2, lo + hi], dim=1)
         xc = points[:, 0] + (bbox_pred[:, 1] - bbox_pred[:, 0]) / 2
         yc = points[:, 1] + (bbox_pred[:, 3] - bbox_pred[:, 2]) / 2
         zc = points[:, 2] + (bbox_pred[:, 5] - bbox_pred[:, 4]) / 2
         base = torch.stack([xc, yc, zc, bbox_pred[:, 0] + bbox_pred[:, 1], bbox_pred[:, 2] + bbox_pred[:, 3],
                             bbox_pred[:, 4] + bbox_pred[:, 5]], -1)
-        if bbox_pred.shape[1] == 6:
-            return base
         if self.yaw_parametrization == "naive":
             return torch.cat((base, bbox_pred[:, 6:7]), -1)
         if self.yaw_parametrization == "sin-cos":
