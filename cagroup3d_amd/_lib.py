@@ -53,6 +53,11 @@ _SIGNATURES = {
     "cg3d_focal_loss_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, c_float, P, P]),
     "cg3d_spconv_prep_weights_bf16_multi": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, P]),
     "cg3d_spconv_prep_weights_bf16_table": (c_int32, [P, c_int64, P]),
+    "cg3d_spconv_prep_weights_frag": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, P]),
+    "cg3d_tile_plan_build": (c_int32, [P, c_int32, c_int64, P, c_int64, c_int32, c_int32, P, P, P, P, P, c_int64, P, P]),
+    "cg3d_spconv_tile_lds_bytes": (c_int64, [c_int32]),
+    "cg3d_spconv_tile_fwd": (c_int32, [P, P, P, P, P, P, P, c_int32, c_int32, P, c_int64, P, P, c_int64, c_int64, c_int32,
+                                       c_int32, c_int32, c_int32, P]),
     "cg3d_bn_stats": (c_int32, [P, P, c_int64, P, c_int32, c_int32, P, P, P, P, P, P, c_float, P]),
     "cg3d_bn_apply": (c_int32, [P, P, P, c_int64, c_int32, P, P, c_float, P, P, c_int32, P, P, P]),
     "cg3d_bn_bwd_reduce": (c_int32, [P, P, P, P, c_int64, P, c_int32, c_int32, P, P, c_float, c_int32, P, P, P, P]),

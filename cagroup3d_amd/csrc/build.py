@@ -14,6 +14,7 @@ ARCH = "gfx950"
 SOURCES = {
     "coords.hip": ["-ffp-contract=off"],
     "spconv.hip": ["-munsafe-fp-atomics"],
+    "spconv_tile.hip": ["-munsafe-fp-atomics"],
     "gather_scatter.hip": ["-munsafe-fp-atomics"],
     "iou3d_nms.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],

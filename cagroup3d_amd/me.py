@@ -378,6 +378,78 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs, tiles
 BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 mode: gather from bf16 row copies
 
 
+# ----------------------------------------------------------------------------- tile plans (cg3d_spconv_tile_fwd)
+TILE_ROWS = 128
+TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS rows per pass: (ucap+1) x 128 B = 64 KB
+
+
+class TilePlan:
+    """A kernel map re-encoded per tile of 128 output rows (include/cagroup3d_hip.h, cg3d_tile_plan_build)."""
+    __slots__ = ("slots", "live", "pass_tab", "npass", "ulist", "cursor", "maxpass", "ucap", "ntile", "tiles", "K", "n_out")
+
+    def tensors(self):
+        return [self.slots, self.live, self.pass_tab, self.npass, self.ulist, self.cursor, self.tiles]
+
+
+def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None):
+    """nbr int32 [K, n_out] (k-major) -> TilePlan.  `n_pairs` (host int, >= the number of nbr >= 0) sizes `ulist`;
+    tiles: None or (device int32 [ntile,3], ntile)."""
+    lib = _lib.get()
+    lib.check(nbr)
+    K, n_out = nbr.shape
+    dev = nbr.device
+    p = TilePlan()
+    p.K, p.n_out = K, n_out
+    p.ucap = int(ucap or TILE_UCAP)
+    p.tiles = tiles[0] if tiles is not None else None
+    p.ntile = int(tiles[1]) if tiles is not None else -(-n_out // TILE_ROWS)
+    p.maxpass = K
+    nt = max(p.ntile, 1)
+    p.slots = torch.empty((nt, K, TILE_ROWS), dtype=torch.int16, device=dev)
+    p.live = torch.empty((nt, K), dtype=torch.uint8, device=dev)
+    p.pass_tab = torch.empty((nt, p.maxpass, 4), dtype=torch.int32, device=dev)
+    p.npass = torch.empty(nt, dtype=torch.int32, device=dev)
+    p.ulist = torch.empty(max(int(n_pairs), 1), dtype=torch.int32, device=dev)
+    p.cursor = torch.empty(2, dtype=torch.int32, device=dev)
+    lib.call("cg3d_tile_plan_build", ptr(nbr), c_int32(K), c_int64(n_out), ptr(p.tiles), c_int64(p.ntile), c_int32(p.ucap),
+             c_int32(p.maxpass), ptr(p.slots), ptr(p.live), ptr(p.pass_tab), ptr(p.npass), ptr(p.ulist),
+             c_int64(p.ulist.shape[0]), ptr(p.cursor), lib.stream())
+    return p
+
+
+def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1):
+    """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] through a tile plan; x16: int16 view of the bf16 rows, wf: the weights in
+    MFMA fragment order (cg3d_spconv_prep_weights_frag)."""
+    lib = _lib.get()
+    lib.check(x16, wf, bias)
+    y = torch.empty((plan.n_out, cout), dtype=torch.float32, device=x16.device)
+    prof = KernelProfile.enabled and lib.is_device
+    if prof:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    lib.call("cg3d_spconv_tile_fwd", ptr(x16), ptr(wf), ptr(plan.slots), ptr(plan.live), ptr(plan.pass_tab), ptr(plan.npass),
+             ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(bias), ptr(y),
+             c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit), lib.stream())
+    if prof:
+        ev1.record()
+        # SURVEY 8(d) bytes: every input row once, every output row once, the weights once, the map once (2-byte slots)
+        KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
+                                      2.0 * n_in * cin + 4.0 * plan.n_out * cout + 2.0 * plan.K * cin * cout + 2.0 * plan.K * plan.n_out,
+                                      ("tile_bf16", plan.K, cin, cout, n_pairs, plan.n_out, 0)))
+    return y
+
+
+def _prep_frag(w3, want_t=True, want_p=False):
+    """fp32 [K, cin, cout] -> (Wf_t, Wf) int16 views of the bf16 weights in MFMA fragment order (either may be None)."""
+    lib = _lib.get()
+    K, cin, cout = w3.shape
+    wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device) if want_t else None
+    wp = torch.empty((K, cin, cout), dtype=torch.int16, device=w3.device) if want_p else None
+    lib.call("cg3d_spconv_prep_weights_frag", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K), c_int32(cin),
+             c_int32(cout), lib.stream())
+    return wt, wp
+
+
 # Coordinate-only dry run (CAGroup3D.prefetch_coordinates): modules build every coordinate / kernel map, pair list and
 # segment table they will need -- with their host reads -- but launch no feature kernel and return uninitialised
 # feature tensors of the right shape.  Run on a side stream for the NEXT batch while the GPU is still busy with the

@@ -9,6 +9,29 @@ import torch.nn as nn
 from .. import backbones_3d, dense_heads, roi_heads
 
 
+CHECKPOINT_VERSION = "cagroup3d_amd"        # written by cagroup3d_amd.train.checkpoint_state
+
+
+def convert_me_kernel_order(model_state):
+    """MinkowskiEngine kernel-offset order <-> this engine's, for every sparse-conv kernel of a state dict.
+
+    Both store a k x k x k kernel as [k^3, Cin, Cout] (and a k = 1 kernel as [Cin, Cout], which needs nothing), but
+    ME v0.5.4's kernel-region iterator advances the FIRST spatial axis fastest (offset index = ix + k*(iy + k*iz))
+    while `me._make_offsets` enumerates (ix, iy, iz) with iz fastest (index = (ix*k + iy)*k + iz).  The two differ
+    by the x <-> z transpose of the k^3 grid -- an involution, so the same call converts either way.  Without it a
+    checkpoint released by the reference's authors (README.md:120-121; same keys, same shapes) would load silently
+    with every 3^3 / 5^3 / 9^3 / 7^3 kernel spatially mirrored.  Returns a new dict; tensors that are not cubic
+    [k^3, Cin, Cout] `.kernel`s are passed through."""
+    out = {}
+    for key, val in model_state.items():
+        if key.endswith(".kernel") and torch.is_tensor(val) and val.dim() == 3 and val.shape[0] > 1:
+            k = round(val.shape[0] ** (1.0 / 3.0))
+            if k * k * k == val.shape[0]:
+                val = val.reshape(k, k, k, val.shape[1], val.shape[2]).permute(2, 1, 0, 3, 4).reshape(val.shape).contiguous()
+        out[key] = val
+    return out
+
+
 class Detector3DTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__()
@@ -81,22 +104,44 @@ class Detector3DTemplate(nn.Module):
             self.load_state_dict(state)
         return state, update
 
-    def load_params_from_file(self, filename, logger=None, to_cpu=False):
+    @staticmethod
+    def _native_model_state(ckpt, kernel_order, logger=None):
+        """The checkpoint's `model_state` in THIS engine's kernel-offset order.  kernel_order: "auto" -- checkpoints
+        carrying this build's version tag are native, anything else (the reference writes its pcdet version or none,
+        detector3d_template.py:379-381, train_utils.py:199-220) is taken to be MinkowskiEngine-ordered and converted;
+        "me" / "native" force the choice."""
+        if kernel_order not in ("auto", "me", "native"):
+            raise ValueError("kernel_order must be 'auto', 'me' or 'native'")
+        is_me = kernel_order == "me" or (kernel_order == "auto" and ckpt.get("version") != CHECKPOINT_VERSION)
+        if not is_me:
+            return ckpt["model_state"]
+        if logger is not None:
+            logger.info("==> Checkpoint version %r: sparse-conv kernels converted from MinkowskiEngine offset order"
+                        % (ckpt.get("version"),))
+        return convert_me_kernel_order(ckpt["model_state"])
+
+    def load_params_from_file(self, filename, logger=None, to_cpu=False, kernel_order="auto"):
         if not os.path.isfile(filename):
             raise FileNotFoundError(filename)
         ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
-        state, update = self._load_state_dict(ckpt["model_state"], strict=False)
+        state, update = self._load_state_dict(self._native_model_state(ckpt, kernel_order, logger), strict=False)
         if logger is not None:
             for k in state:
                 if k not in update:
                     logger.info("Not updated weight %s: %s" % (k, str(state[k].shape)))
             logger.info("==> Done (loaded %d/%d)" % (len(update), len(state)))
 
-    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None, kernel_order="auto"):
         if not os.path.isfile(filename):
             raise FileNotFoundError(filename)
         ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
-        self._load_state_dict(ckpt["model_state"], strict=True)
+        foreign = kernel_order == "me" or (kernel_order == "auto" and ckpt.get("version") != CHECKPOINT_VERSION)
+        self._load_state_dict(self._native_model_state(ckpt, kernel_order, logger), strict=True)
         if optimizer is not None and ckpt.get("optimizer_state") is not None:
+            if foreign:
+                # AdamW moments are laid out like the kernels they belong to; a foreign optimizer state would pair
+                # mirrored moments with converted weights
+                raise ValueError("optimizer state of a MinkowskiEngine-ordered checkpoint cannot be resumed; "
+                                 "load the weights with load_params_from_file and start a new optimizer")
             optimizer.load_state_dict(ckpt["optimizer_state"])
         return ckpt.get("it", 0.0), ckpt.get("epoch", -1)

@@ -26,21 +26,38 @@ from .pcdet.datasets.indoor_eval import indoor_eval
 from .pcdet.models import load_data_to_gpu, model_fn_decorator
 
 
+def shard_ids(ids, rank, world):
+    """This rank's share of `ids`, as torch's DistributedSampler deals it (the reference's sampler,
+    pcdet/datasets/__init__.py:66-71): the list is padded with its own head to a multiple of the world size, then
+    rank r takes every world-th entry from r.  Every rank gets the SAME number of scenes -- hence the same number of
+    batches and the same last-batch size -- so the per-step collectives (gradient buckets, the (B,3) loss-normaliser
+    all-reduce) line up on every rank up to the end of the epoch."""
+    ids = list(ids)
+    if world <= 1 or not ids:
+        return ids
+    total = -(-len(ids) // world) * world
+    while len(ids) < total:
+        ids += ids[:total - len(ids)]
+    return ids[rank:total:world]
+
+
 class SyntheticIndoorDataset:
-    """Scenes 0..n-1 of a synthetic configuration, sharded like DistributedSampler (scene i -> rank i mod W) and
-    collated into the reference's batch_dict (dataset.py:159-230)."""
+    """Scenes 0..n-1 of a synthetic configuration, sharded like DistributedSampler (scene i -> rank i mod W, padded to
+    equal shares) and collated into the reference's batch_dict (dataset.py:159-230)."""
 
     def __init__(self, config, n_scenes, batch_size, rank=0, world=1, first_scene=0):
-        self.config, self.batch_size = config, batch_size
-        self.scene_ids = list(range(first_scene + rank, first_scene + n_scenes, world))
+        self.config, self.batch_size, self.rank, self.world = config, batch_size, rank, world
+        self.all_ids = list(range(first_scene, first_scene + n_scenes))
+        self.scene_ids = shard_ids(self.all_ids, rank, world)
 
     def __len__(self):
         return (len(self.scene_ids) + self.batch_size - 1) // self.batch_size
 
     def batches(self, epoch=0, shuffle=False):
-        ids = list(self.scene_ids)
+        ids = list(self.all_ids)
         if shuffle:
-            np.random.RandomState(epoch).shuffle(ids)           # epoch-seeded, like sampler.set_epoch
+            np.random.RandomState(epoch).shuffle(ids)           # epoch-seeded, like sampler.set_epoch: shuffle, THEN deal
+        ids = shard_ids(ids, self.rank, self.world)
         for i in range(0, len(ids), self.batch_size):
             chunk = ids[i:i + self.batch_size]
             scenes = [synthetic.make_scene(self.config, s) for s in chunk]
@@ -75,16 +92,16 @@ class DiskIndoorDataset:
         self.batch_size, self.training, self.rank, self.world, self.workers, self.seed = batch_size, training, rank, world, workers, seed
 
     def __len__(self):
-        return (len(range(self.rank, len(self.data), self.world)) + self.batch_size - 1) // self.batch_size
+        return (len(shard_ids(range(len(self.data)), self.rank, self.world)) + self.batch_size - 1) // self.batch_size
 
     def gt_annos(self):
-        return [self.data.gt_annos()[i] for i in range(self.rank, len(self.data), self.world)]
+        return [self.data.gt_annos()[i] for i in shard_ids(range(len(self.data)), self.rank, self.world)]
 
     def batches(self, epoch=0, shuffle=False):
         ids = np.arange(len(self.data))
         if shuffle:
             np.random.RandomState(self.seed + epoch).shuffle(ids)
-        ids = ids[self.rank::self.world].tolist()
+        ids = shard_ids(ids.tolist(), self.rank, self.world)
         seed = self.seed
 
         def init(worker_id):

@@ -168,6 +168,46 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
                             int32_t precision, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sparse convolution on LDS-staged neighbour tiles (forward and data gradient of every MinkowskiConvolution with
+ * K > 1, cin % 64 == 0, cout % 64 == 0 in the bf16 mode; ME ConvolutionForwardGPU / BackwardGPU, call sites
+ * backbones_3d/biresnet.py:358-406, dense_heads/cagroup_head.py:259-275).
+ *
+ * A TILE is 128 consecutive output rows (tile t = rows [128 t, 128 t + 128), or a row of `tiles` int32 [ntile,3] =
+ * (weight group, first row, row count <= 128) for grouped convolutions).  A tile PLAN re-encodes the kernel map
+ * nbr[K, n_out] per tile so that the distinct input rows a tile touches are staged ONCE into LDS:
+ *   pass_tab int32 [ntile, maxpass, 4] = (k0, k1, u_off, u_cnt): the offsets [k0,k1) of the pass touch the u_cnt
+ *            distinct input rows ulist[u_off .. u_off+u_cnt) (u_cnt <= ucap, the LDS row capacity); npass int32 [ntile]
+ *   slots    uint16 [ntile, K, 128]: 0 = no neighbour, s > 0 = input row ulist[u_off + s - 1] of the pass holding k
+ *   live     uint8  [ntile, K]: bit m set = some row of the 32-row block m of the tile has a neighbour at offset k
+ *   ulist    int32  [ulist_cap]; ulist_cap >= the number of pairs of the map is always enough; cursor int32 [2]:
+ *            [0] = entries used, [1] != 0 = ulist / pass_tab overflowed (the plan is unusable)
+ * The slot numbering inside a pass is the implementation's choice (tests check the plan by decoding it).
+ * 128 <= ucap <= 1023; maxpass >= K is always enough.
+ *
+ * cg3d_spconv_prep_weights_frag: fp32 [slot][cin][cout] (one tensor W0, or G tensors Ws like
+ *   cg3d_spconv_prep_weights_bf16_multi) -> bf16 in MFMA B-fragment order,
+ *     Wf_t (forward operand):        [slot][co/32][ci/16][(ci/8 & 1)*32 + co%32][ci%8]   cin % 16 == 0, cout % 32 == 0
+ *     Wf   (data-gradient operand):  [slot][ci/32][co/16][(co/8 & 1)*32 + ci%32][co%8]   cout % 16 == 0, cin % 32 == 0
+ *   either may be NULL.
+ * cg3d_spconv_tile_fwd: Y[o,:] = bias + sum_k X[nbr[k,o],:] @ W[k] with X bf16 rows uint16 [n_in, cin] (cg3d_to_bf16),
+ *   Wf the fragment-ordered weights, fp32 accumulation, every output row stored once.  ksplit > 1 splits the live
+ *   offsets over that many workgroups per tile (small maps); their partial sums meet in Y through fp32 atomics (the
+ *   callee zero-fills Y).  The data gradient is the same call on the plan of the transposed map with the plain
+ *   fragment copy.  Launch needs cg3d_spconv_tile_lds_bytes(ucap) <= 160 KB of LDS per workgroup.
+ * ---------------------------------------------------------------------------------------- */
+#define CG3D_TILE_ROWS 128
+int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
+                         int32_t ucap, int32_t maxpass, uint16_t *slots, uint8_t *live, int32_t *pass_tab,
+                         int32_t *npass, int32_t *ulist, int64_t ulist_cap, int32_t *cursor, cg3d_stream_t stream);
+int cg3d_spconv_prep_weights_frag(const float *W0, const float *const *Ws, uint16_t *Wf_t, uint16_t *Wf, int32_t G,
+                                  int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t stream);
+int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap);
+int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
+                         const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
+                         int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
+                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates
  * (SparseTensor.features_at_coordinates; reference call sites biresnet.py:182-197,376,389,394).
  *   q float32 [nq,4] (batch, x, y, z) in input-grid units.

@@ -1,0 +1,213 @@
+"""Tile plans (cg3d_tile_plan_build) and the LDS-staged sparse convolution built on them (cg3d_spconv_tile_fwd).
+
+A plan's slot numbering is the implementation's choice, so a plan is checked by DECODING it back into the kernel map
+it encodes (bit-exact) and through its invariants; the convolution is compared with the oracle's dense-map bf16
+emulation (same RNE operand rounding, fp32 accumulate: only the summation order differs).
+CPU (-m "not gpu"): the oracle's plan builder / plan-driven convolution.  -m gpu: the HIP kernels against them."""
+import numpy as np
+import pytest
+import torch
+
+from cagroup3d_amd import _lib, me
+from util import rand_coords, surface_coords
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _kernel_map(coords, ks=3, stride=1):
+    x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1, device=coords.device))
+    mgr = x.coordinate_manager
+    out_key = mgr.stride(x.coordinate_map_key, stride) if stride > 1 else x.coordinate_map_key
+    return mgr.kernel_map(x.coordinate_map_key, out_key, ks, 1, False)
+
+
+def decode_plan(plan):
+    """TilePlan -> nbr int32 [K, n_out] (numpy), checking the plan's invariants on the way."""
+    K, n_out = plan.K, plan.n_out
+    slots = plan.slots.cpu().numpy().view(np.uint16)
+    live = plan.live.cpu().numpy()
+    ptab, npass, ulist, cursor = plan.pass_tab.cpu().numpy(), plan.npass.cpu().numpy(), plan.ulist.cpu().numpy(), plan.cursor.cpu().numpy()
+    tiles = plan.tiles.cpu().numpy() if plan.tiles is not None else None
+    assert cursor[1] == 0, "plan overflowed"
+    nbr = np.full((K, n_out), -1, np.int32)
+    used = 0
+    for t in range(plan.ntile):
+        row0, rows = (tiles[t, 1], tiles[t, 2]) if tiles is not None else (t * 128, min(128, n_out - t * 128))
+        k_next = 0
+        for p in range(npass[t]):
+            k0, k1, uoff, ucnt = ptab[t, p]
+            assert k0 == k_next and k1 > k0 or (k0 == k1 == K == 0), "passes must partition the offsets in order"
+            assert 0 <= ucnt <= plan.ucap
+            k_next = k1
+            used += ucnt
+            ul = ulist[uoff:uoff + ucnt]
+            assert len(np.unique(ul)) == ucnt, "a pass stages every input row once"
+            s = slots[t, k0:k1, :]
+            assert s.max(initial=0) <= ucnt
+            assert (s[:, rows:] == 0).all()
+            dec = np.where(s > 0, ul[np.maximum(s.astype(np.int64) - 1, 0)] if ucnt else -1, -1).astype(np.int32)
+            nbr[k0:k1, row0:row0 + rows] = dec[:, :rows]
+            lv = np.stack([(s[:, m * 32:(m + 1) * 32] > 0).any(1) for m in range(4)], 1)
+            lv_plan = (live[t, k0:k1, None] >> np.arange(4)[None]) & 1
+            assert (lv == lv_plan.astype(bool)).all(), "liveness bits"
+        assert k_next == K
+    assert used == cursor[0]
+    return nbr
+
+
+def _plan_roundtrip(nbr, P, ucap, tiles=None):
+    plan = me.build_tile_plan(nbr, P, tiles=tiles, ucap=ucap)
+    dec = decode_plan(plan)
+    return plan, dec
+
+
+@pytest.mark.parametrize("n,ks,stride,ucap", [(3000, 3, 1, 511), (3000, 3, 1, 128), (2500, 3, 2, 200), (900, 5, 1, 300), (130, 3, 1, 511),
+                                             (1, 3, 1, 511)])
+def test_oracle_plan_decodes_to_kernel_map(oracle, n, ks, stride, ucap):
+    with _lib.use_library(oracle):
+        km = _kernel_map(surface_coords(n, batch=2, extent=max(6, int(n ** 0.5) // 3), seed=n + ks), ks, stride)
+        P = int((km.nbr >= 0).sum())
+        plan, dec = _plan_roundtrip(km.nbr.contiguous(), P, ucap)
+        assert np.array_equal(dec, km.nbr.numpy())
+        if ucap == 128 and n >= 1000:
+            assert int(plan.npass.max()) > 1, "a 128-row LDS must force several passes on a 3^3 map"
+
+
+def test_oracle_plan_empty_map_and_grouped_tiles(oracle):
+    with _lib.use_library(oracle):
+        nbr = torch.full((27, 0), -1, dtype=torch.int32)
+        plan = me.build_tile_plan(nbr, 0)
+        assert plan.ntile == 0 and decode_plan(plan).shape == (27, 0)
+        km = _kernel_map(surface_coords(2000, batch=2, extent=14, seed=4))
+        n = km.n_out
+        bounds = (0, n // 3, n // 3 + 5, n)                     # three row groups, one of them tiny
+        tiles = km.tiles(bounds)
+        plan, dec = _plan_roundtrip(km.nbr.contiguous(), int((km.nbr >= 0).sum()), 511, tiles)
+        assert np.array_equal(dec, km.nbr.numpy())
+
+
+def _tile_conv(coords, x, w, bias, ks, stride, ucap, ksplit, transposed):
+    """conv through a plan; transposed: the data-gradient problem (dY rows -> dX rows, W^T)."""
+    km = _kernel_map(coords, ks, stride)
+    nbr = (km.nbrT if transposed else km.nbr).contiguous()
+    n_in = km.n_out if transposed else km.n_in
+    P = int((nbr >= 0).sum())
+    plan = me.build_tile_plan(nbr, P, ucap=ucap)
+    wt, wp = me._prep_frag(w, want_t=not transposed, want_p=transposed)
+    cin, cout = (w.shape[2], w.shape[1]) if transposed else (w.shape[1], w.shape[2])
+    x16 = me._to_bf16(x[:n_in].contiguous())
+    y = me._conv_tile(x16, wp if transposed else wt, plan, bias, cin, cout, n_in, P, ksplit)
+    # the same operator on the dense map (bf16 rows, classic weight layout)
+    wb = me._prep_bf16_both(w)[1 if transposed else 0]
+    yref = me._conv_implicit_bf16(x16, wb, nbr, bias, nbr.shape[1], cin, cout, P)
+    return y, yref
+
+
+@pytest.mark.parametrize("cin,cout,n,ks,stride", [(64, 64, 2500, 3, 1), (64, 128, 2000, 3, 2), (128, 128, 1500, 3, 1)])
+def test_oracle_plan_conv_equals_dense_map_conv(oracle, cin, cout, n, ks, stride):
+    """CPU: the oracle's plan-driven convolution reads neighbours only through the plan == its dense-map convolution."""
+    torch.manual_seed(cin + cout)
+    coords = surface_coords(n, batch=2, extent=max(8, int(n ** 0.5) // 3), seed=n)
+    x = torch.randn(coords.shape[0], cin)
+    w = torch.randn(ks ** 3, cin, cout) / (cin * 27) ** 0.5
+    with _lib.use_library(oracle):
+        for transposed in (False, True):
+            xx = torch.randn(coords.shape[0], cout) if transposed else x
+            y, yref = _tile_conv(coords, xx, w, None if transposed else torch.randn(cout), ks, stride, 200, 1, transposed)
+            torch.testing.assert_close(y, yref, rtol=RTOL, atol=ATOL * max(float(yref.abs().max()), 1.0))
+
+
+def test_fragment_order_is_a_permutation_of_the_classic_layout(oracle):
+    with _lib.use_library(oracle):
+        w = torch.randn(5, 64, 96)
+        wt, wp = me._prep_frag(w, True, False)
+        classic_t, classic_p = me._prep_bf16_both(w)
+        assert sorted(wt.view(5, -1)[2].tolist()) == sorted(classic_t.view(5, -1)[2].tolist())
+        # element (co, ci) sits at [co/32][ci/16][(ci/8 & 1)*32 + co%32][ci%8]
+        f = wt.view(5, 96 // 32, 64 // 16, 64, 8)
+        for co, ci in ((0, 0), (33, 17), (95, 63), (40, 8)):
+            assert f[3, co // 32, ci // 16, ((ci // 8) & 1) * 32 + co % 32, ci % 8] == classic_t[3, co, ci]
+        w2 = torch.randn(2, 64, 32)
+        _, wp2 = me._prep_frag(w2, False, True)
+        cp = me._prep_bf16_both(w2)[1]
+        g = wp2.view(2, 64 // 32, 32 // 16, 64, 8)
+        for ci, co in ((0, 0), (33, 17), (63, 31)):
+            assert g[1, ci // 32, co // 16, ((co // 8) & 1) * 32 + ci % 32, co % 8] == cp[1, ci, co]
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ks,stride,ucap", [(9000, 3, 1, 511), (9000, 3, 1, 128), (6000, 3, 2, 255), (1500, 5, 1, 300), (700, 9, 1, 511),
+                                             (130, 3, 1, 511), (1, 3, 1, 511)])
+def test_hip_plan_decodes_to_kernel_map(hip, n, ks, stride, ucap):
+    with _lib.use_library(hip):
+        km = _kernel_map(surface_coords(n, batch=2, extent=max(6, int(n ** 0.5) // 3), seed=n + ks).cuda(), ks, stride)
+        P = int((km.nbr >= 0).sum())
+        for nbr in (km.nbr, km.nbrT):
+            plan, dec = _plan_roundtrip(nbr.contiguous(), P, ucap)
+            assert np.array_equal(dec, nbr.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_hip_plan_grouped_tiles_and_empty(hip):
+    with _lib.use_library(hip):
+        plan = me.build_tile_plan(torch.full((27, 0), -1, dtype=torch.int32, device="cuda"), 0)
+        assert plan.ntile == 0
+        km = _kernel_map(surface_coords(5000, batch=2, extent=20, seed=4).cuda())
+        n = km.n_out
+        bounds = (0, n // 3, n // 3 + 5, n)
+        plan, dec = _plan_roundtrip(km.nbr.contiguous(), int((km.nbr >= 0).sum()), 511, km.tiles(bounds))
+        assert np.array_equal(dec, km.nbr.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,n,ks,stride,ucap,ksplit", [
+    (64, 64, 9000, 3, 1, 511, 1), (64, 128, 6000, 3, 2, 511, 1), (128, 128, 4000, 3, 1, 511, 1), (128, 128, 4000, 3, 1, 128, 1),
+    (256, 256, 1500, 3, 1, 511, 1), (256, 256, 1500, 3, 1, 511, 3), (128, 256, 3000, 3, 2, 300, 2), (512, 512, 600, 3, 1, 511, 4),
+    (64, 64, 700, 9, 1, 511, 1), (64, 128, 1500, 5, 1, 200, 1), (128, 64, 3000, 3, 1, 511, 1), (64, 64, 100, 3, 1, 511, 1),
+])
+def test_hip_tile_conv_matches_oracle(oracle, hip, cin, cout, n, ks, stride, ucap, ksplit):
+    """forward and data-gradient problem through the HIP plan + LDS-staged kernel == the oracle's dense-map bf16
+    emulation (and == the HIP dense-map kernel it replaces)."""
+    torch.manual_seed(cin * 7 + cout + ks)
+    coords = surface_coords(n, batch=2, extent=max(8, int(n ** 0.5) // 3), seed=n + ks)
+    w = torch.randn(ks ** 3, cin, cout) / (cin * min(ks, 3) ** 3) ** 0.5
+    for transposed in (False, True):
+        x = torch.randn(coords.shape[0], cout if transposed else cin)
+        bias = None if transposed else torch.randn(cout)
+        with _lib.use_library(oracle):
+            _, ref = _tile_conv(coords, x, w, bias, ks, stride, ucap, 1, transposed)
+        with _lib.use_library(hip):
+            y, ydense = _tile_conv(coords.cuda(), x.cuda(), w.cuda(), bias.cuda() if bias is not None else None, ks, stride, ucap,
+                                   ksplit, transposed)
+        scale = max(float(ref.abs().max()), 1.0)
+        torch.testing.assert_close(y.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
+        torch.testing.assert_close(ydense.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
+
+
+@pytest.mark.gpu
+def test_hip_tile_conv_grouped_rows_use_their_group_weights(oracle, hip):
+    torch.manual_seed(3)
+    coords = surface_coords(5000, batch=2, extent=20, seed=11)
+    cin = cout = 64
+    G = 3
+    w = torch.randn(G * 27, cin, cout) / (cin * 27) ** 0.5
+    x = torch.randn(coords.shape[0], cin)
+
+    def run(c, xx, ww):
+        km = _kernel_map(c)
+        n = km.n_out
+        bounds = (0, n // 3, n // 3 + 70, n)
+        tiles = km.tiles(bounds)
+        P = int((km.nbr >= 0).sum())
+        plan = me.build_tile_plan(km.nbr.contiguous(), P, tiles=tiles)
+        wt, _ = me._prep_frag(ww, True, False)
+        x16 = me._to_bf16(xx[:km.n_in].contiguous())
+        y = me._conv_tile(x16, wt, plan, None, cin, cout, km.n_in, P)
+        yref = me._conv_implicit_bf16(x16, me._prep_bf16_t(ww), km.nbr, None, km.n_out, cin, cout, P, tiles)
+        return y, yref
+    with _lib.use_library(oracle):
+        _, ref = run(coords, x, w)
+    with _lib.use_library(hip):
+        y, _ = run(coords.cuda(), x.cuda(), w.cuda())
+    torch.testing.assert_close(y.cpu(), ref, rtol=RTOL, atol=ATOL * max(float(ref.abs().max()), 1.0))

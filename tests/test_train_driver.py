@@ -35,6 +35,21 @@ def test_dataset_shards_like_distributed_sampler():
     assert annos[0]["gt_num"] == len(annos[0]["class"]) > 0 and annos[0]["gt_boxes_upright_depth"].shape[1] == 7
 
 
+def test_uneven_shards_are_padded_to_equal_shares():
+    """n_scenes % world != 0: every rank must see the same number of scenes, batches and last-batch size (ADVICE r1:
+    mismatched collectives at the end of the epoch otherwise) -- the deal torch's DistributedSampler makes."""
+    from torch.utils.data.distributed import DistributedSampler
+    for n, world, bs in ((10, 4, 2), (7, 2, 4), (13, 8, 4), (3, 4, 2)):
+        shares = [train.shard_ids(range(n), r, world) for r in range(world)]
+        assert len({len(s) for s in shares}) == 1 and set(sum(shares, [])) == set(range(n))
+        for r in range(world):
+            ref = list(DistributedSampler(list(range(n)), num_replicas=world, rank=r, shuffle=False))
+            assert shares[r] == ref, (n, world, r)
+        ds = [train.SyntheticIndoorDataset("S5k", n, bs, rank=r, world=world) for r in range(world)]
+        assert len({len(d) for d in ds}) == 1
+        assert len({tuple(len(d.scene_ids[i:i + bs]) for i in range(0, len(d.scene_ids), bs)) for d in ds}) == 1
+
+
 def test_train_checkpoint_resume_eval(oracle, tmp_path):
     ck = str(tmp_path / "ck.pth")
     with _lib.use_library(oracle):

@@ -11,6 +11,20 @@ batch = synthetic.make_batch("S50k", 4)
 pts = torch.from_numpy(batch["points"]).cuda()
 coords = pts[:, :4].clone()
 coords[:, 1:] /= 0.02
+if os.environ.get("SORT") == "morton":
+    c = coords.floor().long()
+
+    def spread(v):
+        v = v & 0x1FFFFF
+        v = (v | (v << 32)) & 0x1F00000000FFFF
+        v = (v | (v << 16)) & 0x1F0000FF0000FF
+        v = (v | (v << 8)) & 0x100F00F00F00F00F
+        v = (v | (v << 4)) & 0x10C30C30C30C30C3
+        v = (v | (v << 2)) & 0x1249249249249249
+        return v
+    key = (c[:, 0] << 58) | (spread(c[:, 1] + 2048) << 2) | (spread(c[:, 2] + 2048) << 1) | spread(c[:, 3] + 2048)
+    order = key.argsort()
+    coords, pts = coords[order].contiguous(), pts[order].contiguous()
 x = me.SparseTensor(coordinates=coords, features=pts[:, 4:] / 255.)
 mgr = x.coordinate_manager
 keys = {1: x.coordinate_map_key}
