@@ -241,6 +241,9 @@ def main():
         tf = prof["flops"] / secs / 1e12 if secs > 0 else 0.0
         gbs = prof["bytes"] / secs / 1e9 if secs > 0 else 0.0
         kname, ksym = {
+            "tile_bf16": ("k_spconv_tile (sparse conv fwd + dgrad on LDS-staged neighbour tiles: persistent workgroups, loader waves "
+                          "gather the tile's distinct rows into LDS, consumer waves run bf16 MFMA from LDS with fragment-ordered "
+                          "weights streamed from L2, one store per output row)", "k_spconv_tile"),
             "implicit_bf16": ("k_spconv_implicit_bf16_ad (sparse conv fwd + dgrad, output-stationary: neighbour rows -> "
                               "registers -> bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
             "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)",

@@ -43,3 +43,9 @@ __device__ static inline int32_t cg3d_lookup(const uint64_t *__restrict__ keys, 
         slot = (slot + 1) & capm1;
     }
 }
+
+// Element (n_idx = MFMA column, k_idx = contraction index) of a [N][kdim] bf16 operand stored in MFMA B-fragment order
+// (cg3d_spconv_prep_weights_frag): [n/32][k/16][lane = (k/8 & 1)*32 + n%32][k%8] -- a wave's fragment is one contiguous KB.
+__host__ __device__ static inline int64_t cg3d_frag_index(int n_idx, int k_idx, int kdim) {
+    return ((((int64_t)(n_idx >> 5) * (kdim >> 4) + (k_idx >> 4)) * 64) + ((k_idx >> 3) & 1) * 32 + (n_idx & 31)) * 8 + (k_idx & 7);
+}

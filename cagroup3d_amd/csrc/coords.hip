@@ -6,10 +6,11 @@
 // conv), dense_heads/cagroup_head.py:254-276, roi_heads/cagroup_roi_head.py:62-69).
 // All integer work: HBM/L2-latency bound random probes; kernels are one thread per probe with
 // coalesced coordinate reads and coalesced map writes (k-major maps: nbr[k][row]).
+#include <rocprim/device/device_radix_sort.hpp>
 #include "cg3d_common.h"
 
 extern "C" int cg3d_is_device_library(void) { return 1; }
-extern "C" int cg3d_abi_version(void) { return 1; }
+extern "C" int cg3d_abi_version(void) { return 2; }
 
 extern "C" int64_t cg3d_hash_capacity(int64_t n) {
     int64_t cap = 64;
@@ -165,14 +166,13 @@ extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qs
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (hipMemsetAsync(n_out, 0, sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(n_out, 0, 2 * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (n == 0) return CG3D_OK;
     int32_t *slot_of = (int32_t *)ws;
     int32_t *pos = slot_of + n;
     int64_t nb = cg3d_divup(n, SCAN_ELEMS);
     int32_t *bsum = pos + n;
-    int32_t *status = bsum + nb + 1;
-    (void)hipMemsetAsync(status, 0, sizeof(int32_t), s);
+    int32_t *status = n_out + 1;           // read back by the caller together with the row count
     unsigned g = (unsigned)cg3d_divup(n, 256);
     hipLaunchKernelGGL(k_insert, dim3(g), dim3(256), 0, s, coords, n, qstride, (unsigned long long *)keys, vals,
                        (uint64_t)(cap - 1), slot_of, status);
@@ -183,6 +183,61 @@ extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qs
     hipLaunchKernelGGL(k_compact, dim3(g), dim3(256), 0, s, coords, n, qstride, vals, slot_of, pos, out_coords,
                        unique_index, inverse);
     hipLaunchKernelGGL(k_retarget, dim3(g), dim3(256), 0, s, n, vals, slot_of, unique_index, n_out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------ Morton row order
+// order[i] = input row of the i-th row in (batch, Morton(x, y, z)) order -- the row order every map inserted by the host
+// engine is built in, so that 128 consecutive rows are a spatially compact patch (the tile plans of spconv_tile.hip stage
+// the distinct neighbour rows of such a patch in LDS: ~2 x 128 rows when the rows are Morton ordered, ~11 x 128 in the
+// random order points arrive in).  The strided maps derived from a Morton-ordered map inherit the order: the first
+// occurrence of floor(c / s) * s along a Morton-sorted sequence is Morton sorted again (bit interleaving nests).
+__device__ static inline uint64_t spread3(uint32_t v) {           // 15 bits -> every third bit
+    uint64_t x = v & 0x7fffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void k_morton_keys(const int32_t *__restrict__ coords, int64_t n, unsigned long long *__restrict__ keys,
+                              int32_t *__restrict__ vals) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const uint32_t ux = (uint32_t)(c.y + CG3D_COORD_LIMIT), uy = (uint32_t)(c.z + CG3D_COORD_LIMIT), uz = (uint32_t)(c.w + CG3D_COORD_LIMIT);
+    unsigned long long key = ~0ull;                                // out of range: last (cg3d_coord_map_build reports it)
+    if ((uint32_t)c.x < (uint32_t)CG3D_BATCH_LIMIT && (ux | uy | uz) < (uint32_t)(2 * CG3D_COORD_LIMIT))
+        key = ((unsigned long long)c.x << 45) | (spread3(ux) << 2) | (spread3(uy) << 1) | spread3(uz);
+    keys[i] = key;
+    vals[i] = (int32_t)i;
+}
+static size_t morton_sort_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                  (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 64, (hipStream_t)0) != hipSuccess)
+        bytes = (size_t)n * 32 + (1 << 20);
+    return (bytes + 255) & ~(size_t)255;
+}
+extern "C" int64_t cg3d_morton_order_ws_bytes(int64_t n) {
+    const int64_t n8 = (n * 8 + 255) & ~255ll, n4 = (n * 4 + 255) & ~255ll;
+    return 2 * n8 + n4 + (int64_t)morton_sort_temp_bytes(n > 0 ? n : 1);
+}
+extern "C" int cg3d_morton_order(const int32_t *coords, int64_t n, int32_t *order, void *ws, cg3d_stream_t stream) {
+    if (n < 0 || n >= (1ll << 31) || ((uintptr_t)coords & 15)) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipStream_t s = cg3d_hs(stream);
+    char *w = (char *)ws;
+    const int64_t n8 = (n * 8 + 255) & ~255ll, n4 = (n * 4 + 255) & ~255ll;
+    unsigned long long *keys = (unsigned long long *)w, *keys_s = (unsigned long long *)(w + n8);
+    int32_t *vals = (int32_t *)(w + 2 * n8);
+    void *temp = w + 2 * n8 + n4;
+    size_t temp_bytes = morton_sort_temp_bytes(n);
+    hipLaunchKernelGGL(k_morton_keys, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, s, coords, n, keys, vals);
+    // radix sort is stable: rows of one voxel keep their input order, the representative stays the first occurrence
+    if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, order, (size_t)n, 0, 64, s) != hipSuccess) return CG3D_ERR_LAUNCH;
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

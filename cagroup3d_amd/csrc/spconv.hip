@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__res
     const float *src = reinterpret_cast<const float *>(row[0]);
     uint16_t *Wb_t = reinterpret_cast<uint16_t *>(row[1]);
     uint16_t *Wb = reinterpret_cast<uint16_t *>(row[2]);
-    const int cin = (int)row[3], cout = (int)row[4], tile = (int)row[5];
+    const int cin = (int)row[3], cout = (int)row[4], tile = (int)(row[5] & 0xfffffff);
+    const bool frag_t = (row[5] >> 30) & 1, frag_p = (row[5] >> 29) & 1;       // copies in MFMA fragment order (cg3d_spconv_tile_fwd)
     const int co_tiles = (cout + 63) / 64;
     const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
     for (int i = threadIdx.x; i < 4096; i += 256) {
@@ -450,13 +451,14 @@ __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__res
         const bool ok = ci0 + r < cin && co0 + c < cout;
         const uint16_t b = ok ? (uint16_t)f2bf(src[(int64_t)(ci0 + r) * cout + co0 + c]) : (uint16_t)0;
         T[r][c] = b;
-        if (Wb && ok) Wb[(int64_t)(ci0 + r) * cout + co0 + c] = b;
+        if (Wb && ok) Wb[frag_p ? cg3d_frag_index(ci0 + r, co0 + c, cout) : (int64_t)(ci0 + r) * cout + co0 + c] = b;
     }
     __syncthreads();
     if (!Wb_t) return;
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int r = i >> 6, c = i & 63;                       // r: output channel, c: input channel
-        if (co0 + r < cout && ci0 + c < cin) Wb_t[(int64_t)(co0 + r) * cin + ci0 + c] = T[c][r];
+        if (co0 + r < cout && ci0 + c < cin)
+            Wb_t[frag_t ? cg3d_frag_index(co0 + r, ci0 + c, cin) : (int64_t)(co0 + r) * cin + ci0 + c] = T[c][r];
     }
 }
 extern "C" int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream) {

@@ -23,6 +23,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "cg3d_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -160,10 +161,6 @@ __device__ static inline uint32_t tf2bf(float f) {        // round-to-nearest-ev
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ static inline int64_t frag_index(int n_idx, int k_idx, int kdim) {
-    // element (n_idx = MFMA column, k_idx = contraction index) of a [N][kdim] operand
-    return ((((int64_t)(n_idx >> 5) * (kdim >> 4) + (k_idx >> 4)) * 64) + ((k_idx >> 3) & 1) * 32 + (n_idx & 31)) * 8 + (k_idx & 7);
-}
 __global__ __launch_bounds__(256) void k_prep_weights_frag(const float *__restrict__ W0, const float *const *__restrict__ Ws,
                                                            uint16_t *__restrict__ Wf_t, uint16_t *__restrict__ Wf,
                                                            int64_t slots_per, int32_t cin, int32_t cout) {
@@ -173,8 +170,8 @@ __global__ __launch_bounds__(256) void k_prep_weights_frag(const float *__restri
     for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.y * 256) {
         const int ci = (int)(i / cout), co = (int)(i % cout);
         const uint16_t b = (uint16_t)tf2bf(src[i]);
-        if (Wf_t) Wf_t[slot * per + frag_index(co, ci, cin)] = b;
-        if (Wf) Wf[slot * per + frag_index(ci, co, cout)] = b;
+        if (Wf_t) Wf_t[slot * per + cg3d_frag_index(co, ci, cin)] = b;
+        if (Wf) Wf[slot * per + cg3d_frag_index(ci, co, cout)] = b;
     }
 }
 extern "C" int cg3d_spconv_prep_weights_frag(const float *W0, const float *const *Ws, uint16_t *Wf_t, uint16_t *Wf,
@@ -194,241 +191,451 @@ extern "C" int cg3d_spconv_prep_weights_frag(const float *W0, const float *const
 }
 
 // ------------------------------------------------------------------------------------------------ convolution
-// Workgroup = 4 waves on one tile of 128 output rows x (NCO x 64) output channels.  Wave (g, h): h = its 64-channel
-// output block, g = its share of the tile's live offsets (KG = 4 / NCO offset groups; the groups' partial sums meet
-// through LDS at the end).  A wave's register tile is 128 rows x 64 channels = 4 x 2 MFMA blocks (128 accumulator
-// registers): every A fragment read from LDS feeds 2 MFMAs and every weight fragment streamed from L2 feeds 4 -- the
-// 128 x 32 tile of the first version read one A fragment per MFMA and ran into the LDS pipe (16 waves' indexed
-// ds_read_b128, x1.8 bank conflicts) at a quarter of the matrix peak.
+// Persistent workgroup, one per CU: 4 consumer waves + 1 loader wave, two LDS stage buffers.
 //
-// LDS (dynamic): A tile (ucap + 1) x 128 B = the pass's distinct input rows, 64 channels at a time (row 0 = zeros;
-// 16-byte granule g of row s sits at g ^ ((s >> 1) & 7): 16 lanes reading the same channel granule of 16 consecutive
-// slots hit 16 different bank groups); slot table of the resident offsets [TP_KB][32][4] uint16 (lane r reads the slots
-// of rows r, 32+r, 64+r, 96+r as ONE 8-byte word); list of live offsets.  The A tile doubles as the exchange buffer of
-// the final reduction over offset groups.
+// A STAGE is (unit, pass, slot-table block of <= TP_KB offsets, 64-channel chunk); a unit is (tile of 128 output rows,
+// 128-channel output block, offset share z).  The loader wave walks the stages of the workgroup's units (u = blockIdx.x,
+// + gridDim.x, ...) one stage AHEAD of the consumers: it gathers the stage's distinct input rows from HBM into the
+// other LDS buffer (coalesced 16-byte loads, 32 in flight per lane), re-lays the slot table, compacts the live offsets
+// with a ballot and leaves a descriptor; one barrier per stage hands the buffer over.  Row gathers (HBM latency) and
+// weight fragments (L2 latency) therefore sit in DIFFERENT waves' memory queues -- in one wave the in-order vmcnt made
+// every weight fragment wait behind the outstanding row loads.
 //
-// Software pipeline of one wave, unit = (offset, 16 channels) = 4 A fragments x 2 weight fragments -> 8 MFMAs on 8
-// different accumulators: while a unit is on the matrix pipe the 4 A fragments of the next unit are on their way from
-// LDS (two fragment sets) and each weight fragment is re-requested for the NEXT offset right after its last use, i.e.
-// 3-4 units (~1000 cycles) ahead.
+// Consumer wave (g, h): h = its 64-channel output block, g = its share of the stage's live offsets (KG = 4 / NCO offset
+// groups).  Register tile 128 rows x 64 channels = 4 x 2 MFMA blocks (128 accumulators): every A fragment read from
+// LDS feeds 2 MFMAs, every weight fragment streamed from L2 feeds 4 (the 128 x 32 tile of the first version read one A
+// fragment per MFMA and ran into the LDS pipe at a quarter of the matrix peak).  Unit of the software
+// pipeline = (offset, 16 channels) = 4 A fragments x 2 weight fragments -> 8 MFMAs on 8 different accumulators: while
+// it is on the matrix pipe the A fragments of the next unit are on their way from LDS and each weight fragment is
+// re-requested for the NEXT offset right after its last use (3-4 units ahead).  At the end of a unit the offset groups
+// exchange halves of their partial sums through the LDS buffer just consumed (pairwise flags, no workgroup barrier:
+// the loader keeps filling the other buffer) and every output row is stored once.
+//
+// Stage buffer: A tile (ucap + 1) x 128 B (row 0 = zeros; 16-byte granule g of row s sits at g ^ ((s >> 1) & 7): 16 lanes
+// reading the same channel granule of 16 consecutive slots hit 16 different bank groups), >= 64 KB (it doubles as the
+// exchange buffer); slot table [TP_KB][32][4] uint16 (lane r reads the slots of rows r, 32+r, 64+r, 96+r as ONE 8-byte
+// word); list of live offsets; descriptor.
+__device__ unsigned long long g_tile_steps[8 * 16];     // dev aid (DBG & 256): time stamp of every step of the first 8 stages, workgroup 0 wave 0
+__device__ unsigned long long g_tile_dbg[8];        // dev aid (DBG & 128): cycles per consumer phase, summed over workgroups
+extern "C" int cg3d_tile_debug_steps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_steps), sizeof(g_tile_steps)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+extern "C" int cg3d_tile_debug_read(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_dbg), sizeof(g_tile_dbg)) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_dbg), z, sizeof(z)) != hipSuccess) return CG3D_ERR_LAUNCH; }
+    return CG3D_OK;
+}
+struct StageDesc {
+    int32_t valid, first, last, kb, c, rows, yb, zi;
+    int64_t row0, wslot0;
+};
+#define TP_NLV 16            // row granules a loader thread stages per chunk: 4 loader waves x 64 lanes x 16 = 4096 = 512 rows x 8
+
 template <int NCO, int DBG>
-__global__ __launch_bounds__(256, 2) void k_spconv_tile(
+__global__ __launch_bounds__(512, 2) void k_spconv_tile(
     const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf, const uint16_t *__restrict__ slots,
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
     const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,
-    const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t maxk_dbg) {
+    const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+    int32_t nunit, int32_t ny, int32_t gz, int32_t maxk_dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
-    constexpr int NTHR = 256;
     const int a_bytes = (ucap + 1) * 128 > 65536 ? (ucap + 1) * 128 : 65536;
-    uint8_t *As = smem;
-    uint16_t *slot_s = reinterpret_cast<uint16_t *>(smem + a_bytes);
-    uint16_t *klist = slot_s + TP_KB * TP_TM;          // [TP_KB] (kk | live << 8), then nlive
+    const int buf_bytes = a_bytes + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12 + (int)sizeof(StageDesc);      // multiple of 16
+    volatile int32_t *xflag = reinterpret_cast<volatile int32_t *>(smem + 2 * buf_bytes);                    // [2][4] data / ack flags
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, kg = lane >> 5;
-    const int g = wave / NCO, h = wave % NCO;
-    const int64_t tile = blockIdx.x;
-    int64_t row0 = tile * TP_TM;
-    int rows = (int)(n_out - row0 < TP_TM ? n_out - row0 : TP_TM);
-    int64_t wslot0 = 0;                                 // first weight slot of this tile's group
-    if (tiles) { wslot0 = (int64_t)tiles[tile * 3] * K; row0 = tiles[tile * 3 + 1]; rows = tiles[tile * 3 + 2]; }
-    const int nt0 = (blockIdx.y * NCO + h) * 2;         // this wave's first 32-channel output block
     const int nt_total = cout >> 5, ks_total = cin >> 4, nchunk = cin >> 6;
-    const int gz = gridDim.z, zi = blockIdx.z;
-    const int first = zi * KG + g, stride = gz * KG;    // this wave's share of the live offsets
+    const int G = gridDim.x;
+    if (tid < 20) const_cast<int32_t *>(xflag)[tid] = 0;
+    __syncthreads();
 
-    f32x16 acc[4][2];
+    if (wave >= 4) {
+        // =========================================================================================== loader waves
+        // Software pipeline of the loaders: the pass descriptor (npass / pass_tab) is requested one PASS ahead, the row
+        // indices (ulist) one STAGE ahead of the pass that needs them, so a stage costs one memory latency (its row
+        // gathers, all in flight at once: 16 granules per thread) plus the LDS writes -- not a chain of three.
+        const int lw = wave - 4, lt = lw * 64 + lane;     // 256 loader threads
+        struct PassRec { int valid, np, k0, k1, uoff, ucnt; };
+        auto load_pass = [&](int u, int p) -> PassRec {
+            PassRec P = {0, 0, 0, 0, 0, 0};
+            if (u < nunit) {
+                const int64_t t = u / (ny * gz);
+                const int32_t *pt = pass_tab + (t * maxpass + p) * 4;
+                P.valid = 1; P.np = npass[t]; P.k0 = pt[0]; P.k1 = pt[1]; P.uoff = pt[2]; P.ucnt = pt[3];
+            }
+            return P;
+        };
+        int32_t idx[TP_NLV], idx_next[TP_NLV];
+        auto issue_idx = [&](int32_t (&dst)[TP_NLV], int uoff, int ucnt) {
+            const int ngran = ucnt * 8;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+            for (int j = 0; j < TP_NLV; j++) {
+                const int i = j * 256 + lt;
+                if (j * 256 < ngran) dst[j] = ulist[uoff + ((i < ngran ? i : ngran - 1) >> 3)];       // uniform guard
+            }
+        };
+        // the output tile a unit's last stage left in its buffer (row-major per consumer wave) -> global memory
+        StageDesc hist[2];
+        hist[0].valid = hist[1].valid = 0; hist[0].last = hist[1].last = 0;
+        auto drain = [&](int bufi) {
+            const StageDesc &H = hist[bufi];
+            if (!H.valid || !H.last || (DBG & 32)) return;
+            constexpr int rows_per = TP_TM / KG;
+            const int cw = lw, cg_ = cw / NCO, ch = cw % NCO;            // loader wave lw drains consumer wave lw
+            const float *tb = reinterpret_cast<const float *>(smem + bufi * buf_bytes) + (size_t)cw * 4096;
+            const int c4 = (lane & 15) * 4, rq = lane >> 4;
+            const int col0 = (H.yb * NCO + ch) * 64 + c4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias && H.zi == 0) bv = *reinterpret_cast<const float4 *>(bias + col0);
+            float *ybase = Y + (H.row0 + cg_ * rows_per + rq) * (int64_t)cout + col0;
 #pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
-    if (tid < 8) reinterpret_cast<uint4 *>(As)[tid] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
-
-    const int np = npass[tile];
-    const uint16_t *slots_t = slots + tile * (int64_t)K * TP_TM;
-    const uint8_t *live_t = live + tile * (int64_t)K;
-    const uint32_t cg[4] = {(uint32_t)kg, 2u + kg, 4u + kg, 6u + kg};        // channel granule of (ks, this lane's half)
-    for (int p = 0; p < np; p++) {
-        const int32_t *pt = pass_tab + (tile * (int64_t)maxpass + p) * 4;
-        const int k0 = pt[0], k1 = pt[1], uoff = pt[2], ucnt = pt[3];
-        for (int kb = k0; kb < k1; kb += TP_KB) {
-            const int nk = k1 - kb < TP_KB ? k1 - kb : TP_KB;
-            for (int c = 0; c < nchunk; c++) {
-                __syncthreads();                        // every wave is done with the previous A tile / slot table
-                // ---- stage the distinct rows of the pass, channels [64c, 64c+64): 8 granules of 16 B per row
-                if (!(DBG & 8) && (nchunk > 1 || kb == k0)) {
-                    const int ngran = ucnt * 8;
-                    for (int i0 = 0; i0 < ngran; i0 += NTHR * 4) {
-                        uint4 v[4];
-                        int sl[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int i = i0 + j * NTHR + tid;
-                            const int ic = i < ngran ? i : ngran - 1;
-                            const int32_t grow = ulist[uoff + (ic >> 3)];
-                            v[j] = *reinterpret_cast<const uint4 *>(X + ((int64_t)grow * cin + c * 64 + (ic & 7) * 8));
-                            sl[j] = i < ngran ? i : -1;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (sl[j] < 0) continue;
-                            const int s = (sl[j] >> 3) + 1, gr = sl[j] & 7;
-                            *reinterpret_cast<uint4 *>(As + s * 128 + ((gr ^ ((s >> 1) & 7)) << 4)) = v[j];
-                        }
-                    }
+            for (int i = 0; i < rows_per / 4; i++) {
+                float4 v = *reinterpret_cast<const float4 *>(tb + (i * 4 + rq) * 64 + c4);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (cg_ * rows_per + i * 4 + rq < H.rows) {
+                    float *dst = ybase + (int64_t)i * 4 * cout;
+                    if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
+                    else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 }
-                if (c == 0) {
-                    // ---- slot table of offsets [kb, kb+nk): global [k][row] -> LDS [kk][r][m]
-                    for (int i = tid; i < nk * (TP_TM / 8); i += NTHR) {           // 8 slots (16 B) per thread
-                        const int kk = i >> 4, row8 = (i & 15) * 8;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(slots_t + (int64_t)(kb + kk) * TP_TM + row8);
-                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            }
+            hist[bufi].valid = 0;
+        };
+        int sidx = 0;
+        PassRec cur = load_pass(blockIdx.x, 0);
+        if (cur.valid) issue_idx(idx, cur.uoff, cur.ucnt);
+        int u = blockIdx.x, p = 0;
+        while (cur.valid) {
+            const int64_t tile = u / (ny * gz);
+            const bool last_pass = p == cur.np - 1;
+            const int un = last_pass ? u + G : u, pn = last_pass ? 0 : p + 1;
+            const PassRec nxt = load_pass(un, pn);       // requested now, needed at this pass's last stage
+            StageDesc D;
+            D.valid = 1;
+            D.yb = (u / gz) % ny;
+            D.zi = u % gz;
+            D.row0 = tile * TP_TM;
+            D.rows = (int)(n_out - D.row0 < TP_TM ? n_out - D.row0 : TP_TM);
+            D.wslot0 = 0;
+            if (tiles) { D.wslot0 = (int64_t)tiles[tile * 3] * K; D.row0 = tiles[tile * 3 + 1]; D.rows = tiles[tile * 3 + 2]; }
+            const int ngran = cur.ucnt * 8;
+            for (int kb = cur.k0; kb < cur.k1 || kb == cur.k0; kb += TP_KB) {      // (an empty pass still is one stage)
+                const int nk = cur.k1 - kb < TP_KB ? (cur.k1 - kb > 0 ? cur.k1 - kb : 0) : TP_KB;
+                for (int c = 0; c < nchunk; c++) {
+                    const bool last_stage = kb + TP_KB >= cur.k1 && c == nchunk - 1;
+                    D.first = (p == 0 && kb == cur.k0 && c == 0) ? 1 : 0;
+                    D.last = (last_pass && last_stage) ? 1 : 0;
+                    D.kb = kb;
+                    D.c = c;
+                    uint8_t *As = smem + (sidx & 1) * buf_bytes;
+                    uint16_t *slot_s = reinterpret_cast<uint16_t *>(As + a_bytes);
+                    uint16_t *klist = slot_s + TP_KB * TP_TM;
+                    drain(sidx & 1);                    // the output tile stage sidx - 2 left in this buffer
+                    hist[sidx & 1] = D;
+                    // ---- requests: slot table (wave 4), the stage's rows, the next pass's row indices
+                    uint4 sv[8];
+                    int lv = 0;
+                    if (lw == 0 && c == 0 && !((DBG & 64) && sidx > 1)) {
+                        const uint16_t *slots_t = slots + (tile * K + kb) * (int64_t)TP_TM;
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const int row = row8 + j;
-                            slot_s[kk * TP_TM + (row & 31) * 4 + (row >> 5)] = (uint16_t)(w4[j >> 1] >> ((j & 1) * 16));
+                            const int i = j * 64 + lane;
+                            if (i < nk * (TP_TM / 8)) sv[j] = *reinterpret_cast<const uint4 *>(slots_t + (int64_t)(i >> 4) * TP_TM + (i & 15) * 8);
+                        }
+                        lv = lane < nk ? live[tile * (int64_t)K + kb + lane] : 0;
+                    }
+                    uint4 v[TP_NLV];
+                    if (!(DBG & 8)) {
+#pragma unroll
+                        for (int j = 0; j < TP_NLV; j++) {
+                            const int i = j * 256 + lt;
+                            if (j * 256 < ngran)
+                                v[j] = *reinterpret_cast<const uint4 *>(X + ((int64_t)idx[j] * cin + c * 64 + ((i < ngran ? i : ngran - 1) & 7) * 8));
                         }
                     }
-                    if (wave == 0) {                    // live offsets of this block, compacted with one ballot
-                        const int lv = lane < nk ? live_t[kb + lane] : 0;
+                    if (last_stage && nxt.valid) issue_idx(idx_next, nxt.uoff, nxt.ucnt);
+                    // ---- LDS: descriptor, zero row, slot table / list of live offsets, rows
+                    if (lt == 0) *reinterpret_cast<StageDesc *>(As + buf_bytes - sizeof(StageDesc)) = D;
+                    if (lt < 8) reinterpret_cast<uint4 *>(As)[lt] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
+                    if (lw == 0 && c == 0 && !((DBG & 64) && sidx > 1)) {
+                        // slot table of offsets [kb, kb+nk): global [k][row] -> LDS [kk][r][m]; live offsets compacted with one ballot
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int i = j * 64 + lane;
+                            if (i < nk * (TP_TM / 8)) {
+                                const int kk = i >> 4, row8 = (i & 15) * 8;
+                                const uint32_t w4[4] = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    const int row = row8 + q;
+                                    slot_s[kk * TP_TM + (row & 31) * 4 + (row >> 5)] = (uint16_t)(w4[q >> 1] >> ((q & 1) * 16));
+                                }
+                            }
+                        }
                         const uint64_t bal = __ballot(lv != 0);
                         if (lv) klist[__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(lane | (lv << 8));
                         if (lane == 0) klist[TP_KB] = (uint16_t)__popcll(bal);
+                    } else if (lw == 1 && (c > 0 || ((DBG & 64) && sidx > 1))) {
+                        // same block of offsets as the previous stage (the other buffer): copy its slot table and list
+                        const uint4 *src = reinterpret_cast<const uint4 *>(smem + ((sidx + 1) & 1) * buf_bytes + a_bytes);
+                        uint4 *dst = reinterpret_cast<uint4 *>(As + a_bytes);
+                        for (int i = lane; i < (TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12) / 16; i += 64) dst[i] = src[i];
                     }
-                }
-                __syncthreads();
-                int nlive = klist[TP_KB];
-                if (DBG & 16) nlive = nlive < maxk_dbg ? nlive : maxk_dbg;       // dev aid: time per step = slope over the step count
-                if (first >= nlive) continue;
-                // weight fragments of (offset kk, 16-channel group ks, output block n): Wf[slot][nt][ks][lane][8]
-                const uint16_t *wbase = Wf + ((wslot0 + kb) * nt_total + nt0) * (int64_t)ks_total * 512 + (int64_t)c * 4 * 512 + lane * 8;
-                const int64_t wstride = (int64_t)nt_total * ks_total * 512;       // per offset
-                const int64_t wn = (int64_t)ks_total * 512;                        // per 32-channel output block
-                struct Rows { uint32_t base[4], sw[4]; };                          // LDS row address / swizzle of the 4 row blocks
-                auto rows_of = [&](int kk) -> Rows {
-                    const uint2 sv = *reinterpret_cast<const uint2 *>(slot_s + kk * TP_TM + r * 4);
-                    uint32_t s4[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
-                    if (DBG & 2) { s4[0] = 1 + r; s4[1] = 33 + r; s4[2] = 65 + r; s4[3] = 97 + r; }      // conflict-free reads
-                    Rows R;
+                    if (!(DBG & 8)) {
 #pragma unroll
-                    for (int m = 0; m < 4; m++) { R.base[m] = s4[m] * 128u; R.sw[m] = (s4[m] >> 1) & 7u; }
-                    return R;
-                };
-                auto read_a = [&](bf16x8 (&a)[4], const Rows &R, int ks) {
-#pragma unroll
-                    for (int m = 0; m < 4; m++)
-                        a[m] = *reinterpret_cast<const bf16x8 *>(As + R.base[m] + ((cg[ks] ^ R.sw[m]) << 4));
-                };
-                auto load_b = [&](uint4 (&b)[2], int kk, int ks) {
-                    const uint16_t *wk = wbase + kk * wstride + ks * 512;
-                    b[0] = *reinterpret_cast<const uint4 *>(wk);
-                    b[1] = *reinterpret_cast<const uint4 *>(wk + wn);
-                };
-                auto mma = [&](const bf16x8 (&a)[4], const uint4 (&b)[2]) {
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        if (DBG & 4) { acc[m][0][0] += (float)a[m][0] * (float)b0[0]; acc[m][1][0] += (float)a[m][0] * (float)b1[0]; }
-                        else {
-                            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b0, acc[m][0], 0, 0, 0);
-                            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b1, acc[m][1], 0, 0, 0);
+                        for (int j = 0; j < TP_NLV; j++) {
+                            const int i = j * 256 + lt;
+                            if (i < ngran) {
+                                const int sl = (i >> 3) + 1, gr = i & 7;
+                                *reinterpret_cast<uint4 *>(As + sl * 128 + ((gr ^ ((sl >> 1) & 7)) << 4)) = v[j];
+                            }
                         }
                     }
-                };
-                const int nstep = (nlive - first + stride - 1) / stride;          // offsets of this wave in this block
-                auto kk_of = [&](int st) -> int { return klist[first + (st < nstep ? st : nstep - 1) * stride] & 0xff; };
-                uint4 b[4][2];
-                bf16x8 aA[4], aB[4];
-                int kcur = kk_of(0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) load_b(b[ks], kcur, ks);
-                Rows R = rows_of(kcur);
-                read_a(aA, R, 0);
-                for (int st = 0; st < nstep; st++) {
-                    const int knext = kk_of(st + 1);                              // past the end: this offset again, unused
-                    // unit 0
-                    read_a(aB, R, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(aA, b[0]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(DBG & 1)) load_b(b[0], knext, 0);
-                    // unit 1
-                    read_a(aA, R, 2);
-                    const Rows Rn = rows_of(knext);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(aB, b[1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(DBG & 1)) load_b(b[1], knext, 1);
-                    // unit 2
-                    read_a(aB, R, 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(aA, b[2]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(DBG & 1)) load_b(b[2], knext, 2);
-                    // unit 3
-                    read_a(aA, Rn, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(aB, b[3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(DBG & 1)) load_b(b[3], knext, 3);
-                    R = Rn;
+                    __syncthreads();                    // hand the buffer over; the consumers start on it
+                    sidx++;
                 }
             }
-        }
-    }
-    // ---- reduction over the offset groups of the workgroup (binary tree through LDS; the A tile is free now)
-    float4 *xch = reinterpret_cast<float4 *>(smem);
+            cur = nxt;
 #pragma unroll
-    for (int sd = 1; sd < KG; sd *= 2) {
+            for (int j = 0; j < TP_NLV; j++) idx[j] = idx_next[j];
+            u = un;
+            p = pn;
+        }
+        // end marker
+        drain(sidx & 1);
+        if (lt == 0) {
+            StageDesc E;
+            E.valid = 0; E.first = E.last = 0; E.kb = E.c = E.rows = E.yb = E.zi = 0; E.row0 = E.wslot0 = 0;
+            *reinterpret_cast<StageDesc *>(smem + (sidx & 1) * buf_bytes + buf_bytes - sizeof(StageDesc)) = E;
+        }
         __syncthreads();
-        if ((g % (2 * sd)) == sd) {
-            float4 *dst = xch + ((size_t)((g / (2 * sd)) * NCO + h) * 32) * 64 + lane;
+        drain((sidx + 1) & 1);                          // the last unit's tile
+        return;
+    }
+
+    // =============================================================================================== consumer waves
+    const int r = lane & 31, kg = lane >> 5;
+    const int g = wave / NCO, h = wave % NCO;
+    const uint32_t cg[4] = {(uint32_t)kg, 2u + kg, 4u + kg, 6u + kg};        // channel granule of (ks, this lane's half)
+    f32x16 acc[4][2];
+    int seq = 0;                                        // units finished by this workgroup (exchange flag values)
+    unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG & 128) ? __builtin_readcyclecounter() : 0;
+    auto stamp = [&](int ph) {
+        if (DBG & 128) { const unsigned long long t = __builtin_readcyclecounter(); tph[ph] += t - tprev; tprev = t; }
+    };
+    for (int sidx = 0;; sidx++) {
+        __syncthreads();                                // the loader has filled buffer sidx & 1
+        stamp(0);
+        uint8_t *As = smem + (sidx & 1) * buf_bytes;
+        const uint16_t *slot_s = reinterpret_cast<const uint16_t *>(As + a_bytes);
+        const uint16_t *klist = slot_s + TP_KB * TP_TM;
+        const StageDesc D = *reinterpret_cast<const StageDesc *>(As + buf_bytes - sizeof(StageDesc));
+        if (!D.valid) break;
+        stamp(1);
+        if (D.first) {
 #pragma unroll
             for (int m = 0; m < 4; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[m][n][e] = 0.f;
+        }
+        const int nt0 = (D.yb * NCO + h) * 2;           // this wave's first 32-channel output block
+        const int first = D.zi * KG + g, stride = gz * KG;   // this wave's share of the live offsets
+        int nlive = klist[TP_KB];
+        if (DBG & 16) nlive = nlive < maxk_dbg ? nlive : maxk_dbg;           // dev aid: time per step = slope over the step count
+        const int nstep = first < nlive ? (nlive - first + stride - 1) / stride : 0;     // offsets of this wave
+        if (nstep > 0) {
+            // weight fragments of (offset kk, 16-channel group ks, output block n): Wf[slot][nt][ks][lane][8]
+            const uint16_t *wbase = Wf + ((D.wslot0 + D.kb) * nt_total + nt0) * (int64_t)ks_total * 512 + (int64_t)D.c * 4 * 512 + lane * 8;
+            const int64_t wstride = (int64_t)nt_total * ks_total * 512;       // per offset
+            const int64_t wn = (int64_t)ks_total * 512;                        // per 32-channel output block
+            struct Rows { uint32_t base[4], sw[4]; };                          // LDS row address / swizzle of the 4 row blocks
+            auto rows_of = [&](int kk) -> Rows {
+                const uint2 sv = *reinterpret_cast<const uint2 *>(slot_s + kk * TP_TM + r * 4);
+                uint32_t s4[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
+                if (DBG & 2) { s4[0] = 1 + r; s4[1] = 33 + r; s4[2] = 65 + r; s4[3] = 97 + r; }      // conflict-free reads
+                Rows R;
+#pragma unroll
+                for (int m = 0; m < 4; m++) { R.base[m] = s4[m] * 128u; R.sw[m] = (s4[m] >> 1) & 7u; }
+                return R;
+            };
+            auto read_a = [&](bf16x8 (&a)[4], const Rows &R, int ks) {
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    a[m] = *reinterpret_cast<const bf16x8 *>(As + R.base[m] + ((cg[ks] ^ R.sw[m]) << 4));
+            };
+            auto load_b = [&](uint4 (&b)[2], int kk, int ks) {
+                const uint16_t *wk = wbase + kk * wstride + ks * 512;
+                b[0] = *reinterpret_cast<const uint4 *>(wk);
+                b[1] = *reinterpret_cast<const uint4 *>(wk + wn);
+            };
+            auto mma = [&](const bf16x8 (&a)[4], const uint4 (&b)[2]) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    if (DBG & 4) { acc[m][0][0] += (float)a[m][0] * (float)b0[0]; acc[m][1][0] += (float)a[m][0] * (float)b1[0]; }
+                    else {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b0, acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b1, acc[m][1], 0, 0, 0);
+                    }
+                }
+            };
+            auto kk_of = [&](int st) -> int { return klist[first + (st < nstep ? st : nstep - 1) * stride] & 0xff; };
+            uint4 b[4][2];
+            bf16x8 aA[4], aB[4];
+            const int kcur = kk_of(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) load_b(b[ks], kcur, ks);
+            Rows R = rows_of(kcur);
+            read_a(aA, R, 0);
+            if (DBG & 128) { __builtin_amdgcn_s_waitcnt(0); stamp(6); }      // prologue: first weights / slots / A fragments have arrived
+            // One scheduling region per unit: its 8 MFMAs, the 4 LDS reads of the NEXT unit's A fragments and the 2
+            // weight-fragment loads of the next offset, interleaved by rule (one wave per SIMD computes: whatever is not
+            // issued between two MFMAs of the block is not overlapped with the matrix pipe).  Three fragment sets (requests
+            // two units ahead) were tried: 13-20 spilled registers and no faster (111 vs 98 us on the 128 -> 128 layer).
+#define TILE_UNIT_SCHED()                                                                       \
+    do {                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* MFMA */                      \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  /* VALU (address) */            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  /* DS read */                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);  /* VALU / SALU */               \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* VMEM read */                 \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+            for (int st = 0; st < nstep; st++) {
+                if ((DBG & 256) && blockIdx.x == 0 && tid == 0 && sidx < 8 && st < 15) g_tile_steps[sidx * 16 + st] = __builtin_readcyclecounter();
+                const int knext = kk_of(st + 1);                              // past the end: this offset again, unused
+                // unit 0
+                read_a(aB, R, 1);
+                mma(aA, b[0]);
+                if (!(DBG & 1)) load_b(b[0], knext, 0);
+                TILE_UNIT_SCHED();
+                // unit 1
+                read_a(aA, R, 2);
+                const Rows Rn = rows_of(knext);
+                mma(aB, b[1]);
+                if (!(DBG & 1)) load_b(b[1], knext, 1);
+                TILE_UNIT_SCHED();
+                // unit 2
+                read_a(aB, R, 3);
+                mma(aA, b[2]);
+                if (!(DBG & 1)) load_b(b[2], knext, 2);
+                TILE_UNIT_SCHED();
+                // unit 3
+                read_a(aA, Rn, 0);
+                mma(aB, b[3]);
+                if (!(DBG & 1)) load_b(b[3], knext, 3);
+                TILE_UNIT_SCHED();
+                R = Rn;
+            }
+#undef TILE_UNIT_SCHED
+        }
+        if ((DBG & 256) && blockIdx.x == 0 && tid == 0 && sidx < 8) g_tile_steps[sidx * 16 + 15] = __builtin_readcyclecounter();
+        stamp(2);
+        if (!D.last || (DBG & 32)) continue;             // DBG 32: no exchange / stores
+
+        // ---- end of the unit: the KG waves holding partial sums of the same 128 x 64 block exchange halves through
+        // the buffer just consumed (monotonic per-wave flags, no workgroup barrier: the loader is busy with the other
+        // buffer), level by level; wave g ends up owning 4 / KG of the 4 row blocks and stores them.
+        seq++;
+        float4 *xch = reinterpret_cast<float4 *>(As);
+        volatile int32_t *f_done = xflag, *f_d0 = xflag + 4, *f_a0 = xflag + 8, *f_d1 = xflag + 12, *f_a1 = xflag + 16;
+        (void)f_a1;
+        // every consumer wave must have left the compute loop of this stage before the A tile is overwritten
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) f_done[wave] = seq;
+        for (int w = 0; w < 4; w++)
+            while (f_done[w] < seq) __builtin_amdgcn_s_sleep(1);
+        stamp(3);
+        auto level = [&](auto GIVE, auto KEEP, auto HALF, volatile int32_t *f_data, int partner) {
+            constexpr int give = decltype(GIVE)::value, keep = decltype(KEEP)::value, half = decltype(HALF)::value;
+            float4 *dst = xch + (size_t)wave * 16 * 64 + lane;               // 16 KB per wave
+#pragma unroll
+            for (int m = 0; m < half; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        dst[((m * 2 + n) * 4 + q) * 64] = make_float4(acc[m][n][q * 4], acc[m][n][q * 4 + 1], acc[m][n][q * 4 + 2], acc[m][n][q * 4 + 3]);
-        }
-        __syncthreads();
-        if ((g % (2 * sd)) == 0 && g + sd < KG) {
-            const float4 *src = xch + ((size_t)((g / (2 * sd)) * NCO + h) * 32) * 64 + lane;
+                        dst[((m * 2 + n) * 4 + q) * 64] = make_float4(acc[give + m][n][q * 4], acc[give + m][n][q * 4 + 1],
+                                                                      acc[give + m][n][q * 4 + 2], acc[give + m][n][q * 4 + 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) f_data[wave] = seq;
+            while (f_data[partner] < seq) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float4 *src = xch + (size_t)partner * 16 * 64 + lane;
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < half; m++)
 #pragma unroll
-                for (int n = 0; n < 2; n++)
+                for (int n = 0; n < 2; n++) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const float4 v = src[((m * 2 + n) * 4 + q) * 64];
-                        acc[m][n][q * 4] += v.x; acc[m][n][q * 4 + 1] += v.y; acc[m][n][q * 4 + 2] += v.z; acc[m][n][q * 4 + 3] += v.w;
+                        acc[keep + m][n][q * 4] += v.x; acc[keep + m][n][q * 4 + 1] += v.y;
+                        acc[keep + m][n][q * 4 + 2] += v.z; acc[keep + m][n][q * 4 + 3] += v.w;
                     }
+                    __builtin_amdgcn_sched_barrier(0);                      // at most 16 registers of partner data in flight
+                }
+        };
+        // Epilogue.  A dword store per accumulator register is store-ISSUE bound (128 store instructions per wave: ~13 us
+        // per tile measured, the largest fixed cost of the first versions).  The wave leaves its final 32*cnt rows x 64
+        // channels ROW-MAJOR in its own 16 KB exchange region (the partner has acknowledged reading it) and goes on to the
+        // next stage; the loader waves store the tile 16 bytes per lane -- 4 rows x 256 contiguous bytes per instruction --
+        // before they refill this buffer.
+        auto store = [&](auto LO, auto CNT, volatile int32_t *f_ack, int partner) {
+            constexpr int lo = decltype(LO)::value, cnt = decltype(CNT)::value;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) f_ack[wave] = seq;            // I have read the partner's region
+            while (f_ack[partner] < seq) __builtin_amdgcn_s_sleep(1);
+            float *tb = reinterpret_cast<float *>(xch) + (size_t)wave * 4096;
+#pragma unroll
+            for (int m = 0; m < cnt; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        tb[(m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) * 64 + n * 32 + r] = acc[lo + m][n][e];
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if constexpr (KG == 2) {
+            const int partner = (g ^ 1) * NCO + h;
+            if (g == 0) { level(I2{}, I0{}, I2{}, f_d0, partner); stamp(4); store(I0{}, I2{}, f_a0, partner); }
+            else        { level(I0{}, I2{}, I2{}, f_d0, partner); stamp(4); store(I2{}, I2{}, f_a0, partner); }
+            stamp(5);
+        } else {
+            // KG == 4 (NCO == 1): level 0 between g and g ^ 2 (halves), level 1 between g and g ^ 1 (quarters)
+            const int p0 = (g ^ 2), p1 = (g ^ 1);
+            if ((g & 2) == 0) level(I2{}, I0{}, I2{}, f_d0, p0); else level(I0{}, I2{}, I2{}, f_d0, p0);
+            // my level-0 region is reused at level 1: the level-0 partner must have read it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) f_a0[wave] = seq;
+            while (f_a0[p0] < seq) __builtin_amdgcn_s_sleep(1);
+            if ((g & 2) == 0) {
+                if ((g & 1) == 0) { level(I1{}, I0{}, I1{}, f_d1, p1); store(I0{}, I1{}, f_a1, p1); }
+                else              { level(I0{}, I1{}, I1{}, f_d1, p1); store(I1{}, I1{}, f_a1, p1); }
+            } else {
+                if ((g & 1) == 0) { level(I3{}, I2{}, I1{}, f_d1, p1); store(I2{}, I1{}, f_a1, p1); }
+                else              { level(I2{}, I3{}, I1{}, f_d1, p1); store(I3{}, I1{}, f_a1, p1); }
+            }
         }
     }
-    if (g != 0) return;
-    // ---- epilogue: every output row of the tile is written once (or added, when the offsets are split over z)
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int col = (nt0 + n) * 32 + r;
-        const float bv = bias && zi == 0 ? bias[col] : 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int lrow = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-                if (lrow >= rows) continue;
-                float *dst = &Y[(row0 + lrow) * (int64_t)cout + col];
-                if (gz == 1) *dst = acc[m][n][e] + bv;
-                else unsafeAtomicAdd(dst, acc[m][n][e] + bv);
-            }
+    if ((DBG & 128) && wave == 0 && lane == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_tile_dbg[i], tph[i]);
+        atomicAdd(&g_tile_dbg[7], 1ull);
     }
 }
 
 extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
     const int64_t a = (int64_t)(ucap + 1) * 128;
-    return (a > 65536 ? a : 65536) + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2;       // the A tile doubles as the 64 KB reduction buffer
+    const int64_t buf = (a > 65536 ? a : 65536) + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12 + (int64_t)sizeof(StageDesc);
+    return 2 * buf + 96;            // two stage buffers (the A tile doubles as the 64 KB exchange buffer) + flags
 }
 
 extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
@@ -438,12 +645,24 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
                                     int32_t ksplit, cg3d_stream_t stream) {
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
         return CG3D_ERR_ARG;
-    if (ucap < TP_TM || ucap > 1023 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
+    if (ucap < TP_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
     if (ntile == 0) return CG3D_OK;
     hipStream_t s = cg3d_hs(stream);
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     static const int ldspad = getenv("CG3D_TILE_LDSPAD") ? atoi(getenv("CG3D_TILE_LDSPAD")) : 0;   // dev aid: occupancy experiments
     const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap) + (size_t)ldspad;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG3D_ERR_LAUNCH;
+        ncu = prop.multiProcessorCount;
+    }
+    // persistent workgroups, one per CU (two 64 KB stage buffers fill the LDS)
+    const int32_t ny = cout >= 128 ? cout / 128 : 1;
+    const int64_t nunit = ntile * ny * ksplit;
+    if (nunit > 0x7fffffffll) return CG3D_ERR_ARG;
+    const int64_t grid = nunit < ncu ? nunit : ncu;
     static const int dbg = getenv("CG3D_TILE_DBG") ? atoi(getenv("CG3D_TILE_DBG")) : 0;      // dev aid: knock-out variants (wrong results)
 #define TILE_LAUNCH(NW, DBG)                                                                                                   \
     do {                                                                                                                       \
@@ -455,13 +674,12 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
             attr = true;                                                                                                       \
             if (getenv("CG3D_TILE_INFO")) {                                                                                    \
                 int nb = -1;                                                                                                   \
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spconv_tile<NW, DBG>, 256, lds);                 \
-                fprintf(stderr, "k_spconv_tile<%d,%d>: lds %zu B, occupancy %d workgroups/CU\n", NW, DBG, lds, nb);            \
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spconv_tile<NW, DBG>, 512, lds);                     \
+                fprintf(stderr, "k_spconv_tile<%d,%d>: lds %zu B, occupancy %d workgroups/CU, %d CUs\n", NW, DBG, lds, nb, ncu); \
             }                                                                                                                  \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_spconv_tile<NW, DBG>), dim3((unsigned)ntile, (unsigned)(cout / (NW * 64)), (unsigned)ksplit),     \
-                           dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist, maxpass, ucap, tiles, bias, Y,       \
-                           n_out, K, cin, cout, maxk);                                                                         \
+        hipLaunchKernelGGL((k_spconv_tile<NW, DBG>), dim3((unsigned)grid), dim3(512), lds, s, X, Wf, slots, live, pass_tab,    \
+                           npass, ulist, maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, maxk); \
     } while (0)
 #define TILE_LAUNCH_NW(DBG)                                                                                                    \
     do { if (cout >= 128) TILE_LAUNCH(2, DBG); else TILE_LAUNCH(1, DBG); } while (0)
@@ -473,6 +691,19 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     case 20: TILE_LAUNCH_NW(20); break;
     case 24: TILE_LAUNCH_NW(24); break;
     case 31: TILE_LAUNCH_NW(31); break;
+    case 128: TILE_LAUNCH_NW(128); break;
+    case 256: TILE_LAUNCH_NW(256); break;
+    case 257: TILE_LAUNCH_NW(257); break;
+    case 258: TILE_LAUNCH_NW(258); break;
+    case 259: TILE_LAUNCH_NW(259); break;
+    case 260: TILE_LAUNCH_NW(260); break;
+    case 264: TILE_LAUNCH_NW(264); break;
+    case 129: TILE_LAUNCH_NW(129); break;
+    case 130: TILE_LAUNCH_NW(130); break;
+    case 136: TILE_LAUNCH_NW(136); break;
+    case 56: TILE_LAUNCH_NW(56); break;
+    case 88: TILE_LAUNCH_NW(88); break;
+    case 120: TILE_LAUNCH_NW(120); break;
     case 1: TILE_LAUNCH_NW(1); break;
     case 2: TILE_LAUNCH_NW(2); break;
     case 3: TILE_LAUNCH_NW(3); break;

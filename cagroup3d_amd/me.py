@@ -176,6 +176,17 @@ class KernelMap:
             self._pairs[row_bounds] = hit
         return hit
 
+    def tile_plan(self, transposed):
+        """TilePlan of the map (forward) or of its transpose (data gradient); cached."""
+        ck = ("plan", bool(transposed))
+        pl = self._segs.get(ck)
+        if pl is None:
+            _, _, _, P = self.pairs(None)
+            nbr = self.nbrT if transposed else self.nbr
+            pl = build_tile_plan(nbr.contiguous(), P)
+            self._segs[ck] = pl
+        return pl
+
     def tiles(self, row_bounds, rows=128):
         """int32 [ntile,3] (group, first row, row count <= rows) covering the output rows group by group; cached."""
         ck = ("tiles", row_bounds, rows)
@@ -222,11 +233,32 @@ def _build_map(coords_i32, qstride):
     out_coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(2, dtype=torch.int32, device=dev)          # [row count, status]
     lib.call("cg3d_coord_map_build", ptr(coords_i32), c_int64(n), c_int32(qstride), ptr(keys), ptr(vals),
              c_int64(cap), ptr(ws), ptr(out_coords), ptr(uniq), ptr(inv), ptr(n_out), lib.stream())
-    m = int(n_out.item())  # host sync: the row count sizes every later tensor on this map
+    m, status = n_out.tolist()  # host sync: the row count sizes every later tensor on this map
+    if status != 0:
+        raise _lib.CG3DError("cg3d_coord_map_build: a coordinate or batch index does not fit the packed voxel key "
+                             "(|x|,|y|,|z| < %d, 0 <= batch < %d): the rows would be dropped silently" % (16384, 524288))
     return out_coords[:m], keys, vals, cap, uniq[:m], inv[:n]
+
+
+# Row order of every map inserted from raw coordinates: (batch, Morton(x, y, z)) instead of the order the points arrive in
+# (cg3d_morton_order).  The strided maps inherit it.  128 consecutive rows are then a spatially compact patch, which is
+# what the LDS-staged tile kernel needs (cg3d_tile_plan_build); no result of the path depends on the row order beyond
+# fp32 summation order, and `unique_index` / `inverse_mapping` keep referring to the caller's rows.
+MORTON_ROWS = __import__("os").environ.get("CG3D_MORTON_ROWS", "1") != "0"
+
+
+def _morton_order(coords_i32):
+    """int64 [n]: input row of the i-th row in (batch, Morton) order."""
+    lib = _lib.get()
+    n = coords_i32.shape[0]
+    dev = coords_i32.device
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ws = torch.empty(max(int(lib.raw("cg3d_morton_order_ws_bytes")(n)), 16), dtype=torch.uint8, device=dev)
+    lib.call("cg3d_morton_order", ptr(coords_i32), c_int64(n), ptr(order), ptr(ws), lib.stream())
+    return order[:n].long()
 
 
 _offset_cache = {}
@@ -256,8 +288,20 @@ class CoordinateManager:
         self._uid = itertools.count()
 
     # -- maps
-    def insert(self, coords_i32, tensor_stride=1):
-        out, keys, vals, cap, uniq, inv = _build_map(coords_i32.contiguous(), 1)
+    def insert(self, coords_i32, tensor_stride=1, sort=False):
+        """sort: build the map in (batch, Morton) row order (SparseTensor construction: the features are re-indexed through
+        `unique_index` / `inverse_mapping` anyway).  Maps at caller-given output coordinates (`conv(x, coordinates)`) keep
+        the caller's order: row i of the result belongs to coordinate i."""
+        coords_i32 = coords_i32.contiguous()
+        if sort and MORTON_ROWS and coords_i32.shape[0] > 1:
+            _lib.get().check(coords_i32)
+            order = _morton_order(coords_i32)
+            out, keys, vals, cap, uniq, inv_s = _build_map(coords_i32[order].contiguous(), 1)
+            uniq = order[uniq.long()].to(torch.int32)           # representative rows / inverse map in the caller's row numbering
+            inv = torch.empty_like(inv_s)
+            inv[order] = inv_s
+        else:
+            out, keys, vals, cap, uniq, inv = _build_map(coords_i32, 1)
         key = CoordinateMapKey(tensor_stride, next(self._uid))
         self._maps[key] = _CoordMap(out, keys, vals, cap, out.shape[0], int(tensor_stride))
         return key, uniq, inv
@@ -440,7 +484,11 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1):
 
 
 def _prep_frag(w3, want_t=True, want_p=False):
-    """fp32 [K, cin, cout] -> (Wf_t, Wf) int16 views of the bf16 weights in MFMA fragment order (either may be None)."""
+    """fp32 [K, cin, cout] -> (Wf_t, Wf) int16 views of the bf16 weights in MFMA fragment order (either may be None);
+    answered from the step's weight arena when the layer is recorded there."""
+    e = _planned_single(w3, want_p, True)
+    if e is not None:
+        return (e[3] if want_t else None), (e[4] if want_p else None)
     lib = _lib.get()
     K, cin, cout = w3.shape
     wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device) if want_t else None
@@ -475,6 +523,8 @@ def _walk_tensors(o, seen):
         _walk_tensors([o.coords, o.keys, o.vals, o._perms], seen)
     elif isinstance(o, KernelMap):
         _walk_tensors([o.nbr, o._nbrT, o._pairs, o._segs], seen)
+    elif isinstance(o, TilePlan):
+        _walk_tensors(o.tensors(), seen)
 
 
 def release_to_stream(mgr, extra, stream):
@@ -516,7 +566,7 @@ class _WeightPlan:
     spot and recorded; from then on `prepare_weights()` -- called by the detector at the start of every forward --
     converts every recorded weight whose tensor version changed (i.e. after every optimizer step, never in inference)
     into one persistent arena with a single launch, and the per-layer requests are answered from the arena."""
-    singles = {}        # data_ptr -> [w3, need_plain, version, wt_view, wp_view]
+    singles = {}        # (data_ptr, frag) -> [w3, need_plain, version, wt_view, wp_view]; frag: MFMA fragment order (tile kernel)
     groups = {}         # (ptrs, transposed) -> [weights, versions, out_view]
     table = None        # device int64 [nrows, 6]
     nrows = 0
@@ -539,7 +589,7 @@ class _WeightPlan:
         arena_p = torch.empty(max(n_p, 1), dtype=torch.int16, device=device)
         rows, ot, op = [], 0, 0
 
-        def add(w, off_t, off_p):
+        def add(w, off_t, off_p, frag=False):
             K, cin, cout = w.shape
             per = cin * cout
             tiles = -(-cin // 64) * -(-cout // 64)
@@ -549,12 +599,12 @@ class _WeightPlan:
             r[:, 0] = w.data_ptr() + k * per * 4
             r[:, 1] = 0 if off_t is None else arena_t.data_ptr() + (off_t + k * per) * 2
             r[:, 2] = 0 if off_p is None else arena_p.data_ptr() + (off_p + k * per) * 2
-            r[:, 3], r[:, 4], r[:, 5] = cin, cout, t
+            r[:, 3], r[:, 4], r[:, 5] = cin, cout, t | ((3 << 29) if frag else 0)
             rows.append(r)
-        for e in cls.singles.values():
+        for (_, frag), e in cls.singles.items():
             w = e[0]
             K, cin, cout = w.shape
-            add(w, ot, op if e[1] else None)
+            add(w, ot, op if e[1] else None, frag)
             e[3] = arena_t[ot:ot + w.numel()].view(K, cout, cin)
             ot += w.numel()
             if e[1]:
@@ -617,15 +667,15 @@ def finish_weights():
     _WeightPlan.live = False
 
 
-def _planned_single(w3, need_plain):
+def _planned_single(w3, need_plain, frag=False):
     P = _WeightPlan
-    e = P.singles.get(w3.data_ptr())
+    e = P.singles.get((w3.data_ptr(), frag))
     if e is not None and e[0].shape == w3.shape and (e[1] or not need_plain):
         if P.live and e[3] is not None and e[2] == w3._version:
             return e
         return None
     if _lib.get().is_device and w3.dim() == 3:
-        P.singles[w3.data_ptr()] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
+        P.singles[(w3.data_ptr(), frag)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
         P.dirty = True
     return None
 
@@ -776,6 +826,19 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
     return max(256, -(-per // 256) * 256)
 
 
+TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
+TILE_KERNEL = __import__("os").environ.get("CG3D_TILE_KERNEL", "1") != "0"
+
+
+def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
+    """The LDS-staged tile kernel (cg3d_spconv_tile_fwd): bf16 mode with bf16 row copies, a map of a coordinate map onto
+    itself (the distinct neighbour rows of a 128-row tile then fit the LDS tile in one pass; strided maps need 2-3 passes
+    and stay with the dense-map kernel), >= 128 channels on both sides (below that the layer is bound by its output
+    stream and the kernels tie), enough rows to give every CU a tile."""
+    return (TILE_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and row_bounds is None and kmap.same_map
+            and 1 < K <= 32 and cin % 64 == 0 and cout % 128 == 0 and cin >= 128 and n_rows >= TILE_MIN_ROWS)
+
+
 class SparseConvFunction(torch.autograd.Function):
     """Y = conv(X, W) on a kernel map; gather -> MFMA -> atomic scatter over the pair lists.
 
@@ -794,10 +857,14 @@ class SparseConvFunction(torch.autograd.Function):
     def warm(kmap, K, cin, cout, row_bounds=None, backward=True):
         """Build (and cache on the map) everything forward / backward of this layer will read from the host."""
         _, _, _, P = kmap.pairs(row_bounds)
-        if not SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
+        if _use_tile(kmap, K, cin, cout, kmap.n_out, row_bounds):
+            kmap.tile_plan(False)
+        elif not SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
             kmap.segments(_seg_len_fwd(), row_bounds)
         if backward:
-            if SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, row_bounds):
+            if _use_tile(kmap, K, cout, cin, kmap.n_in, row_bounds):
+                kmap.tile_plan(True)
+            elif SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, row_bounds):
                 _ = kmap.nbrT
             else:
                 kmap.segments(_seg_len_fwd(), row_bounds)
@@ -816,10 +883,24 @@ class SparseConvFunction(torch.autograd.Function):
         # weight gradient) moves half the bytes
         xg = _to_bf16(x, keep=True) if (BF16_ROWS and _use_bf16(cin)) else x
         wt = wp = None
-        if _use_bf16(cin):
+        K = w3.shape[0]
+        tile_f = _use_tile(kmap, K, cin, cout, kmap.n_out, row_bounds)
+        tile_b = ctx.needs_input_grad[0] and _use_tile(kmap, K, cout, cin, kmap.n_in, row_bounds)
+        ctx.tile_b = tile_b
+        if tile_f or tile_b:
+            # fragment-ordered copies (one launch; from the step's arena when recorded): forward and data-gradient operand
+            wt, wp = _prep_frag(w3, tile_f, tile_b)
+            if not tile_f:
+                wt = _prep_bf16_t(w3)
+            ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
+            if tile_f:
+                return _conv_tile(xg, wt, kmap.tile_plan(False), b, cin, cout, kmap.n_in, P)
+        elif _use_bf16(cin):
             # both bf16 copies of the weights in one launch; the plain one is the data gradient's operand
             wt, wp = _prep_bf16_both(w3) if _use_bf16(cout) else (_prep_bf16_t(w3), None)
-        ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
+            ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
+        else:
+            ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
         if SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, row_bounds):
             return _conv_implicit_bf16(xg, wt, kmap.nbr, b, kmap.n_out, cin, cout, P)
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
@@ -836,7 +917,10 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dw = db = None
         dyg = _to_bf16(dy) if (BF16_ROWS and _use_bf16(cout)) else dy     # shared by dgrad and wgrad
         if ctx.needs_input_grad[0]:
-            if SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
+            if getattr(ctx, "tile_b", False):
+                # the swapped problem on the plan of the transposed map; operand = the plain fragment-ordered copy
+                dx = _conv_tile(dyg, wp, kmap.tile_plan(True), None, cout, cin, kmap.n_out, P)
+            elif SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
                 dx = _conv_implicit_bf16(dyg, wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16),
                                          kmap.nbrT, None, kmap.n_in, cout, cin, P)
@@ -1299,12 +1383,12 @@ class SparseTensor:
             if coordinates.dtype.is_floating_point:
                 coordinates = torch.floor(coordinates)
             ci = coordinates.to(torch.int32).contiguous()
-            key, uniq, inv = self.coordinate_manager.insert(ci, int(tensor_stride))
+            key, uniq, inv = self.coordinate_manager.insert(ci, int(tensor_stride), sort=True)
             self.coordinate_map_key = key
             self.unique_index, self.inverse_mapping = uniq, inv
             n_out = uniq.shape[0]
-            if n_out == ci.shape[0]:
-                self.F = features
+            if n_out == ci.shape[0] and not (MORTON_ROWS and n_out > 1):
+                self.F = features                       # one row per voxel, rows in the caller's order
             elif quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
                 self.F = ScatterMeanFunction.apply(features, inv.view(1, -1), n_out)
             else:

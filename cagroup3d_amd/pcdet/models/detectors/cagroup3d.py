@@ -27,7 +27,7 @@ class CAGroup3D(Detector3DTemplate):
             ME.release_to_stream(mgr, [keep, targets], torch.cuda.current_stream())
             if targets is not None and self.training:
                 self.dense_head._data_targets, self.dense_head._forced_pre = targets.get("loss"), targets.get("forced")
-            feats = points[:, 4:] if uniq.shape[0] == n_in else points[:, 4:][uniq.long()]
+            feats = points[:, 4:][uniq.long()]          # rows are in (batch, Morton) order: always re-index
             return ME.SparseTensor(features=feats.clone(), coordinate_map_key=key, coordinate_manager=mgr)
         coordinates = points[:, :4].clone()
         coordinates[:, 1:] /= self.voxel_size

@@ -69,12 +69,22 @@ int cg3d_abi_version(void);
  *     out_coords   int32 [>=n,4] : unique quantised coordinates (first *n_out rows valid)
  *     unique_index int32 [>=n]   : representative input row of each output row
  *     inverse      int32 [n]     : output row of each input row
- *     n_out        int32 [1]     : number of unique voxels (device scalar)
+ *     n_out        int32 [2]     : [0] number of unique voxels, [1] status: CG3D_OK, or CG3D_ERR_RANGE when a
+ *                                  coordinate / batch index does not fit the packed key (the map is unusable then);
+ *                                  device memory -- the caller reads both with the one copy that sizes its tensors
  *   After the call the table maps coordinate -> output row.
  *   `ws` needs cg3d_coord_map_ws_bytes(n) bytes.
+ *
+ * cg3d_morton_order: order[i] = input row of the i-th row in (batch, Morton(x, y, z)) order (15-bit interleave of the
+ *   biased coordinates; rows of one voxel keep their input order; out-of-range rows last).  The host engine inserts every
+ *   map in this order (me.MORTON_ROWS): 128 consecutive rows are then a spatially compact patch -- what the tile plans of
+ *   cg3d_tile_plan_build rely on -- and the strided maps derived from it inherit the order.  ME's own row order is its
+ *   hash-map iteration order (unspecified); no output of the path depends on it beyond fp32 summation order.
  * ---------------------------------------------------------------------------------------- */
 int64_t cg3d_hash_capacity(int64_t n);
 int64_t cg3d_coord_map_ws_bytes(int64_t n);
+int64_t cg3d_morton_order_ws_bytes(int64_t n);
+int cg3d_morton_order(const int32_t *coords, int64_t n, int32_t *order, void *ws, cg3d_stream_t stream);
 int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride,
                          uint64_t *keys, int32_t *vals, int64_t cap, void *ws,
                          int32_t *out_coords, int32_t *unique_index, int32_t *inverse,
@@ -152,7 +162,9 @@ int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws,
 /* Table form: the bf16 copies of ANY set of weight slots in one launch.  `table` = device int64 [nrows, 6], one row per
  * 64 x 64 tile of one slot: { address of the float32 slot [cin][cout], address of its transposed bf16 copy [cout][cin]
  * or 0, address of its plain bf16 copy [cin][cout] or 0, cin, cout, tile = ci_tile * ceil(cout / 64) + co_tile }.
- * Same values as cg3d_spconv_prep_weights_bf16_multi writes. */
+ * Same values as cg3d_spconv_prep_weights_bf16_multi writes.  Bit 30 of the tile field: the transposed copy is written in
+ * MFMA fragment order (the Wf_t layout of cg3d_spconv_prep_weights_frag; cin % 16 == 0, cout % 32 == 0), bit 29: the plain
+ * copy is (the Wf layout; cout % 16 == 0, cin % 32 == 0) -- the operands of cg3d_spconv_tile_fwd. */
 int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream);
 int64_t cg3d_pairs_ws_bytes(int64_t total /* K*n_out */);
 int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,

@@ -24,6 +24,9 @@ static inline float os_bf16(float v) {
     return r;
 }
 
+static inline int64_t os_frag_index(int n_idx, int k_idx, int kdim) {       /* cg3d_spconv_prep_weights_frag layout */
+    return ((((int64_t)(n_idx >> 5) * (kdim >> 4) + (k_idx >> 4)) * 64) + ((k_idx >> 3) & 1) * 32 + (n_idx & 31)) * 8 + (k_idx & 7);
+}
 int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float *const *Ws, uint16_t *Wb_t, uint16_t *Wb, int32_t G,
                                         int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t s) {
     (void)s;
@@ -172,7 +175,8 @@ int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3
         const int64_t *row = table + b * 6;
         const float *src = (const float *)(uintptr_t)row[0];
         uint16_t *wt = (uint16_t *)(uintptr_t)row[1], *wp = (uint16_t *)(uintptr_t)row[2];
-        const int cin = (int)row[3], cout = (int)row[4], tile = (int)row[5];
+        const int cin = (int)row[3], cout = (int)row[4], tile = (int)(row[5] & 0xfffffff);
+        const int frag_t = (int)((row[5] >> 30) & 1), frag_p = (int)((row[5] >> 29) & 1);   /* MFMA fragment order */
         const int co_tiles = (cout + 63) / 64;
         const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
         for (int r = ci0; r < ci0 + 64 && r < cin; r++)
@@ -180,8 +184,8 @@ int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3
                 const float f = os_bf16(src[(int64_t)r * cout + c]);
                 uint32_t u; memcpy(&u, &f, 4);
                 const uint16_t v = (uint16_t)(u >> 16);
-                if (wp) wp[(int64_t)r * cout + c] = v;
-                if (wt) wt[(int64_t)c * cin + r] = v;
+                if (wp) wp[frag_p ? os_frag_index(r, c, cout) : (int64_t)r * cout + c] = v;
+                if (wt) wt[frag_t ? os_frag_index(c, r, cin) : (int64_t)c * cin + r] = v;
             }
     }
     return CG3D_OK;

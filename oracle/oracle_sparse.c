@@ -30,7 +30,7 @@
 #include "../include/cagroup3d_hip.h"
 
 int cg3d_is_device_library(void) { return 0; }
-int cg3d_abi_version(void) { return 1; }
+int cg3d_abi_version(void) { return 2; }
 
 #define OS_EMPTY (~0ULL)
 
@@ -84,7 +84,7 @@ int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride, uint
             z = os_floordiv(z, qstride) * qstride;
         }
         uint64_t key;
-        if (!os_pack(b, x, y, z, &key)) return CG3D_ERR_RANGE;
+        if (!os_pack(b, x, y, z, &key)) { n_out[0] = 0; n_out[1] = CG3D_ERR_RANGE; return CG3D_OK; }   /* as the device: status word */
         uint64_t slot = os_hash(key) & (uint64_t)(cap - 1);
         for (;;) {
             if (keys[slot] == key) { inverse[i] = vals[slot]; break; }
@@ -97,7 +97,45 @@ int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride, uint
             slot = (slot + 1) & (uint64_t)(cap - 1);
         }
     }
-    *n_out = m;
+    n_out[0] = m;
+    n_out[1] = 0;
+    return CG3D_OK;
+}
+
+/* Morton row order (the row order the host engine builds every inserted map in): order[i] = input row of the i-th row
+ * in (batch, Morton(x,y,z)) order, ties (rows of one voxel) in input order. */
+static uint64_t os_spread3(uint32_t v) {
+    uint64_t x = v & 0x7fffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+typedef struct { uint64_t key; int32_t row; } os_mrow;
+static int os_mrow_cmp(const void *a, const void *b) {
+    const os_mrow *x = (const os_mrow *)a, *y = (const os_mrow *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->row < y->row ? -1 : (x->row > y->row ? 1 : 0);
+}
+int64_t cg3d_morton_order_ws_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(os_mrow); }
+int cg3d_morton_order(const int32_t *coords, int64_t n, int32_t *order, void *ws, cg3d_stream_t s) {
+    (void)s;
+    if (n < 0) return CG3D_ERR_ARG;
+    os_mrow *rows = (os_mrow *)ws;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t b = coords[i * 4];
+        const uint32_t ux = (uint32_t)(coords[i * 4 + 1] + CG3D_COORD_LIMIT), uy = (uint32_t)(coords[i * 4 + 2] + CG3D_COORD_LIMIT),
+                       uz = (uint32_t)(coords[i * 4 + 3] + CG3D_COORD_LIMIT);
+        uint64_t key = ~0ull;
+        if ((uint32_t)b < (uint32_t)CG3D_BATCH_LIMIT && (ux | uy | uz) < (uint32_t)(2 * CG3D_COORD_LIMIT))
+            key = ((uint64_t)b << 45) | (os_spread3(ux) << 2) | (os_spread3(uy) << 1) | os_spread3(uz);
+        rows[i].key = key;
+        rows[i].row = (int32_t)i;
+    }
+    qsort(rows, (size_t)n, sizeof(os_mrow), os_mrow_cmp);
+    for (int64_t i = 0; i < n; i++) order[i] = rows[i].row;
     return CG3D_OK;
 }
 

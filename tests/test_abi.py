@@ -26,12 +26,12 @@ def test_header_and_binding_agree():
 def test_hip_library_exports_every_symbol():
     assert os.path.exists(_lib.HIP_LIB_PATH), "run `python cagroup3d_amd/csrc/build.py`"
     lib = _lib.bind(_lib.HIP_LIB_PATH)            # resolves every symbol, sets signatures
-    assert lib.is_device and lib.raw("cg3d_abi_version")() == 1
+    assert lib.is_device and lib.raw("cg3d_abi_version")() == 2
     assert lib.raw("cg3d_hash_capacity")(1000) == 2048   # host-only helper
 
 
 def test_oracle_exports_every_symbol(oracle):
-    assert not oracle.is_device and oracle.raw("cg3d_abi_version")() == 1
+    assert not oracle.is_device and oracle.raw("cg3d_abi_version")() == 2
     assert oracle.raw("cg3d_coord_map_ws_bytes")(4096) == _lib.bind(_lib.HIP_LIB_PATH).raw("cg3d_coord_map_ws_bytes")(4096)
 
 

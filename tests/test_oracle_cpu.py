@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from cagroup3d_amd import _lib, me
 from cagroup3d_amd.ops import iou3d_nms_utils, knn as knn_mod, rotated_iou
-from util import rand_boxes, rand_coords, surface_coords
+from util import morton_keys, rand_boxes, rand_coords, surface_coords
 
 
 @pytest.fixture(autouse=True)
@@ -27,7 +27,9 @@ def dense_of(x, G, pad=0):
     return d, o
 
 
-def test_coordinate_map_first_occurrence_order():
+def test_coordinate_map_first_occurrence_order(monkeypatch):
+    """cg3d_coord_map_build itself: duplicates merged, representative = first occurrence, rows in first-occurrence order."""
+    monkeypatch.setattr(me, "MORTON_ROWS", False)
     c = torch.tensor([[0, 5, 5, 5], [0, 1, 1, 1], [0, 5, 5, 5], [1, 1, 1, 1], [0, 1, 1, 1], [0, -3, 2, 9]], dtype=torch.int32)
     f = torch.arange(6, dtype=torch.float32).view(6, 1)
     x = me.SparseTensor(coordinates=c, features=f)
@@ -36,12 +38,40 @@ def test_coordinate_map_first_occurrence_order():
     assert x.F.view(-1).tolist() == [0., 1., 3., 5.]                     # first row of each voxel
     xa = me.SparseTensor(coordinates=c, features=f, quantization_mode=me.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
     assert xa.F.view(-1).tolist() == [1.0, 2.5, 3.0, 5.0]                # mean over the voxel's rows
+
+
+def test_inserted_maps_are_in_batch_morton_order():
+    """The engine inserts every map in (batch, Morton) order; unique_index / inverse_mapping keep the caller's row numbers,
+    the representative of a voxel stays its first occurrence, and strided maps inherit the order."""
+    assert me.MORTON_ROWS
+    c = torch.tensor([[0, 5, 5, 5], [0, 1, 1, 1], [0, 5, 5, 5], [1, 1, 1, 1], [0, 1, 1, 1], [0, -3, 2, 9]], dtype=torch.int32)
+    f = torch.arange(6, dtype=torch.float32).view(6, 1)
+    x = me.SparseTensor(coordinates=c, features=f)
+    assert x.C.tolist() == [[0, -3, 2, 9], [0, 1, 1, 1], [0, 5, 5, 5], [1, 1, 1, 1]]
+    assert x.unique_index.tolist() == [5, 1, 0, 3] and x.inverse_mapping.tolist() == [2, 1, 2, 3, 1, 0]
+    assert x.F.view(-1).tolist() == [5., 1., 0., 3.]
+    xa = me.SparseTensor(coordinates=c, features=f, quantization_mode=me.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE)
+    assert xa.F.view(-1).tolist() == [5.0, 2.5, 1.0, 3.0]
+    # a bigger map against numpy: sorted by key, first occurrence per voxel, strided maps sorted by THEIR keys as well
+    coords = rand_coords(4000, batch=3, extent=40, seed=3)
+    x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1))
+    keys = morton_keys(x.C.numpy())
+    assert (np.diff(keys.astype(np.float64)) > 0).all() and len(keys) == len(np.unique(coords.numpy(), axis=0))
+    first = {}
+    for i, row in enumerate(map(tuple, coords.tolist())):
+        first.setdefault(row, i)
+    assert x.unique_index.tolist() == [first[tuple(r)] for r in x.C.tolist()]
+    assert torch.equal(x.C[x.inverse_mapping.long()], coords)
+    key2 = x.coordinate_manager.stride(x.coordinate_map_key, 2)
+    k2 = morton_keys(x.coordinate_manager.get(key2).coords.numpy())
+    assert (np.diff(k2.astype(np.float64)) > 0).all()
     # float coordinates are floored (negative values too)
     xf = me.SparseTensor(coordinates=torch.tensor([[0, -0.5, 0.5, 1.99], [0, -1.0, 0.0, 1.0]]), features=torch.ones(2, 1))
     assert xf.C.tolist() == [[0, -1, 0, 1]]
 
 
-def test_stride_map_floors_negative_coordinates():
+def test_stride_map_floors_negative_coordinates(monkeypatch):
+    monkeypatch.setattr(me, "MORTON_ROWS", False)
     c = torch.tensor([[0, -1, -2, -3], [0, 0, 1, 3], [0, -4, 2, 2], [0, 1, 0, 2]], dtype=torch.int32)
     x = me.SparseTensor(coordinates=c, features=torch.ones(4, 1))
     key = x.coordinate_manager.stride(x.coordinate_map_key, 2)

@@ -41,3 +41,20 @@ def rand_boxes(n, seed=0, yaw=True, extent=4.0, device="cpu"):
     size = torch.rand(n, 3, generator=g) * 1.5 + 0.2
     ang = (torch.rand(n, 1, generator=g) - 0.5) * 6.28 if yaw else torch.zeros(n, 1)
     return torch.cat([ctr, size, ang], 1).float().contiguous().to(device)
+
+
+def morton_keys(coords):
+    """numpy uint64 keys of int32 [n,4] (batch, x, y, z) rows: batch << 45 | 15-bit interleave of the coordinates biased
+    by 2^14 (x most significant) -- the order cg3d_morton_order sorts by."""
+    c = np.asarray(coords).astype(np.int64)
+
+    def spread(v):
+        v = v.astype(np.uint64) & np.uint64(0x7fff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+    return (c[:, 0].astype(np.uint64) << np.uint64(45)) | (spread(c[:, 1] + 16384) << np.uint64(2)) | \
+        (spread(c[:, 2] + 16384) << np.uint64(1)) | spread(c[:, 3] + 16384)

@@ -2,14 +2,14 @@
 on exactly NT tiles (one round of workgroups).  dev tool, GPU only.   usage: python tools/mb_tile_slope.py"""
 import sys, os, subprocess
 if len(sys.argv) == 1:
-    for ntile, pad in ((256, 40000), (512, 0)):
-        for dbg in (16, 17, 18, 20, 24, 31):
+    for ntile, pad in ((256, 0), (512, 0)):
+        for dbg in (16, 24):
             ts = []
             for mk in (3, 27):
                 out = subprocess.run([sys.executable, __file__, str(ntile)], capture_output=True, text=True,
                                      env=dict(os.environ, CG3D_TILE_DBG=str(dbg), CG3D_TILE_MAXK=str(mk), CG3D_TILE_LDSPAD=str(pad)))
                 ts.append(float(out.stdout.strip().split()[-1]) if out.stdout.strip() else float("nan"))
-            print("tiles %d (%d WG/CU) DBG %2d: maxk 3 -> %6.1f us, maxk 27 -> %6.1f us: %5.2f us per offset (2 steps), intercept %5.1f us" % (
+            print("tiles %d (%d) DBG %2d: maxk 3 -> %6.1f us, maxk 27 -> %6.1f us: %5.2f us per offset (2 steps), intercept %5.1f us" % (
                 ntile, 1 if pad else 2, dbg - 16, ts[0], ts[1], (ts[1] - ts[0]) / 24, ts[0] - 3 * (ts[1] - ts[0]) / 24), flush=True)
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
