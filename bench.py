@@ -12,10 +12,14 @@ grad-norm clip, AdamW step; inputs are resident in HBM when the timed region sta
 one batch per rank (weak scaling); the only collectives are DDP's gradient all-reduce and the
 fused 3-scalar reduce_mean per scene, over RCCL.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the conv kernel that accumulates the most time (bf16:
-k_spconv_implicit_bf16_ad, fp32: k_spconv_pairs_lds), every conv launch timed live with HIP events on the launch stream on
-up to six of the timed steps spread over the timed region (`roofline.timed_steps`); `cpu_baseline` times the CPU oracle
-(oracle/liboracle.so, the checker -- never the product) on a bounded sample, in a child process.
+Prints ONE JSON line (rank 0).  `roofline` is for the conv kernel that accumulates the most time (bf16: k_spconv_tile),
+every conv launch (forward, data gradient, weight gradient) timed live with HIP events on the launch stream on up to six of
+the timed steps spread over the timed region (`roofline.timed_steps`).  Work per launch follows SURVEY.md 8(d): flops =
+2 P Cin Cout, bytes = every tensor once (input rows + output rows + weights + the map); the bound of a launch is
+max(flops / MFMA peak, bytes / HBM peak), `frac` = achieved / peak of whichever bounds the dominant kernel, and
+`frac_8d_per_layer` = sum of the launches' bounds / sum of their measured times.  `fp32` is the parity configuration timed
+in the same process; `cpu_baseline` times the CPU oracle (oracle/liboracle.so, the checker -- never the product) on a bounded
+sample in child processes: 2 warm-up steps + the median of 5, all host cores and one thread.
 """
 import argparse
 import json
@@ -59,6 +63,8 @@ def parse():
                          "accumulation, storage and the weight gradient are fp32 in both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="S50k:1", help="config:scenes timed on the CPU oracle")
+    ap.add_argument("--cpu-sample-1t", default="S5k:1", help="config:scenes of the single-thread CPU leg")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     return ap.parse_args()
 
@@ -107,7 +113,9 @@ def train_step(model, opt, batch, clip):
 
 
 def cpu_baseline(args, forced):
-    """Same training step on the host CPU with the oracle library bound in place of the HIP one."""
+    """Same training step on the host CPU with the oracle library bound in place of the HIP one: BASELINE.md section 2
+    protocol -- 2 warm-up steps, then the median of up to 5 timed steps, bounded by a time budget (the repeats actually
+    taken are stated in `sample`)."""
     oracle_so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(oracle_so):
         import subprocess
@@ -115,6 +123,7 @@ def cpu_baseline(args, forced):
     cfgname, nsc = args.cpu_sample.split(":")
     nsc = int(nsc)
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    budget = float(os.environ.get("CG3D_CPU_BUDGET_S", "45"))
     torch.set_num_threads(cores)
     prec, me.PRECISION = me.PRECISION, 0      # the CPU port computes in fp32 (bf16 emulation would only slow it down)
     with _lib.use_library(_lib.bind(oracle_so)):
@@ -122,24 +131,34 @@ def cpu_baseline(args, forced):
         model.train()
         opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
         batch = build_model.synthetic_batch(cfgname, nsc, device="cpu")
-        t0 = time.time()
-        train_step(model, opt, batch, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-        dt = time.time() - t0
+        t_start, warm, times = time.time(), 0, []
+        while len(times) < 5:
+            t0 = time.time()
+            train_step(model, opt, batch, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+            dt = time.time() - t0
+            if warm < 2 and time.time() - t_start + 3 * dt < budget:     # warm-up only while the budget leaves room for timed steps
+                warm += 1
+                continue
+            times.append(dt)
+            if time.time() - t_start + dt > budget:
+                break
     me.PRECISION = prec
-    return {"value": nsc / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "%d scene(s) of %s, one fwd+bwd+AdamW step of the full detector on the CPU oracle "
-                      "(OpenMP + torch CPU threads), %.1f s" % (nsc, cfgname, dt)}
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": nsc / med, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "%d scene(s) of %s per step, fwd+bwd+AdamW of the full detector on the CPU oracle in fp32 (OpenMP + torch CPU "
+                      "threads = %d); %d warm-up + median of %d timed step(s), %.1f s per step" % (nsc, cfgname, cores, warm, len(times), med)}
 
 
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv; separate runs, as the profiling guide prescribes).
+    (profiles/r02_pmc_{FETCH,WRITE}_SIZE.csv; separate runs, as the profiling guide prescribes).
     gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
     import csv
     try:
         tot = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_%s.csv" % c)))
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.csv" % c)))
                     if kernel_substr in r["Kernel_Name"]]
             if not rows:
                 return None
@@ -149,13 +168,14 @@ def pmc_traffic(kernel_substr):
         return None
 
 
-def cpu_baseline_subprocess(args):
-    """The cpu_baseline leg in a child process with every core (this process runs torch's host ops on one thread)."""
+def cpu_baseline_subprocess(args, threads=None, sample=None, budget=45):
+    """The cpu_baseline leg in a child process (this process runs torch's host ops on one thread): all host cores
+    (the oracle stops scaling beyond 64 threads) or `threads`."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(min(os.cpu_count() or 1, 64)))   # the oracle stops scaling beyond 64
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads or min(os.cpu_count() or 1, 64)), CG3D_CPU_BUDGET_S=str(budget))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", args.cpu_sample,
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", sample or args.cpu_sample,
            "--dataset", args.dataset] + (["--natural"] if args.natural else [])
     every = (lambda: os.sched_setaffinity(0, _ALL_CPUS)) if _ALL_CPUS else None      # the child is not pinned
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, preexec_fn=every)
@@ -216,61 +236,109 @@ def main():
 
     # live HIP-event timing of every conv launch (the roofline figures) -- on at most ~6 of the timed steps, spread evenly
     # over the timed region: two events per launch add up (20 k live events in a 100-step run slowed the run itself)
-    me.KernelProfile.reset()
-    stride = max(1, -(-args.steps // 6))
-    profiled_steps = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        me.KernelProfile.enabled = i % stride == 0
-        profiled_steps += int(me.KernelProfile.enabled)
-        tb = train_step(net, opt, batch, clip)
-    barrier()
-    dt = time.perf_counter() - t0
-    me.KernelProfile.enabled = False
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run(steps):
+        me.KernelProfile.reset()
+        me.KernelProfile.wgrad = True               # the weight gradient is part of the step's 8(d) work
+        stride = max(1, -(-steps // 6))
+        profiled = 0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            me.KernelProfile.enabled = i % stride == 0
+            profiled += int(me.KernelProfile.enabled)
+            tb_ = train_step(net, opt, batch, clip)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        me.KernelProfile.enabled = False
+        if use_dist:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, profiled, tb_
 
-    if rank == 0:
+    KNAMES = {
+        "tile_bf16": ("k_spconv_tile (sparse conv fwd + dgrad on LDS-staged neighbour tiles: persistent workgroups, loader waves "
+                      "gather the tile's distinct rows into LDS, consumer waves run bf16 MFMA from LDS with fragment-ordered "
+                      "weights streamed from L2, one store per output row)", "k_spconv_tile"),
+        "implicit_bf16": ("k_spconv_implicit_bf16_ad (sparse conv fwd + dgrad, output-stationary: neighbour rows -> "
+                          "registers -> bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
+        "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)", "k_spconv_pairs_bf16"),
+        "pairs": ("k_spconv_pairs_lds (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)", "k_spconv_pairs_lds"),
+        "wgrad_bf16": ("k_spconv_pairs_wgrad_rows16 (sparse conv weight gradient, bf16 rows -> bf16 MFMA, fp32 accumulate)",
+                       "k_spconv_pairs_wgrad_rows16"),
+        "wgrad_bf16_fp32rows": ("k_spconv_pairs_wgrad_bf16 (weight gradient, fp32 rows rounded to bf16 operands)", "k_spconv_pairs_wgrad_bf16"),
+        "wgrad": ("k_spconv_pairs_wgrad / _t128 (weight gradient, fp32 MFMA)", "k_spconv_pairs_wgrad"),
+    }
+
+    def roofline_of(dt_, profiled, steps, precision):
+        """per launch flops = 2 P Cin Cout, bytes = every tensor once; bound = max(flops / MFMA peak, bytes / HBM peak)."""
         kinds = me.KernelProfile.summary()
-        kind = max(kinds, key=lambda k: kinds[k]["ms"])          # the dominant conv kernel of this run
+        fwd = {k: v for k, v in kinds.items() if not k.startswith("wgrad")}
+        kind = max(fwd, key=lambda k: fwd[k]["ms"])                      # the dominant forward / data-gradient kernel of this run
         prof = kinds[kind]
         secs = prof["ms"] * 1e-3
+        bf16 = precision == 1
+
+        def peak_of(k):      # operand type of the kernel: fp32 MFMA only for the fp32-operand kernels
+            return (FP32_MFMA_PEAK_TFLOPS if k in ("pairs", "wgrad") else BF16_MFMA_PEAK_TFLOPS) * 1e12
+        bw = HBM_PEAK_GBS * 1e9
+        t_f, t_b = prof["flops"] / peak_of(kind), prof["bytes"] / bw
         tf = prof["flops"] / secs / 1e12 if secs > 0 else 0.0
         gbs = prof["bytes"] / secs / 1e9 if secs > 0 else 0.0
-        kname, ksym = {
-            "tile_bf16": ("k_spconv_tile (sparse conv fwd + dgrad on LDS-staged neighbour tiles: persistent workgroups, loader waves "
-                          "gather the tile's distinct rows into LDS, consumer waves run bf16 MFMA from LDS with fragment-ordered "
-                          "weights streamed from L2, one store per output row)", "k_spconv_tile"),
-            "implicit_bf16": ("k_spconv_implicit_bf16_ad (sparse conv fwd + dgrad, output-stationary: neighbour rows -> "
-                              "registers -> bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
-            "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)",
-                           "k_spconv_pairs_bf16"),
-            "pairs": ("k_spconv_pairs_lds (sparse conv fwd + dgrad: gather -> fp32 MFMA -> atomic scatter)",
-                      "k_spconv_pairs_lds"),
-        }[kind]
-        if me.PRECISION == 1:
-            # bf16 MFMA runs at 16x the fp32 rate: the kernel is bound by the row gather (+ row scatter)
-            roof = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "achieved_tflops": tf,
-                    "frac_of_bf16_mfma_peak": tf / BF16_MFMA_PEAK_TFLOPS}
+        if t_f >= t_b:
+            roof = {"kernel": KNAMES[kind][0], "bound": "mfma", "achieved": tf, "peak": peak_of(kind) / 1e12, "unit": "TFLOP/s",
+                    "frac": tf / (peak_of(kind) / 1e12), "traffic": None, "algorithmic_gbytes_per_s": gbs}
         else:
-            roof = {"kernel": kname, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_gbytes_per_s": gbs}
+            roof = {"kernel": KNAMES[kind][0], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "achieved_tflops": tf}
+        per_kind = {}
+        for r in me.KernelProfile.records:
+            d = per_kind.setdefault(r[4][0], [0.0, 0.0])
+            d[0] += max(r[2] / peak_of(r[4][0]), r[3] / bw)
+            d[1] += r[0].elapsed_time(r[1]) * 1e-3
         roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
-                    kernel_time_share=secs / (dt * profiled_steps / args.steps), timed_steps=profiled_steps,
+                    kernel_time_share=secs / (dt_ * profiled / steps), timed_steps=profiled,
                     algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1),
-                    other_conv_kernels={k: {"launches": v["launches"], "ms_per_step": v["ms"] / profiled_steps}
-                                        for k, v in kinds.items() if k != kind})
-        roof["traffic"] = pmc_traffic(ksym)   # bytes per launch, from profiles/ (separate --pmc runs)
-        # SURVEY 8(d) aggregate over every timed conv launch (forward + data gradient): sum of per-launch roofline
-        # bounds max(flops / MFMA peak, bytes / HBM peak) over the sum of measured times
-        mfma_peak = (BF16_MFMA_PEAK_TFLOPS if me.PRECISION == 1 else FP32_MFMA_PEAK_TFLOPS) * 1e12
-        bound_s = sum(max(r[2] / mfma_peak, r[3] / (HBM_PEAK_GBS * 1e9)) for r in me.KernelProfile.records)
-        meas_s = sum(v["ms"] for v in kinds.values()) * 1e-3
-        roof["conv_fwd_dgrad_bound_over_measured"] = bound_s / meas_s if meas_s > 0 else None
+                    algorithmic_flops_per_launch=prof["flops"] / max(prof["launches"], 1),
+                    # sum of the launches' own bounds / sum of their measured times (a kernel mixing MFMA-bound and
+                    # HBM-bound layers is priced layer by layer)
+                    frac_8d_per_layer=per_kind[kind][0] / per_kind[kind][1] if per_kind[kind][1] > 0 else None,
+                    # round 1's figure: a gathered row counted once per pair it takes part in (NOT the 8(d) numerator)
+                    per_pair_gbytes_per_s=prof["bytes_per_pair"] / secs / 1e9 if secs > 0 else None,
+                    conv_kernels={k: {"launches_per_step": v["launches"] / profiled, "ms_per_step": v["ms"] / profiled,
+                                      "bound_over_measured": per_kind[k][0] / per_kind[k][1] if per_kind[k][1] > 0 else None,
+                                      "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
+                                      "gbytes_per_s_8d": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None}
+                                  for k, v in kinds.items()})
+        roof["traffic"] = pmc_traffic(KNAMES[kind][1]) if bf16 else None      # bytes per launch, from profiles/ (separate --pmc runs)
+        bound_all = sum(v[0] for v in per_kind.values())
+        meas_all = sum(v[1] for v in per_kind.values())
+        # every sparse convolution of the step (forward, data and weight gradient): their 8(d) bounds over their measured
+        # time, and over the whole step (which also holds BN, the heads, losses, target assignment, AdamW, map building)
+        roof["conv_bound_over_conv_time"] = bound_all / meas_all if meas_all > 0 else None
+        roof["conv_bound_over_step_time"] = (bound_all / profiled) / (dt_ / steps)
+        return roof
+
+    dt, profiled_steps, tb = timed_run(args.steps)
+    roof = roofline_of(dt, profiled_steps, args.steps, me.PRECISION) if rank == 0 else None
+
+    fp32 = None
+    if me.PRECISION == 1 and not args.no_fp32 and os.environ.get("CG3D_BENCH_FP32", "1") != "0":
+        # the parity configuration (fp32 operands everywhere) in the same process, same model and batch
+        me.PRECISION = 0
+        n32 = max(3, min(args.steps, 6))
+        for _ in range(2):
+            train_step(net, opt, batch, clip)
+        dt32, prof32, _ = timed_run(n32)
+        if rank == 0:
+            r32 = roofline_of(dt32, prof32, n32, 0)
+            fp32 = {"value": world * args.batch * n32 / dt32, "unit": "scenes/s", "ms_per_step": dt32 / n32 * 1e3, "steps": n32,
+                    "warmup": 2, "dominant_kernel": r32["kernel"], "bound": r32["bound"], "achieved": r32["achieved"],
+                    "roofline_unit": r32["unit"], "frac": r32["frac"], "frac_8d_per_layer": r32["frac_8d_per_layer"],
+                    "avg_launch_ms": r32["avg_launch_ms"], "conv_bound_over_step_time": r32["conv_bound_over_step_time"]}
+        me.PRECISION = 1
+
+    if rank == 0:
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -280,13 +348,24 @@ def main():
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
-                          "precision": ("bf16 MFMA operands in conv fwd/dgrad, fp32 accumulate/storage/wgrad"
+                          "precision": ("bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
+                                        "backbone, class branches and RoI pooling; forward, data gradient AND weight gradient "
+                                        "(k_spconv_pairs_wgrad_rows16 on the bf16 row copies); activations, weights, gradients, "
+                                        "BatchNorm, 1x1x1 convolutions, heads, losses and the optimizer stay fp32"
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
                           "last_loss": tb.get("loss_all")},
                "roofline": roof}
+        if fp32 is not None:
+            out["fp32"] = fp32
+        if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):
+            out["comm"] = model.grad_sync.report()
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline_subprocess(args)
+                try:        # one thread: the same step on a smaller scene (a 50 k-point step takes minutes on one core)
+                    out["cpu_baseline"]["single_thread"] = cpu_baseline_subprocess(args, threads=1, sample=args.cpu_sample_1t, budget=40)
+                except Exception as e:
+                    out["cpu_baseline"]["single_thread"] = {"value": None, "sample": "failed: %r" % (e,)}
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -66,10 +66,12 @@ _SIGNATURES = {
     "cg3d_bn_bwd_apply": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, c_float, P, P, P, P, c_int32, c_int32, P, P, P, P]),
     "cg3d_boxes_overlap_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
     "cg3d_boxes_iou_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
+    "cg3d_boxes_iou_bev_cpu": (c_int32, [P, c_int64, P, c_int64, P]),
     "cg3d_nms": (c_int32, [P, c_int64, c_float, c_int32, P, P, P, P]),
     "cg3d_nms_batched": (c_int32, [P, P, P, c_int32, c_int64, c_float, c_int32, P, P, P, P]),
     "cg3d_knn_ws_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "cg3d_knn": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P]),
+    "cg3d_ball_query": (c_int32, [c_int32, c_int32, c_int32, c_float, c_int32, P, P, P, P]),
     "cg3d_sort_vertices": (c_int32, [c_int32, c_int32, c_int32, P, P, P, P, P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -20,19 +20,19 @@
 #define DG_DP2 2.4187564849853515625e-4f
 #define DG_DP3 3.77489497744594108e-8f
 
-__device__ static inline float dg_poly_sin(float x, float z) {
+__host__ __device__ static inline float dg_poly_sin(float x, float z) {
     float p = -1.9515295891E-4f;
     p = p * z + 8.3321608736E-3f;
     p = p * z + -1.6666654611E-1f;
     return p * z * x + x;
 }
-__device__ static inline float dg_poly_cos(float z) {
+__host__ __device__ static inline float dg_poly_cos(float z) {
     float p = 2.443315711809948E-005f;
     p = p * z + -1.388731625493765E-003f;
     p = p * z + 4.166664568298827E-002f;
     return p * z * z - 0.5f * z + 1.0f;
 }
-__device__ static inline float dg_sinf(float x) {
+__host__ __device__ static inline float dg_sinf(float x) {
     float sign = 1.0f;
     if (x < 0.0f) { sign = -1.0f; x = -x; }
     int j = (int)(DG_FOPI * x);
@@ -45,7 +45,7 @@ __device__ static inline float dg_sinf(float x) {
     float r = (j == 1 || j == 2) ? dg_poly_cos(z) : dg_poly_sin(x, z);
     return sign * r;
 }
-__device__ static inline float dg_cosf(float x) {
+__host__ __device__ static inline float dg_cosf(float x) {
     float sign = 1.0f;
     if (x < 0.0f) x = -x;
     int j = (int)(DG_FOPI * x);
@@ -59,7 +59,7 @@ __device__ static inline float dg_cosf(float x) {
     float r = (j == 1 || j == 2) ? dg_poly_sin(x, z) : dg_poly_cos(z);
     return sign * r;
 }
-__device__ static inline float dg_atanf(float x) {
+__host__ __device__ static inline float dg_atanf(float x) {
     float sign = 1.0f, y;
     if (x < 0.0f) { sign = -1.0f; x = -x; }
     if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
@@ -73,7 +73,7 @@ __device__ static inline float dg_atanf(float x) {
     y += p * z * x + x;
     return sign * y;
 }
-__device__ static inline float dg_atan2f(float y, float x) {
+__host__ __device__ static inline float dg_atan2f(float y, float x) {
     const float PIF = 3.141592653589793f, PIO2F = 1.5707963267948966f;
     int code = 0;
     if (x < 0.0f) code = 2;
@@ -92,24 +92,24 @@ __device__ static inline float dg_atan2f(float y, float x) {
 #define DG_EPS 1e-8f
 struct dpt { float x, y; };
 
-__device__ static inline float d_cross3(dpt p1, dpt p2, dpt p0) {
+__host__ __device__ static inline float d_cross3(dpt p1, dpt p2, dpt p0) {
     return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
 }
-__device__ static inline float d_min(float a, float b) { return a > b ? b : a; }
-__device__ static inline float d_max(float a, float b) { return a > b ? a : b; }
-__device__ static inline bool d_rect_cross(dpt p1, dpt p2, dpt q1, dpt q2) {
+__host__ __device__ static inline float d_min(float a, float b) { return a > b ? b : a; }
+__host__ __device__ static inline float d_max(float a, float b) { return a > b ? a : b; }
+__host__ __device__ static inline bool d_rect_cross(dpt p1, dpt p2, dpt q1, dpt q2) {
     return d_min(p1.x, p2.x) <= d_max(q1.x, q2.x) && d_min(q1.x, q2.x) <= d_max(p1.x, p2.x) &&
            d_min(p1.y, p2.y) <= d_max(q1.y, q2.y) && d_min(q1.y, q2.y) <= d_max(p1.y, p2.y);
 }
 // corner-in-box test with the box's cos(-h), sin(-h) hoisted by the caller
-__device__ static inline bool d_in_box2d(const float *box, float ac, float as, dpt p) {
+__host__ __device__ static inline bool d_in_box2d(const float *box, float ac, float as, dpt p) {
     const float MARGIN = 1e-2f;
     float cx = box[0], cy = box[1];
     float rx = (p.x - cx) * ac + (p.y - cy) * (-as);
     float ry = (p.x - cx) * as + (p.y - cy) * ac;
     return (fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN);
 }
-__device__ static inline bool d_intersection(dpt p1, dpt p0, dpt q1, dpt q0, dpt *ans) {
+__host__ __device__ static inline bool d_intersection(dpt p1, dpt p0, dpt q1, dpt q0, dpt *ans) {
     if (!d_rect_cross(p0, p1, q0, q1)) return false;
     float s1 = d_cross3(q0, p1, p0);
     float s2 = d_cross3(p1, q1, p0);
@@ -129,14 +129,14 @@ __device__ static inline bool d_intersection(dpt p1, dpt p0, dpt q1, dpt q0, dpt
     }
     return true;
 }
-__device__ static inline dpt d_rot(dpt c, float ac, float as, dpt p) {
+__host__ __device__ static inline dpt d_rot(dpt c, float ac, float as, dpt p) {
     dpt r;
     r.x = (p.x - c.x) * ac + (p.y - c.y) * (-as) + c.x;
     r.y = (p.x - c.x) * as + (p.y - c.y) * ac + c.y;
     return r;
 }
 
-__device__ static float d_box_overlap(const float *a, const float *b) {
+__host__ __device__ static float d_box_overlap(const float *a, const float *b) {
     float adx = a[3] / 2, bdx = b[3] / 2, ady = a[4] / 2, bdy = b[4] / 2;
     float ax1 = a[0] - adx, ay1 = a[1] - ady, ax2 = a[0] + adx, ay2 = a[1] + ady;
     float bx1 = b[0] - bdx, by1 = b[1] - bdy, bx2 = b[0] + bdx, by2 = b[1] + bdy;
@@ -181,12 +181,12 @@ __device__ static float d_box_overlap(const float *a, const float *b) {
     }
     return fabsf(area) / 2.0f;
 }
-__device__ static inline float d_iou_bev(const float *a, const float *b) {
+__host__ __device__ static inline float d_iou_bev(const float *a, const float *b) {
     float sa = a[3] * a[4], sb = b[3] * b[4];
     float so = d_box_overlap(a, b);
     return so / fmaxf(sa + sb - so, DG_EPS);
 }
-__device__ static inline float d_iou_normal(const float *a, const float *b) {
+__host__ __device__ static inline float d_iou_normal(const float *a, const float *b) {
     float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
     float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
     float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
@@ -226,6 +226,15 @@ extern "C" int cg3d_boxes_overlap_bev(const float *A, int64_t na, const float *B
     hipLaunchKernelGGL(k_pairwise<false>, dim3((unsigned)cg3d_divup(nb, 16), (unsigned)cg3d_divup(na, 16)), dim3(256), 0,
                        cg3d_hs(stream), A, na, B, nb, out);
     CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+// boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:16, iou3d_cpu.cpp:232-252): the same pairwise BEV IoU on HOST
+// pointers, computed by the host instantiation of the very functions the kernels run (bit-identical results; no device,
+// no stream).  It is the reference's own CPU entry point of this module, not a fallback of the device path.
+extern "C" int cg3d_boxes_iou_bev_cpu(const float *A, int64_t na, const float *B, int64_t nb, float *out) {
+    if (na < 0 || nb < 0) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < na; i++)
+        for (int64_t j = 0; j < nb; j++) out[i * nb + j] = d_iou_bev(A + i * 7, B + j * 7);
     return CG3D_OK;
 }
 extern "C" int cg3d_boxes_iou_bev(const float *A, int64_t na, const float *B, int64_t nb, float *out,

@@ -316,3 +316,52 @@ extern "C" int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float 
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+
+// ------------------------------------------------------------------ ball query
+// Replaces ball_query_kernel_fast (pcdet/ops/pointnet2/pointnet2_batch/src/ball_query_gpu.cu:15-52; named in north_star,
+// caller pcdet/models/dense_heads/rbg_head.py:767-820): for every query the FIRST nsample reference points (in index
+// order) closer than `radius`, the remaining slots repeat the first hit, a query without any hit gets zeros (the
+// reference leaves its zero-initialised output untouched).  The reference gives a query to one thread that walks all n
+// points; here a wave64 owns a query and tests 64 candidates per step: the hit mask is a wave ballot, a hit's output
+// slot is the popcount of the lower lanes' hits (prefix sum), and the wave leaves as soon as nsample slots are filled.
+__global__ __launch_bounds__(256) void k_ball_query(int32_t n, int32_t m, float radius2, int32_t nsample,
+                                                    const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                    int32_t *__restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= m) return;
+    const int64_t bi = blockIdx.y;
+    const float *p = new_xyz + (bi * m + q) * 3;
+    const float *X = xyz + bi * (int64_t)n * 3;
+    int32_t *out = idx + (bi * m + q) * (int64_t)nsample;
+    const float px = p[0], py = p[1], pz = p[2];
+    int cnt = 0, first = -1;
+    for (int32_t k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+        const int32_t k = k0 + lane;
+        bool hit = false;
+        if (k < n) {
+            const float x = X[k * 3], y = X[k * 3 + 1], z = X[k * 3 + 2];
+            const float d2 = (px - x) * (px - x) + (py - y) * (py - y) + (pz - z) * (pz - z);      // the reference's expression
+            hit = d2 < radius2;
+        }
+        const uint64_t bal = __ballot(hit);
+        if (bal) {
+            if (first < 0) first = k0 + __builtin_ctzll(bal);
+            const int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && pos < nsample) out[pos] = k;
+            cnt += __popcll(bal);
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    for (int l = cnt + lane; l < nsample; l += 64) out[l] = first < 0 ? 0 : first;
+}
+extern "C" int cg3d_ball_query(int32_t b, int32_t n, int32_t m, float radius, int32_t nsample, const float *new_xyz,
+                               const float *xyz, int32_t *idx, cg3d_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0 || nsample < 1 || b > 65535) return CG3D_ERR_ARG;
+    if (b == 0 || m == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_ball_query, dim3((unsigned)cg3d_divup(m, 4), (unsigned)b), dim3(256), 0, cg3d_hs(stream), n, m,
+                       radius * radius, nsample, new_xyz, xyz, idx);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -46,6 +46,12 @@ class TwoBucketGradSync:
         self._avg = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         self._world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         self._early_sent = False
+        # optional bf16 wire format (CG3D_GRAD_BF16=1): the fp32 bucket is rounded into a bf16 buffer, that one is
+        # all-reduced (half the bytes per xGMI link) and widened back before clipping / AdamW.  Off by default: the
+        # reference exchanges fp32 (torch DDP), and on one node the early / mid buckets hide under the backward pass anyway.
+        self.grad_dtype = torch.bfloat16 if __import__("os").environ.get("CG3D_GRAD_BF16") == "1" else None
+        self._wire = {}
+        self._ev = []                                # (start, end) CUDA events around finish()'s exposed wait, per step
         # identical starting point on every rank (what DDP's constructor does)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for p in params:
@@ -77,7 +83,29 @@ class TwoBucketGradSync:
 
     def _reduce(self, flat, async_op):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if self.grad_dtype is not None:
+            wire = self._wire.get(flat.data_ptr())
+            if wire is None:
+                wire = self._wire[flat.data_ptr()] = (torch.empty_like(flat, dtype=self.grad_dtype), flat)
+            wire[0].copy_(flat)
+            return dist.all_reduce(wire[0], op=op, group=self.group, async_op=async_op)
         return dist.all_reduce(flat, op=op, group=self.group, async_op=async_op)
+
+    def report(self):
+        """What the exchange costs THIS rank per step: bucket sizes and the exposed time -- the part of `finish()` the
+        main stream spends on the late bucket's all-reduce and on waiting for the early / mid buckets sent from the
+        backward pass (HIP events on the main stream; the overlapped part of the early / mid all-reduces is not in it)."""
+        sizes = {k: int(self._buf[k][0].numel() * self._buf[k][0].element_size()) for k in self._buf}
+        ms = []
+        for e0, e1 in self._ev[-64:]:
+            try:
+                ms.append(e0.elapsed_time(e1))
+            except Exception:
+                pass
+        ms.sort()
+        return {"world": self._world, "bucket_bytes": sizes, "collectives_per_step": len(sizes),
+                "exposed_ms_per_step_median": ms[len(ms) // 2] if ms else None, "exposed_ms_per_step_max": ms[-1] if ms else None,
+                "steps_sampled": len(ms), "wire_dtype": str(self.grad_dtype or torch.float32)}
 
     # -- called from the detector's forward (training): hook the tensor where the head(s) attach to the backbone
     def attach(self, tensor):
@@ -110,6 +138,10 @@ class TwoBucketGradSync:
 
     # -- called after loss.backward()
     def finish(self):
+        timed = bool(self.late or self.early) and torch.cuda.is_available() and (self.late or self.early)[0].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if not self._early_sent and self.early:
             flat, _ = self._pack("early", self.early)
             self._work = self._reduce(flat, True)
@@ -124,6 +156,13 @@ class TwoBucketGradSync:
                 w.wait()
         self._work = self._mid_work = None
         self._mid_sent = False
+        for wire, flat in self._wire.values():
+            flat.copy_(wire)
+        if timed:
+            e1.record()
+            self._ev.append((e0, e1))
+            if len(self._ev) > 256:
+                del self._ev[:128]
         if not self._avg and self._world > 1:
             for key in self._buf:
                 self._buf[key][0].div_(self._world)

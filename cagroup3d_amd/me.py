@@ -413,9 +413,12 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs, tiles
     if prof:
         ev1.record()
         xb = 2.0 if rows16 else 4.0     # bytes per gathered element
+        # SURVEY 8(d) bytes: every tensor once (input rows, output rows, weights, the dense map); last field: the per-pair
+        # figure (a gathered row counted once per pair it takes part in) round 1 reported
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      xb * n_pairs * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out,
-                                      ("implicit_bf16", K, cin, cout, n_pairs, n_out, 0)))
+                                      xb * x.shape[0] * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out,
+                                      ("implicit_bf16", K, cin, cout, n_pairs, n_out, 0),
+                                      xb * n_pairs * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out))
     return y
 
 
@@ -479,7 +482,8 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1):
         # SURVEY 8(d) bytes: every input row once, every output row once, the weights once, the map once (2-byte slots)
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
                                       2.0 * n_in * cin + 4.0 * plan.n_out * cout + 2.0 * plan.K * cin * cout + 2.0 * plan.K * plan.n_out,
-                                      ("tile_bf16", plan.K, cin, cout, n_pairs, plan.n_out, 0)))
+                                      ("tile_bf16", plan.K, cin, cout, n_pairs, plan.n_out, 0),
+                                      2.0 * n_pairs * cin + 4.0 * plan.n_out * cout + 2.0 * plan.K * cin * cout + 2.0 * plan.K * plan.n_out))
     return y
 
 
@@ -742,7 +746,7 @@ class KernelProfile:
     stream; bench.py turns it on for the timed region (roofline.achieved)."""
     enabled = False
     wgrad = False  # also time cg3d_spconv_pairs_wgrad (dev tool; the bench roofline is fwd/dgrad only)
-    records = []   # (start_event, end_event, flops, bytes, meta)
+    records = []   # (start_event, end_event, flops, SURVEY-8(d) bytes, meta, per-pair bytes)
 
     @classmethod
     def reset(cls):
@@ -752,12 +756,13 @@ class KernelProfile:
     def summary(cls):
         """Per kernel kind: launches, total ms, algorithmic flops and bytes."""
         out = {}
-        for ev0, ev1, flops, nbytes, meta in cls.records:
-            d = out.setdefault(meta[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for ev0, ev1, flops, nbytes, meta, pbytes in cls.records:
+            d = out.setdefault(meta[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "bytes_per_pair": 0.0})
             d["launches"] += 1
             d["ms"] += ev0.elapsed_time(ev1)
             d["flops"] += float(flops)
             d["bytes"] += float(nbytes)
+            d["bytes_per_pair"] += float(pbytes)
         return out
 
 
@@ -796,10 +801,11 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
         # scattered output row once (the PMC passes in profiles/ count the atomic payload once as well)
         # + the weights once + the two pair lists
         wb = 2.0 if prec == 1 else 4.0
+        xb = 2.0 if rows16 else 4.0
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      n_pairs * ((2.0 if rows16 else 4.0) * cin + 4.0 * cout) + wb * K * cin * cout
-                                      + 8.0 * n_pairs,
-                                      ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg)))
+                                      xb * x.shape[0] * cin + 4.0 * n_out * cout + wb * K * cin * cout + 8.0 * n_pairs,
+                                      ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg),
+                                      n_pairs * (xb * cin + 4.0 * cout) + wb * K * cin * cout + 8.0 * n_pairs))
     return y
 
 
@@ -949,8 +955,11 @@ class SparseConvFunction(torch.autograd.Function):
             if prof:
                 ev1.record()
                 eb = 2.0 if wprec == 2 else 4.0
-                KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout, eb * P * (cin + cout) + 4.0 * KK * cin * cout,
-                                              ("wgrad_bf16" if wprec else "wgrad", KK, cin, cout, P, kmap.n_out, nseg)))
+                KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout,
+                                              eb * (kmap.n_in * cin + kmap.n_out * cout) + 4.0 * KK * cin * cout + 8.0 * P,
+                                              ("wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"),
+                                               KK, cin, cout, P, kmap.n_out, nseg),
+                                              eb * P * (cin + cout) + 4.0 * KK * cin * cout))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None

@@ -35,6 +35,19 @@ def points_in_boxes(points, boxes, point_seg=None, box_seg=None):
     return out.bool()
 
 
+def boxes_bev_iou_cpu(boxes_a, boxes_b):
+    """(N,7),(M,7) CPU tensors or numpy arrays -> (N,M) rotated BEV IoU on the host (iou3d_nms_utils.py:12-29 over
+    `boxes_iou_bev_cpu`, iou3d_cpu.cpp:232-252): the library's host instantiation of the functions its kernels run."""
+    is_numpy = not torch.is_tensor(boxes_a)
+    a = torch.as_tensor(boxes_a).float().contiguous()
+    b = torch.as_tensor(boxes_b).float().contiguous()
+    assert not (a.is_cuda or b.is_cuda), "Only support CPU tensors"
+    assert a.shape[1] == 7 and b.shape[1] == 7
+    out = a.new_zeros((a.shape[0], b.shape[0]))
+    _lib.get().call("cg3d_boxes_iou_bev_cpu", ptr(a), c_int64(a.shape[0]), ptr(b), c_int64(b.shape[0]), ptr(out))
+    return out.numpy() if is_numpy else out
+
+
 def boxes_overlap_bev(boxes_a, boxes_b):
     """(N,7),(M,7) -> (N,M) rotated BEV intersection area (iou3d_nms.cpp:49-66)."""
     return _pair("cg3d_boxes_overlap_bev", boxes_a, boxes_b)

@@ -11,10 +11,11 @@ import numpy as np
 CONFIGS = {
     # name: (config_id, n_points, n_classes, yaw, single_view)
     "S50k": (1, 50000, 18, False, False),
-    "S100k-yaw": (4, 100000, 10, True, False),
+    "S100k-yaw": (4, 100000, 10, True, True),     # SUN RGB-D shaped: one depth camera in a room corner
     "S200k": (5, 200000, 18, False, False),
     "S5k": (9, 5000, 18, False, False),   # small parity-test scene
     "S5k-yaw": (8, 5000, 10, True, False),
+    "S5k-yaw-sv": (7, 5000, 10, True, True),      # small single-view scene (tests)
 }
 
 
@@ -39,8 +40,54 @@ def _box_surface_points(rng, center, size, yaw, n):
     return p + np.asarray(center)[None]
 
 
+def _visible(cam, pts, centers, sizes, yaws):
+    """Which points a camera at `cam` sees: the segment cam -> point must not cross any object box (slab test in the box
+    frame; a point on a face turned away from the camera is hidden by its own box)."""
+    vis = np.ones(len(pts), bool)
+    d = pts - cam[None]
+    for c, sz, yw in zip(centers, sizes, yaws):
+        co, si = np.cos(-yw), np.sin(-yw)
+        rot = np.array([[co, -si, 0.0], [si, co, 0.0], [0.0, 0.0, 1.0]])
+        o = (cam - c) @ rot.T
+        dd = d @ rot.T
+        half = np.asarray(sz) / 2 - 1e-4                       # slightly shrunk: points ON a visible face stay visible
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t1 = (-half[None] - o[None]) / dd
+            t2 = (half[None] - o[None]) / dd
+        tmin = np.nanmax(np.minimum(t1, t2), axis=1)
+        tmax = np.nanmin(np.maximum(t1, t2), axis=1)
+        vis &= ~((tmax >= np.maximum(tmin, 0.0)) & (tmin < 1.0 - 1e-3))
+    return vis
+
+
 def make_scene(config="S50k", scene_idx=0):
+    cid, n_pts, n_cls, with_yaw, single_view = CONFIGS[config]
+    if single_view:
+        return _make_scene_single_view(config, scene_idx)
+    return _make_scene_full(config, scene_idx)
+
+
+def _make_scene_single_view(config, scene_idx):
+    """the SUN RGB-D-shaped scene keeps only what ONE corner camera sees -- the full scene is
+    sampled 4x denser, occluded points (behind or on the far side of an object) are dropped, and n_points of the visible
+    ones are kept: fewer surfaces at a higher density, as a single depth frame has."""
     cid, n_pts, n_cls, with_yaw, _ = CONFIGS[config]
+    dense = _make_scene_full(config, scene_idx, n_points=4 * n_pts)
+    rng = np.random.RandomState(1000 * cid + scene_idx + 500000)
+    p = dense["points"][:, :3].astype(np.float64)
+    lo, hi = p.min(0), p.max(0)
+    cam = np.array([lo[0] + 0.15, lo[1] + 0.15, 1.5])
+    gt = dense["gt_boxes"]
+    vis = _visible(cam, p, gt[:, :3].astype(np.float64), gt[:, 3:6].astype(np.float64), gt[:, 6].astype(np.float64))
+    keep = np.nonzero(vis)[0]
+    keep = keep[rng.permutation(len(keep))[:n_pts]] if len(keep) >= n_pts else keep[rng.randint(0, len(keep), n_pts)]
+    return {"points": dense["points"][keep], "gt_boxes": gt, "instance_mask": dense["instance_mask"][keep],
+            "semantic_mask": dense["semantic_mask"][keep]}
+
+
+def _make_scene_full(config="S50k", scene_idx=0, n_points=None):
+    cid, n_pts, n_cls, with_yaw, _ = CONFIGS[config]
+    n_pts = n_points or n_pts
     rng = np.random.RandomState(1000 * cid + scene_idx)
     L, W, H = rng.uniform(4, 8), rng.uniform(3, 6), rng.uniform(2.4, 3.0)
     n_obj = rng.randint(12, 21)

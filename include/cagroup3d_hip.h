@@ -321,6 +321,8 @@ int cg3d_boxes_overlap_bev(const float *boxes_a, int64_t na, const float *boxes_
                            float *out, cg3d_stream_t stream);
 int cg3d_boxes_iou_bev(const float *boxes_a, int64_t na, const float *boxes_b, int64_t nb,
                        float *out, cg3d_stream_t stream);
+/* boxes_iou_bev_cpu (iou3d_nms_api.cpp:16, iou3d_cpu.cpp:232-252): the same IoU on HOST pointers, no stream. */
+int cg3d_boxes_iou_bev_cpu(const float *boxes_a, int64_t na, const float *boxes_b, int64_t nb, float *out);
 int cg3d_nms(const float *boxes, int64_t n, float thresh, int32_t rotated,
              uint64_t *mask_ws, int64_t *keep, int32_t *num_keep, cg3d_stream_t stream);
 int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off,
@@ -339,6 +341,15 @@ int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *
 int64_t cg3d_knn_ws_bytes(int32_t b, int32_t n, int32_t m, int32_t k);
 int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const float *new_xyz,
              int32_t *idx, float *dist2, void *ws, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ball query (reference pybind `pointnet2_batch_cuda.ball_query_wrapper`, pointnet2_api.cpp / ball_query.cpp:20-37,
+ *   kernel ball_query_gpu.cu:15-52; Python caller pointnet2_utils.py:205-228): for every query new_xyz[b,m,:] the first
+ *   `nsample` rows of xyz[b,n,:] (ascending row index) with squared distance < radius^2; unfilled slots repeat the first
+ *   hit; a query without any hit gets zeros.  idx int32 [b,m,nsample].  Same argument order as the reference wrapper.
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_ball_query(int32_t b, int32_t n, int32_t m, float radius, int32_t nsample, const float *new_xyz,
+                    const float *xyz, int32_t *idx, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * sort_vertices (reference sort_vert_kernel.cu:42-134): per box pair, order the <= 8 valid

@@ -224,6 +224,10 @@ int cg3d_boxes_iou_bev(const float *A, int64_t na, const float *B, int64_t nb, f
     return CG3D_OK;
 }
 
+int cg3d_boxes_iou_bev_cpu(const float *A, int64_t na, const float *B, int64_t nb, float *out) { /* iou3d_cpu.cpp:232-252 */
+    return cg3d_boxes_iou_bev(A, na, B, nb, out, (cg3d_stream_t)0);
+}
+
 /* mask tiles (.cu:267-311 / 328-372) + greedy scan (iou3d_nms.cpp:117-132 / 167-182) */
 static void og_nms_one(const float *boxes, int64_t n, float thr, int rotated, uint64_t *mask,
                        int64_t *keep, int32_t *num_keep) {
@@ -308,6 +312,36 @@ int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float *xyz, const
             }
             int64_t o = ((int64_t)bi * m + q) * k;
             for (int i = 0; i < k; i++) { idx[o + i] = bx[i]; dist2[o + i] = bd[i]; }
+        }
+    return CG3D_OK;
+}
+
+/* ---------------------------------------------------------------- ball query
+ * follows pcdet/ops/pointnet2/pointnet2_batch/src/ball_query_gpu.cu:15-52 literally (one query = one loop over the
+ * reference points in index order); a query without a hit keeps the zeros its caller initialised (here: written). */
+int cg3d_ball_query(int32_t b, int32_t n, int32_t m, float radius, int32_t nsample, const float *new_xyz, const float *xyz,
+                    int32_t *idx, cg3d_stream_t s) {
+    (void)s;
+    if (b < 0 || n < 0 || m < 0 || nsample < 1) return CG3D_ERR_ARG;
+    const float radius2 = radius * radius;                      /* .cu:28 */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int32_t bi = 0; bi < b; bi++)
+        for (int32_t q = 0; q < m; q++) {
+            const float *p = new_xyz + ((int64_t)bi * m + q) * 3;
+            const float *X = xyz + (int64_t)bi * n * 3;
+            int32_t *out = idx + ((int64_t)bi * m + q) * nsample;
+            for (int l = 0; l < nsample; l++) out[l] = 0;
+            int cnt = 0;
+            for (int k = 0; k < n; ++k) {                       /* .cu:34-49 */
+                float x = X[k * 3 + 0], y = X[k * 3 + 1], z = X[k * 3 + 2];
+                float d2 = (p[0] - x) * (p[0] - x) + (p[1] - y) * (p[1] - y) + (p[2] - z) * (p[2] - z);
+                if (d2 < radius2) {
+                    if (cnt == 0) for (int l = 0; l < nsample; ++l) out[l] = k;
+                    out[cnt] = k;
+                    ++cnt;
+                    if (cnt >= nsample) break;
+                }
+            }
         }
     return CG3D_OK;
 }

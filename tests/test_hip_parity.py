@@ -469,6 +469,43 @@ def test_knn_bit_exact(oracle, hip, b, n, m, k):
         assert int(out[0][0, 0, 0]) == 2
 
 
+def test_boxes_bev_iou_cpu_entry_point_equals_device_kernel(oracle, hip):
+    """boxes_iou_bev_cpu (iou3d_nms_api.cpp:16): host pointers through the HIP library's host instantiation of the same
+    functions == its kernel == the oracle, bit for bit."""
+    a, b = rand_boxes(150, seed=3), rand_boxes(90, seed=4)
+    with _lib.use_library(hip):
+        host = iou3d_nms_utils.boxes_bev_iou_cpu(a, b)
+        dev = iou3d_nms_utils.boxes_iou_bev(a.cuda(), b.cuda())
+        assert isinstance(iou3d_nms_utils.boxes_bev_iou_cpu(a.numpy(), b.numpy()), np.ndarray)
+    with _lib.use_library(oracle):
+        ref = iou3d_nms_utils.boxes_iou_bev(a, b)
+    eq(host, dev)
+    eq(host, ref)
+
+
+@pytest.mark.parametrize("b,n,m,radius,nsample", [(1, 5000, 3000, 0.3, 16), (2, 700, 300, 0.5, 64), (1, 200, 65, 0.05, 8),
+                                                  (2, 64, 10, 10.0, 100), (1, 1, 3, 0.1, 4), (1, 50000, 2000, 0.2, 32)])
+def test_ball_query_bit_exact(oracle, hip, b, n, m, radius, nsample):
+    """f4: the wave-ballot ball query == the reference's one-thread-per-query walk (first nsample hits in index order, the
+    first hit repeated in unfilled slots, zeros when a ball is empty), including exact ties at the radius."""
+    from cagroup3d_amd.ops.ball_query import ball_query
+    g = torch.Generator().manual_seed(n + m)
+    xyz = torch.rand(b, n, 3, generator=g) * 4
+    q = torch.rand(b, m, 3, generator=g) * 4
+    q[:, 0] = 100.0                                                   # an empty ball
+    ref, out = both(oracle, hip, lambda x, c: ball_query(radius, nsample, x, c), xyz.contiguous(), q.contiguous())
+    eq(ref, out)
+    assert int(out[0, 0].abs().sum()) == 0
+    # independent check of the semantics on one batch element
+    d2 = ((q[0, :, None, :] - xyz[0, None, :, :]) ** 2).sum(-1)
+    for qi in (1, m - 1):
+        hits = torch.nonzero(d2[qi] < radius * radius).view(-1)[:nsample].tolist()
+        exp = (hits + [hits[0]] * (nsample - len(hits))) if hits else [0] * nsample
+        got = out[0, qi].cpu().tolist()
+        # (torch's broadcast expression may round a distance at the radius differently: only such rows may differ)
+        assert got == exp or any(abs(float(d2[qi, k]) - radius * radius) < 1e-5 for k in set(got) ^ set(exp))
+
+
 @pytest.mark.parametrize("b,n,m,far", [(1, 6000, 2000, 0.0), (2, 9000, 5000, 0.2), (1, 20000, 30000, 1.0)])
 def test_knn1_uniform_grid_is_exact(oracle, hip, b, n, m, far):
     """k = 1 on large problems goes through the cell grid: same indices and distances as the exhaustive scan, including

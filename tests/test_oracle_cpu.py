@@ -276,3 +276,20 @@ def test_sort_vertices_is_anticlockwise_from_positive_x_axis():
         # ascending angle starting just above -0 ... the first vertex is the one closest after the +x axis
         assert bool((a[1:] > a[:-1]).all()), (a, order)
         assert idx[0, i, k] == idx[0, i, 0]
+
+
+def test_ball_query_oracle_against_torch():
+    """f4: first nsample in-radius reference rows in index order, first hit repeated, zeros for an empty ball."""
+    from cagroup3d_amd.ops.ball_query import ball_query
+    g = torch.Generator().manual_seed(1)
+    xyz, q = torch.rand(2, 400, 3, generator=g) * 2, torch.rand(2, 90, 3, generator=g) * 2
+    q[0, 3] = 50.0
+    r, ns = 0.35, 12
+    idx = ball_query(r, ns, xyz.contiguous(), q.contiguous())
+    assert idx.shape == (2, 90, ns) and idx.dtype == torch.int32
+    d2 = ((q[:, :, None, :] - xyz[:, None, :, :]) ** 2).sum(-1)
+    for b in range(2):
+        for j in range(90):
+            hits = torch.nonzero(d2[b, j] < r * r).view(-1)[:ns].tolist()
+            exp = (hits + [hits[0]] * (ns - len(hits))) if hits else [0] * ns
+            assert idx[b, j].tolist() == exp, (b, j)
