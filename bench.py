@@ -75,8 +75,8 @@ def fresh(batch):
     return b
 
 
-def make_model(dataset, forced, device):
-    model, cfg = build_model.build_cagroup3d(dataset, seed=0)
+def make_model(dataset, forced, device, voxel_size=None):
+    model, cfg = build_model.build_cagroup3d(dataset, seed=0, voxel_size=voxel_size)
     if forced:
         model.dense_head.force_gt_selection = True
         # trained-like stage-1 scores: the map of class c fires for class c, so proposals survive
@@ -206,7 +206,7 @@ def main():
     forced = not args.natural
     me.PRECISION = 1 if args.precision == "bf16" else 0
 
-    model, cfg = make_model(args.dataset, forced, dev)
+    model, cfg = make_model(args.dataset, forced, dev, build_model.VOXEL_SIZE_OF_CONFIG.get(args.config))
     model.train()
     net = model
     if use_dist and os.environ.get("CG3D_TORCH_DDP") == "1":      # A/B: torch DDP (per-parameter hooks + bucket copies)

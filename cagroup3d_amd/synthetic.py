@@ -16,7 +16,13 @@ CONFIGS = {
     "S5k": (9, 5000, 18, False, False),   # small parity-test scene
     "S5k-yaw": (8, 5000, 10, True, False),
     "S5k-yaw-sv": (7, 5000, 10, True, True),      # small single-view scene (tests)
+    # LEARNABLE variants (the convergence / mAP evidence runs, tools/synthetic_convergence.py): the class of an object is
+    # a function of its shape (6 length bins x 3 height bins) instead of SURVEY 8(d)'s uniformly random label, which no
+    # detector can predict on held-out scenes
+    "S50k-shape": (11, 50000, 18, False, False),
+    "S20k-shape": (12, 20000, 18, False, False),
 }
+SHAPE_LABELS = ("S50k-shape", "S20k-shape")
 
 
 def _box_surface_points(rng, center, size, yaw, n):
@@ -96,6 +102,8 @@ def _make_scene_full(config="S50k", scene_idx=0, n_points=None):
                     sizes[:, 2] / 2]
     yaws = rng.uniform(-np.pi, np.pi, n_obj) if with_yaw else np.zeros(n_obj)
     labels = rng.randint(0, n_cls, n_obj)
+    if config in SHAPE_LABELS:
+        labels = (np.clip(((sizes[:, 0] - 0.4) / 1.4 * 6).astype(int), 0, 5) * 3 + np.clip(((sizes[:, 2] - 0.4) / 1.2 * 3).astype(int), 0, 2))
     # surfaces: floor, 4 walls, objects
     areas = [L * W, L * H, L * H, W * H, W * H] + [2 * (s[0] * s[2] + s[1] * s[2]) + s[0] * s[1] for s in sizes]
     areas = np.asarray(areas)

@@ -53,6 +53,17 @@ class SyntheticIndoorDataset:
     def __len__(self):
         return (len(self.scene_ids) + self.batch_size - 1) // self.batch_size
 
+    _cache = {}
+
+    def _scene(self, s):
+        """Scenes are deterministic in (config, index): generated once per process (0.3 s each at 50 k points)."""
+        key = (self.config, s)
+        if key not in SyntheticIndoorDataset._cache:
+            if len(SyntheticIndoorDataset._cache) > 512:
+                SyntheticIndoorDataset._cache.clear()
+            SyntheticIndoorDataset._cache[key] = synthetic.make_scene(self.config, s)
+        return SyntheticIndoorDataset._cache[key]
+
     def batches(self, epoch=0, shuffle=False):
         ids = list(self.all_ids)
         if shuffle:
@@ -60,7 +71,7 @@ class SyntheticIndoorDataset:
         ids = shard_ids(ids, self.rank, self.world)
         for i in range(0, len(ids), self.batch_size):
             chunk = ids[i:i + self.batch_size]
-            scenes = [synthetic.make_scene(self.config, s) for s in chunk]
+            scenes = [self._scene(s) for s in chunk]
             pts = np.concatenate([np.c_[np.full(len(s["points"]), j, np.float32), s["points"]] for j, s in enumerate(scenes)])
             gmax = max(len(s["gt_boxes"]) for s in scenes)
             gt = np.zeros((len(scenes), gmax, 8), np.float32)
@@ -152,7 +163,7 @@ def checkpoint_state(model, optimizer, epoch, it):
 _FROZEN = [False]
 
 
-def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=0, log=print):
+def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=0, log=print, losses=None):
     model.train()
     model_func = model_fn_decorator()
     params = [p for p in model.parameters() if p.requires_grad]
@@ -192,6 +203,8 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
             gc.collect()
             gc.freeze()
             _FROZEN[0] = True
+        if losses is not None:
+            losses.append(float(loss.detach()))
         if rank == 0:
             log("epoch %d it %d lr %.2e loss %.4f (%s)" % (epoch, it, optimizer.param_groups[0]["lr"], float(loss.detach()),
                                                           ", ".join("%s %.3f" % (k, v) for k, v in sorted(tb.items()) if k.startswith("loss_"))))

@@ -206,3 +206,128 @@ def test_full_size_knn_self_query_and_nms_idempotence(hip):
     iou = inter / (area[:, None] + area[None] - inter).clamp(min=1e-8)
     iou.fill_diagonal_(0)
     assert float(iou.max()) <= 0.5 + 1e-6           # no surviving pair overlaps more than the threshold
+
+
+def _backbone_stage_outputs(model, batch):
+    """Features after every stage of BiResNet (forward hooks on its direct children), keyed by module name."""
+    feats, hooks = {}, []
+    for name, mod in model.backbone_3d.named_children():
+        def hook(m, inp, out, name=name):
+            t = out.F if hasattr(out, "F") else (out["sp_tensor"].F if isinstance(out, dict) and "sp_tensor" in out else None)
+            if t is not None:
+                feats[name] = t.detach().float().clone()
+        hooks.append(mod.register_forward_hook(hook))
+    try:
+        ret, tb, _ = model(batch)
+    finally:
+        for h in hooks:
+            h.remove()
+    return feats, ret, tb
+
+
+def _backbone_functional_grads(model, dev):
+    """Gradients of a fixed linear functional of the backbone output (no vote quantisation, class-map membership or NMS in
+    the path): {parameter name: gradient}."""
+    model.zero_grad()
+    batch = build_model.synthetic_batch("S5k", 2, device=dev)
+    batch["points"][:, -3:] = batch["points"][:, -3:] / 255.
+    sp = model.voxelization(batch["points"])
+    out = model.backbone_3d({"sp_tensor": sp, "batch_size": 2})["sp_tensor"]
+    proj = torch.randn(out.F.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    (out.F * proj).sum().backward()
+    return {n: p.grad.detach().cpu().clone() for n, p in model.backbone_3d.named_parameters() if p.grad is not None}
+
+
+def _rel_l2(g1, g0):
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    return (num / den) ** 0.5
+
+
+def test_bf16_per_stage_features_and_backbone_gradients(oracle, hip):
+    """SURVEY 8(d) bf16 tolerance, stage by stage: every BiResNet stage output within 2e-2 of its scale, the end-to-end loss
+    within 1 %.
+
+    Gradients: bf16 vs fp32 differ by ~0.2 in relative L2 even for a fixed linear functional of the backbone output (no
+    vote quantisation / class membership / NMS in the path), i.e. the deviation of the full step (0.16, test above) IS
+    operand rounding -- ~60 convolutions in series, each rounding its input rows and output gradients to 8 mantissa bits,
+    through BatchNorm backward passes of an untrained net whose parameter gradients are sums with heavy cancellation.
+    It is a property of the arithmetic, not of the kernels: the CPU oracle's independent bit-level emulation of the same
+    rounding deviates from ITS fp32 run by the same amount, and the HIP bf16 gradients agree with the oracle's bf16
+    gradients to 1e-2."""
+    res = []
+    for lib, dev, prec in ((hip, "cuda", 0), (hip, "cuda", 1), (oracle, "cpu", 0), (oracle, "cpu", 1)):
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        model.dense_head.force_gt_selection = True
+        model.dense_head.force_class_logit_boost = 6.0
+        model = model.to(dev).train()
+        me.PRECISION = prec
+        try:
+            with _lib.use_library(lib):
+                feats = tb = None
+                if dev == "cuda":
+                    torch.manual_seed(1)
+                    np.random.seed(1)
+                    feats, ret, tb = _backbone_stage_outputs(model, build_model.synthetic_batch("S5k", 2, device=dev))
+                grads = _backbone_functional_grads(model, dev)
+        finally:
+            me.PRECISION = 0
+        res.append((feats, tb, grads))
+    (f0, tb0, g_hip32), (f1, tb1, g_hip16), (_, _, g_or32), (_, _, g_or16) = res
+    assert len(f0) >= 8, sorted(f0)
+    worst = {}
+    for name in f0:
+        if f0[name].shape == f1[name].shape:
+            worst[name] = float((f1[name] - f0[name]).abs().max()) / max(float(f0[name].abs().max()), 1e-6)
+    assert max(worst.values()) <= 2e-2, worst
+    assert abs(tb0["loss_all"] - tb1["loss_all"]) <= 1e-2 * abs(tb0["loss_all"]), (tb0["loss_all"], tb1["loss_all"])
+    dev_hip, dev_or = _rel_l2(g_hip16, g_hip32), _rel_l2(g_or16, g_or32)
+    fp32_pair, bf16_pair = _rel_l2(g_hip32, g_or32), _rel_l2(g_hip16, g_or16)
+    report = dict(hip_bf16_vs_fp32=dev_hip, oracle_bf16_vs_fp32=dev_or, hip_vs_oracle_fp32=fp32_pair, hip_vs_oracle_bf16=bf16_pair)
+    print("backbone gradient deviations (relative L2):", report)
+    # fp32: the two implementations differ by summation order only (1e-7 per operation) -- and the gradients already by
+    # 3e-3: the net amplifies a perturbation ~10^4-fold on its way back through ~60 layers and their BatchNorms
+    assert fp32_pair < 1e-2, report
+    assert dev_hip < 0.35 and dev_or < 0.35 and abs(dev_hip - dev_or) < 0.08, report
+    assert bf16_pair < max(dev_hip, dev_or), report              # two bf16 implementations are closer to each other than to fp32
+
+
+@pytest.mark.parametrize("dataset,cfgname,bs", [("sunrgbd", "S100k-yaw", 8), ("scannet", "S200k", 4)])
+def test_full_size_training_step_of_the_other_configs(hip, dataset, cfgname, bs):
+    """BASELINE.json configs[3] (SUN RGB-D shaped: 8 single-view 100k-point scenes with yaw, 10 classes) and configs[4]
+    (200k points at 0.01 m): one full training step in the bench precision at full size -- finite loss and gradients --
+    plus size-independent properties of the structures it builds (voxel rows == distinct voxels, rows in (batch, Morton)
+    order, every strided map a subset lattice of its parent, proposals inside the scene)."""
+    from cagroup3d_amd.pcdet.config import cfg_from_yaml_file  # noqa: F401
+    model, cfg = build_model.build_cagroup3d(dataset, seed=0, voxel_size=build_model.VOXEL_SIZE_OF_CONFIG.get(cfgname))
+    assert float(model.voxel_size) == (0.01 if cfgname == "S200k" else 0.02)
+    model.dense_head.force_gt_selection = True
+    model.dense_head.force_class_logit_boost = 6.0
+    model = model.cuda().train()
+    me.PRECISION = 1
+    try:
+        with _lib.use_library(hip):
+            batch = build_model.synthetic_batch(cfgname, bs, device="cuda")
+            n_pts = batch["points"].shape[0]
+            ret, tb, _ = model(batch)
+            ret["loss"].backward()
+            torch.cuda.synchronize()
+    finally:
+        me.PRECISION = 0
+    assert np.isfinite(tb["loss_all"]) and tb["loss_all"] > 0
+    gn = torch.stack([p.grad.float().norm() for p in model.parameters() if p.grad is not None])
+    assert torch.isfinite(gn).all() and float(gn.sum()) > 0
+    sp = batch["sp_tensor"]
+    C = sp.C.cpu().numpy()
+    assert n_pts == bs * int(cfgname[1:4]) * 1000
+    from util import morton_keys
+    keys = morton_keys(C)
+    assert (np.diff(keys.astype(np.float64)) > 0).all(), "distinct voxels in (batch, Morton) order"
+    vs = float(model.voxel_size)
+    pts = batch["points"][:, :4].clone()
+    ref = torch.unique(torch.cat([pts[:, :1], torch.floor(pts[:, 1:4] / vs)], 1).int(), dim=0).shape[0]
+    assert abs(C.shape[0] - ref) <= 2, (C.shape[0], ref)           # (GPU vs CPU float division at exact voxel boundaries)
+    out = batch["middle_feature_list"][3]
+    assert (out.C[:, 1:] % 2 == 0).all() and out.F.shape[1] == 64
+    boxes = torch.cat([p[0] for p in batch["pred_bbox_list"]])
+    assert torch.isfinite(boxes).all() and boxes.shape[1] == 7

@@ -24,7 +24,7 @@ for _ in range(STEPS):
 torch.cuda.synchronize()
 me.KernelProfile.enabled = False
 agg = collections.OrderedDict()
-for ev0, ev1, flops, nbytes, meta in me.KernelProfile.records:
+for ev0, ev1, flops, nbytes, meta, _pair_bytes in me.KernelProfile.records:       # nbytes: SURVEY 8(d) (every tensor once)
     d = agg.setdefault(meta[:4] + (meta[5],), [0, 0.0, 0.0, 0.0, 0])
     d[0] += 1; d[1] += ev0.elapsed_time(ev1); d[2] += flops; d[3] += nbytes; d[4] += meta[4]
 print("%-14s %3s %5s %5s %8s %9s %5s %8s %8s %7s %7s %6s" % ("kind", "K", "cin", "cout", "rows", "pairs", "n/st", "ms/step", "avg us", "GB/s", "TF/s", "bound%"))
@@ -32,7 +32,7 @@ tot = collections.Counter()
 for key, (n, ms, fl, by, pairs) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     kind, K, cin, cout, rows = key
     s = ms * 1e-3
-    bound = max(fl / 2.5e15, by / 8e12)
+    bound = max(fl / (157.3e12 if kind in ("pairs", "wgrad") else 2.5e15), by / 8e12)
     tot[kind] += ms / STEPS
     print("%-14s %3d %5d %5d %8d %9d %5.1f %8.3f %8.1f %7.0f %7.1f %6.1f" % (
         kind, K, cin, cout, rows, pairs // n, n / STEPS, ms / STEPS, ms / n * 1e3, by / s / 1e9, fl / s / 1e12, 100 * bound / s))
