@@ -326,7 +326,14 @@ class CAGroup3DHead(nn.Module):
         nb = len(img_metas)
         if pts_semantic_mask is None:
             pts_semantic_mask = pts_instance_mask = [None] * nb
-        if self.batched and self._merged is not None and all(len(g) > 0 for g in gt_bboxes):
+        has_gt = all(len(g) > 0 for g in gt_bboxes)
+        if not has_gt and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            # the two loss paths issue different collectives (one [B,3] all-reduce vs three scalars per scene): which one
+            # runs must not depend on rank-local data.  The reference cannot train on such a scene either -- its proposal
+            # target layer indexes an empty label tensor (cagroup_proposal_target_layer.py:120) -- so this is an input error.
+            raise ValueError("a training scene without ground-truth boxes reached the dense head in a data-parallel run")
+        if self.batched and self._merged is not None and has_gt:
             return self._loss_batched(semantic_scores, voxel_offset, gt_bboxes, gt_labels, scene_points,
                                       pts_semantic_mask, pts_instance_mask)
         assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == nb \
