@@ -34,35 +34,41 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define TP_HASH 2048         // LDS hash entries of the plan builder (ucap <= 1023)
 
 // ------------------------------------------------------------------------------------------------ tile plan
-// One workgroup of 128 threads per tile, thread t = output row t of the tile.  Offsets are processed in order; the
-// neighbour rows of one offset are distinct (a kernel map is injective per offset), so "new" rows get their slots from
-// a ballot + popcount prefix sum.  When an offset would push the number of staged rows past `ucap` the current pass is
-// closed and a new one starts with that offset (the conv kernel restages per pass).
-__global__ __launch_bounds__(TP_TM) void k_tile_plan(const int32_t *__restrict__ nbr, int32_t K, int64_t n_out,
-                                                      const int32_t *__restrict__ tiles, int32_t ucap, int32_t maxpass,
-                                                      uint16_t *__restrict__ slots, uint8_t *__restrict__ live,
-                                                      int32_t *__restrict__ pass_tab, int32_t *__restrict__ npass,
-                                                      int32_t *__restrict__ ulist, int64_t ulist_cap,
-                                                      int32_t *__restrict__ cursor) {
+// One WAVE per tile, lane l = output rows l and l + 64 of the tile: every step of the loop over the offsets is
+// wave-synchronous (no workgroup barrier; the first version ran two waves with five barriers per offset and took ~2 us
+// per offset -- 1.5 ms for a 9^3 map), and the neighbour rows of the next TP_PF offsets are requested ahead.  Offsets are
+// processed in order; the neighbour rows of one offset are distinct (a kernel map is injective per offset), so "new"
+// rows get their slots from a ballot + popcount prefix sum in row order.  When an offset would push the number of
+// staged rows past `ucap` the current pass is closed and a new one starts with that offset (the conv kernel restages
+// per pass).
+#define TP_PF 8
+__global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nbr, int32_t K, int64_t n_out,
+                                                  const int32_t *__restrict__ tiles, int32_t ucap, int32_t maxpass,
+                                                  uint16_t *__restrict__ slots, uint8_t *__restrict__ live,
+                                                  int32_t *__restrict__ pass_tab, int32_t *__restrict__ npass,
+                                                  int32_t *__restrict__ ulist, int64_t ulist_cap,
+                                                  int32_t *__restrict__ cursor) {
     __shared__ int32_t hkey[TP_HASH];
     __shared__ uint16_t hval[TP_HASH];
     __shared__ int32_t ul[1024];
-    __shared__ int32_t wcnt[2];
-    __shared__ int32_t sh_base;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     int64_t row0 = tile * TP_TM;
     int rows = (int)(n_out - row0 < TP_TM ? n_out - row0 : TP_TM);
     if (tiles) { row0 = tiles[tile * 3 + 1]; rows = tiles[tile * 3 + 2]; }
-    const bool row_ok = t < rows;
+    const bool ok0 = lane < rows, ok1 = lane + 64 < rows;
     uint16_t *slots_t = slots + tile * (int64_t)K * TP_TM;
     uint8_t *live_t = live + tile * (int64_t)K;
     int32_t *ptab = pass_tab + tile * (int64_t)maxpass * 4;
+    const uint64_t below = (1ull << lane) - 1ull;
 
-    for (int i = t; i < TP_HASH; i += TP_TM) hkey[i] = -1;
-    __syncthreads();
-    int ucount = 0, pass_k0 = 0, np = 0;
-
+    // one wave: its LDS operations execute in program order, so this only has to stop the COMPILER from moving LDS
+    // accesses across (a workgroup fence over all address spaces would also wait for the prefetched global loads)
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); };
+    auto clear = [&]() {
+        for (int i = lane; i < TP_HASH; i += 64) hkey[i] = -1;
+        wave_sync();
+    };
     auto lookup = [&](int32_t g) -> int {          // slot of row g, 0 = not in the table
         uint32_t h = ((uint32_t)g * 2654435761u) >> 21;            // 11 bits
         for (;;) {
@@ -72,66 +78,79 @@ __global__ __launch_bounds__(TP_TM) void k_tile_plan(const int32_t *__restrict__
             h = (h + 1) & (TP_HASH - 1);
         }
     };
+    int ucount = 0, pass_k0 = 0, np = 0;
     auto flush = [&](int k1) {                      // close the pass [pass_k0, k1) with ucount staged rows
-        __syncthreads();
-        if (t == 0) {
-            int32_t base = atomicAdd(&cursor[0], ucount);
+        wave_sync();
+        int32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&cursor[0], ucount);
             if ((int64_t)base + ucount > ulist_cap || np >= maxpass) { cursor[1] = 1; base = 0; }
-            sh_base = base;
             if (np < maxpass) { ptab[np * 4] = pass_k0; ptab[np * 4 + 1] = k1; ptab[np * 4 + 2] = base; ptab[np * 4 + 3] = ucount; }
         }
-        __syncthreads();
-        const int32_t base = sh_base;
+        base = __shfl(base, 0);
         if ((int64_t)base + ucount <= ulist_cap)
-            for (int i = t; i < ucount; i += TP_TM) ulist[base + i] = ul[i];
+            for (int i = lane; i < ucount; i += 64) ulist[base + i] = ul[i];
         np++;
     };
-
-    for (int k = 0; k < K; k++) {
-        const int32_t g = row_ok ? nbr[(int64_t)k * n_out + row0 + t] : -1;
-        int s = g >= 0 ? lookup(g) : 0;
-        bool isnew = g >= 0 && s == 0;
-        uint64_t bal = __ballot(isnew);
-        if (lane == 0) wcnt[wave] = __popcll(bal);
-        __syncthreads();
-        int newcount = wcnt[0] + wcnt[1];
-        if (ucount + newcount > ucap) {             // uniform: close the pass before this offset
-            flush(k);
-            for (int i = t; i < TP_HASH; i += TP_TM) hkey[i] = -1;
-            ucount = 0;
-            pass_k0 = k;
-            isnew = g >= 0;
-            s = 0;
-            bal = __ballot(isnew);
-            __syncthreads();
-            if (lane == 0) wcnt[wave] = __popcll(bal);
-            __syncthreads();
-            newcount = wcnt[0] + wcnt[1];
+    auto insert = [&](int32_t g, int s) -> int {    // claim slot s for row g; -1 = already there (a duplicate within the offset)
+        uint32_t h = ((uint32_t)g * 2654435761u) >> 21;
+        for (;;) {
+            const int32_t prev = atomicCAS(&hkey[h], -1, g);
+            if (prev == -1) { hval[h] = (uint16_t)s; ul[s - 1] = g; return s; }
+            if (prev == g) return -1;
+            h = (h + 1) & (TP_HASH - 1);
         }
-        if (isnew) {
-            const int rank = __popcll(bal & ((1ull << lane) - 1ull)) + (wave ? wcnt[0] : 0);
-            s = ucount + rank + 1;
-            uint32_t h = ((uint32_t)g * 2654435761u) >> 21;
-            for (;;) {
-                const int32_t prev = atomicCAS(&hkey[h], -1, g);
-                if (prev == -1) { hval[h] = (uint16_t)s; ul[s - 1] = g; break; }
-                if (prev == g) { s = -1; break; }       // a duplicate within the offset (not a kernel map): resolved below
-                h = (h + 1) & (TP_HASH - 1);
+    };
+    clear();
+    int32_t pf0[TP_PF], pf1[TP_PF];
+    // (unconditional loads from clamped addresses: a load under a divergent branch makes the compiler wait for ALL
+    // outstanding memory operations right after it -- no prefetch)
+    const int r0c = ok0 ? lane : 0, r1c = ok1 ? lane + 64 : 0;
+    auto fetch = [&](int k, int32_t &g0, int32_t &g1) {
+        const int32_t *src = nbr + (int64_t)(k < K ? k : K - 1) * n_out + row0;
+        g0 = src[r0c];
+        g1 = src[r1c];
+    };
+#pragma unroll
+    for (int j = 0; j < TP_PF; j++) fetch(j, pf0[j], pf1[j]);
+    for (int kb = 0; kb < K; kb += TP_PF) {
+#pragma unroll
+        for (int j = 0; j < TP_PF; j++) {
+            const int k = kb + j;
+            const int32_t g0 = ok0 ? pf0[j] : -1, g1 = ok1 ? pf1[j] : -1;
+            fetch(k + TP_PF, pf0[j], pf1[j]);      // this register pair's next use
+            if (k < K) {
+                int s0 = g0 >= 0 ? lookup(g0) : 0, s1 = g1 >= 0 ? lookup(g1) : 0;
+                bool new0 = g0 >= 0 && s0 == 0, new1 = g1 >= 0 && s1 == 0;
+                uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
+                int newcount = __popcll(b0) + __popcll(b1);
+                if (ucount + newcount > ucap) {             // uniform: close the pass before this offset
+                    flush(k);
+                    clear();
+                    ucount = 0;
+                    pass_k0 = k;
+                    new0 = g0 >= 0; new1 = g1 >= 0;
+                    s0 = s1 = 0;
+                    b0 = __ballot(new0); b1 = __ballot(new1);
+                    newcount = __popcll(b0) + __popcll(b1);
+                }
+                if (new0) s0 = insert(g0, ucount + __popcll(b0 & below) + 1);
+                if (new1) s1 = insert(g1, ucount + __popcll(b0) + __popcll(b1 & below) + 1);
+                ucount += newcount;
+                wave_sync();
+                if (s0 < 0) s0 = lookup(g0);
+                if (s1 < 0) s1 = lookup(g1);
+                slots_t[(int64_t)k * TP_TM + lane] = (uint16_t)s0;
+                slots_t[(int64_t)k * TP_TM + lane + 64] = (uint16_t)s1;
+                // liveness of the four 32-row blocks of the tile for this offset
+                const uint64_t l0 = __ballot(g0 >= 0), l1 = __ballot(g1 >= 0);
+                if (lane == 0)
+                    live_t[k] = (uint8_t)(((l0 & 0xffffffffull) ? 1 : 0) | ((l0 >> 32) ? 2 : 0) | ((l1 & 0xffffffffull) ? 4 : 0) | ((l1 >> 32) ? 8 : 0));
             }
         }
-        ucount += newcount;
-        __syncthreads();
-        if (s < 0) s = lookup(g);
-        slots_t[(int64_t)k * TP_TM + t] = (uint16_t)s;
-        // liveness of the four 32-row blocks of the tile for this offset
-        const uint64_t lb = __ballot(g >= 0);
-        if (lane == 0) wcnt[wave] = ((lb & 0xffffffffull) ? 1 : 0) | ((lb >> 32) ? 2 : 0);
-        __syncthreads();
-        if (t == 0) live_t[k] = (uint8_t)(wcnt[0] | (wcnt[1] << 2));
-        __syncthreads();
     }
     flush(K);
-    if (t == 0) npass[tile] = np < maxpass ? np : maxpass;
+    if (lane == 0) npass[tile] = np < maxpass ? np : maxpass;
 }
 
 extern "C" int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
@@ -143,7 +162,7 @@ extern "C" int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(cursor, 0, 2 * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (ntile == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_tile_plan, dim3((unsigned)ntile), dim3(TP_TM), 0, s, nbr, K, n_out, tiles, ucap, maxpass, slots,
+    hipLaunchKernelGGL(k_tile_plan, dim3((unsigned)ntile), dim3(64), 0, s, nbr, K, n_out, tiles, ucap, maxpass, slots,
                        live, pass_tab, npass, ulist, ulist_cap, cursor);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
@@ -228,6 +247,7 @@ extern "C" int cg3d_tile_debug_read(unsigned long long *out, int reset) {
 struct StageDesc {
     int32_t valid, first, last, kb, c, rows, yb, zi;
     int64_t row0, wslot0;
+    int32_t abuf, pad_[3];       // which of the two row tiles this stage reads (sizeof stays a multiple of 16)
 };
 #define TP_NLV 16            // row granules a loader thread stages per chunk: 4 loader waves x 64 lanes x 16 = 4096 = 512 rows x 8
 
@@ -237,12 +257,18 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
     const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,
     const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-    int32_t nunit, int32_t ny, int32_t gz, int32_t maxk_dbg) {
+    int32_t nunit, int32_t ny, int32_t gz, int32_t maxk_dbg, int32_t wrev) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
     const int a_bytes = (ucap + 1) * 128 > 65536 ? (ucap + 1) * 128 : 65536;
-    const int buf_bytes = a_bytes + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12 + (int)sizeof(StageDesc);      // multiple of 16
-    volatile int32_t *xflag = reinterpret_cast<volatile int32_t *>(smem + 2 * buf_bytes);                    // [2][4] data / ack flags
+    // LDS: row tile 0 | row tile 1 | stage block 0 | stage block 1 | flags.  A stage block = slot table of <= 32 offsets,
+    // the list of live ones, the stage descriptor; it alternates every stage.  The ROW tile alternates only when a stage
+    // brings new rows: the slot-table blocks of one pass of a single-chunk layer (K > 32: the 5^3 / 9^3 class
+    // convolutions) all read the rows staged once for the pass.
+    constexpr int s_tab = TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12;                                          // slot table + live list
+    constexpr int s_bytes = s_tab + (int)sizeof(StageDesc);                                                  // multiple of 16
+    uint8_t *const sblk = smem + 2 * a_bytes;
+    volatile int32_t *xflag = reinterpret_cast<volatile int32_t *>(sblk + 2 * s_bytes);                      // [5][4] data / ack flags
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt_total = cout >> 5, ks_total = cin >> 4, nchunk = cin >> 6;
     const int G = gridDim.x;
@@ -282,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             if (!H.valid || !H.last || (DBG & 32)) return;
             constexpr int rows_per = TP_TM / KG;
             const int cw = lw, cg_ = cw / NCO, ch = cw % NCO;            // loader wave lw drains consumer wave lw
-            const float *tb = reinterpret_cast<const float *>(smem + bufi * buf_bytes) + (size_t)cw * 4096;
+            const float *tb = reinterpret_cast<const float *>(smem + bufi * a_bytes) + (size_t)cw * 4096;
             const int c4 = (lane & 15) * 4, rq = lane >> 4;
             const int col0 = (H.yb * NCO + ch) * 64 + c4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             }
             hist[bufi].valid = 0;
         };
-        int sidx = 0;
+        int sidx = 0, abuf = 1;
         PassRec cur = load_pass(blockIdx.x, 0);
         if (cur.valid) issue_idx(idx, cur.uoff, cur.ucnt);
         int u = blockIdx.x, p = 0;
@@ -326,11 +352,17 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     D.last = (last_pass && last_stage) ? 1 : 0;
                     D.kb = kb;
                     D.c = c;
-                    uint8_t *As = smem + (sidx & 1) * buf_bytes;
-                    uint16_t *slot_s = reinterpret_cast<uint16_t *>(As + a_bytes);
+                    const bool stage_rows = nchunk > 1 || kb == cur.k0;       // else: the rows of this pass are already there
+                    if (stage_rows) {
+                        abuf ^= 1;
+                        drain(abuf);                    // the output tile an earlier unit's last stage left in this row tile
+                    }
+                    D.abuf = abuf;
+                    uint8_t *As = smem + abuf * a_bytes;
+                    uint8_t *Ss = sblk + (sidx & 1) * s_bytes;
+                    uint16_t *slot_s = reinterpret_cast<uint16_t *>(Ss);
                     uint16_t *klist = slot_s + TP_KB * TP_TM;
-                    drain(sidx & 1);                    // the output tile stage sidx - 2 left in this buffer
-                    hist[sidx & 1] = D;
+                    hist[abuf] = D;
                     // ---- requests: slot table (wave 4), the stage's rows, the next pass's row indices
                     uint4 sv[8];
                     int lv = 0;
@@ -344,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                         lv = lane < nk ? live[tile * (int64_t)K + kb + lane] : 0;
                     }
                     uint4 v[TP_NLV];
-                    if (!(DBG & 8)) {
+                    if (!(DBG & 8) && stage_rows) {
 #pragma unroll
                         for (int j = 0; j < TP_NLV; j++) {
                             const int i = j * 256 + lt;
@@ -354,8 +386,8 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     }
                     if (last_stage && nxt.valid) issue_idx(idx_next, nxt.uoff, nxt.ucnt);
                     // ---- LDS: descriptor, zero row, slot table / list of live offsets, rows
-                    if (lt == 0) *reinterpret_cast<StageDesc *>(As + buf_bytes - sizeof(StageDesc)) = D;
-                    if (lt < 8) reinterpret_cast<uint4 *>(As)[lt] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
+                    if (lt == 0) *reinterpret_cast<StageDesc *>(Ss + s_tab) = D;
+                    if (lt < 8 && stage_rows) reinterpret_cast<uint4 *>(As)[lt] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
                     if (lw == 0 && c == 0 && !((DBG & 64) && sidx > 1)) {
                         // slot table of offsets [kb, kb+nk): global [k][row] -> LDS [kk][r][m]; live offsets compacted with one ballot
 #pragma unroll
@@ -376,11 +408,11 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                         if (lane == 0) klist[TP_KB] = (uint16_t)__popcll(bal);
                     } else if (lw == 1 && (c > 0 || ((DBG & 64) && sidx > 1))) {
                         // same block of offsets as the previous stage (the other buffer): copy its slot table and list
-                        const uint4 *src = reinterpret_cast<const uint4 *>(smem + ((sidx + 1) & 1) * buf_bytes + a_bytes);
-                        uint4 *dst = reinterpret_cast<uint4 *>(As + a_bytes);
-                        for (int i = lane; i < (TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12) / 16; i += 64) dst[i] = src[i];
+                        const uint4 *src = reinterpret_cast<const uint4 *>(sblk + ((sidx + 1) & 1) * s_bytes);
+                        uint4 *dst = reinterpret_cast<uint4 *>(Ss);
+                        for (int i = lane; i < s_tab / 16; i += 64) dst[i] = src[i];
                     }
-                    if (!(DBG & 8)) {
+                    if (!(DBG & 8) && stage_rows) {
 #pragma unroll
                         for (int j = 0; j < TP_NLV; j++) {
                             const int i = j * 256 + lt;
@@ -401,14 +433,14 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             p = pn;
         }
         // end marker
-        drain(sidx & 1);
+        drain(abuf ^ 1);
         if (lt == 0) {
             StageDesc E;
-            E.valid = 0; E.first = E.last = 0; E.kb = E.c = E.rows = E.yb = E.zi = 0; E.row0 = E.wslot0 = 0;
-            *reinterpret_cast<StageDesc *>(smem + (sidx & 1) * buf_bytes + buf_bytes - sizeof(StageDesc)) = E;
+            E.valid = 0; E.first = E.last = 0; E.kb = E.c = E.rows = E.yb = E.zi = 0; E.row0 = E.wslot0 = 0; E.abuf = 0;
+            *reinterpret_cast<StageDesc *>(sblk + (sidx & 1) * s_bytes + s_tab) = E;
         }
         __syncthreads();
-        drain((sidx + 1) & 1);                          // the last unit's tile
+        drain(abuf);                                    // the last unit's tile
         return;
     }
 
@@ -425,11 +457,12 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     for (int sidx = 0;; sidx++) {
         __syncthreads();                                // the loader has filled buffer sidx & 1
         stamp(0);
-        uint8_t *As = smem + (sidx & 1) * buf_bytes;
-        const uint16_t *slot_s = reinterpret_cast<const uint16_t *>(As + a_bytes);
+        const uint8_t *Ss = sblk + (sidx & 1) * s_bytes;
+        const uint16_t *slot_s = reinterpret_cast<const uint16_t *>(Ss);
         const uint16_t *klist = slot_s + TP_KB * TP_TM;
-        const StageDesc D = *reinterpret_cast<const StageDesc *>(As + buf_bytes - sizeof(StageDesc));
+        const StageDesc D = *reinterpret_cast<const StageDesc *>(Ss + s_tab);
         if (!D.valid) break;
+        uint8_t *As = smem + D.abuf * a_bytes;
         stamp(1);
         if (D.first) {
 #pragma unroll
@@ -446,8 +479,9 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
         const int nstep = first < nlive ? (nlive - first + stride - 1) / stride : 0;     // offsets of this wave
         if (nstep > 0) {
             // weight fragments of (offset kk, 16-channel group ks, output block n): Wf[slot][nt][ks][lane][8]
-            const uint16_t *wbase = Wf + ((D.wslot0 + D.kb) * nt_total + nt0) * (int64_t)ks_total * 512 + (int64_t)D.c * 4 * 512 + lane * 8;
-            const int64_t wstride = (int64_t)nt_total * ks_total * 512;       // per offset
+            // (wrev: offset k reads weight slot K-1-k -- the data gradient of a map onto itself walks the FORWARD plan)
+            const uint16_t *wbase = Wf + ((D.wslot0 + (wrev ? K - 1 - D.kb : D.kb)) * nt_total + nt0) * (int64_t)ks_total * 512 + (int64_t)D.c * 4 * 512 + lane * 8;
+            const int64_t wstride = (wrev ? -1 : 1) * (int64_t)nt_total * ks_total * 512;       // per offset
             const int64_t wn = (int64_t)ks_total * 512;                        // per 32-channel output block
             struct Rows { uint32_t base[4], sw[4]; };                          // LDS row address / swizzle of the 4 row blocks
             auto rows_of = [&](int kk) -> Rows {
@@ -642,7 +676,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
                                     const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist,
                                     int32_t maxpass, int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias,
                                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-                                    int32_t ksplit, cg3d_stream_t stream) {
+                                    int32_t ksplit, int32_t wrev, cg3d_stream_t stream) {
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
         return CG3D_ERR_ARG;
     if (ucap < TP_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
@@ -679,7 +713,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
             }                                                                                                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spconv_tile<NW, DBG>), dim3((unsigned)grid), dim3(512), lds, s, X, Wf, slots, live, pass_tab,    \
-                           npass, ulist, maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, maxk); \
+                           npass, ulist, maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, maxk, wrev ? 1 : 0); \
     } while (0)
 #define TILE_LAUNCH_NW(DBG)                                                                                                    \
     do { if (cout >= 128) TILE_LAUNCH(2, DBG); else TILE_LAUNCH(1, DBG); } while (0)

@@ -133,6 +133,7 @@ class KernelMap:
         self._pairs = None
         self._segs = {}
         self.same_map = False
+        self.symmetric = False
 
     @property
     def nbrT(self):
@@ -176,14 +177,16 @@ class KernelMap:
             self._pairs[row_bounds] = hit
         return hit
 
-    def tile_plan(self, transposed):
-        """TilePlan of the map (forward) or of its transpose (data gradient); cached."""
-        ck = ("plan", bool(transposed))
+    def tile_plan(self, transposed, row_bounds=None):
+        """TilePlan of the map (forward) or of its transpose (data gradient); cached.  With `row_bounds` the tiles are
+        cut group by group (`tiles(row_bounds)`: no tile straddles two groups' weights)."""
+        ck = ("plan", bool(transposed) and not self.symmetric, row_bounds)        # symmetric: one plan, weights reversed
+        transposed = ck[1]
         pl = self._segs.get(ck)
         if pl is None:
-            _, _, _, P = self.pairs(None)
+            _, _, _, P = self.pairs(row_bounds)
             nbr = self.nbrT if transposed else self.nbr
-            pl = build_tile_plan(nbr.contiguous(), P)
+            pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds))
             self._segs[ck] = pl
         return pl
 
@@ -351,6 +354,11 @@ class CoordinateManager:
             km = KernelMap(nbr.contiguous(), offs.shape[0], src.n, dst.n,
                            lambda: lookup(src.coords, dst, bwd_off).contiguous())
             km.same_map = in_key == out_key          # row groups of the output are row groups of the input
+            # a map onto itself with a centred odd kernel: off[K-1-k] == -off[k], hence nbrT[k] == nbr[K-1-k] -- no second
+            # hash lookup for the transposed map, and the tile kernel's data gradient reuses the forward plan (wrev)
+            km.symmetric = km.same_map and int(kernel_size) % 2 == 1
+            if km.symmetric:
+                km._make_T = lambda n=km.nbr: n.flip(0).contiguous()
             self._kmaps[ck] = km
         return km
 
@@ -464,7 +472,7 @@ def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None):
     return p
 
 
-def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1):
+def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups=1, wrev=False):
     """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] through a tile plan; x16: int16 view of the bf16 rows, wf: the weights in
     MFMA fragment order (cg3d_spconv_prep_weights_frag)."""
     lib = _lib.get()
@@ -476,14 +484,16 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1):
         ev0.record()
     lib.call("cg3d_spconv_tile_fwd", ptr(x16), ptr(wf), ptr(plan.slots), ptr(plan.live), ptr(plan.pass_tab), ptr(plan.npass),
              ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(bias), ptr(y),
-             c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit), lib.stream())
+             c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit),
+             c_int32(1 if wrev else 0), lib.stream())
     if prof:
         ev1.record()
         # SURVEY 8(d) bytes: every input row once, every output row once, the weights once, the map once (2-byte slots)
+        wbytes = 2.0 * groups * plan.K * cin * cout
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      2.0 * n_in * cin + 4.0 * plan.n_out * cout + 2.0 * plan.K * cin * cout + 2.0 * plan.K * plan.n_out,
+                                      2.0 * n_in * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out,
                                       ("tile_bf16", plan.K, cin, cout, n_pairs, plan.n_out, 0),
-                                      2.0 * n_pairs * cin + 4.0 * plan.n_out * cout + 2.0 * plan.K * cin * cout + 2.0 * plan.K * plan.n_out))
+                                      2.0 * n_pairs * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out))
     return y
 
 
@@ -571,7 +581,7 @@ class _WeightPlan:
     converts every recorded weight whose tensor version changed (i.e. after every optimizer step, never in inference)
     into one persistent arena with a single launch, and the per-layer requests are answered from the arena."""
     singles = {}        # (data_ptr, frag) -> [w3, need_plain, version, wt_view, wp_view]; frag: MFMA fragment order (tile kernel)
-    groups = {}         # (ptrs, transposed) -> [weights, versions, out_view]
+    groups = {}         # (ptrs, transposed, frag) -> [weights, versions, out_view]
     table = None        # device int64 [nrows, 6]
     nrows = 0
     dirty = False
@@ -615,12 +625,12 @@ class _WeightPlan:
                 e[4] = arena_p[op:op + w.numel()].view(K, cin, cout)
                 op += w.numel()
             e[2] = -1
-        for (ptrs, transposed), g in cls.groups.items():
+        for (ptrs, transposed, frag), g in cls.groups.items():
             ws = g[0]
             K, cin, cout = ws[0].shape
             base = ot if transposed else op
             for i, w in enumerate(ws):
-                add(w, base + i * w.numel() if transposed else None, None if transposed else base + i * w.numel())
+                add(w, base + i * w.numel() if transposed else None, None if transposed else base + i * w.numel(), frag)
             tot = sum(w.numel() for w in ws)
             if transposed:
                 g[2] = arena_t[ot:ot + tot].view(len(ws) * K, cout, cin)
@@ -713,18 +723,19 @@ def _prep_bf16_both(w3):
 _wptr_cache = {}
 
 
-def _prep_bf16_group(weights, transposed):
+def _prep_bf16_group(weights, transposed, frag=False):
     """Per-group weights (G tensors [K, cin, cout], never stacked in fp32) -> int16 view of the stacked bf16 buffer
-    [G*K, cout, cin] (transposed) or [G*K, cin, cout]."""
+    [G*K, cout, cin] (transposed) or [G*K, cin, cout]; frag: each [cin, cout] block in MFMA fragment order instead
+    (the tile kernel's operand, cg3d_spconv_prep_weights_frag)."""
     lib = _lib.get()
     G, (K, cin, cout) = len(weights), weights[0].shape
     key = tuple(w.data_ptr() for w in weights)
-    g = _WeightPlan.groups.get((key, transposed))
+    g = _WeightPlan.groups.get((key, transposed, frag))
     if g is not None:
         if _WeightPlan.live and g[2] is not None and g[1] == tuple(w._version for w in weights):
             return g[2]
     elif lib.is_device:
-        _WeightPlan.groups[(key, transposed)] = [[w.detach() for w in weights], None, None]
+        _WeightPlan.groups[(key, transposed, frag)] = [[w.detach() for w in weights], None, None]
         _WeightPlan.dirty = True
     tab = _wptr_cache.get(key)
     if tab is None:
@@ -732,8 +743,9 @@ def _prep_bf16_group(weights, transposed):
             _wptr_cache.clear()
         tab = _wptr_cache[key] = h2d(list(key), torch.int64, weights[0].device) if lib.is_device else torch.tensor(key, dtype=torch.int64)
     out = torch.empty((G * K, cout, cin) if transposed else (G * K, cin, cout), dtype=torch.int16, device=weights[0].device)
-    lib.call("cg3d_spconv_prep_weights_bf16_multi", ptr(None), ptr(tab), ptr(out if transposed else None),
-             ptr(None if transposed else out), c_int32(G), c_int64(K), c_int32(cin), c_int32(cout), lib.stream())
+    lib.call("cg3d_spconv_prep_weights_frag" if frag else "cg3d_spconv_prep_weights_bf16_multi", ptr(None), ptr(tab),
+             ptr(out if transposed else None), ptr(None if transposed else out), c_int32(G), c_int64(K), c_int32(cin),
+             c_int32(cout), lib.stream())
     return out
 
 
@@ -834,6 +846,7 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
 
 TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
 TILE_KERNEL = __import__("os").environ.get("CG3D_TILE_KERNEL", "1") != "0"
+GROUP_TILE_KERNEL = __import__("os").environ.get("CG3D_GROUP_TILE_KERNEL", "1") != "0"
 
 
 def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
@@ -925,7 +938,7 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if getattr(ctx, "tile_b", False):
                 # the swapped problem on the plan of the transposed map; operand = the plain fragment-ordered copy
-                dx = _conv_tile(dyg, wp, kmap.tile_plan(True), None, cout, cin, kmap.n_out, P)
+                dx = _conv_tile(dyg, wp, kmap.tile_plan(True), None, cout, cin, kmap.n_out, P, wrev=kmap.symmetric)
             elif SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
                 dx = _conv_implicit_bf16(dyg, wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16),
@@ -977,6 +990,21 @@ class GroupedConvFunction(torch.autograd.Function):
         return closed and kmap.same_map and K > 1 and P >= IMPLICIT_MIN_OCCUPANCY * K * max(kmap.n_out, 1)
 
     @staticmethod
+    def _lds_tile(kmap, K, cin, cout, closed):
+        """The LDS-staged tile kernel on group-aligned tiles: closed same-map groups (forward and data gradient share the
+        row groups), bf16 row copies, channel counts the kernel's register tile covers.  The rows of a pass are staged once
+        for all of its slot-table blocks, so the 5^3 / 9^3 class convolutions (K = 125 / 729) gather each distinct
+        neighbour row once per pass instead of once per offset."""
+        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and PRECISION == 1 and BF16_ROWS
+                and cin % 64 == 0 and cout % 64 == 0 and (cin == 64 or cin % 128 == 0) and (cout == 64 or cout % 128 == 0))
+
+    @staticmethod
+    def _ksplit(plan, K):
+        """Offset shares per tile (atomics into a zeroed output) when the tiles alone cannot fill the chip."""
+        ncu = 256
+        return max(1, min(8, K // 16, ncu // max(plan.ntile, 1)))
+
+    @staticmethod
     def forward(ctx, x, kmap, row_bounds, closed, *weights):
         x = x.contiguous()
         G, (K, cin, cout) = len(weights), weights[0].shape
@@ -984,9 +1012,13 @@ class GroupedConvFunction(torch.autograd.Function):
         pin, pout, _, P = kmap.pairs(row_bounds)
         xg = _to_bf16(x, keep=True) if BF16_ROWS else x
         ctx.save_for_backward(x, xg if xg is not x else None, *weights)
-        wt = _prep_bf16_group(weights, True)
+        lds_tile = ctx.lds_tile = GroupedConvFunction._lds_tile(kmap, K, cin, cout, closed)
+        wt = _prep_bf16_group(weights, True, lds_tile)
         # the data gradient's operand: free while the step's arena is live (backward runs after the forward closed it)
-        ctx.wp_plain = _prep_bf16_group(weights, False) if (_WeightPlan.live and ctx.needs_input_grad[0]) else None
+        ctx.wp_plain = _prep_bf16_group(weights, False, lds_tile) if (_WeightPlan.live and ctx.needs_input_grad[0]) else None
+        if lds_tile:
+            plan = kmap.tile_plan(False, row_bounds)
+            return _conv_tile(xg, wt, plan, None, cin, cout, kmap.n_in, P, GroupedConvFunction._ksplit(plan, K), G)
         if GroupedConvFunction._tiled(kmap, P, K, closed):
             return _conv_implicit_bf16(xg, wt, kmap.nbr, None, kmap.n_out, cin, cout, P, kmap.tiles(row_bounds))
         seg, nseg = kmap.segments(_seg_len_fwd(), row_bounds)
@@ -1004,8 +1036,12 @@ class GroupedConvFunction(torch.autograd.Function):
         dyg = _to_bf16(dy) if BF16_ROWS else dy
         dx = None
         if ctx.needs_input_grad[0]:
-            wp = ctx.wp_plain if ctx.wp_plain is not None else _prep_bf16_group(weights, False)
-            if GroupedConvFunction._tiled(kmap, P, K, ctx.closed):
+            wp = ctx.wp_plain if ctx.wp_plain is not None else _prep_bf16_group(weights, False, ctx.lds_tile)
+            if ctx.lds_tile:
+                plan = kmap.tile_plan(True, rb)
+                dx = _conv_tile(dyg, wp, plan, None, cout, cin, kmap.n_out, P, GroupedConvFunction._ksplit(plan, K), G,
+                                wrev=kmap.symmetric)
+            elif GroupedConvFunction._tiled(kmap, P, K, ctx.closed):
                 dx = _conv_implicit_bf16(dyg, wp, kmap.nbrT, None, kmap.n_in, cout, cin, P, kmap.tiles(rb))
             else:
                 seg, nseg = kmap.segments(_seg_len_fwd(), rb)
@@ -1242,11 +1278,16 @@ _BN_CHUNK = 256
 _chunk_cache = {}
 
 
-def _bn_chunks(bounds, device):
+def _bn_chunks(bounds, device, C=64):
     """Chunk tables for row groups `bounds` (host tuple of G+1 offsets), cached on the device:
     reduce table (<=1024 chunks per group: few, long chunks for the statistics kernels + their group offsets),
-    apply table (128-row chunks: many workgroups for the streaming kernels), group_n float32 [G]."""
-    ck = (bounds, str(device))
+    apply table (many workgroups for the streaming kernels), group_n float32 [G].
+    A 256-thread workgroup covers 256 / (C/4) rows per trip (4 trips in flight), so a chunk is 8 trips' worth of rows:
+    128 rows at C = 64 down to 8 at C = 1024 -- with 128-row chunks for every C the 5330 x 512 and 1229 x 1024 layers
+    ran 42 / 10 workgroups, each thread walking 64 / 128 rows one latency at a time (23 / 41 us for 11 / 5 MB)."""
+    rpb = 256 // max(1, min(C // 4, 256))
+    step_rows = max(8, min(128, 8 * rpb))
+    ck = (bounds, str(device), step_rows)
     hit = _chunk_cache.get(ck)
     if hit is None:
         def table(step_of):
@@ -1258,8 +1299,8 @@ def _bn_chunks(bounds, device):
                 gco.append(len(rows))
             tab = h2d(rows if rows else [(0, 0, 0)], torch.int32, device).view(-1, 3)
             return tab, len(rows), h2d(gco, torch.int32, device)
-        red, nred, gco = table(lambda ng: max(128, -(-ng // 1024)))
-        app, napp, _ = table(lambda ng: 128)
+        red, nred, gco = table(lambda ng: max(step_rows, -(-ng // 1024)))
+        app, napp, _ = table(lambda ng: step_rows)
         ns = [max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)]
         unb = h2d([n / max(n - 1, 1) for n in ns], torch.float32, device).view(-1, 1)   # biased -> unbiased variance
         hit = (red, nred, gco, h2d(ns, torch.float32, device), app, napp, unb)
@@ -1280,7 +1321,7 @@ class FusedBNActFunction(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         G = len(bounds) - 1
-        chunks, nchunk, gco, group_n, achunks, nachunk, _ = _bn_chunks(bounds, x.device)
+        chunks, nchunk, gco, group_n, achunks, nachunk, _ = _bn_chunks(bounds, x.device, C)
         gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
         res = residual.contiguous() if residual is not None else None
         lib.check(x, gamma, beta, res, chunks)
@@ -1367,7 +1408,7 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     if track and running is None:
         with torch.no_grad():
             m = b0.momentum
-            unb = var * _bn_chunks(tuple(bounds), feats.device)[6]
+            unb = var * _bn_chunks(tuple(bounds), feats.device, C)[6]
             rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
             torch._foreach_mul_(rms, 1 - m)
             torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)

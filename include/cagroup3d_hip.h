@@ -205,7 +205,11 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
  *   Wf the fragment-ordered weights, fp32 accumulation, every output row stored once.  ksplit > 1 splits the live
  *   offsets over that many workgroups per tile (small maps); their partial sums meet in Y through fp32 atomics (the
  *   callee zero-fills Y).  The data gradient is the same call on the plan of the transposed map with the plain
- *   fragment copy.  Launch needs cg3d_spconv_tile_lds_bytes(ucap) <= 160 KB of LDS per workgroup.
+ *   fragment copy; for a map of a coordinate map ONTO ITSELF with a centred odd kernel (nbrT[k] == nbr[K-1-k]) it is
+ *   the call on the FORWARD plan with wrev = 1: offset k then reads weight slot K-1-k (per group when `tiles` is
+ *   given), so neither the transposed map nor its plan is ever built.  The slot-table blocks (32 offsets each) of one
+ *   pass of a cin == 64 layer share the rows staged for the pass (K = 125 / 729 class convolutions).
+ *   Launch needs cg3d_spconv_tile_lds_bytes(ucap) <= 160 KB of LDS per workgroup.
  * ---------------------------------------------------------------------------------------- */
 #define CG3D_TILE_ROWS 128
 int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
@@ -217,7 +221,8 @@ int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap);
 int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
                          int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
-                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, cg3d_stream_t stream);
+                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev,
+                         cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates

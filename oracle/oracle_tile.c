@@ -105,7 +105,7 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
 int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
                          int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
-                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, cg3d_stream_t s) {
+                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev, cg3d_stream_t s) {
     (void)s; (void)n_in; (void)ucap; (void)ksplit;
     if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127))) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -122,7 +122,7 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
             const int32_t *pt = pass_tab + (t * (int64_t)maxpass + p) * 4;
             for (int k = pt[0]; k < pt[1]; k++) {
                 const int lv = live[t * (int64_t)K + k];
-                const uint16_t *wk = Wf + (wslot0 + k) * (int64_t)cin * cout;
+                const uint16_t *wk = Wf + (wslot0 + (wrev ? K - 1 - k : k)) * (int64_t)cin * cout;
                 for (int r = 0; r < rows; r++) {
                     const int sl = slots[(t * (int64_t)K + k) * TP_TM + r];
                     if (!sl || !((lv >> (r >> 5)) & 1)) continue;     /* a dead block is skipped by the kernel: its slots must be 0 */

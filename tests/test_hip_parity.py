@@ -218,11 +218,12 @@ def test_linear_split_row_weight_gradient(oracle, hip, cin, cout, prec):
     assert (out[2].cpu() - exact).abs().max() <= tol
 
 
-@pytest.mark.parametrize("ks,frac", [(3, (0, 0.2, 0.2, 0.6, 1.0)), (5, (0, 0.0005, 0.05, 1.0))])
+@pytest.mark.parametrize("ks,frac", [(3, (0, 0.2, 0.2, 0.6, 1.0)), (5, (0, 0.0005, 0.05, 1.0)), (9, (0, 0.3, 1.0))])
 def test_grouped_conv_row_groups_with_their_own_weights(oracle, hip, ks, frac):
     """me.grouped_conv (the class branches): every row group convolves with its own weights; bf16 mode runs the
-    group-tiled output-stationary kernel on the device, the oracle side the stacked pair form -- same operator,
-    per-group weight gradients come back as separate tensors."""
+    LDS-staged tile kernel on group-aligned tiles on the device (forward, and the data gradient on the SAME plan with
+    the weight slots reversed), the oracle side the stacked pair form -- same operator, per-group weight gradients come
+    back as separate tensors."""
     cin, cout, G = 64, 64, len(frac) - 1
     coords = torch.unique(rand_coords(4000, batch=1, extent=7, seed=ks, dup=0.0), dim=0)     # ~60 % of the cells: dense map
     n = coords.shape[0]

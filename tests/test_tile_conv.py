@@ -117,6 +117,52 @@ def test_oracle_plan_conv_equals_dense_map_conv(oracle, cin, cout, n, ks, stride
             torch.testing.assert_close(y, yref, rtol=RTOL, atol=ATOL * max(float(yref.abs().max()), 1.0))
 
 
+def test_map_onto_itself_transposes_by_flipping_the_offsets(oracle):
+    """nbrT[k] == nbr[K-1-k] for a centred odd kernel on one coordinate map: the manager answers `nbrT` with the flipped
+    map (no second hash lookup); checked against the transposed map found by lookup."""
+    with _lib.use_library(oracle):
+        for ks in (3, 5):
+            coords = surface_coords(1500, batch=2, extent=10, seed=ks)
+            x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1))
+            mgr = x.coordinate_manager
+            km = mgr.kernel_map(x.coordinate_map_key, x.coordinate_map_key, ks, 1, False)
+            assert km.symmetric
+            src = mgr.get(x.coordinate_map_key)
+            offs = me._offsets(ks, 1, coords.device)
+            by_lookup = me.CoordinateManager._lookup_map(src.coords, src, (-offs).contiguous())      # i - off = o
+            assert torch.equal(km.nbrT, by_lookup)
+        km2 = _kernel_map(surface_coords(1500, batch=2, extent=10, seed=1), 3, 2)
+        assert not km2.symmetric
+
+
+@pytest.mark.parametrize("ks,cin,cout", [(3, 64, 64), (5, 64, 128)])
+def test_oracle_data_gradient_on_the_forward_plan_with_reversed_weights(oracle, ks, cin, cout):
+    """wrev: conv(dY, W^T) through the plan of the transposed map == the same call on the FORWARD plan with weight slot
+    K-1-k for offset k (grouped: reversed within every group)."""
+    torch.manual_seed(ks)
+    with _lib.use_library(oracle):
+        y_t, y_rev = _wrev_case(surface_coords(1200, batch=2, extent=9, seed=ks), ks, cin, cout)
+    torch.testing.assert_close(y_rev, y_t, rtol=RTOL, atol=ATOL * max(float(y_t.abs().max()), 1.0))
+
+
+def _wrev_case(coords, ks, cin, cout, G=2):
+    km = _kernel_map(coords, ks)
+    n = km.n_out
+    bounds = (0, n // 3, n)
+    K = ks ** 3
+    w = (torch.randn(G * K, cin, cout) / (cin * 27) ** 0.5).to(coords.device)
+    dy = torch.randn(n, cout).to(coords.device)
+    P = int((km.nbr >= 0).sum())
+    tiles = km.tiles(bounds)
+    _, wp = me._prep_frag(w, False, True)
+    dy16 = me._to_bf16(dy)
+    plan_t = me.build_tile_plan(km.nbrT.contiguous(), P, tiles=tiles, ucap=300)
+    plan_f = me.build_tile_plan(km.nbr.contiguous(), P, tiles=tiles, ucap=300)
+    y_t = me._conv_tile(dy16, wp, plan_t, None, cout, cin, n, P)
+    y_rev = me._conv_tile(dy16, wp, plan_f, None, cout, cin, n, P, wrev=True)
+    return y_t.cpu(), y_rev.cpu()
+
+
 def test_fragment_order_is_a_permutation_of_the_classic_layout(oracle):
     with _lib.use_library(oracle):
         w = torch.randn(5, 64, 96)
@@ -183,6 +229,22 @@ def test_hip_tile_conv_matches_oracle(oracle, hip, cin, cout, n, ks, stride, uca
         scale = max(float(ref.abs().max()), 1.0)
         torch.testing.assert_close(y.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
         torch.testing.assert_close(ydense.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks,cin,cout", [(3, 64, 64), (3, 128, 128), (5, 64, 64), (9, 64, 64)])
+def test_hip_data_gradient_on_the_forward_plan_with_reversed_weights(oracle, hip, ks, cin, cout):
+    """the device kernel's wrev path (and, for K > 32 at 64 channels, its rows-staged-once-per-pass path) == the oracle"""
+    coords = surface_coords(1200 if ks == 9 else 4000, batch=2, extent=9 if ks == 9 else 16, seed=ks)
+    torch.manual_seed(ks)
+    with _lib.use_library(oracle):
+        ref_t, ref_rev = _wrev_case(coords, ks, cin, cout)
+    torch.manual_seed(ks)
+    with _lib.use_library(hip):
+        y_t, y_rev = _wrev_case(coords.cuda(), ks, cin, cout)
+    scale = max(float(ref_t.abs().max()), 1.0)
+    torch.testing.assert_close(y_t, ref_t, rtol=RTOL, atol=ATOL * scale)
+    torch.testing.assert_close(y_rev, ref_t, rtol=RTOL, atol=ATOL * scale)
 
 
 @pytest.mark.gpu
