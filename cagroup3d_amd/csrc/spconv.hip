@@ -795,12 +795,16 @@ __global__ __launch_bounds__(256, 3) void k_spconv_implicit_bf16_ad(const uint16
     nbr += (int64_t)kz0 * n_out;
     K = kz1 - kz0;
     const int nstep = K * nchunk;
-    int64_t tile_row0 = (int64_t)blockIdx.x * 128;
+    // XCD-aware tile order: workgroup x runs on XCD x % 8 (own L2), so XCD c takes the c-th contiguous eighth of the
+    // tiles and walks it in order -- the halo rows of neighbouring tiles are then shared through ONE L2
+    const unsigned t_lo = gridDim.x >> 3, t_rem = gridDim.x & 7, xcd = blockIdx.x & 7;
+    const unsigned bx = xcd * t_lo + (xcd < t_rem ? xcd : t_rem) + (blockIdx.x >> 3);
+    int64_t tile_row0 = (int64_t)bx * 128;
     int tile_rows = (int)(n_out - tile_row0 < 128 ? n_out - tile_row0 : 128);
     if (tiles) {
-        Wb += (int64_t)tiles[blockIdx.x * 3] * K * cin * cout;
-        tile_row0 = tiles[blockIdx.x * 3 + 1];
-        tile_rows = tiles[blockIdx.x * 3 + 2];
+        Wb += (int64_t)tiles[bx * 3] * K * cin * cout;
+        tile_row0 = tiles[bx * 3 + 1];
+        tile_rows = tiles[bx * 3 + 2];
     }
     const bool row_ok = wave * 32 + r < tile_rows;
     const int64_t row_c = row_ok ? tile_row0 + wave * 32 + r : tile_row0;
@@ -1413,19 +1417,33 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
     const bool xin = ci0 + xc8 < cin, din = co0 + dc8 < cout;       // cin, cout are multiples of 8 here
     const uint16_t *xbase = X + (xin ? ci0 + xc8 : 0);
     const uint16_t *dbase = dY + (din ? co0 + dc8 : 0);
-    auto issue = [&](WRows<TM> &xr, WRows<TN> &dr, int32_t p0) {
+    // The row gather of a pair needs the pair's row INDEX first: two dependent memory round trips per stage, and the
+    // kernel ran at (index latency + row latency) / 2 per stage.  The indices are therefore requested two issues
+    // ahead of the rows they address (8 registers per set), so a stage costs one round trip.
+    struct WIdx { int32_t xi[XPQ], di[DPQ]; };
+    auto load_idx = [&](WIdx &ix, int32_t p0) {
 #pragma unroll
         for (int i = 0; i < XPQ; i++) {
             const int32_t p = p0 + xp0 + i;
-            const int32_t pp = p < count ? p : count - 1;           // clamped, unconditional (masked below)
-            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + (int64_t)pin[start + pp] * cin);
+            ix.xi[i] = pin[start + (p < count ? p : count - 1)];     // clamped, unconditional (rows masked below)
+        }
+#pragma unroll
+        for (int i = 0; i < DPQ; i++) {
+            const int32_t p = p0 + dp0 + i;
+            ix.di[i] = pout[start + (p < count ? p : count - 1)];
+        }
+    };
+    auto issue = [&](WRows<TM> &xr, WRows<TN> &dr, const WIdx &ix, int32_t p0) {
+#pragma unroll
+        for (int i = 0; i < XPQ; i++) {
+            const int32_t p = p0 + xp0 + i;
+            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + (int64_t)ix.xi[i] * cin);
             xr.v[i] = (p < count && xin) ? a : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < DPQ; i++) {
             const int32_t p = p0 + dp0 + i;
-            const int32_t pp = p < count ? p : count - 1;
-            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + (int64_t)pout[start + pp] * cout);
+            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + (int64_t)ix.di[i] * cout);
             dr.v[i] = (p < count && din) ? b : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -1481,21 +1499,30 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
     const int nstage = (count + WB_S - 1) / WB_S;
     WRows<TM> xa, xb;
     WRows<TN> da, db;
-    issue(xa, da, 0);
-    issue(xb, db, WB_S);                     // past the end: clamped rows, masked to zero, never used
+    WIdx i0, i1, iA, iB;
+    load_idx(i0, 0);
+    load_idx(i1, WB_S);                      // past the end: clamped rows, masked to zero, never used
+    load_idx(iA, 2 * WB_S);
+    load_idx(iB, 3 * WB_S);
+    issue(xa, da, i0, 0);
+    issue(xb, db, i1, WB_S);
+    load_idx(i0, 4 * WB_S);                  // i0 / iB from here on: the index sets of the odd / even half below
     commit(xa, da, 0);
-    issue(xa, da, 2 * WB_S);
+    issue(xa, da, iA, 2 * WB_S);
     __syncthreads();
+    // iB holds the indices of stage 3 (next xb issue), i0 those of stage 4 (next xa issue)
     for (int st = 0; st < nstage; st += 2) {
         // even stage: xb/db hold stage st+1, xa/da stage st+2
         mfma_stage(0);
         commit(xb, db, 1);
-        issue(xb, db, (st + 3) * WB_S);
+        issue(xb, db, iB, (st + 3) * WB_S);
+        load_idx(iB, (st + 5) * WB_S);
         __syncthreads();
         if (st + 1 < nstage) {
             mfma_stage(1);
             commit(xa, da, 0);
-            issue(xa, da, (st + 4) * WB_S);
+            issue(xa, da, i0, (st + 4) * WB_S);
+            load_idx(i0, (st + 6) * WB_S);
             __syncthreads();
         }
     }

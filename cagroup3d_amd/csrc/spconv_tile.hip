@@ -282,6 +282,15 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
         // gathers, all in flight at once: 16 granules per thread) plus the LDS writes -- not a chain of three.
         const int lw = wave - 4, lt = lw * 64 + lane;     // 256 loader threads
         struct PassRec { int valid, np, k0, k1, uoff, ucnt; };
+        // XCD-aware unit order: workgroup b runs on XCD b % 8 (own L2); position pos = b + i * gridDim of the round-robin
+        // maps to unit  first unit of XCD (pos % 8) + pos / 8,  so an XCD walks ONE contiguous range of tiles and the
+        // halo rows two neighbouring tiles share are found in its L2 (tile t, t+1 on different XCDs: both fetch them)
+        const int u_lo = nunit >> 3, u_rem = nunit & 7;
+        auto unit_of = [&](int pos) -> int {
+            if (pos >= nunit) return nunit;
+            const int x = pos & 7;
+            return x * u_lo + (x < u_rem ? x : u_rem) + (pos >> 3);
+        };
         auto load_pass = [&](int u, int p) -> PassRec {
             PassRec P = {0, 0, 0, 0, 0, 0};
             if (u < nunit) {
@@ -327,13 +336,14 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             hist[bufi].valid = 0;
         };
         int sidx = 0, abuf = 1;
-        PassRec cur = load_pass(blockIdx.x, 0);
+        int pos = blockIdx.x;
+        PassRec cur = load_pass(unit_of(pos), 0);
         if (cur.valid) issue_idx(idx, cur.uoff, cur.ucnt);
-        int u = blockIdx.x, p = 0;
+        int u = unit_of(pos), p = 0;
         while (cur.valid) {
             const int64_t tile = u / (ny * gz);
             const bool last_pass = p == cur.np - 1;
-            const int un = last_pass ? u + G : u, pn = last_pass ? 0 : p + 1;
+            const int un = last_pass ? unit_of(pos + G) : u, pn = last_pass ? 0 : p + 1;
             const PassRec nxt = load_pass(un, pn);       // requested now, needed at this pass's last stage
             StageDesc D;
             D.valid = 1;
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
 #pragma unroll
             for (int j = 0; j < TP_NLV; j++) idx[j] = idx_next[j];
             u = un;
+            if (last_pass) pos += G;
             p = pn;
         }
         // end marker

@@ -218,9 +218,39 @@ class KernelMap:
             cnt = np.minimum(maxlen, off[slot + 1] - start)
             widx = (slot % G) * self.K + slot // G
             tab = np.stack([widx, start, cnt], 1).astype(np.int32)
+            if SEG_XCD_ORDER and tab.shape[0] >= 64 and _lib.get().is_device:
+                tab = tab[_xcd_order(slot, start, cnt, off, G, row_bounds, self.n_out)]
             seg = (h2d(torch.from_numpy(tab), torch.int32, pin.device), int(tab.shape[0]))
             self._segs[ck] = seg
         return seg
+
+
+SEG_XCD_ORDER = __import__("os").environ.get("CG3D_SEG_XCD", "1") != "0"
+N_XCD = 8
+
+
+def _xcd_order(slot, start, cnt, off, G, row_bounds, n_out):
+    """Launch order of the segments of a pair-list kernel (workgroup i runs segment i) that keeps every XCD on ONE row
+    range of the tensors.  MI355X hands workgroup i to XCD i % 8, each with its own 4 MB L2; in (offset, row) order an XCD
+    gets every 8th segment of every offset -- it streams ALL rows once per offset (27 x the tensor through the fabric,
+    no reuse: 5 MB per sweep against 4 MB of L2).  Here the segments are sorted by the position of their rows (the pairs
+    of one offset are in output-row order, so the position is estimated from the segment's place in its offset's
+    list), cut into 8 equal runs and dealt out round-robin: XCD x sees the 27 offsets of the x-th eighth of the rows,
+    sweeping it front to back, and finds the neighbour rows another offset just fetched in its own L2."""
+    nslot_cnt = np.maximum(off[slot + 1] - off[slot], 1).astype(np.float64)
+    f = (start - off[slot] + 0.5 * cnt) / nslot_cnt                     # 0..1 within the slot's (offset, group) list
+    if row_bounds is None:
+        pos = f
+    else:
+        rb = np.asarray(row_bounds, dtype=np.float64)
+        g = slot % G
+        pos = (rb[g] + f * (rb[g + 1] - rb[g])) / max(float(n_out), 1.0)
+    order = np.lexsort((slot, pos))                                      # by position, ties by offset
+    runs = np.array_split(order, N_XCD)                                  # the longer runs come first
+    out = np.empty(order.shape[0], dtype=np.int64)
+    for x, run in enumerate(runs):
+        out[x:x + N_XCD * len(run):N_XCD][:len(run)] = run
+    return out
 
 
 def _build_map(coords_i32, qstride):

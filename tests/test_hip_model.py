@@ -317,16 +317,22 @@ def test_full_size_training_step_of_the_other_configs(hip, dataset, cfgname, bs)
     assert np.isfinite(tb["loss_all"]) and tb["loss_all"] > 0
     gn = torch.stack([p.grad.float().norm() for p in model.parameters() if p.grad is not None])
     assert torch.isfinite(gn).all() and float(gn.sum()) > 0
-    sp = batch["sp_tensor"]
-    C = sp.C.cpu().numpy()
     assert n_pts == bs * int(cfgname[1:4]) * 1000
     from util import morton_keys
+    vs = float(model.voxel_size)
+    with _lib.use_library(hip):
+        vox = model.voxelization(batch["points"])                   # the input map of the step (batch["sp_tensor"] is the backbone's OUTPUT by now)
+    C = vox.C.cpu().numpy()
     keys = morton_keys(C)
     assert (np.diff(keys.astype(np.float64)) > 0).all(), "distinct voxels in (batch, Morton) order"
-    vs = float(model.voxel_size)
-    pts = batch["points"][:, :4].clone()
-    ref = torch.unique(torch.cat([pts[:, :1], torch.floor(pts[:, 1:4] / vs)], 1).int(), dim=0).shape[0]
-    assert abs(C.shape[0] - ref) <= 2, (C.shape[0], ref)           # (GPU vs CPU float division at exact voxel boundaries)
+    pts = batch["points"][:, :4]
+    ref = torch.unique(torch.cat([pts[:, :1], torch.floor(pts[:, 1:4] / vs)], 1).int(), dim=0)
+    assert C.shape[0] == ref.shape[0], (C.shape[0], ref.shape[0])  # both divisions run on the device: the same voxels
+    # the backbone's output map (stride 2): exactly the parent voxels' cells of the coarser lattice
+    out_C = batch["sp_tensor"].C
+    assert (out_C[:, 1:] % 2 == 0).all()
+    parent = torch.unique(torch.cat([ref[:, :1], torch.div(ref[:, 1:], 2, rounding_mode="floor") * 2], 1), dim=0)
+    assert out_C.shape[0] == parent.shape[0], (out_C.shape[0], parent.shape[0])
     out = batch["middle_feature_list"][3]
     assert (out.C[:, 1:] % 2 == 0).all() and out.F.shape[1] == 64
     boxes = torch.cat([p[0] for p in batch["pred_bbox_list"]])
