@@ -88,6 +88,7 @@ def make_model(dataset, forced, device, voxel_size=None):
 _PARAMS = {}
 _PREPARED = {}
 PREFETCH = os.environ.get("CG3D_PREFETCH", "1") != "0"
+PREFETCH_THREAD = os.environ.get("CG3D_PREFETCH_THREAD", "1") != "0"     # the dry run of the next batch on a worker thread
 
 
 def train_step(model, opt, batch, clip):
@@ -98,17 +99,21 @@ def train_step(model, opt, batch, clip):
     b = fresh(batch)
     core = model.module if hasattr(model, "module") else model
     if PREFETCH and _PREPARED.get(id(core)) is not None:
-        b["prepared"] = _PREPARED.pop(id(core))
+        b["prepared"] = _PREPARED.pop(id(core)).result()
+    if PREFETCH and PREFETCH_THREAD and batch["points"].is_cuda:
+        # the NEXT batch's coordinate structures (here: the same synthetic scenes again -- every step builds them anew,
+        # nothing is reused) on the worker thread and the side stream, while this step is issued and runs
+        _PREPARED[id(core)] = core.prefetch_coordinates_async(batch)
     ret, tb, disp = model(b)
     ret["loss"].backward()
     if getattr(core, "grad_sync", None) is not None:
         core.grad_sync.finish()                 # early/mid buckets were sent from the backward pass, late bucket here
     torch.nn.utils.clip_grad_norm_(params, clip)
     opt.step()
-    if PREFETCH:
-        # the NEXT batch's coordinate structures (here: the same synthetic scenes again), on a side stream while the
-        # GPU still works through the backward just queued -- every step builds them anew, nothing is reused
-        _PREPARED[id(core)] = core.prefetch_coordinates(batch)
+    if PREFETCH and not (PREFETCH_THREAD and batch["points"].is_cuda):
+        # single-threaded variant: on the side stream while the GPU still works through the backward just queued
+        from cagroup3d_amd.pcdet.models.detectors.cagroup3d import _Done
+        _PREPARED[id(core)] = _Done(core.prefetch_coordinates(batch))
     return tb
 
 

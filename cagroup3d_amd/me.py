@@ -218,7 +218,7 @@ class KernelMap:
             cnt = np.minimum(maxlen, off[slot + 1] - start)
             widx = (slot % G) * self.K + slot // G
             tab = np.stack([widx, start, cnt], 1).astype(np.int32)
-            if SEG_XCD_ORDER and tab.shape[0] >= 64 and _lib.get().is_device:
+            if SEG_XCD_ORDER and 64 <= tab.shape[0] <= 4096 and maxlen >= 256 and _lib.get().is_device:
                 tab = tab[_xcd_order(slot, start, cnt, off, G, row_bounds, self.n_out)]
             seg = (h2d(torch.from_numpy(tab), torch.int32, pin.device), int(tab.shape[0]))
             self._segs[ck] = seg
@@ -238,19 +238,18 @@ def _xcd_order(slot, start, cnt, off, G, row_bounds, n_out):
     list), cut into 8 equal runs and dealt out round-robin: XCD x sees the 27 offsets of the x-th eighth of the rows,
     sweeping it front to back, and finds the neighbour rows another offset just fetched in its own L2."""
     nslot_cnt = np.maximum(off[slot + 1] - off[slot], 1).astype(np.float64)
-    f = (start - off[slot] + 0.5 * cnt) / nslot_cnt                     # 0..1 within the slot's (offset, group) list
-    if row_bounds is None:
-        pos = f
-    else:
+    pos = (start - off[slot] + 0.5 * cnt) / nslot_cnt                   # 0..1 within the slot's (offset, group) list
+    if row_bounds is not None:
         rb = np.asarray(row_bounds, dtype=np.float64)
         g = slot % G
-        pos = (rb[g] + f * (rb[g + 1] - rb[g])) / max(float(n_out), 1.0)
-    order = np.lexsort((slot, pos))                                      # by position, ties by offset
-    runs = np.array_split(order, N_XCD)                                  # the longer runs come first
-    out = np.empty(order.shape[0], dtype=np.int64)
-    for x, run in enumerate(runs):
-        out[x:x + N_XCD * len(run):N_XCD][:len(run)] = run
-    return out
+        pos = (rb[g] + pos * (rb[g + 1] - rb[g])) / max(float(n_out), 1.0)
+    order = np.argsort(pos, kind="stable")                              # by position, ties in offset order
+    n = order.shape[0]
+    run = -(-n // N_XCD)                                                # rank i -> run i // run, place i % run in it
+    dest = (np.arange(n) % run) * N_XCD + np.arange(n) // run           # a run shorter than the others leaves holes:
+    out = np.full(run * N_XCD, -1, dtype=np.int64)
+    out[dest] = order
+    return out[out >= 0]                                                # ... closed up (only the last few places shift)
 
 
 def _build_map(coords_i32, qstride):
@@ -546,7 +545,23 @@ def _prep_frag(w3, want_t=True, want_p=False):
 # segment table they will need -- with their host reads -- but launch no feature kernel and return uninitialised
 # feature tensors of the right shape.  Run on a side stream for the NEXT batch while the GPU is still busy with the
 # current step's backward, it takes the data-dependent host syncs out of the timed forward pass.
-COORDS_ONLY = False
+# The flag is PER THREAD: the dry run of batch i+1 may run on a worker thread (CAGroup3D.prefetch_coordinates_async)
+# while the main thread is in the real forward / backward of batch i.
+_TLS = __import__("threading").local()
+
+
+def coords_only():
+    return getattr(_TLS, "coords_only", False)
+
+
+def set_coords_only(flag):
+    _TLS.coords_only = bool(flag)
+
+
+def __getattr__(name):              # `ME.COORDS_ONLY` (read-only view of this thread's flag)
+    if name == "COORDS_ONLY":
+        return coords_only()
+    raise AttributeError(name)
 
 
 def _fake(n, c, like):
@@ -1408,7 +1423,7 @@ class FusedBNActFunction(torch.autograd.Function):
 def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     """BatchNorm1d modules `bns` (one per contiguous row group of `bounds`) + residual + activation in
     two launches (statistics, apply); updates the modules' running statistics like nn.BatchNorm1d."""
-    if COORDS_ONLY:
+    if coords_only():
         return feats
     bns = list(bns)
     G, N, C = len(bns), feats.shape[0], feats.shape[1]
@@ -1534,7 +1549,7 @@ class SparseTensor:
 
     def features_at_coordinates(self, query):
         """Trilinear interpolation of this tensor at continuous coordinates [nq,4] (b,x,y,z)."""
-        if COORDS_ONLY:
+        if coords_only():
             return _fake(query.shape[0], self.F.shape[1], self.F)
         lib = _lib.get()
         q = query.to(torch.float32).contiguous()
@@ -1568,7 +1583,7 @@ class SparseTensor:
 def cat(*tensors):
     for t in tensors[1:]:
         tensors[0]._same_map(t)
-    if COORDS_ONLY:
+    if coords_only():
         return tensors[0]._like(_fake(tensors[0].F.shape[0], sum(t.F.shape[1] for t in tensors), tensors[0].F))
     return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
 
@@ -1616,10 +1631,10 @@ class MinkowskiConvolution(_ConvBase):
             out_key = x.coordinate_map_key
         bias = self.bias.view(-1) if self.bias is not None else None
         if self.kernel_volume == 1 and coordinates is None and self.stride == 1:
-            out = _fake(x.F.shape[0], self.out_channels, x.F) if COORDS_ONLY else linear(x.F, self.kernel, bias)
+            out = _fake(x.F.shape[0], self.out_channels, x.F) if coords_only() else linear(x.F, self.kernel, bias)
         else:
             km = mgr.kernel_map(x.coordinate_map_key, out_key, self.kernel_size, self.dilation, False)
-            if COORDS_ONLY:
+            if coords_only():
                 SparseConvFunction.warm(km, self.kernel_volume, self.in_channels, self.out_channels, None, self.training)
                 out = _fake(km.n_out, self.out_channels, x.F)
             else:
@@ -1643,7 +1658,7 @@ class MinkowskiConvolutionTranspose(_ConvBase):
             out_key = cands[0]
         km = mgr.kernel_map(x.coordinate_map_key, out_key, self.kernel_size, self.dilation, True)
         bias = self.bias.view(-1) if self.bias is not None else None
-        if COORDS_ONLY:
+        if coords_only():
             SparseConvFunction.warm(km, self.kernel_volume, self.in_channels, self.out_channels, None, self.training)
             return SparseTensor(features=_fake(km.n_out, self.out_channels, x.F), coordinate_map_key=out_key, coordinate_manager=mgr)
         out = SparseConvFunction.apply(x.F, self._w3(), bias, km)
@@ -1678,7 +1693,7 @@ class MinkowskiAvgPooling(nn.Module):
                      c_int64(dst.cap), ptr(pmap), lib.stream())
             pmap = pmap[:, :src.n].contiguous() if src.n > 0 else pmap[:, :0]
             mgr._kmaps[ck] = pmap
-        out = _fake(dst.n, x.F.shape[1], x.F) if COORDS_ONLY else ScatterMeanFunction.apply(x.F, pmap, dst.n)
+        out = _fake(dst.n, x.F.shape[1], x.F) if coords_only() else ScatterMeanFunction.apply(x.F, pmap, dst.n)
         return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
@@ -1694,7 +1709,7 @@ class MinkowskiBatchNorm(nn.Module):
 
 class _Pointwise(nn.Module):
     def forward(self, x):
-        return x if COORDS_ONLY else x._like(self.fn(x.F))
+        return x if coords_only() else x._like(self.fn(x.F))
 
 
 class MinkowskiReLU(_Pointwise):

@@ -172,7 +172,7 @@ class BiResNet(nn.Module):
         x = self.conv1(input_dict["sp_tensor"])                       # ts 1
         l1 = self.layer1(x)                                           # ts 2
         l2 = self.layer2(self.relu(l1))                               # ts 4
-        if self.training and getattr(self, "grad_sync", None) is not None:
+        if self.training and getattr(self, "grad_sync", None) is not None and not ME.coords_only():
             self.grad_sync.attach_mid(l2.F)          # every deeper layer's gradient is complete when this one is
         l3 = self.layer3(self.relu(l2))                               # ts 8
         hi = self.layer3_(self.relu(l2))                              # ts 4 (high-resolution branch)

@@ -8,6 +8,60 @@ from ..dense_heads.cagroup_head import split_gt_boxes
 from .detector3d_template import Detector3DTemplate
 
 
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
+class _PrefetchWorker:
+    """One daemon thread per detector; jobs are served in order, one result handle per job."""
+
+    def __init__(self, detector, device):
+        import queue
+        import threading
+        import weakref
+        self.jobs = queue.Queue()
+        det = weakref.ref(detector)          # the thread must not keep the model alive
+
+        def loop():
+            torch.cuda.set_device(device)    # the current device is per thread
+            while True:
+                job = self.jobs.get()
+                if job is None:
+                    return
+                batch, handle = job
+                d = det()
+                try:
+                    handle.value = d.prefetch_coordinates(batch) if d is not None else None
+                except BaseException as e:  # noqa: BLE001  (handed to the thread that asks for the result)
+                    handle.error = e
+                finally:
+                    del d
+                    handle.done.set()
+        self.thread = threading.Thread(target=loop, name="cg3d-coordinate-prefetch", daemon=True)
+        self.thread.start()
+
+    def submit(self, batch):
+        h = _Pending()
+        self.jobs.put((batch, h))
+        return h
+
+
+class _Pending:
+    def __init__(self):
+        import threading
+        self.done, self.value, self.error = threading.Event(), None, None
+
+    def result(self):
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        return self.value
+
+
 class CAGroup3D(Detector3DTemplate):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
@@ -50,13 +104,13 @@ class CAGroup3D(Detector3DTemplate):
         with torch.cuda.stream(side), torch.no_grad():
             coordinates = points[:, :4].clone()
             coordinates[:, 1:] /= self.voxel_size
-            ME.COORDS_ONLY = True
+            ME.set_coords_only(True)
             try:
                 sp = ME.SparseTensor(coordinates=coordinates, features=points[:, 4:])
                 out = self.backbone_3d({"sp_tensor": sp, "batch_size": batch_dict["batch_size"]})["sp_tensor"]
                 _ = out.decomposition_permutations            # the head's first host read
             finally:
-                ME.COORDS_ONLY = False
+                ME.set_coords_only(False)
             targets = None
             if self.training and "gt_boxes" in batch_dict and getattr(self.dense_head, "batched", False):
                 # training targets that depend on the data only (semantic labels, vote targets, the bench's forced mask)
@@ -73,6 +127,19 @@ class CAGroup3D(Detector3DTemplate):
             event.record(side)
         return (sp.coordinate_manager, sp.coordinate_map_key, sp.unique_index, points.shape[0], event,
                 [sp.unique_index, sp.inverse_mapping], targets)
+
+    def prefetch_coordinates_async(self, batch_dict):
+        """`prefetch_coordinates` on a worker thread: returns a handle whose `.result()` is what `prefetch_coordinates`
+        returns.  Submit the NEXT batch before starting the current step: the dry run is Python glue, short launches and
+        ~30 host reads of device counters (each a wait for the side stream); on its own thread those waits and every
+        GIL-free stretch (launches, ATen calls, the autograd engine's C++ side) overlap with the issue path of the
+        current step, which is what bounds the step once the kernels are fast (host path)."""
+        if batch_dict is None or not batch_dict["points"].is_cuda:
+            return _Done(None)
+        w = getattr(self, "_prefetch_worker", None)
+        if w is None or not w.thread.is_alive():
+            w = self._prefetch_worker = _PrefetchWorker(self, batch_dict["points"].device)
+        return w.submit(batch_dict)
 
     def forward(self, batch_dict):
         cur_epoch = batch_dict.get("cur_epoch", None)

@@ -185,7 +185,9 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
     prepared = None
     for batch, nxt in staged(dataset.batches(epoch, shuffle=True)):
         if prepared is not None:
-            batch["prepared"] = prepared
+            batch["prepared"] = prepared.result()
+        # the next batch's coordinate structures: worker thread + side stream, under this whole step
+        prepared = core.prefetch_coordinates_async(nxt) if (nxt is not None and device.type == "cuda") else None
         optimizer.zero_grad(set_to_none=True)
         loss, tb, disp = model_func(model, batch)
         loss.backward()
@@ -194,7 +196,6 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
         torch.nn.utils.clip_grad_norm_(params, clip)
         optimizer.step()
         scheduler.step()
-        prepared = core.prefetch_coordinates(nxt) if (nxt is not None and device.type == "cuda") else None
         it += 1
         if not _FROZEN[0] and device.type == "cuda":
             # the model, the optimizer state and the cached tables are permanent: out of the cyclic collector's

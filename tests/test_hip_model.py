@@ -118,6 +118,40 @@ def test_prefetched_coordinates_give_the_same_step(hip):
     assert (num / den) ** 0.5 < 2e-2
 
 
+def test_worker_thread_prefetch_while_another_step_runs(hip):
+    """prefetch_coordinates_async: the dry run of batch B on the worker thread WHILE the main thread runs a full training
+    step on batch A (its own coordinate structures, autograd, the per-thread COORDS_ONLY flag) -- then B's step with the
+    prefetched structures == B's step without them, from the same weights."""
+    res = []
+    for use_prefetch in (False, True):
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        model.dense_head.force_gt_selection = True
+        model = model.cuda().train()
+        a = build_model.synthetic_batch("S5k", 2, device="cuda")
+        b = build_model.synthetic_batch("S5k", 2, first_scene=2, device="cuda")   # other scenes
+        with _lib.use_library(hip):
+            handle = model.prefetch_coordinates_async(b) if use_prefetch else None
+            ret, _, _ = model(a)
+            ret["loss"].backward()                                            # A's step; gradients are discarded below
+            assert not me.coords_only(), "the worker's COORDS_ONLY flag must not leak into this thread"
+            for p in model.parameters():
+                p.grad = None
+            if use_prefetch:
+                b["prepared"] = handle.result()
+                assert b["prepared"] is not None
+            ret, tb, _ = model(b)
+            ret["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((b["sp_tensor"].C.clone(), tb, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (c0, tb0, g0), (c1, tb1, g1) = res
+    assert torch.equal(c0, c1)
+    for k in tb0:
+        assert abs(tb0[k] - tb1[k]) <= 1e-3 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    assert (num / den) ** 0.5 < 2e-2
+
+
 def _s50k_tensor():
     batch = synthetic.make_batch("S50k", 4)
     pts = torch.from_numpy(batch["points"]).cuda()

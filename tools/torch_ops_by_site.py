@@ -1,15 +1,36 @@
-"""Where the framework-op (torch) GPU time of a train step comes from: torch.profiler with stacks, device time of every
-non-cg3d kernel attributed to the innermost cagroup3d_amd / bench source line that launched it (dev tool, GPU box)."""
+"""Which source lines of the framework issue the torch (ATen) ops of a train step: a TorchDispatchMode counts every op and
+charges it to the innermost cagroup3d_amd / bench frame on the Python stack (backward ops run on the autograd thread and are
+charged to the autograd node instead).  dev tool; runs on the GPU box (or CPU with the oracle for a rough picture)."""
 import collections
 import os
 import sys
+import traceback
 
 import torch
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import bench  # noqa: E402
 from cagroup3d_amd import build_model, me  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Count(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.sites, self.ops = collections.Counter(), collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        site = "?"
+        for fr in reversed(traceback.extract_stack(limit=40)[:-1]):
+            if fr.filename.startswith(ROOT) and "tools/" not in fr.filename:
+                site = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)
+                break
+        self.sites[site] += 1
+        self.ops[str(func)] += 1
+        return func(*args, **(kwargs or {}))
+
 
 me.PRECISION = 1
 dev = torch.device("cuda", 0)
@@ -17,33 +38,16 @@ model, cfg = bench.make_model("scannet", True, dev)
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 batch = build_model.synthetic_batch("S50k", 4, device=dev)
-for _ in range(4):
+for _ in range(3):
     bench.train_step(model, opt, batch, 10.0)
 torch.cuda.synchronize()
-STEPS = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    for _ in range(STEPS):
-        bench.train_step(model, opt, batch, 10.0)
-    torch.cuda.synchronize()
-site_t, site_n, op_t = collections.Counter(), collections.Counter(), collections.Counter()
-for ev in prof.events():
-    if ev.device_type != torch.autograd.DeviceType.CPU:
-        continue
-    dt = ev.self_device_time_total
-    if dt <= 0:
-        continue
-    site = "?"
-    for fr in ev.stack or []:
-        if ("cagroup3d_amd" in fr or "bench.py" in fr) and "torch/" not in fr:
-            site = fr.split("/repo/")[-1]
-            break
-    site_t[site] += dt
-    site_n[site] += 1
-    op_t[ev.name] += dt
-tot = sum(site_t.values())
-print(f"torch-op device time {tot / STEPS / 1e3:.2f} ms/step over {sum(site_n.values()) / STEPS:.0f} ops/step")
-for s, t in site_t.most_common(60):
-    print(f"{t / STEPS:9.1f} us {site_n[s] / STEPS:6.1f}  {s}")
+c = Count()
+with c:
+    bench.train_step(model, opt, batch, 10.0)
+torch.cuda.synchronize()
+print("ops in one step:", sum(c.sites.values()))
+for s, n in c.sites.most_common(90):
+    print("%5d  %s" % (n, s))
 print("--- by op")
-for s, t in op_t.most_common(30):
-    print(f"{t / STEPS:9.1f} us  {s}")
+for s, n in c.ops.most_common(40):
+    print("%5d  %s" % (n, s))
