@@ -55,80 +55,77 @@ __global__ void k_insert(const int32_t *__restrict__ coords, int64_t n, int32_t 
     }
 }
 
-__global__ void k_flag(int64_t n, const int32_t *__restrict__ vals, const int32_t *__restrict__ slot_of,
-                       int32_t *flag) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int32_t s = slot_of[i];
-    flag[i] = (s >= 0 && vals[s] == (int32_t)i) ? 1 : 0;
-}
-
-// three-kernel exclusive scan over int32 (2048 elements per block)
+// Two-kernel exclusive scan of 0/1 flags (2048 elements per block), the flags computed on the fly:
+//   k_scan_count   block b: number of set flags in its 2048 elements -> bsum[b]
+//   k_scan_write   block b: its base = sum of bsum[0..b) (every block adds the few thousand block counts up itself: they
+//                  sit in L2, and it saves the single-block middle kernel and its two launch gaps), then the exclusive
+//                  positions of its elements; the last block stores the total.
+// FLAG 1: nbr[i] >= 0 (pair lists).  FLAG 2: input row i is the representative of its voxel (coordinate maps).
 #define SCAN_ELEMS 2048
-__global__ __launch_bounds__(256) void k_scan_reduce(const int32_t *__restrict__ in, int64_t n, int32_t *bsum) {
-    __shared__ int32_t red[256];
-    int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS;
+struct ScanSrc { const int32_t *a; const int32_t *b; };
+template <int FLAG> __device__ static inline int32_t scan_flag(const ScanSrc &S, int64_t i) {
+    if (FLAG == 1) return S.a[i] >= 0 ? 1 : 0;
+    const int32_t sl = S.b[i];                                   // FLAG 2: a = table values, b = slot of row i
+    return (sl >= 0 && S.a[sl] == (int32_t)i) ? 1 : 0;
+}
+__device__ static inline int32_t block_sum_256(int32_t v, int32_t *red) {       // sum over the 256 threads, to all
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int32_t t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+template <int FLAG>
+__global__ __launch_bounds__(256) void k_scan_count(ScanSrc S, int64_t n, int32_t *__restrict__ bsum) {
+    __shared__ int32_t red[4];
+    const int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS + threadIdx.x * 8;
     int32_t s = 0;
-    for (int j = threadIdx.x; j < SCAN_ELEMS; j += 256) {
-        int64_t i = base + j;
-        if (i < n) s += in[i];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (base + j < n) s += scan_flag<FLAG>(S, base + j);
+    const int32_t t = block_sum_256(s, red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(256) void k_scan_bsums(int32_t *bsum, int64_t nb, int32_t *total) {
-    __shared__ int32_t buf[256];
-    __shared__ int32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < nb; base += 256) {
-        int64_t i = base + threadIdx.x;
-        int32_t v = (i < nb) ? bsum[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            int32_t t = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        int32_t incl = buf[threadIdx.x];
-        if (i < nb) bsum[i] = carry + incl - v;  // exclusive
-        __syncthreads();
-        if (threadIdx.x == 255) carry += incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-__global__ __launch_bounds__(256) void k_scan_apply(int32_t *data, int64_t n, const int32_t *__restrict__ bsum) {
-    // in-place exclusive scan of one 2048-element block: 8 elements per thread
-    __shared__ int32_t tsum[256];
-    int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS + threadIdx.x * 8;
+template <int FLAG>
+__global__ __launch_bounds__(256) void k_scan_write(ScanSrc S, int64_t n, const int32_t *__restrict__ bsum,
+                                                    int32_t *__restrict__ pos, int32_t *__restrict__ total) {
+    __shared__ int32_t red[4];
+    __shared__ int32_t wsum[4];
+    // base of this block
+    int32_t pre = 0;
+    for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += 256) pre += bsum[i];
+    const int32_t blk_base = block_sum_256(pre, red);
+    const int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS + threadIdx.x * 8;
     int32_t v[8], s = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        v[j] = (base + j < n) ? data[base + j] : 0;
+        v[j] = (base + j < n) ? scan_flag<FLAG>(S, base + j) : 0;
         s += v[j];
     }
-    tsum[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int32_t t = (threadIdx.x >= (unsigned)o) ? tsum[threadIdx.x - o] : 0;
-        __syncthreads();
-        tsum[threadIdx.x] += t;
-        __syncthreads();
+    // exclusive prefix of s over the block: inclusive wave scan, then the waves before
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
     }
-    int32_t run = bsum[blockIdx.x] + tsum[threadIdx.x] - s;
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int32_t run = blk_base + inc - s;
+    for (int w = 0; w < wave; w++) run += wsum[w];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        if (base + j < n) data[base + j] = run;
+        if (base + j < n) pos[base + j] = run;
         run += v[j];
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total = run;       // the last thread has walked past every element
+}
+
+__global__ void k_table_init(unsigned long long *__restrict__ keys, int32_t *__restrict__ vals, int64_t cap, int32_t *n_out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = ~0ull; vals[i] = 0x7f7f7f7f; }
+    if (i < 2) n_out[i] = 0;
 }
 
 __global__ void k_compact(const int32_t *__restrict__ coords, int64_t n, int32_t qs,
@@ -164,10 +161,9 @@ extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qs
     if (n < 0 || qstride < 1 || cap < 2 * n || (cap & (cap - 1)) || cap > (1LL << 30)) return CG3D_ERR_ARG;
     if (((uintptr_t)coords & 15) || ((uintptr_t)out_coords & 15)) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
-    if (hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (hipMemsetAsync(n_out, 0, 2 * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    if (n == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_table_init, dim3((unsigned)cg3d_divup(cap, 256)), dim3(256), 0, s, (unsigned long long *)keys, vals, cap,
+                       n_out);                        // empty keys (all ones), "no row" values, row count and status = 0: one launch
+    if (n == 0) { CG3D_CHECK_LAUNCH(); return CG3D_OK; }
     int32_t *slot_of = (int32_t *)ws;
     int32_t *pos = slot_of + n;
     int64_t nb = cg3d_divup(n, SCAN_ELEMS);
@@ -176,10 +172,9 @@ extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qs
     unsigned g = (unsigned)cg3d_divup(n, 256);
     hipLaunchKernelGGL(k_insert, dim3(g), dim3(256), 0, s, coords, n, qstride, (unsigned long long *)keys, vals,
                        (uint64_t)(cap - 1), slot_of, status);
-    hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, s, n, vals, slot_of, pos);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, pos, n, bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, s, bsum, nb, n_out);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, pos, n, bsum);
+    const ScanSrc src = {vals, slot_of};
+    hipLaunchKernelGGL(k_scan_count<2>, dim3((unsigned)nb), dim3(256), 0, s, src, n, bsum);
+    hipLaunchKernelGGL(k_scan_write<2>, dim3((unsigned)nb), dim3(256), 0, s, src, n, bsum, pos, n_out);
     hipLaunchKernelGGL(k_compact, dim3(g), dim3(256), 0, s, coords, n, qstride, vals, slot_of, pos, out_coords,
                        unique_index, inverse);
     hipLaunchKernelGGL(k_retarget, dim3(g), dim3(256), 0, s, n, vals, slot_of, unique_index, n_out);
@@ -345,10 +340,6 @@ extern "C" int cg3d_pool_map(const int32_t *in, int64_t n_in, int32_t out_stride
 // ------------------------------------------------------------------ pair-compacted kernel maps
 extern "C" int64_t cg3d_pairs_ws_bytes(int64_t total) { return (total + total / 1024 + 64) * (int64_t)sizeof(int32_t); }
 
-__global__ void k_pair_flags(const int32_t *__restrict__ nbr, int64_t total, int32_t *__restrict__ pos) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t < total) pos[t] = nbr[t] >= 0 ? 1 : 0;
-}
 __global__ void k_pair_offsets(const int32_t *__restrict__ pos, int32_t K, int64_t n_out,
                                const int32_t *__restrict__ row_bounds, int32_t G, const int32_t *total,
                                int32_t *__restrict__ pair_off) {
@@ -375,10 +366,9 @@ extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, co
     const int64_t nb = cg3d_divup(total, SCAN_ELEMS);
     int32_t *bsum = pos + total;
     int32_t *tot = bsum + nb + 1;
-    hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, nbr, total, pos);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, s, bsum, nb, tot);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, pos, total, bsum);
+    const ScanSrc src = {nbr, nullptr};
+    hipLaunchKernelGGL(k_scan_count<1>, dim3((unsigned)nb), dim3(256), 0, s, src, total, bsum);
+    hipLaunchKernelGGL(k_scan_write<1>, dim3((unsigned)nb), dim3(256), 0, s, src, total, bsum, pos, tot);
     hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)cg3d_divup((int64_t)K * G + 1, 256)), dim3(256), 0, s, pos, K, n_out,
                        row_bounds, G, tot, pair_off);
     CG3D_CHECK_LAUNCH();

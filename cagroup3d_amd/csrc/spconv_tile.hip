@@ -42,16 +42,23 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // staged rows past `ucap` the current pass is closed and a new one starts with that offset (the conv kernel restages
 // per pass).
 #define TP_PF 8
-__global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nbr, int32_t K, int64_t n_out,
-                                                  const int32_t *__restrict__ tiles, int32_t ucap, int32_t maxpass,
-                                                  uint16_t *__restrict__ slots, uint8_t *__restrict__ live,
-                                                  int32_t *__restrict__ pass_tab, int32_t *__restrict__ npass,
-                                                  int32_t *__restrict__ ulist, int64_t ulist_cap,
-                                                  int32_t *__restrict__ cursor) {
-    __shared__ int32_t hkey[TP_HASH];
-    __shared__ uint16_t hval[TP_HASH];
-    __shared__ int32_t ul[1024];
-    const int lane = threadIdx.x;
+#define TP_CHUNK_K 96       // offsets per wave when a large kernel (5^3, 9^3) is split over the waves of the workgroup
+// Large K: the offsets are cut into up to 8 runs, one WAVE each, with their own hash table and pass list (any partition
+// of the offsets into passes is a valid plan; a run boundary just forces a pass boundary), so a 9^3 map takes the time
+// of ~92 offsets instead of 729 (0.55 ms -> ~0.1 ms per plan).  Wave w writes its passes at pass_tab[tile][k_lo(w) + i];
+// wave 0 closes the gaps at the end.
+__global__ __launch_bounds__(512) void k_tile_plan(const int32_t *__restrict__ nbr, int32_t K, int64_t n_out,
+                                                   const int32_t *__restrict__ tiles, int32_t ucap, int32_t maxpass,
+                                                   uint16_t *__restrict__ slots, uint8_t *__restrict__ live,
+                                                   int32_t *__restrict__ pass_tab, int32_t *__restrict__ npass,
+                                                   int32_t *__restrict__ ulist, int64_t ulist_cap,
+                                                   int32_t *__restrict__ cursor) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t plan_smem[];
+    __shared__ int32_t np_of[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    int32_t *hkey = reinterpret_cast<int32_t *>(plan_smem + (size_t)wave * (TP_HASH * 6 + 4096));
+    uint16_t *hval = reinterpret_cast<uint16_t *>(hkey + TP_HASH);
+    int32_t *ul = reinterpret_cast<int32_t *>(hval + TP_HASH);
     const int64_t tile = blockIdx.x;
     int64_t row0 = tile * TP_TM;
     int rows = (int)(n_out - row0 < TP_TM ? n_out - row0 : TP_TM);
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nb
     uint8_t *live_t = live + tile * (int64_t)K;
     int32_t *ptab = pass_tab + tile * (int64_t)maxpass * 4;
     const uint64_t below = (1ull << lane) - 1ull;
+    const int k_lo = (int)((int64_t)K * wave / nwave), k_hi = (int)((int64_t)K * (wave + 1) / nwave);   // this wave's offsets
 
     // one wave: its LDS operations execute in program order, so this only has to stop the COMPILER from moving LDS
     // accesses across (a workgroup fence over all address spaces would also wait for the prefetched global loads)
@@ -78,14 +86,15 @@ __global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nb
             h = (h + 1) & (TP_HASH - 1);
         }
     };
-    int ucount = 0, pass_k0 = 0, np = 0;
+    int ucount = 0, pass_k0 = k_lo, np = 0;
     auto flush = [&](int k1) {                      // close the pass [pass_k0, k1) with ucount staged rows
         wave_sync();
         int32_t base = 0;
+        const int at = k_lo + np;                   // np <= offsets done so far: stays inside this wave's range of pass_tab
         if (lane == 0) {
             base = atomicAdd(&cursor[0], ucount);
-            if ((int64_t)base + ucount > ulist_cap || np >= maxpass) { cursor[1] = 1; base = 0; }
-            if (np < maxpass) { ptab[np * 4] = pass_k0; ptab[np * 4 + 1] = k1; ptab[np * 4 + 2] = base; ptab[np * 4 + 3] = ucount; }
+            if ((int64_t)base + ucount > ulist_cap || at >= maxpass) { cursor[1] = 1; base = 0; }
+            if (at < maxpass) { ptab[at * 4] = pass_k0; ptab[at * 4 + 1] = k1; ptab[at * 4 + 2] = base; ptab[at * 4 + 3] = ucount; }
         }
         base = __shfl(base, 0);
         if ((int64_t)base + ucount <= ulist_cap)
@@ -112,14 +121,14 @@ __global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nb
         g1 = src[r1c];
     };
 #pragma unroll
-    for (int j = 0; j < TP_PF; j++) fetch(j, pf0[j], pf1[j]);
-    for (int kb = 0; kb < K; kb += TP_PF) {
+    for (int j = 0; j < TP_PF; j++) fetch(k_lo + j, pf0[j], pf1[j]);
+    for (int kb = k_lo; kb < k_hi; kb += TP_PF) {
 #pragma unroll
         for (int j = 0; j < TP_PF; j++) {
             const int k = kb + j;
             const int32_t g0 = ok0 ? pf0[j] : -1, g1 = ok1 ? pf1[j] : -1;
             fetch(k + TP_PF, pf0[j], pf1[j]);      // this register pair's next use
-            if (k < K) {
+            if (k < k_hi) {
                 int s0 = g0 >= 0 ? lookup(g0) : 0, s1 = g1 >= 0 ? lookup(g1) : 0;
                 bool new0 = g0 >= 0 && s0 == 0, new1 = g1 >= 0 && s1 == 0;
                 uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
@@ -149,8 +158,22 @@ __global__ __launch_bounds__(64) void k_tile_plan(const int32_t *__restrict__ nb
             }
         }
     }
-    flush(K);
-    if (lane == 0) npass[tile] = np < maxpass ? np : maxpass;
+    if (k_hi > k_lo) flush(k_hi);
+    if (lane == 0) np_of[wave] = np;
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0) {
+        // close the gaps between the waves' pass lists (wave w's entries start at its k_lo); 4 ints per entry, lanes 0-3
+        int total = np_of[0];
+        for (int w = 1; w < nwave; w++) {
+            const int src0 = (int)((int64_t)K * w / nwave), cnt = np_of[w];
+            if (src0 != total && lane < 4)
+                for (int i = 0; i < cnt; i++)
+                    if (src0 + i < maxpass && total + i < maxpass) ptab[(total + i) * 4 + lane] = ptab[(src0 + i) * 4 + lane];
+            total += cnt;
+        }
+        if (lane == 0) npass[tile] = total < maxpass ? total : maxpass;
+    }
 }
 
 extern "C" int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
@@ -162,8 +185,17 @@ extern "C" int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out
     hipStream_t s = cg3d_hs(stream);
     if (hipMemsetAsync(cursor, 0, 2 * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (ntile == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_tile_plan, dim3((unsigned)ntile), dim3(64), 0, s, nbr, K, n_out, tiles, ucap, maxpass, slots,
-                       live, pass_tab, npass, ulist, ulist_cap, cursor);
+    const int nwave = K <= 32 ? 1 : (int)(cg3d_divup(K, TP_CHUNK_K) < 8 ? cg3d_divup(K, TP_CHUNK_K) : 8);
+    const size_t plan_lds = (size_t)nwave * (TP_HASH * 6 + 4096);          // per wave: hash keys + values, the pass's row list
+    static bool plan_attr = false;
+    if (!plan_attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                8 * (TP_HASH * 6 + 4096)) != hipSuccess)
+            return CG3D_ERR_LAUNCH;
+        plan_attr = true;
+    }
+    hipLaunchKernelGGL(k_tile_plan, dim3((unsigned)ntile), dim3(64 * nwave), plan_lds, s, nbr, K, n_out, tiles, ucap, maxpass,
+                       slots, live, pass_tab, npass, ulist, ulist_cap, cursor);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

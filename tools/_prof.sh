@@ -1,7 +1,7 @@
+#!/bin/bash
 cd /tmp; export TMPDIR=/tmp
-R=/root/repo; O=$R/gpurun_out/prof_mid; mkdir -p $O
-rm -rf /tmp/prof_bf16
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bf16 -o bench -- python $R/bench.py --no-cpu-baseline > $O/rocprof.log 2>&1
-find /tmp/prof_bf16 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-tail -1 $O/rocprof.log | cut -c1-200
-head -60 $O/kernel_stats.csv | cut -c1-170
+rm -rf /tmp/prof_x
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_x -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-fp32 --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_x.log 2>&1
+mkdir -p /root/repo/gpurun_out/prof_x
+find /tmp/prof_x -name "*kernel_stats.csv" -exec cp {} /root/repo/gpurun_out/prof_x/kernel_stats.csv \;
+tail -1 /root/repo/gpurun_out/prof_x.log | cut -c1-200
