@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_lds(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int n0 = blockIdx.y * CT;
     const int local = wave * 32 + r;
     const bool valid = local < count;
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_bf16(const XT *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kg = lane >> 5;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int n0 = blockIdx.y * CT;
     const int local = wave * 32 + r;
     const bool valid = local < count;
@@ -942,6 +944,7 @@ __global__ __launch_bounds__(256) void k_spconv_pairs(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int n0 = blockIdx.y * CT;
     const int local = wave * 32 + r;
     const bool valid = local < count;
@@ -1075,6 +1078,7 @@ __global__ __launch_bounds__(256) void k_spconv_pairs_wgrad(const float *__restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int ci0 = (blockIdx.y / co_tiles) * 64, co0 = (blockIdx.y % co_tiles) * 64;
 
     for (int i = threadIdx.x; i < 64 * 64; i += 256) tile[i] = 0.f;
@@ -1176,6 +1180,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_t128(const float 
     const int r = lane & 31, h = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int ci0 = (blockIdx.y / co_tiles) * 128, co0 = (blockIdx.y % co_tiles) * 128;
 
     f32x16 acc[2][2];
@@ -1281,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
     const int r = lane & 31, h = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int ci0 = (blockIdx.y / co_tiles) * TM, co0 = (blockIdx.y % co_tiles) * TN;
 
     f32x16 acc[MI][NJ];
@@ -1401,6 +1407,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
     const int r = lane & 31, h = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int ci0 = (blockIdx.y / co_tiles) * TM, co0 = (blockIdx.y % co_tiles) * TN;
 
     f32x16 acc[MI][NJ];

@@ -158,13 +158,23 @@ class KernelMap:
             dev = self.nbr.device
             total = self.K * self.n_out
             G = 1 if row_bounds is None else len(row_bounds) - 1
-            rb = None if row_bounds is None else h2d(row_bounds, torch.int32, dev)
+            # ungrouped maps: the same launch also reports where every block of WGRAD_BLOCK_ROWS output rows starts in
+            # each offset's list (the blocks are "groups" to the counting kernel) -- `wgrad_segments` cuts along them
+            blocks = None
+            if WGRAD_ROW_BLOCKS and row_bounds is None and lib.is_device and self.n_out >= WGRAD_BLOCK_MIN_ROWS:
+                nb = -(-self.n_out // WGRAD_BLOCK_ROWS)
+                blocks = tuple(range(0, nb * WGRAD_BLOCK_ROWS, WGRAD_BLOCK_ROWS)) + (self.n_out,)
+                G = nb
+            rb = h2d(blocks if blocks is not None else row_bounds, torch.int32, dev) if (blocks is not None or row_bounds is not None) else None
             ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
             off = torch.zeros(self.K * G + 1, dtype=torch.int32, device=dev)
             lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
                      ptr(off), lib.stream())
             any_hit = next(iter(self._pairs.values()), None)
             off_h = off.cpu().numpy().astype(np.int64)  # host sync, once per kernel map (and grouping)
+            if blocks is not None:
+                self._blocks = (G, off_h)
+                off_h = np.concatenate([off_h[0:self.K * G:G], off_h[-1:]])
             P = int(off_h[-1])
             if any_hit is not None:
                 pin, pout = any_hit[0], any_hit[1]       # the lists do not depend on the grouping
@@ -176,6 +186,36 @@ class KernelMap:
             hit = (pin, pout, off_h, P)
             self._pairs[row_bounds] = hit
         return hit
+
+    def wgrad_segments(self, maxlen, row_bounds=None):
+        """Segment table of the weight-gradient launch.  Ungrouped maps of >= WGRAD_BLOCK_MIN_ROWS rows are cut along
+        blocks of WGRAD_BLOCK_ROWS OUTPUT ROWS instead of equal pair counts: segment (block b, offset k) = the pairs of
+        offset k whose output row lies in block b, launched in the order  k-major inside groups of 8 blocks, so that
+        workgroup i (XCD i % 8) works on block 8*(i / 8K) + i % 8: every XCD walks its own blocks one after the other, all
+        27 offsets of a block at the same time, and the block's rows (2048 x 512 B of bf16 X and dY rows) are fetched
+        into that XCD's L2 once and found there by the other 26 offsets -- with equal-count segments the offsets move
+        through the rows at different speeds (sparser offsets cover more rows per pair) and the L2 hit rate of the
+        gathers was 33 % (10 % before the XCD-aware order), 3.4 x the tensors' bytes on the memory side.  Entries past
+        the last block are empty placeholders (count 0) that keep the alignment."""
+        self.pairs(row_bounds)
+        blk = getattr(self, "_blocks", None)
+        if row_bounds is not None or blk is None or not WGRAD_ROW_BLOCKS:
+            return self.segments(maxlen, row_bounds)
+        ck = ("wrows",)
+        seg = self._segs.get(ck)
+        if seg is None:
+            nb, ob = blk
+            K = self.K
+            i = np.arange(-(-nb // N_XCD) * N_XCD * K, dtype=np.int64)
+            b = N_XCD * (i // (N_XCD * K)) + i % N_XCD
+            k = (i // N_XCD) % K
+            slot = k * nb + np.minimum(b, nb - 1)
+            start = ob[slot]
+            cnt = np.where(b < nb, ob[slot + 1] - start, 0)
+            tab = np.stack([k, start, cnt], 1).astype(np.int32)
+            seg = (h2d(torch.from_numpy(tab), torch.int32, self.nbr.device), int(tab.shape[0]))
+            self._segs[ck] = seg
+        return seg
 
     def tile_plan(self, transposed, row_bounds=None):
         """TilePlan of the map (forward) or of its transpose (data gradient); cached.  With `row_bounds` the tiles are
@@ -226,6 +266,13 @@ class KernelMap:
 
 
 SEG_XCD_ORDER = __import__("os").environ.get("CG3D_SEG_XCD", "1") != "0"
+# Off by default: measured on MI355X (82107 rows, 128 -> 128) the row-block order cuts the memory-side traffic of the launch
+# from 3.4 x to 1.4 x the tensors' bytes (L2 hit rate of the gathers 33 % -> 68 %) but runs 97 us against 78 us -- 2.7 x more
+# workgroups, each with its 64 KB atomic epilogue and a pipeline fill; the kernel is bound by dependent latencies
+# (SQ_WAIT_ANY 46 % of wave cycles, MFMA busy 17 %, LDS 34 %), not by where its rows come from.
+WGRAD_ROW_BLOCKS = __import__("os").environ.get("CG3D_WGRAD_ROW_BLOCKS", "0") != "0"
+WGRAD_BLOCK_ROWS = int(__import__("os").environ.get("CG3D_WGRAD_BLOCK_ROWS", "2048"))
+WGRAD_BLOCK_MIN_ROWS = 16384
 N_XCD = 8
 
 
@@ -933,7 +980,7 @@ class SparseConvFunction(torch.autograd.Function):
             else:
                 kmap.segments(_seg_len_fwd(), row_bounds)
             wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
-            kmap.segments(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), row_bounds)
+            (kmap.wgrad_segments if wprec else kmap.segments)(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), row_bounds)
 
     @staticmethod
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
@@ -1002,7 +1049,7 @@ class SparseConvFunction(torch.autograd.Function):
             xw, dyw = x, dy
             if wprec and xb is not None and cout % 8 == 0:
                 xw, dyw, wprec = xb, (dyg if dyg is not dy else _to_bf16(dy)), 2
-            seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, KK), rb)
+            seg, nseg = (kmap.wgrad_segments if wprec else kmap.segments)(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, KK), rb)
             lib.check(xw, dyw, pin, pout, seg)
             prof = KernelProfile.enabled and KernelProfile.wgrad and lib.is_device
             if prof:
@@ -1332,23 +1379,27 @@ def _bn_chunks(bounds, device, C=64):
     ran 42 / 10 workgroups, each thread walking 64 / 128 rows one latency at a time (23 / 41 us for 11 / 5 MB)."""
     rpb = 256 // max(1, min(C // 4, 256))
     step_rows = max(8, min(128, 8 * rpb))
-    ck = (bounds, str(device), step_rows)
+    ck = (bounds, device, step_rows)
     hit = _chunk_cache.get(ck)
     if hit is None:
-        def table(step_of):
-            rows, gco = [], [0]
-            for g in range(len(bounds) - 1):
-                step = step_of(bounds[g + 1] - bounds[g])
-                for r0 in range(bounds[g], bounds[g + 1], step):
-                    rows.append((g, r0, min(step, bounds[g + 1] - r0)))
-                gco.append(len(rows))
-            tab = h2d(rows if rows else [(0, 0, 0)], torch.int32, device).view(-1, 3)
-            return tab, len(rows), h2d(gco, torch.int32, device)
-        red, nred, gco = table(lambda ng: max(step_rows, -(-ng // 1024)))
-        app, napp, _ = table(lambda ng: step_rows)
-        ns = [max(bounds[g + 1] - bounds[g], 1) for g in range(len(bounds) - 1)]
-        unb = h2d([n / max(n - 1, 1) for n in ns], torch.float32, device).view(-1, 1)   # biased -> unbiased variance
-        hit = (red, nred, gco, h2d(ns, torch.float32, device), app, napp, unb)
+        b = np.asarray(bounds, dtype=np.int64)
+        ng = b[1:] - b[:-1]
+
+        def table(step):                      # step: int64 [G] rows per chunk of each group
+            nch = -(-ng // np.maximum(step, 1))                        # chunks per group (0 for an empty group)
+            gco = np.concatenate([[0], np.cumsum(nch)])
+            g = np.repeat(np.arange(len(ng), dtype=np.int64), nch)
+            j = np.arange(int(gco[-1]), dtype=np.int64) - gco[g]
+            r0 = b[g] + j * step[g]
+            rows = np.stack([g, r0, np.minimum(step[g], b[g + 1] - r0)], 1).astype(np.int32)
+            if rows.shape[0] == 0:
+                rows = np.zeros((1, 3), np.int32)
+            return h2d(torch.from_numpy(rows), torch.int32, device).view(-1, 3), int(gco[-1]), h2d(torch.from_numpy(gco.astype(np.int32)), torch.int32, device)
+        red, nred, gco = table(np.maximum(step_rows, -(-ng // 1024)))
+        app, napp, _ = table(np.full_like(ng, step_rows))
+        ns = np.maximum(ng, 1).astype(np.float64)
+        unb = h2d(torch.from_numpy((ns / np.maximum(ns - 1, 1)).astype(np.float32)), torch.float32, device).view(-1, 1)   # biased -> unbiased variance
+        hit = (red, nred, gco, h2d(torch.from_numpy(ns.astype(np.float32)), torch.float32, device), app, napp, unb)
         if len(_chunk_cache) > 512:
             _chunk_cache.clear()
         _chunk_cache[ck] = hit

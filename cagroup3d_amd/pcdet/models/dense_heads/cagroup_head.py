@@ -125,11 +125,12 @@ class CAGroup3DHead(nn.Module):
         sem_prob = semantic_scores.F.detach().sigmoid()
         forced = None
         if self.force_gt_selection:
-            forced, self._forced_pre = self._forced_pre, None
+            forced = self._forced_pre
+            object.__setattr__(self, "_forced_pre", None)     # (plain attribute: skip nn.Module.__setattr__'s registration checks)
             if forced is None or forced.shape[0] != ori_xyz.shape[0]:
                 forced = self._forced_selection(input_dict, out, ori_xyz)
 
-        self._merged = None
+        object.__setattr__(self, "_merged", None)
         branch = self._class_branches_batched if self.batched else self._class_branches_loop
         outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
         centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
@@ -293,8 +294,8 @@ class CAGroup3DHead(nn.Module):
         points = fine_C[:, 1:].float() * vs_tab[rc]
         perm = torch.sort(fb, stable=True)[1]                              # (class, scene)-major, rows ascending inside
         merged = [t[perm] for t in (centerness, bbox_pred, cls_score, points)]
-        self._merged = {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2], "points": merged[3],
-                        "seg": fb[perm], "per_scene": per_scene}
+        object.__setattr__(self, "_merged", {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2],
+                                             "points": merged[3], "seg": fb[perm], "per_scene": per_scene})
         pieces = [torch.split(t, per_scene) for t in merged]
         outs = []
         for c in range(C):
@@ -417,7 +418,7 @@ class CAGroup3DHead(nn.Module):
         gt_scene = torch.repeat_interleave(torch.arange(B, device=dev), ME.h2d(n_gt, torch.long, dev), output_size=sum(n_gt))
         with torch.no_grad():
             pre = self._data_targets
-            self._data_targets = None
+            object.__setattr__(self, "_data_targets", None)
             if pre is None or pre["n"] != semantic_scores.C.shape[0]:
                 pre = self.data_targets(semantic_scores.C, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks)
             semantic_labels, vox_scene, off_t, off_m, n_vox = (pre[k] for k in ("semantic_labels", "vox_scene", "off_t", "off_m", "n_vox"))

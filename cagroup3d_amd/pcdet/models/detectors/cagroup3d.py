@@ -80,7 +80,8 @@ class CAGroup3D(Detector3DTemplate):
             torch.cuda.current_stream().wait_event(event)
             ME.release_to_stream(mgr, [keep, targets], torch.cuda.current_stream())
             if targets is not None and self.training:
-                self.dense_head._data_targets, self.dense_head._forced_pre = targets.get("loss"), targets.get("forced")
+                object.__setattr__(self.dense_head, "_data_targets", targets.get("loss"))
+                object.__setattr__(self.dense_head, "_forced_pre", targets.get("forced"))
             feats = points[:, 4:][uniq.long()]          # rows are in (batch, Morton) order: always re-index
             return ME.SparseTensor(features=feats.clone(), coordinate_map_key=key, coordinate_manager=mgr)
         coordinates = points[:, :4].clone()
@@ -153,8 +154,8 @@ class CAGroup3D(Detector3DTemplate):
             ME.finish_weights()
 
     def _forward(self, batch_dict, cur_epoch):
-        self.module_list[1].semantic_threshold = max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value,
-                                                     self.semantic_min_threshold)
+        object.__setattr__(self.module_list[1], "semantic_threshold",
+                           max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value, self.semantic_min_threshold))
         batch_dict["points"][:, -3:] = batch_dict["points"][:, -3:] / 255.
         batch_dict["sp_tensor"] = self.voxelization(batch_dict["points"], batch_dict.pop("prepared", None))
         for i, module in enumerate(self.module_list):
