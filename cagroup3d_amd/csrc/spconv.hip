@@ -1406,6 +1406,15 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
+    // Which channel of its 32-channel block lane r feeds to the MFMA.  A ds_read_b128 is served in the lane groups
+    // {0-3,12-15,20-27} / {4-11,16-19,28-31} (and the same + 32); the XOR swizzle of the transposing stores depends on
+    // bit 4 of the channel row, so with channel = r a group mixes rows of both halves and 7 of its 8 row pairs share a
+    // bank (SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles).  pr sends the first group to channels 0-15 and the second to
+    // 16-31: equal swizzle inside a group, rows 9 bank-quads apart -> conflict free.  The epilogue undoes it.
+    auto perm32 = [](int l) -> int {
+        return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l;
+    };
+    const int pr = perm32(r);
     const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
     if (count <= 0) return;               // placeholder entries keep the XCD alignment of a segment table (uniform branch)
     const int ci0 = (blockIdx.y / co_tiles) * TM, co0 = (blockIdx.y % co_tiles) * TN;
@@ -1487,12 +1496,12 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
             bf16x8 a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; i++) {
-                const int row = wi * (TM / 2) + i * 32 + r;
+                const int row = wi * (TM / 2) + i * 32 + pr;
                 a[i] = *reinterpret_cast<const bf16x8 *>(&Xs[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
             }
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                const int row = wj * (TN / 2) + j * 32 + r;
+                const int row = wj * (TN / 2) + j * 32 + pr;
                 b[j] = *reinterpret_cast<const bf16x8 *>(&Ds[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
             }
 #pragma unroll
@@ -1540,8 +1549,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
         for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int ci = ci0 + wi * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int co = co0 + wj * (TN / 2) + j * 32 + r;
+                const int ci = ci0 + wi * (TM / 2) + i * 32 + perm32((e & 3) + 8 * (e >> 2) + 4 * h);
+                const int co = co0 + wj * (TN / 2) + j * 32 + pr;
                 if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
             }
 }

@@ -113,3 +113,70 @@ def test_data_parallel_two_ranks_gloo(oracle):
     assert l0 != l1                                    # different scenes per rank
     np.testing.assert_allclose(g0, g1, rtol=1e-5, atol=1e-7)     # all-reduced gradients agree
     assert abs(s0 - s1) <= 1e-4 * s0 and s0 > 0
+
+
+# ------------------------------------------------------------------ checkpoints written by the reference's stack
+def test_me_kernel_order_converter_matches_the_stated_minkowski_convention(oracle):
+    """convert_me_kernel_order: a 3^3 kernel stored in MinkowskiEngine's offset order (first spatial axis fastest, as
+    the docstring restates ME v0.5.4 -- ME itself is not in the image, so the convention is restated, not pinned by one
+    of its own vectors) gives, after conversion, the same convolution on THIS engine as a brute-force sum that walks the
+    ME order directly.  Also: the conversion is an involution and leaves non-cubic tensors alone."""
+    from cagroup3d_amd import me
+    from cagroup3d_amd.pcdet.models.detectors.detector3d_template import convert_me_kernel_order
+    torch.manual_seed(0)
+    cin, cout, k = 4, 5, 3
+    coords = torch.unique(torch.cat([torch.zeros(60, 1), torch.randint(0, 5, (60, 3)).float()], 1), dim=0)
+    feats = torch.randn(coords.shape[0], cin)
+    w_me = torch.randn(k ** 3, cin, cout)
+    state = {"conv.kernel": w_me, "lin.kernel": torch.randn(cin, cout), "bn.weight": torch.randn(5), "odd.kernel": torch.randn(10, 2, 2)}
+    conv_state = convert_me_kernel_order(state)
+    assert torch.equal(conv_state["lin.kernel"], state["lin.kernel"]) and torch.equal(conv_state["odd.kernel"], state["odd.kernel"])
+    assert torch.equal(convert_me_kernel_order(conv_state)["conv.kernel"], w_me)
+    with _lib.use_library(oracle):
+        x = me.SparseTensor(coordinates=coords, features=feats)
+        conv = me.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3)
+        with torch.no_grad():
+            conv.kernel.copy_(conv_state["conv.kernel"])
+        y = conv(x)
+        C, F = y.C, y.F.detach()
+    # brute force in ME order: offset index = ix + k*(iy + k*iz), offsets -1..1
+    table = {tuple(c.tolist()): i for i, c in enumerate(x.C)}
+    ref = torch.zeros(len(C), cout)
+    for o, c in enumerate(C.tolist()):
+        for iz in range(k):
+            for iy in range(k):
+                for ix in range(k):
+                    nb = (c[0], c[1] + ix - 1, c[2] + iy - 1, c[3] + iz - 1)
+                    j = table.get(nb)
+                    if j is not None:
+                        ref[o] += x.F[j] @ w_me[ix + k * (iy + k * iz)]
+    torch.testing.assert_close(F, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_checkpoint_loader_converts_foreign_checkpoints_and_refuses_their_optimizer_state(oracle, tmp_path):
+    from cagroup3d_amd.pcdet.models.detectors.detector3d_template import CHECKPOINT_VERSION, convert_me_kernel_order
+    with _lib.use_library(oracle):
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        other, _ = build_model.build_cagroup3d("scannet", seed=1)
+    native = {k: v.clone() for k, v in model.state_dict().items()}
+    name = next(k for k, v in native.items() if k.endswith(".kernel") and v.dim() == 3 and v.shape[0] == 27)
+    # (a) a checkpoint of this build: loaded as is
+    f_native = str(tmp_path / "native.pth")
+    torch.save({"model_state": native, "version": CHECKPOINT_VERSION, "optimizer_state": None, "it": 7, "epoch": 2}, f_native)
+    other.load_params_from_file(f_native, to_cpu=True)
+    assert torch.equal(other.state_dict()[name], native[name])
+    # (b) the same weights as the reference's stack would have written them (ME order, its own / no version tag)
+    f_me = str(tmp_path / "me.pth")
+    torch.save({"model_state": convert_me_kernel_order(native), "version": "pcdet+0.5.2", "optimizer_state": {"state": {}, "param_groups": []}}, f_me)
+    assert not torch.equal(convert_me_kernel_order(native)[name], native[name])
+    with _lib.use_library(oracle):
+        fresh, _ = build_model.build_cagroup3d("scannet", seed=2)
+    fresh.load_params_from_file(f_me, to_cpu=True)
+    assert torch.equal(fresh.state_dict()[name], native[name]), "foreign checkpoint must come out in this engine's order"
+    fresh.load_params_from_file(f_me, to_cpu=True, kernel_order="native")
+    assert torch.equal(fresh.state_dict()[name], convert_me_kernel_order(native)[name])
+    opt = torch.optim.AdamW(fresh.parameters(), lr=1e-3)
+    with pytest.raises(ValueError):
+        fresh.load_params_with_optimizer(f_me, to_cpu=True, optimizer=opt)
+    it, ep = fresh.load_params_with_optimizer(f_native, to_cpu=True, optimizer=None)
+    assert (it, ep) == (7, 2)
