@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt_total = cout >> 5, ks_total = cin >> 4, nchunk = cin >> 6;
     const int G = gridDim.x;
-    if (tid < 20) const_cast<int32_t *>(xflag)[tid] = 0;
+    if (tid < 24) const_cast<int32_t *>(xflag)[tid] = 0;
     __syncthreads();
 
     if (wave >= 4) {
@@ -334,18 +334,28 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
         };
         int32_t idx[TP_NLV], idx_next[TP_NLV];
         auto issue_idx = [&](int32_t (&dst)[TP_NLV], int uoff, int ucnt) {
+            // all TP_NLV requests unconditionally, on clamped positions (the surplus ones hit one cached address): a guard
+            // per request becomes a branch per request, the requests serialise and the array they land in moves to scratch
             const int ngran = ucnt * 8;
+            if (ngran > 0) {
 #pragma unroll
-            for (int j = 0; j < TP_NLV; j++) {
-                const int i = j * 256 + lt;
-                if (j * 256 < ngran) dst[j] = ulist[uoff + ((i < ngran ? i : ngran - 1) >> 3)];       // uniform guard
+                for (int j = 0; j < TP_NLV; j++) {
+                    const int i = j * 256 + lt;
+                    dst[j] = ulist[uoff + ((i < ngran ? i : ngran - 1) >> 3)];
+                }
             }
         };
         // the output tile a unit's last stage left in its buffer (row-major per consumer wave) -> global memory
-        StageDesc hist[2];
-        hist[0].valid = hist[1].valid = 0; hist[0].last = hist[1].last = 0;
+        // (two named records selected with ternaries, NOT an array indexed by the buffer number: a dynamically indexed local
+        // array lives in scratch memory -- 16 KB of stores per stage and workgroup, 2.4 x the output bytes on the memory side)
+        struct Hist { int32_t valid, last, yb, zi, rows; int64_t row0; };
+        Hist h0 = {0, 0, 0, 0, 0, 0}, h1 = {0, 0, 0, 0, 0, 0};
+        volatile int32_t *ldrain = xflag + 20;            // drains completed, summed over the loader waves
+        int dseq = 0;
         auto drain = [&](int bufi) {
-            const StageDesc &H = hist[bufi];
+            Hist H;
+            H.valid = bufi ? h1.valid : h0.valid; H.last = bufi ? h1.last : h0.last; H.yb = bufi ? h1.yb : h0.yb;
+            H.zi = bufi ? h1.zi : h0.zi; H.rows = bufi ? h1.rows : h0.rows; H.row0 = bufi ? h1.row0 : h0.row0;
             if (!H.valid || !H.last || (DBG & 32)) return;
             constexpr int rows_per = TP_TM / KG;
             const int cw = lw, cg_ = cw / NCO, ch = cw % NCO;            // loader wave lw drains consumer wave lw
@@ -365,7 +375,14 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 }
             }
-            hist[bufi].valid = 0;
+            if (bufi) h1.valid = 0; else h0.valid = 0;
+            // The four loader waves drain disjoint quarters of the buffer, but each one's refill requests are spread over
+            // ALL of it: nobody may refill before everybody has read.  (Uniform: every loader wave drains the same tiles.)
+            dseq++;
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads have returned
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<int32_t *>(ldrain), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (*ldrain < 4 * dseq) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         int sidx = 0, abuf = 1;
         int pos = blockIdx.x;
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             D.rows = (int)(n_out - D.row0 < TP_TM ? n_out - D.row0 : TP_TM);
             D.wslot0 = 0;
             if (tiles) { D.wslot0 = (int64_t)tiles[tile * 3] * K; D.row0 = tiles[tile * 3 + 1]; D.rows = tiles[tile * 3 + 2]; }
-            const int ngran = cur.ucnt * 8;
+            const int ngran_pass = cur.ucnt * 8;
             for (int kb = cur.k0; kb < cur.k1 || kb == cur.k0; kb += TP_KB) {      // (an empty pass still is one stage)
                 const int nk = cur.k1 - kb < TP_KB ? (cur.k1 - kb > 0 ? cur.k1 - kb : 0) : TP_KB;
                 for (int c = 0; c < nchunk; c++) {
@@ -395,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     D.kb = kb;
                     D.c = c;
                     const bool stage_rows = nchunk > 1 || kb == cur.k0;       // else: the rows of this pass are already there
+                    const int ngran = stage_rows ? ngran_pass : 0;            // (no rows: every guard below is false)
                     if (stage_rows) {
                         abuf ^= 1;
                         drain(abuf);                    // the output tile an earlier unit's last stage left in this row tile
@@ -404,7 +422,10 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     uint8_t *Ss = sblk + (sidx & 1) * s_bytes;
                     uint16_t *slot_s = reinterpret_cast<uint16_t *>(Ss);
                     uint16_t *klist = slot_s + TP_KB * TP_TM;
-                    hist[abuf] = D;
+                    {
+                        const Hist hn = {D.valid, D.last, D.yb, D.zi, D.rows, D.row0};
+                        if (abuf) h1 = hn; else h0 = hn;
+                    }
                     // ---- requests: slot table (wave 4), the stage's rows, the next pass's row indices
                     uint4 sv[8];
                     int lv = 0;
@@ -417,13 +438,24 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                         }
                         lv = lane < nk ? live[tile * (int64_t)K + kb + lane] : 0;
                     }
-                    uint4 v[TP_NLV];
-                    if (!(DBG & 8) && stage_rows) {
+                    // rows: global memory -> LDS row tile by LDS-DMA (global_load_lds_dwordx4: no data registers, nothing to
+                    // write back; a request fills wave-uniform base + lane * 16).  Lane i of request j owns PHYSICAL granule
+                    // i & 7 of row slot (i >> 3) + 1, so it fetches the logical granule the swizzle maps there.  (The
+                    // register-staged version kept its 16 uint4 per lane in scratch memory: hipcc did not promote the array
+                    // next to the 256-register consumer path -- one request in flight per lane, and scratch write-backs worth
+                    // 2.4 x the output bytes on the memory side.)
+                    if (!(DBG & 8) && ngran > 0) {
 #pragma unroll
                         for (int j = 0; j < TP_NLV; j++) {
-                            const int i = j * 256 + lt;
-                            if (j * 256 < ngran)
-                                v[j] = *reinterpret_cast<const uint4 *>(X + ((int64_t)idx[j] * cin + c * 64 + ((i < ngran ? i : ngran - 1) & 7) * 8));
+                            if (j * 256 < ngran) {                               // uniform
+                                const int i = j * 256 + lt;
+                                const int sl = (i >> 3) + 1, gr = (i & 7) ^ ((sl >> 1) & 7);
+                                const uint16_t *src = X + ((int64_t)idx[j] * cin + c * 64 + gr * 8);
+                                uint8_t *dst = As + (size_t)(j * 256 + lw * 64 + 8) * 16;
+                                if (i < ngran)
+                                    __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)src,
+                                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                            }
                         }
                     }
                     if (last_stage && nxt.valid) issue_idx(idx_next, nxt.uoff, nxt.ucnt);
@@ -454,16 +486,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                         uint4 *dst = reinterpret_cast<uint4 *>(Ss);
                         for (int i = lane; i < s_tab / 16; i += 64) dst[i] = src[i];
                     }
-                    if (!(DBG & 8) && stage_rows) {
-#pragma unroll
-                        for (int j = 0; j < TP_NLV; j++) {
-                            const int i = j * 256 + lt;
-                            if (i < ngran) {
-                                const int sl = (i >> 3) + 1, gr = i & 7;
-                                *reinterpret_cast<uint4 *>(As + sl * 128 + ((gr ^ ((sl >> 1) & 7)) << 4)) = v[j];
-                            }
-                        }
-                    }
+// (the rows were written by the LDS-DMA requests above; __syncthreads() below waits for them: vmcnt(0))
                     __syncthreads();                    // hand the buffer over; the consumers start on it
                     sidx++;
                 }

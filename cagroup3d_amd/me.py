@@ -942,12 +942,12 @@ GROUP_TILE_KERNEL = __import__("os").environ.get("CG3D_GROUP_TILE_KERNEL", "1") 
 
 
 def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
-    """The LDS-staged tile kernel (cg3d_spconv_tile_fwd): bf16 mode with bf16 row copies, a map of a coordinate map onto
-    itself (the distinct neighbour rows of a 128-row tile then fit the LDS tile in one pass; strided maps need 2-3 passes
-    and stay with the dense-map kernel), >= 128 channels on both sides (below that the layer is bound by its output
-    stream and the kernels tie), enough rows to give every CU a tile."""
-    return (TILE_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and row_bounds is None and kmap.same_map
-            and 1 < K <= 32 and cin % 64 == 0 and cout % 128 == 0 and cin >= 128 and n_rows >= TILE_MIN_ROWS)
+    """The LDS-staged tile kernel (cg3d_spconv_tile_fwd): bf16 mode with bf16 row copies, channel counts its register tile
+    covers (64-channel chunks in, 64 or multiples of 128 out), enough rows to give every CU a tile.  Since the rows reach
+    LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
+    transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
+    return (TILE_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and row_bounds is None
+            and 1 < K <= 32 and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
 
 
 class SparseConvFunction(torch.autograd.Function):

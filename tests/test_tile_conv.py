@@ -248,6 +248,28 @@ def test_hip_data_gradient_on_the_forward_plan_with_reversed_weights(oracle, hip
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 45000), (128, 128, 45000), (256, 256, 22000), (64, 128, 70000)])
+def test_hip_tile_conv_with_several_units_per_workgroup(hip, cin, cout, n):
+    """More (tile, channel block) units than CUs: every persistent workgroup walks 2-3 units -- the loader drains the
+    previous unit's output tile from the LDS buffer it is about to refill.  Against the dense-map kernel on the device
+    (the oracle comparison of both kernels is above, at sizes the CPU finishes in seconds)."""
+    torch.manual_seed(n)
+    with _lib.use_library(hip):
+        coords = surface_coords(n, batch=4, extent=max(8, int(n ** 0.5) // 3), seed=n).cuda()
+        km = _kernel_map(coords, 3, 1)
+        assert -(-km.n_out // 128) * max(cout // 128, 1) > 300, "needs more units than the chip has CUs"
+        P = int((km.nbr >= 0).sum())
+        x16 = me._to_bf16(torch.randn(km.n_in, cin, device="cuda"))
+        w = torch.randn(27, cin, cout, device="cuda") / (cin * 27) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        plan = me.build_tile_plan(km.nbr, P)
+        wf, _ = me._prep_frag(w, True, False)
+        y = me._conv_tile(x16, wf, plan, bias, cin, cout, km.n_in, P)
+        yref = me._conv_implicit_bf16(x16, me._prep_bf16_t(w), km.nbr, bias, km.n_out, cin, cout, P)
+        torch.testing.assert_close(y, yref, rtol=RTOL, atol=ATOL * max(float(yref.abs().max()), 1.0))
+
+
+@pytest.mark.gpu
 def test_hip_tile_conv_grouped_rows_use_their_group_weights(oracle, hip):
     torch.manual_seed(3)
     coords = surface_coords(5000, batch=2, extent=20, seed=11)

@@ -1,42 +1,78 @@
-"""Rebuild profiles/README.md from the rocprofv3 kernel-stats CSVs and bench JSON lines in profiles/."""
-import csv, json, os
+"""Rebuild profiles/README.md from the rocprofv3 kernel-stats CSVs, PMC CSVs and bench JSON lines in profiles/ (round tag
+from $ROUND, default r02)."""
+import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-out = ["# profiles/ — round 1 (MI355X, 1 GPU, ROCm 7.2)\n\n",
-       "Commands (on the GPU box, `cd /tmp && export TMPDIR=/tmp` first):\n\n",
-       "```\nrocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o bench -- python bench.py --no-cpu-baseline [--precision fp32]\n"
-       "rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_spconv_(implicit_bf16|pairs_bf16|pairs_wgrad_rows16)' --output-format csv ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline   # and a second pass with WRITE_SIZE\n"
-       "python bench.py            # r01_bench_bf16.json (incl. cpu_baseline)\npython tools/stream_bw.py  # r01_stream_bw.txt\n```\n\n"
-       "All of it is `tools/refresh_profiles.sh` (one gpurun call).  Device copy rate on this box: " + open(os.path.join(P, "r01_stream_bw.txt")).read().strip().splitlines()[-1] + ".\n\n",
-       "13 steps per run (3 warm-up + 10 timed), batch = 4 synthetic S50k scenes, full training step (fwd + bwd + clip + AdamW).\n"]
+RN = os.environ.get("ROUND", "r02")
+
+
+def rd(name):
+    return open(os.path.join(P, name)).read()
+
+
+out = ["# profiles/ — round 2 (MI355X, 1 GPU, ROCm 7.2)\n\n",
+       "Everything here is produced by `tools/refresh_profiles.sh` in one `gpurun` call (`cd /tmp && export TMPDIR=/tmp` first) and copied "
+       "from `gpurun_out/refresh/`:\n\n```\n"
+       "rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o bench -- python bench.py --no-cpu-baseline --no-fp32 [--precision fp32]\n"
+       "rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_spconv_(tile|implicit_bf16|pairs_bf16|pairs_wgrad_rows16)' --output-format csv ... -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32   # second pass: WRITE_SIZE\n"
+       "python bench.py                      # %s_bench_bf16.json (incl. fp32 sub-record and cpu_baseline)\n"
+       "python tools/conv_shapes.py --wgrad  # %s_conv_shapes.txt: every conv launch shape, time, SURVEY 8(d) bound\n"
+       "bash tools/pmc_sq.sh k_spconv_tile tools/mb_tile_one.py 4 128 128     # SQ counters, 128->128 layer (82 107 rows)\n"
+       "bash tools/pmc_sq.sh wgrad_rows16 tools/mb_wgrad_one.py 4 128 128; bash tools/pmc_wgrad.sh 4 128 128   # weight gradient: SQ and L2 / memory-side counters\n"
+       "python tools/mb_tile.py; python tools/mb_bn.py; python tools/host_profile.py; python tools/stream_bw.py\n```\n\n" % (RN, RN),
+       "Round-1 files (`r01_*`) are kept for comparison.  `%s_synthetic_convergence.json`: `tools/synthetic_convergence.py` (fp32 / bf16 / fp32 repeat, 400 iterations, indoor_eval on held-out scenes).\n\n" % RN,
+       "Device copy rate on the box: " + rd("%s_stream_bw.txt" % RN).strip().splitlines()[-1] + ".\n\n"]
+import bench as _b
 for tag in ("bf16", "fp32"):
-    rows = list(csv.DictReader(open(os.path.join(P, "r01_bench_%s_kernel_stats.csv" % tag))))
-    steps = 13
+    f = os.path.join(P, "%s_bench_%s_kernel_stats.csv" % (RN, tag))
+    if not os.path.exists(f):
+        continue
+    rows = list(csv.DictReader(open(f)))
+    b = json.loads(rd("%s_bench_%s.json" % (RN, tag)).strip().splitlines()[-1])
+    steps = b["steps"] + b["warmup"]
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
     calls = sum(int(r["Calls"]) for r in rows)
-    b = json.loads(open(os.path.join(P, "r01_bench_%s.json" % tag)).read().strip().splitlines()[-1])
     r = b["roofline"]
-    out.append("\n## %s operands — `r01_bench_%s_kernel_stats.csv`, `r01_bench_%s.json`\n\n" % (tag, tag, tag))
-    out.append("bench line: **%.1f scenes/s**, %.1f ms/step. Dominant kernel `%s`: bound %s, achieved %.1f %s = **%.1f %%** of the %.0f %s peak; "
-               "average launch %.3f ms over %d launches (HIP events, live in bench.py; the CSV's average for the same kernel agrees); "
-               "it is %.0f %% of the step.\n\n" % (b["value"], b["ms_per_step"], r["kernel"].split(" ")[0], r["bound"], r["achieved"], r["unit"],
-                                                100 * r["frac"], r["peak"], r["unit"], r["avg_launch_ms"], r["launches"], 100 * r["kernel_time_share"]))
-    if not r.get("traffic") and tag == "bf16":
-        import sys
-        sys.path.insert(0, ROOT)
-        import bench as _b
-        r["traffic"] = _b.pmc_traffic("k_spconv_implicit_bf16")
-    if r.get("traffic"):
-        out.append("PMC (`r01_pmc_FETCH_SIZE.csv`, `r01_pmc_WRITE_SIZE.csv`, separate passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): "
-                   "%.0f MB HBM-side traffic per launch vs %.0f MB algorithmic (gathered rows + output rows + weights + map).\n\n"
-                   % (r["traffic"] / 1e6, r["algorithmic_bytes_per_launch"] / 1e6))
+    out.append("\n## %s operands — `%s_bench_%s_kernel_stats.csv`, `%s_bench_%s.json`\n\n" % (tag, RN, tag, RN, tag))
+    out.append("bench line: **%.1f scenes/s**, %.1f ms/step (%d timed steps). Dominant kernel `%s`: bound %s (SURVEY 8(d): max(flops / peak, every-tensor-once bytes / 8 TB/s)), "
+               "achieved %.1f %s = **%.1f %%** of the %.0f %s peak; average launch %.3f ms over %d launches (HIP events, live in bench.py; the CSV's average for the same kernel: %s); "
+               "%.0f %% of the step.  Sum of the 8(d) bounds of ALL conv launches / their measured time: %.1f %%; / the whole step: %.1f %%.\n\n"
+               % (b["value"], b["ms_per_step"], b["steps"], r["kernel"].split(" ")[0], r["bound"], r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["unit"],
+                  r["avg_launch_ms"], r["launches"],
+                  ", ".join("%.3f ms" % (float(x["AverageNs"]) / 1e6) for x in rows if r["kernel"].split(" ")[0] in x["Name"])[:60] or "n/a",
+                  100 * r["kernel_time_share"], 100 * r.get("conv_bound_over_conv_time", 0), 100 * r.get("conv_bound_over_step_time", 0)))
+    if tag == "bf16":
+        for kn in ("k_spconv_tile", "k_spconv_implicit_bf16", "k_spconv_pairs_wgrad_rows16"):
+            t = _b.pmc_traffic(kn)
+            if t:
+                out.append("PMC `%s`: %.0f MB memory-side traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes, averaged over the step's launches of that kernel; "
+                           "FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)%s.\n\n"
+                           % (kn, t / 1e6, (" vs %.0f MB algorithmic (8(d)) for the dominant kernel" % (r["algorithmic_bytes_per_launch"] / 1e6)) if kn in r["kernel"] else ""))
+        for k, v in sorted(r.get("conv_kernels", {}).items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            out.append("* `%s`: %.1f launches/step, %.2f ms/step, 8(d) bound / measured = %.1f %%, %.0f TF/s on the pairs, %.0f GB/s of 8(d) bytes\n"
+                       % (k, v["launches_per_step"], v["ms_per_step"], 100 * v["bound_over_measured"], v["tflops"], v["gbytes_per_s_8d"]))
+        out.append("\n")
+    if "fp32" in b and isinstance(b["fp32"], dict):
+        f32 = b["fp32"]
+        out.append("fp32 sub-record of the same run: %.1f scenes/s, %.1f ms/step, dominant `%s` at %.1f %% of its %s roofline.\n\n"
+                   % (f32["value"], f32["ms_per_step"], f32["dominant_kernel"].split(" ")[0], 100 * f32["frac"], f32["bound"]))
     if "cpu_baseline" in b:
         c = b["cpu_baseline"]
-        out.append("cpu_baseline (the oracle, `kind: port`): %.3f scenes/s on %d threads — %s. GPU / CPU = %.0fx.\n\n"
-                   % (c["value"], c["cores"], c["sample"], b["value"] / c["value"]))
+        out.append("cpu_baseline (the oracle, `kind: port`): %.3f scenes/s on %d threads — %s." % (c["value"], c["cores"], c["sample"]))
+        if "single_thread" in c:
+            s1 = c["single_thread"]
+            out.append(" Single thread: %.3f scenes/s — %s." % (s1["value"], s1["sample"]))
+        out.append("\n\n")
     out.append("GPU busy %.1f ms/step in %d launches/step.\n\n| ms/step | calls/step | avg µs | kernel |\n|---:|---:|---:|---|\n" % (tot / steps / 1e6, calls / steps))
-    for x in rows[:24]:
-        out.append("| %.2f | %d | %.1f | `%s` |\n" % (int(x["TotalDurationNs"]) / steps / 1e6, int(x["Calls"]) / steps, float(x["AverageNs"]) / 1e3,
-                                                 x["Name"][:90].replace("|", "/")))
+    for x in sorted(rows, key=lambda x: -int(x["TotalDurationNs"]))[:28]:
+        out.append("| %.2f | %.1f | %.1f | `%s` |\n" % (int(x["TotalDurationNs"]) / steps / 1e6, int(x["Calls"]) / steps, float(x["AverageNs"]) / 1e3,
+                                                   re.sub(r"\(.*", "", x["Name"])[:90].replace("|", "/")))
+for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc_sq_tile_128.txt" % RN, "SQ counters, tile kernel, 128->128 @ 82 107 rows"),
+                   ("%s_pmc_sq_wgrad_128.txt" % RN, "SQ counters, weight gradient, same layer"), ("%s_pmc_l2_wgrad_128.txt" % RN, "L2 / memory-side counters, weight gradient"),
+                   ("%s_tile_vs_dense_map.txt" % RN, "tile kernel vs the dense-map kernel per layer shape"), ("%s_bn_shapes.txt" % RN, "BatchNorm launches per shape"),
+                   ("%s_host_issue.txt" % RN, "host issue time vs step time")):
+    if os.path.exists(os.path.join(P, name)):
+        out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
 open(os.path.join(P, "README.md"), "w").write("".join(out))
-print("".join(out)[:1800])
+print("".join(out)[:2500])
