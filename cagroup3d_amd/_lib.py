@@ -25,6 +25,7 @@ P = c_void_p
 _SIGNATURES = {
     "cg3d_is_device_library": (c_int32, []),
     "cg3d_abi_version": (c_int32, []),
+    "cg3d_h2d_async": (c_int32, [P, P, c_int64, P]),
     "cg3d_hash_capacity": (c_int64, [c_int64]),
     "cg3d_coord_map_ws_bytes": (c_int64, [c_int64]),
     "cg3d_coord_map_build": (c_int32, [P, c_int64, c_int32, P, P, c_int64, P, P, P, P, P, P]),

@@ -11,6 +11,11 @@
 
 extern "C" int cg3d_is_device_library(void) { return 1; }
 extern "C" int cg3d_abi_version(void) { return 2; }
+extern "C" int cg3d_h2d_async(void *dst, const void *src, int64_t nbytes, cg3d_stream_t stream) {
+    if (nbytes < 0 || (nbytes > 0 && (!dst || !src))) return CG3D_ERR_ARG;
+    if (nbytes == 0) return CG3D_OK;
+    return hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, cg3d_hs(stream)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
 
 extern "C" int64_t cg3d_hash_capacity(int64_t n) {
     int64_t cap = 64;

@@ -43,6 +43,15 @@ class _PrefetchWorker:
                     handle.done.set()
         self.thread = threading.Thread(target=loop, name="cg3d-coordinate-prefetch", daemon=True)
         self.thread.start()
+        # the thread must be OUT of the HIP runtime and of torch before the interpreter tears them down (a daemon thread
+        # still inside a launch at exit corrupted the heap: "corrupted size vs. prev_size" after the last bench line)
+        import atexit
+        atexit.register(self.close)
+
+    def close(self):
+        if self.thread.is_alive():
+            self.jobs.put(None)
+            self.thread.join(timeout=30)
 
     def submit(self, batch):
         h = _Pending()

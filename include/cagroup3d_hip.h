@@ -54,6 +54,10 @@ typedef void *cg3d_stream_t; /* hipStream_t; ignored by the oracle */
 int cg3d_is_device_library(void);
 /* ABI version, bumped when a signature changes. */
 int cg3d_abi_version(void);
+/* Small host table -> device on `stream` (hipMemcpyAsync through the runtime this library is linked to; `src` should be
+ * pinned for the copy to be asynchronous).  The host mirror stages its segment / chunk / tile tables through this instead of
+ * a chain of framework ops per table. */
+int cg3d_h2d_async(void *dst, const void *src, int64_t nbytes, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Coordinate maps (hash-built voxel grid).

@@ -31,6 +31,12 @@
 
 int cg3d_is_device_library(void) { return 0; }
 int cg3d_abi_version(void) { return 2; }
+int cg3d_h2d_async(void *dst, const void *src, int64_t nbytes, cg3d_stream_t stream) {
+    (void)stream;
+    if (nbytes < 0 || (nbytes > 0 && (!dst || !src))) return CG3D_ERR_ARG;
+    if (nbytes > 0) memcpy(dst, src, (size_t)nbytes);
+    return CG3D_OK;
+}
 
 #define OS_EMPTY (~0ULL)
 

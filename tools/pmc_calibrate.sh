@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc_calibrate.txt; : > $O
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/cal_$c
-  rocprofv3 --pmc $c --kernel-include-regex "k_bn_apply" --output-format csv -d /tmp/cal_$c -o pmc -- python $R/tools/mb_bn.py > /tmp/cal_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex "k_bn_apply" --output-format csv -d /tmp/cal_$c -o pmc -- python $R/tools/mb_bn.py > /tmp/cal_$c.log 2>&1
   f=$(find /tmp/cal_$c -name '*counter_collection.csv' | head -1)
   python - "$f" $c >> $O <<'PY'
 import csv, sys, collections

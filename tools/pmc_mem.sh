@@ -6,7 +6,7 @@ O=$R/gpurun_out/pmc_mem_$RE.txt; : > $O
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pm_$n
-  rocprofv3 --pmc $c --kernel-include-regex "$RE" --output-format csv -d /tmp/pm_$n -o pmc -- python $R/$SC "$@" > /tmp/pm_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex "$RE" --output-format csv -d /tmp/pm_$n -o pmc -- python $R/$SC "$@" > /tmp/pm_$n.log 2>&1
   f=$(find /tmp/pm_$n -name '*counter_collection.csv' | head -1)
   if [ -z "$f" ]; then echo "== $c: no output" >> $O; tail -3 /tmp/pm_$n.log >> $O; continue; fi
   python - "$f" >> $O <<'PY'

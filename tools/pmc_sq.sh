@@ -6,7 +6,7 @@ O=$R/gpurun_out/pmc_sq_$RE.txt; : > $O
 for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/sq_$n
-  rocprofv3 --pmc $c --kernel-include-regex "$RE" --output-format csv -d /tmp/sq_$n -o pmc -- python $R/$SC "$@" > /tmp/sq_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex "$RE" --output-format csv -d /tmp/sq_$n -o pmc -- python $R/$SC "$@" > /tmp/sq_$n.log 2>&1
   f=$(find /tmp/sq_$n -name '*counter_collection.csv' | head -1)
   if [ -z "$f" ]; then echo "== $c: no output" >> $O; tail -5 /tmp/sq_$n.log >> $O; continue; fi
   python - "$f" >> $O <<'PY'

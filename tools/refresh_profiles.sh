@@ -9,12 +9,12 @@ python $R/bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/${RN
 python $R/bench.py --precision fp32 --no-cpu-baseline --no-fp32 > $O/bench_fp32.log 2>&1; tail -1 $O/bench_fp32.log > $O/${RN}_bench_fp32.json
 for prec in bf16 fp32; do
   rm -rf /tmp/prof_$prec
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$prec -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 --precision $prec > $O/rocprof_$prec.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$prec -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 --precision $prec > $O/rocprof_$prec.log 2>&1
   find /tmp/prof_$prec -name "*kernel_stats.csv" -exec cp {} $O/${RN}_bench_${prec}_kernel_stats.csv \;
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-include-regex "k_spconv_(tile|implicit_bf16|pairs_bf16|pairs_wgrad_rows16)" --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 > $O/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-include-regex "k_spconv_(tile|implicit_bf16|pairs_bf16|pairs_wgrad_rows16)" --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 > $O/pmc_$c.log 2>&1
   find /tmp/pmc_$c -name "*counter_collection.csv" -exec cp {} $O/${RN}_pmc_$c.csv \;
 done
 python $R/tools/conv_shapes.py --wgrad > $O/${RN}_conv_shapes.txt 2>&1
@@ -24,4 +24,7 @@ bash $R/tools/pmc_wgrad.sh 4 128 128 > /dev/null 2>&1; cp $R/gpurun_out/pmc_wgra
 python $R/tools/mb_tile.py > $O/${RN}_tile_vs_dense_map.txt 2>&1
 python $R/tools/mb_bn.py > $O/${RN}_bn_shapes.txt 2>&1
 python $R/tools/host_profile.py 2>&1 | head -12 > $O/${RN}_host_issue.txt
+ls -la $O
+bash $R/tools/pmc_mem.sh k_spconv_tile tools/mb_tile_one.py 4 128 128 > /dev/null 2>&1; cp $R/gpurun_out/pmc_mem_k_spconv_tile.txt $O/${RN}_pmc_mem_tile_128.txt
+bash $R/tools/pmc_calibrate.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_calibrate.txt $O/${RN}_pmc_calibrate.txt
 ls -la $O
