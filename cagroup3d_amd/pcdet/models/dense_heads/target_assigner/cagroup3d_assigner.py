@@ -27,6 +27,17 @@ def _face_distances(points, gt_bboxes):
                         gt[..., 6]), dim=-1)
 
 
+def _pairwise_face_distances(points, boxes):
+    """points (n,3), boxes (n,7) -> (n,7): `_face_distances` of point i to box i only."""
+    shift = (points - boxes[:, :3]).unsqueeze(0)                                # (1, n, 3)
+    shift = rotation_3d_in_axis(shift.permute(1, 0, 2), -boxes[:, 6], axis=2).permute(1, 0, 2)[0]
+    ctr = boxes[:, :3] + shift
+    g = boxes
+    return torch.stack((ctr[:, 0] - g[:, 0] + g[:, 3] / 2, g[:, 0] + g[:, 3] / 2 - ctr[:, 0],
+                        ctr[:, 1] - g[:, 1] + g[:, 4] / 2, g[:, 1] + g[:, 4] / 2 - ctr[:, 1],
+                        ctr[:, 2] - g[:, 2] + g[:, 5] / 2, g[:, 2] + g[:, 5] / 2 - ctr[:, 2], g[:, 6]), dim=-1)
+
+
 def find_points_in_boxes(points, gt_bboxes, expanded_volumes=None, point_seg=None, box_seg=None):
     """(n,3) x (m,7) -> bool (n,m): strictly inside the (rotated) box -- one fused launch (cg3d_points_in_boxes) of the
     reference's tensor expression `_face_distances(points, gt)[..., :6].min(-1)[0] > 0`."""
@@ -102,21 +113,43 @@ class CAGroup3DAssigner(object):
             n_per_d = me.h2d(n_per, torch.long, dev)
             pt_cls = torch.repeat_interleave(torch.arange(len(points_list), device=dev), n_per_d, output_size=n)
             n_map = n_per_d[gt_labels.clamp(max=len(n_per) - 1)]
-        targets = _face_distances(points, gt)                                   # (n, m, 7)
-        inside = (targets[..., :6].min(-1)[0] > 0) & (pt_cls.unsqueeze(1) == gt_labels.unsqueeze(0))
-        if same is not None:
-            inside = inside & same
-        cness = compute_centerness(targets)
-        cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
+        # GT boxes are independent columns up to the final "smallest box" choice per point, so the (n, m, 7) face-distance
+        # tensor and its (n, m) companions are built for at most PAIR_CHUNK pairs at a time (all of them at the bench's
+        # sizes: 28 k points x 80 boxes); larger batches walk the boxes in column chunks -- the reference's per-class,
+        # per-scene loop bounds its memory the same way (cagroup3d_assigner.py:62-130)
         k = torch.clamp(n_map, max=self.topk + 1).clamp(min=1)
-        kth = torch.sort(cness, dim=0, descending=True)[0].gather(0, (k - 1).unsqueeze(0)).squeeze(0)
-        in_top = cness > kth.unsqueeze(0)
-        vols = volume(gt).unsqueeze(0).expand(n, m)
-        vols = torch.where(inside & in_top, vols, torch.ones_like(vols) * FLOAT_MAX)
-        min_vol, min_ind = vols.min(dim=1)
+        vol_all = volume(gt)
+        mc = m if n * m <= self.PAIR_CHUNK else max(1, self.PAIR_CHUNK // max(n, 1))
+        min_vol = min_ind = None
+        for c0 in range(0, m, mc):
+            sl = slice(c0, min(c0 + mc, m))
+            targets = _face_distances(points, gt[sl])                           # (n, mc, 7)
+            inside = (targets[..., :6].min(-1)[0] > 0) & (pt_cls.unsqueeze(1) == gt_labels[sl].unsqueeze(0))
+            if same is not None:
+                inside = inside & same[:, sl]
+            cness = compute_centerness(targets)
+            cness = torch.where(inside, cness, torch.ones_like(cness) * -1)
+            kth = torch.sort(cness, dim=0, descending=True)[0].gather(0, (k[sl] - 1).unsqueeze(0)).squeeze(0)
+            in_top = cness > kth.unsqueeze(0)
+            vols = vol_all[sl].unsqueeze(0).expand(n, sl.stop - sl.start)
+            vols = torch.where(inside & in_top, vols, torch.ones_like(vols) * FLOAT_MAX)
+            mv, mi = vols.min(dim=1)
+            if min_vol is None:
+                min_vol, min_ind = mv, mi
+                first_targets = targets if mc == m else None
+            else:
+                better = mv < min_vol                                           # ties keep the earlier (lower-index) box, as one min() does
+                min_vol = torch.where(better, mv, min_vol)
+                min_ind = torch.where(better, mi + c0, min_ind)
         labels = torch.where(min_vol == FLOAT_MAX, -torch.ones_like(min_ind), gt_labels[min_ind])
         rows = torch.arange(n, device=dev)
-        return compute_centerness(targets[rows, min_ind]), gt[min_ind].clone(), labels
+        if first_targets is not None:
+            chosen = first_targets[rows, min_ind]
+        else:                                                                   # face distances to every point's own box only
+            chosen = _pairwise_face_distances(points, gt[min_ind])
+        return compute_centerness(chosen), gt[min_ind].clone(), labels
+
+    PAIR_CHUNK = 1 << 23            # pairs (point, GT box) per pass of assign_all_classes: 8 M x 7 fp32 = 235 MB
 
     @classmethod
     def assign_semantic(cls, points, gt_bboxes, gt_labels, n_classes):

@@ -57,6 +57,12 @@ def test_assigner_matches_reference(oracle):
         assert pos.sum() > 20
         torch.testing.assert_close(ctr2[pos], t("assign_centerness")[pos], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(boxes2[pos], t("assign_boxes")[pos])
+        # ... and walked in column chunks of GT boxes (the memory bound for large batches): the same answer
+        a.PAIR_CHUNK = 3 * sum(len(p) for p in pts)            # three boxes per pass
+        ctr3, boxes3, labels3 = a.assign_all_classes(pts, gt, gl)
+        assert torch.equal(labels3, labels2)
+        torch.testing.assert_close(ctr3[pos], ctr2[pos], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(boxes3[pos], boxes2[pos])
         sem, ins = asg.CAGroup3DAssigner.assign_semantic(torch.cat(pts), gt, gl, 4)
         assert torch.equal(sem, t("assign_sem_labels")) and torch.equal(ins, t("assign_ins_labels"))
         assert torch.equal(asg.find_points_in_boxes(torch.cat(pts), gt), t("assign_inside"))

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
-        self.sites, self.ops = collections.Counter(), collections.Counter()
+        self.sites, self.ops, self.fills = collections.Counter(), collections.Counter(), collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         site = "?"
@@ -29,6 +29,9 @@ class Count(TorchDispatchMode):
                 break
         self.sites[site] += 1
         self.ops[str(func)] += 1
+        name = str(func)
+        if any(k in name for k in ("_to_copy", "zeros", "fill_", "copy_", "clone", "zero_", "ones", "full")):
+            self.fills[(name.split(".")[1], site)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -48,6 +51,9 @@ torch.cuda.synchronize()
 print("ops in one step:", sum(c.sites.values()))
 for s, n in c.sites.most_common(90):
     print("%5d  %s" % (n, s))
+print("--- fills / copies / casts by site")
+for (op, site), n in c.fills.most_common(45):
+    print("%5d  %-10s %s" % (n, op, site))
 print("--- by op")
 for s, n in c.ops.most_common(40):
     print("%5d  %s" % (n, s))
