@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
                                                      const int32_t *__restrict__ gco, int32_t G, int32_t c,
                                                      float *__restrict__ out0, float *__restrict__ out1,
                                                      float *__restrict__ run0, float *__restrict__ run1,
-                                                     long long *__restrict__ nbt, float momentum) {
+                                                     long long *__restrict__ nbt, float momentum,
+                                                     long long rows_arg, int nchunk_arg) {
     __shared__ double r0[256], r1[256];
     __shared__ long long rr[256];
     const int cblocks = (c + 15) / 16;
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
     if (a < c) {
         // four chunks per trip, every load issued before the first add: with one dependent load per trip the whole
         // kernel was a chain of ~40 L2 round trips (11 us for a few hundred KB)
-        int k = gco[g] + lanek;
-        const int kend = gco[g + 1];
+        // (no chunk table: one group, chunks [0, nchunk_arg), rows_arg rows -- partial sums produced by another kernel)
+        int k = (gco ? gco[g] : 0) + lanek;
+        const int kend = gco ? gco[g + 1] : nchunk_arg;
         for (; k + 48 < kend; k += 64) {
             float p0[4], p1[4];
             int pr[4];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
             for (int u = 0; u < 4; u++) {
                 p0[u] = ws[(int64_t)(k + 16 * u) * 2 * c + a];
                 p1[u] = ws[(int64_t)(k + 16 * u) * 2 * c + c + a];
-                pr[u] = MODE == 0 ? chunks[(k + 16 * u) * 3 + 2] : 0;
+                pr[u] = (MODE == 0 && chunks) ? chunks[(k + 16 * u) * 3 + 2] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) { s0 += (double)p0[u]; s1 += (double)p1[u]; rows += pr[u]; }
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
         for (; k < kend; k += 16) {
             s0 += (double)ws[(int64_t)k * 2 * c + a];
             s1 += (double)ws[(int64_t)k * 2 * c + c + a];
-            if (MODE == 0) rows += chunks[k * 3 + 2];
+            if (MODE == 0 && chunks) rows += chunks[k * 3 + 2];
         }
     }
     r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; rr[threadIdx.x] = rows;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
         for (int j = 1; j < 16; j++) { s0 += r0[j * 16 + threadIdx.x]; s1 += r1[j * 16 + threadIdx.x]; rows += rr[j * 16 + threadIdx.x]; }
         const int64_t t = (int64_t)g * c + a;
         if (MODE == 0) {
+            if (!chunks) rows = rows_arg;
             const double n = rows > 0 ? (double)rows : 1.0;
             const double m = s0 / n;
             double v = s1 / n - m * m;
@@ -170,7 +173,17 @@ extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchu
                            nullptr, nullptr, 0.f, 0, ws);
     hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
                        group_chunk_off, G, c, mean, var, running_mean, running_var,
-                       reinterpret_cast<long long *>(num_batches_tracked), momentum);
+                       reinterpret_cast<long long *>(num_batches_tracked), momentum, 0ll, 0);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
+                                           float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                           float momentum, cg3d_stream_t stream) {
+    if (nchunk < 1 || nchunk > 0x7fffffffll || rows < 0 || c < 1 || !ws) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, cg3d_hs(stream), ws, nullptr, nullptr, 1, c,
+                       mean, var, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), momentum,
+                       (long long)rows, (int)nchunk);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
@@ -184,7 +197,7 @@ extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *
         hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
                            act, ws);
     hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
-                       group_chunk_off, G, c, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f);
+                       group_chunk_off, G, c, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0ll, 0);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
     const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,
     const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-    int32_t nunit, int32_t ny, int32_t gz, int32_t maxk_dbg, int32_t wrev) {
+    int32_t nunit, int32_t ny, int32_t gz, int32_t maxk_dbg, int32_t wrev, float *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
     const int a_bytes = (ucap + 1) * 128 > 65536 ? (ucap + 1) * 128 : 65536;
@@ -305,6 +305,11 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     const int nt_total = cout >> 5, ks_total = cin >> 4, nchunk = cin >> 6;
     const int G = gridDim.x;
     if (tid < 24) const_cast<int32_t *>(xflag)[tid] = 0;
+    // per-channel sum / sum of squares of the rows this workgroup stores (BatchNorm statistics of the layer's output,
+    // accumulated by the loader waves while they drain a tile): [2][cout] floats behind the flags
+    float *sacc = reinterpret_cast<float *>(sblk + 2 * s_bytes + 96);
+    if (stats)
+        for (int i = tid; i < 2 * cout; i += 512) sacc[i] = 0.f;
     __syncthreads();
 
     if (wave >= 4) {
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias && H.zi == 0) bv = *reinterpret_cast<const float4 *>(bias + col0);
             float *ybase = Y + (H.row0 + cg_ * rows_per + rq) * (int64_t)cout + col0;
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
 #pragma unroll
             for (int i = 0; i < rows_per / 4; i++) {
                 float4 v = *reinterpret_cast<const float4 *>(tb + (i * 4 + rq) * 64 + c4);
@@ -373,7 +379,14 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
                     float *dst = ybase + (int64_t)i * 4 * cout;
                     if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
                     else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
+                    t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
+                    t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
                 }
+            }
+            if (stats) {                                  // 8 lanes x 2 waves share a column quad: LDS atomics
+                float *a0 = sacc + col0, *a1 = sacc + cout + col0;
+                unsafeAtomicAdd(a0, t0.x); unsafeAtomicAdd(a0 + 1, t0.y); unsafeAtomicAdd(a0 + 2, t0.z); unsafeAtomicAdd(a0 + 3, t0.w);
+                unsafeAtomicAdd(a1, t1.x); unsafeAtomicAdd(a1 + 1, t1.y); unsafeAtomicAdd(a1 + 2, t1.z); unsafeAtomicAdd(a1 + 3, t1.w);
             }
             if (bufi) h1.valid = 0; else h0.valid = 0;
             // The four loader waves drain disjoint quarters of the buffer, but each one's refill requests are spread over
@@ -506,7 +519,9 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
             *reinterpret_cast<StageDesc *>(sblk + (sidx & 1) * s_bytes + s_tab) = E;
         }
         __syncthreads();
-        drain(abuf);                                    // the last unit's tile
+        drain(abuf);                                    // the last unit's tile (its closing counter wait = all four loader waves are done)
+        if (stats)
+            for (int i = lt; i < 2 * cout; i += 256) stats[(int64_t)blockIdx.x * 2 * cout + i] = sacc[i];
         return;
     }
 
@@ -735,14 +750,33 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
 extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
     const int64_t a = (int64_t)(ucap + 1) * 128;
     const int64_t buf = (a > 65536 ? a : 65536) + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12 + (int64_t)sizeof(StageDesc);
-    return 2 * buf + 96;            // two stage buffers (the A tile doubles as the 64 KB exchange buffer) + flags
+    return 2 * buf + 96 + 4096;     // two stage buffers (the A tile doubles as the 64 KB exchange buffer) + flags + BN partial sums [2][<=512]
+}
+
+static int tile_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        ncu = prop.multiProcessorCount;
+    }
+    return ncu;
+}
+// number of (persistent) workgroups cg3d_spconv_tile_fwd launches = rows of its `stats` output
+extern "C" int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
+    const int ncu = tile_ncu();
+    if (ncu <= 0 || ntile < 0 || cout < 64 || ksplit < 1) return -1;
+    const int64_t nunit = ntile * (cout >= 128 ? cout / 128 : 1) * ksplit;
+    return (int32_t)(nunit < ncu ? nunit : ncu);
 }
 
 extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                                     const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist,
                                     int32_t maxpass, int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias,
                                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-                                    int32_t ksplit, int32_t wrev, cg3d_stream_t stream) {
+                                    int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t stream) {
+    if (stats && (ksplit != 1 || tiles || cout > 512)) return CG3D_ERR_ARG;
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
         return CG3D_ERR_ARG;
     if (ucap < TP_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
@@ -751,13 +785,8 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     static const int ldspad = getenv("CG3D_TILE_LDSPAD") ? atoi(getenv("CG3D_TILE_LDSPAD")) : 0;   // dev aid: occupancy experiments
     const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap) + (size_t)ldspad;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG3D_ERR_LAUNCH;
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = tile_ncu();
+    if (ncu <= 0) return CG3D_ERR_LAUNCH;
     // persistent workgroups, one per CU (two 64 KB stage buffers fill the LDS)
     const int32_t ny = cout >= 128 ? cout / 128 : 1;
     const int64_t nunit = ntile * ny * ksplit;
@@ -779,7 +808,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
             }                                                                                                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spconv_tile<NW, DBG>), dim3((unsigned)grid), dim3(512), lds, s, X, Wf, slots, live, pass_tab,    \
-                           npass, ulist, maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, maxk, wrev ? 1 : 0); \
+                           npass, ulist, maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, maxk, wrev ? 1 : 0, stats); \
     } while (0)
 #define TILE_LAUNCH_NW(DBG)                                                                                                    \
     do { if (cout >= 128) TILE_LAUNCH(2, DBG); else TILE_LAUNCH(1, DBG); } while (0)

@@ -525,6 +525,18 @@ BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 
 
 
 # ----------------------------------------------------------------------------- tile plans (cg3d_spconv_tile_fwd)
+FUSED_BN_STATS = __import__("os").environ.get("CG3D_FUSED_BN_STATS", "1") != "0"
+_tile_ncu = {}
+
+
+def _tile_grid(lib, ntile, cout):
+    """Workgroups cg3d_spconv_tile_fwd launches at ksplit 1 (= cg3d_spconv_tile_grid; the CU count is asked once per library)."""
+    ncu = _tile_ncu.get(lib.path)
+    if ncu is None:
+        ncu = _tile_ncu[lib.path] = int(lib.raw("cg3d_spconv_tile_grid")(1 << 40, 64, 1))
+    return min(ntile * max(cout // 128, 1), ncu)
+
+_STATS = {}         # data_ptr of a conv output of THIS forward -> (partials, chunks, rows, channels, output); cleared with _ROWS16
 TILE_ROWS = 128
 TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS rows per pass: (ucap+1) x 128 B = 64 KB
 
@@ -563,12 +575,21 @@ def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None):
     return p
 
 
-def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups=1, wrev=False):
+def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups=1, wrev=False, want_stats=False):
     """Y[o] = bias + sum_k X[nbr[k, o]] @ W[k] through a tile plan; x16: int16 view of the bf16 rows, wf: the weights in
     MFMA fragment order (cg3d_spconv_prep_weights_frag)."""
     lib = _lib.get()
     lib.check(x16, wf, bias)
     y = torch.empty((plan.n_out, cout), dtype=torch.float32, device=x16.device)
+    stats = None
+    if want_stats and FUSED_BN_STATS and ksplit == 1 and plan.tiles is None and cout <= 512 and plan.ntile > 0:
+        # per-workgroup sum / sum of squares of the output channels, accumulated while the tiles are stored: the BatchNorm
+        # that follows finalises these instead of reading Y again (cg3d_bn_stats_from_partials)
+        grid = _tile_grid(lib, plan.ntile, cout)
+        stats = torch.empty((grid, 2, cout), dtype=torch.float32, device=x16.device)
+        if len(_STATS) > 64:
+            _STATS.clear()
+        _STATS[y.data_ptr()] = (stats, grid, plan.n_out, cout, y)        # holds y: its address cannot be reused while the entry lives
     prof = KernelProfile.enabled and lib.is_device
     if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -576,7 +597,7 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
     lib.call("cg3d_spconv_tile_fwd", ptr(x16), ptr(wf), ptr(plan.slots), ptr(plan.live), ptr(plan.pass_tab), ptr(plan.npass),
              ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(bias), ptr(y),
              c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit),
-             c_int32(1 if wrev else 0), lib.stream())
+             c_int32(1 if wrev else 0), ptr(stats), lib.stream())
     if prof:
         ev1.record()
         # SURVEY 8(d) bytes: every input row once, every output row once, the weights once, the map once (2-byte slots)
@@ -1020,7 +1041,7 @@ class SparseConvFunction(torch.autograd.Function):
                 wt = _prep_bf16_t(w3)
             ctx.save_for_backward(x, w3, xg if xg is not x else None, wp)
             if tile_f:
-                return _conv_tile(xg, wt, kmap.tile_plan(False), b, cin, cout, kmap.n_in, P)
+                return _conv_tile(xg, wt, kmap.tile_plan(False), b, cin, cout, kmap.n_in, P, want_stats=True)
         elif _use_bf16(cin):
             # both bf16 copies of the weights in one launch; the plain one is the data gradient's operand
             wt, wp = _prep_bf16_both(w3) if _use_bf16(cout) else (_prep_bf16_t(w3), None)
@@ -1442,8 +1463,14 @@ class FusedBNActFunction(torch.autograd.Function):
             var = torch.empty((G, C), dtype=torch.float32, device=x.device)
             rm, rv, nbt, mom = running if running is not None else (None, None, None, 0.0)
             lib.check(rm, rv, nbt)
-            lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G), c_int32(C), ptr(ws),
-                     ptr(mean), ptr(var), ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
+            pre = _STATS.pop(x.data_ptr(), None) if G == 1 else None
+            if pre is not None and pre[2] == N and pre[3] == C:
+                # the producing convolution already summed its output per channel (tile kernel epilogue)
+                lib.call("cg3d_bn_stats_from_partials", ptr(pre[0]), c_int64(pre[1]), c_int64(N), c_int32(C), ptr(mean), ptr(var),
+                         ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
+            else:
+                lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G), c_int32(C), ptr(ws),
+                         ptr(mean), ptr(var), ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
         else:
             mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
         y = torch.empty_like(x)

@@ -155,6 +155,7 @@ class CAGroup3D(Detector3DTemplate):
         cur_epoch = batch_dict.get("cur_epoch", None)
         assert cur_epoch is not None
         ME._ROWS16.clear()
+        ME._STATS.clear()
         # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
         ME.prepare_weights(self.training)
         try:

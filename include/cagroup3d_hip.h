@@ -226,7 +226,11 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
                          int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
                          int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev,
-                         cg3d_stream_t stream);
+                         float *stats, cg3d_stream_t stream);
+/* stats (optional; needs ksplit == 1, tiles == NULL, cout <= 512): float32 [cg3d_spconv_tile_grid(ntile, cout, ksplit)][2][cout],
+ * per launched workgroup the sum and the sum of squares of every output channel over the rows it stored -- the chunk
+ * partials cg3d_bn_stats would compute in a pass of its own over Y; finalise them with cg3d_bn_stats_from_partials. */
+int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates
@@ -302,6 +306,11 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
 int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off, int32_t G,
                   int32_t c, float *ws, float *mean, float *var, float *running_mean, float *running_var,
                   int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream);
+/* cg3d_bn_stats of ONE group from partial sums somebody else produced (cg3d_spconv_tile_fwd's `stats`): ws float32
+ * [nchunk][2][C] (sum, sum of squares per chunk), `rows` = number of rows the partials cover. */
+int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                                cg3d_stream_t stream);
 int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
                   const float *mean, const float *var, float eps, const float *gamma, const float *beta, int32_t act,
                   float *Y, uint16_t *Y16, cg3d_stream_t stream);

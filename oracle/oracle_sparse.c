@@ -408,6 +408,27 @@ int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const i
     free(sums);
     return CG3D_OK;
 }
+int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                                cg3d_stream_t s) {
+    (void)s;
+    if (nchunk < 1 || rows < 0 || c < 1 || !ws) return CG3D_ERR_ARG;
+    const double n = rows > 0 ? (double)rows : 1.0;
+    for (int32_t a = 0; a < c; a++) {
+        double s0 = 0, s1 = 0;
+        for (int64_t k = 0; k < nchunk; k++) { s0 += ws[k * 2 * c + a]; s1 += ws[k * 2 * c + c + a]; }
+        const double m = s0 / n, v = s1 / n - m * m;
+        mean[a] = (float)m;
+        var[a] = (float)(v > 0 ? v : 0);
+        if (running_mean && running_var) {
+            const float unb = (float)(n / (n > 1 ? n - 1 : 1));
+            running_mean[a] = (1.f - momentum) * running_mean[a] + momentum * (float)m;
+            running_var[a] = (1.f - momentum) * running_var[a] + momentum * ((float)(v > 0 ? v : 0) * unb);
+        }
+    }
+    if (num_batches_tracked) num_batches_tracked[0] += 1;
+    return CG3D_OK;
+}
 int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
                   const float *var, float eps, const float *gamma, const float *beta, int32_t act, float *Y,
                   uint16_t *Y16, cg3d_stream_t s) {

@@ -105,8 +105,9 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
 int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
                          int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
-                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev, cg3d_stream_t s) {
-    (void)s; (void)n_in; (void)ucap; (void)ksplit;
+                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t s) {
+    (void)s; (void)n_in; (void)ucap;
+    if (stats && (ksplit != 1 || tiles || cout > 512)) return CG3D_ERR_ARG;
     if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127))) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t t = 0; t < ntile; t++) {
@@ -139,5 +140,18 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
         }
         free(xq);
     }
+    if (stats) {        /* one "workgroup": row 0 holds the sums over all rows (the grid of this restatement is 1) */
+        for (int c = 0; c < 2 * cout; c++) stats[c] = 0.f;
+        for (int64_t o = 0; o < n_out; o++)
+            for (int c = 0; c < cout; c++) {
+                const float v = Y[o * cout + c];
+                stats[c] += v;
+                stats[cout + c] += v * v;
+            }
+    }
     return CG3D_OK;
+}
+int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
+    if (ntile < 0 || cout < 64 || ksplit < 1) return -1;
+    return 1;
 }

@@ -181,7 +181,60 @@ def test_fragment_order_is_a_permutation_of_the_classic_layout(oracle):
             assert g[1, ci // 32, co // 16, ((co // 8) & 1) * 32 + ci % 32, co % 8] == cp[1, ci, co]
 
 
+def _conv_then_bn(coords, cin, cout, dev, fused):
+    """tile conv -> training-mode BatchNorm through the public functions; returns y, (mean, var), running stats."""
+    km = _kernel_map(coords, 3, 1)
+    P = int((km.nbr >= 0).sum())
+    g = torch.Generator().manual_seed(cin + cout)
+    x16 = me._to_bf16(torch.randn(km.n_in, cin, generator=g).to(dev))
+    w = (torch.randn(27, cin, cout, generator=g) / (cin * 27) ** 0.5).to(dev)
+    plan = me.build_tile_plan(km.nbr, P)
+    wf, _ = me._prep_frag(w, True, False)
+    old = me.FUSED_BN_STATS
+    me.FUSED_BN_STATS = fused
+    me._STATS.clear()
+    try:
+        y = me._conv_tile(x16, wf, plan, None, cin, cout, km.n_in, P, want_stats=True)
+        assert (y.data_ptr() in me._STATS) == bool(fused)
+        bn = torch.nn.BatchNorm1d(cout).to(dev).train()
+        out = me.fused_bn_act(y, [bn], None, me.ACT_RELU)
+        assert y.data_ptr() not in me._STATS, "the BatchNorm consumes the partials"
+    finally:
+        me.FUSED_BN_STATS = old
+        me._STATS.clear()
+    return y, out, bn.running_mean.clone(), bn.running_var.clone()
+
+
+def test_oracle_bn_statistics_from_the_conv_epilogue(oracle):
+    """cg3d_spconv_tile_fwd(stats=...) + cg3d_bn_stats_from_partials == cg3d_bn_stats over the stored rows."""
+    with _lib.use_library(oracle):
+        coords = surface_coords(1500, batch=2, extent=10, seed=5)
+        y1, o1, rm1, rv1 = _conv_then_bn(coords, 64, 128, "cpu", True)
+        y0, o0, rm0, rv0 = _conv_then_bn(coords, 64, 128, "cpu", False)
+    torch.testing.assert_close(y1, y0)
+    torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm1, 0.1 * y1.mean(0), rtol=1e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 9000), (128, 128, 45000), (128, 256, 30000), (256, 512, 3000)])
+def test_hip_bn_statistics_from_the_conv_epilogue(hip, cin, cout, n):
+    """The loader waves of the tile kernel sum every output channel while they store a tile (one to three tiles per
+    workgroup, 1-4 channel blocks): the BatchNorm that follows gets the same mean / variance / running statistics / output
+    as from its own statistics pass."""
+    with _lib.use_library(hip):
+        coords = surface_coords(n, batch=4, extent=max(8, int(n ** 0.5) // 3), seed=n).cuda()
+        y1, o1, rm1, rv1 = _conv_then_bn(coords, cin, cout, "cuda", True)
+        y0, o0, rm0, rv0 = _conv_then_bn(coords, cin, cout, "cuda", False)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rm1, rm0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm1, 0.1 * y1.mean(0), rtol=1e-3, atol=1e-5)
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,ks,stride,ucap", [(9000, 3, 1, 511), (9000, 3, 1, 128), (6000, 3, 2, 255), (1500, 5, 1, 300), (700, 9, 1, 511),
                                              (130, 3, 1, 511), (1, 3, 1, 511)])
