@@ -108,8 +108,11 @@ def train_step(model, opt, batch, clip):
     ret["loss"].backward()
     if getattr(core, "grad_sync", None) is not None:
         core.grad_sync.finish()                 # early/mid buckets were sent from the backward pass, late bucket here
-    torch.nn.utils.clip_grad_norm_(params, clip)
-    opt.step()
+    if hasattr(opt, "clip_and_step"):
+        opt.clip_and_step(clip)                 # clip_grad_norm_ + fused AdamW, the same torch kernels on cached lists
+    else:
+        torch.nn.utils.clip_grad_norm_(params, clip)
+        opt.step()
     if PREFETCH and not (PREFETCH_THREAD and batch["points"].is_cuda):
         # single-threaded variant: on the side stream while the GPU still works through the backward just queued
         from cagroup3d_amd.pcdet.models.detectors.cagroup3d import _Done
@@ -231,8 +234,11 @@ def main():
     elif use_dist:
         from cagroup3d_amd.grad_sync import TwoBucketGradSync
         model.grad_sync = TwoBucketGradSync(model)   # flat buckets over RCCL, sent from inside the backward pass
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY,
-                            fused=True)      # one multi-tensor launch set for the whole update
+    from cagroup3d_amd.optim import ClippedAdamW
+    if os.environ.get("CG3D_PLAIN_ADAMW") == "1":       # A/B: torch.optim.AdamW(fused) + clip_grad_norm_ called separately
+        opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY, fused=True)
+    else:
+        opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
     batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)

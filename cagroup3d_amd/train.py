@@ -133,8 +133,8 @@ def build_optimizer(model, optim_cfg):
     if name == "adam":
         return torch.optim.Adam(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY)
     if name == "adamW":
-        return torch.optim.AdamW(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY,
-                                 fused=params[0].is_cuda)       # one multi-tensor launch set per step on the GPU
+        from .optim import ClippedAdamW                         # torch's fused AdamW + clip_grad_norm_ on cached tensor lists
+        return ClippedAdamW(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY)
     if name == "sgd":
         return torch.optim.SGD(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY, momentum=optim_cfg.MOMENTUM)
     raise NotImplementedError(name)       # adam_onecycle (fastai wrapper) is not used by the CAGroup3D configurations
@@ -193,8 +193,11 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
         loss.backward()
         if getattr(core, "grad_sync", None) is not None:
             core.grad_sync.finish()                 # head/backbone buckets are already in flight; stem bucket here
-        torch.nn.utils.clip_grad_norm_(params, clip)
-        optimizer.step()
+        if hasattr(optimizer, "clip_and_step"):
+            optimizer.clip_and_step(clip)
+        else:
+            torch.nn.utils.clip_grad_norm_(params, clip)
+            optimizer.step()
         scheduler.step()
         it += 1
         if not _FROZEN[0] and device.type == "cuda":

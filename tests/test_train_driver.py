@@ -79,3 +79,39 @@ def test_train_and_eval_on_device(hip, tmp_path):
     from cagroup3d_amd import me
     me.PRECISION = 0
     assert os.path.exists(ck) and "mAP_0.25" in res
+
+
+def test_clipped_adamw_is_clip_grad_norm_plus_torch_adamw():
+    """cagroup3d_amd.optim.ClippedAdamW.clip_and_step == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True).step():
+    bit-identical parameters over steps with and without active clipping, same reported norm, state_dict round trip."""
+    import copy
+    from cagroup3d_amd.optim import ClippedAdamW
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.ReLU(), torch.nn.Linear(13, 3))
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-2, weight_decay=0.01, fused=True)
+    o2 = ClippedAdamW(m2.parameters(), lr=1e-2, weight_decay=0.01)
+    for it in range(6):
+        x = torch.randn(16, 7) * (10 if it % 2 else 0.1)            # gradients above / below the clipping bar
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad(set_to_none=True)
+            (m(x) ** 2).sum().backward()
+        n1 = torch.nn.utils.clip_grad_norm_(list(m1.parameters()), 1.0)
+        o1.step()
+        n2 = o2.clip_and_step(1.0)
+        assert torch.allclose(n1, n2)
+        for a, b in zip(m1.parameters(), m2.parameters()):
+            assert torch.equal(a, b), it
+        if it == 2:                                                 # a reloaded state continues identically
+            o2.load_state_dict(copy.deepcopy(o2.state_dict()))
+    for g in o2.param_groups:
+        g["lr"] = 5e-3                                              # a scheduler's change is picked up
+    o1.param_groups[0]["lr"] = 5e-3
+    for m, o in ((m1, o1), (m2, o2)):
+        o.zero_grad(set_to_none=True)
+        (m(torch.ones(4, 7)) ** 2).sum().backward()
+    torch.nn.utils.clip_grad_norm_(list(m1.parameters()), 1.0)
+    o1.step()
+    o2.clip_and_step(1.0)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
