@@ -51,45 +51,89 @@ extern "C" int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *
     return CG3D_OK;
 }
 
-// (combining runs of equal corner rows in registers, as k_scatter_add_rows does, measured no gain here: 141 vs 150 us --
-// the kernel runs at the rate of the atomics themselves, 84-168 M per launch = 2.2 TB/s of payload)
+// A thread owns one channel of IB_RPT consecutive queries and adds runs of equal corner rows up in registers before they go
+// out as atomics, corner position by corner position.  Rows are in (batch, Morton) order since round 2, so consecutive
+// queries are the children of one coarse cell and share its 8 corners exactly (up to 8 queries per run at stride ratio 2):
+// the kernel runs at the rate of the atomics themselves (84-168 M per launch = 2.2 TB/s of payload), and this divides
+// their number.  (In arrival order the same merging measured no gain -- 141 vs 150 us -- there were no runs.)
+#define IB_RPT 16
 __global__ void k_interp_bwd(const float *__restrict__ dout, const int32_t *__restrict__ idx,
                              const float *__restrict__ w, float *__restrict__ dF, int64_t nq, int32_t c) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    int64_t i = t / c;
-    int a = (int)(t % c);
-    if (i >= nq) return;
-    float d = dout[i * c + a];
+    const int64_t i0 = (t / c) * IB_RPT;
+    const int a = (int)(t % c);
+    if (i0 >= nq) return;
+    const int n = (int)(nq - i0 < IB_RPT ? nq - i0 : IB_RPT);
+    int32_t cur[8];
+    float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int32_t r = idx[i * 8 + j];
-        if (r < 0) continue;
-        unsafeAtomicAdd(&dF[(int64_t)r * c + a], w[i * 8 + j] * d);
+    for (int j = 0; j < 8; j++) { cur[j] = -1; acc[j] = 0.f; }
+    for (int q = 0; q < n; q++) {
+        const int64_t i = i0 + q;
+        const float d = dout[i * c + a];
+        const int4 r0 = *reinterpret_cast<const int4 *>(idx + i * 8), r1 = *reinterpret_cast<const int4 *>(idx + i * 8 + 4);
+        const float4 w0 = *reinterpret_cast<const float4 *>(w + i * 8), w1 = *reinterpret_cast<const float4 *>(w + i * 8 + 4);
+        const int32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (rr[j] != cur[j]) {
+                if (cur[j] >= 0) unsafeAtomicAdd(&dF[(int64_t)cur[j] * c + a], acc[j]);
+                cur[j] = rr[j];
+                acc[j] = 0.f;
+            }
+            acc[j] += ww[j] * d;            // (a missing corner, row -1, collects into an accumulator that is never written)
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (cur[j] >= 0) unsafeAtomicAdd(&dF[(int64_t)cur[j] * c + a], acc[j]);
 }
 extern "C" int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF, int64_t nq,
                                int32_t c, cg3d_stream_t stream) {
-    if (nq < 0 || c < 1) return CG3D_ERR_ARG;
+    if (nq < 0 || c < 1 || (((uintptr_t)idx | (uintptr_t)w) & 15)) return CG3D_ERR_ARG;
     if (nq == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)cg3d_divup(nq * c, 256)), dim3(256), 0, cg3d_hs(stream), dout, idx,
-                       w, dF, nq, c);
+    hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)cg3d_divup(cg3d_divup(nq, IB_RPT) * c, 256)), dim3(256), 0, cg3d_hs(stream), dout,
+                       idx, w, dF, nq, c);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
 
 // ---------------------------------------------------------------- scatter mean
+// Thread = one channel of SS_RPT consecutive input rows; for every candidate position j the runs of equal output rows are
+// summed in registers first (rows in Morton order: the children of one pooling / quantisation cell are consecutive and
+// name the same outputs position by position), one atomic per run instead of one per (input row, output).
+#define SS_RPT 8
 __global__ void k_scatter_sum(const float *__restrict__ F, const int32_t *__restrict__ map, int32_t J,
                               float *__restrict__ out, float *__restrict__ cnt, int64_t n_in, int32_t c) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    int64_t i = t / c;
-    int a = (int)(t % c);
-    if (i >= n_in) return;
-    float f = F[i * c + a];
+    const int64_t i0 = (t / c) * SS_RPT;
+    const int a = (int)(t % c);
+    if (i0 >= n_in) return;
+    const int n = (int)(n_in - i0 < SS_RPT ? n_in - i0 : SS_RPT);
+    float f[SS_RPT];
+#pragma unroll
+    for (int q = 0; q < SS_RPT; q++) f[q] = q < n ? F[(i0 + q) * c + a] : 0.f;
     for (int32_t j = 0; j < J; j++) {
-        int32_t m = map[(int64_t)j * n_in + i];
-        if (m < 0) continue;
-        unsafeAtomicAdd(&out[(int64_t)m * c + a], f);
-        if (a == 0) unsafeAtomicAdd(&cnt[m], 1.0f);
+        const int32_t *mj = map + (int64_t)j * n_in + i0;
+        int32_t cur = -1;
+        float acc = 0.f, k = 0.f;
+#pragma unroll
+        for (int q = 0; q < SS_RPT; q++) {
+            const int32_t m = q < n ? mj[q] : -1;
+            if (m != cur) {
+                if (cur >= 0) {
+                    unsafeAtomicAdd(&out[(int64_t)cur * c + a], acc);
+                    if (a == 0) unsafeAtomicAdd(&cnt[cur], k);
+                }
+                cur = m; acc = 0.f; k = 0.f;
+            }
+            acc += f[q]; k += 1.f;
+        }
+        if (cur >= 0) {
+            unsafeAtomicAdd(&out[(int64_t)cur * c + a], acc);
+            if (a == 0) unsafeAtomicAdd(&cnt[cur], k);
+        }
     }
 }
 __global__ void k_div_rows(float *__restrict__ out, const float *__restrict__ cnt, int64_t n_out, int32_t c) {
@@ -106,8 +150,8 @@ extern "C" int cg3d_scatter_mean_fwd(const float *F, const int32_t *map, int32_t
     if (hipMemsetAsync(out, 0, n_out * c * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (hipMemsetAsync(cnt, 0, n_out * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (n_in > 0)
-        hipLaunchKernelGGL(k_scatter_sum, dim3((unsigned)cg3d_divup(n_in * c, 256)), dim3(256), 0, s, F, map, J, out, cnt,
-                           n_in, c);
+        hipLaunchKernelGGL(k_scatter_sum, dim3((unsigned)cg3d_divup(cg3d_divup(n_in, SS_RPT) * c, 256)), dim3(256), 0, s, F, map, J,
+                           out, cnt, n_in, c);
     hipLaunchKernelGGL(k_div_rows, dim3((unsigned)cg3d_divup(n_out * c, 256)), dim3(256), 0, s, out, cnt, n_out, c);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
