@@ -268,6 +268,42 @@ extern "C" int cg3d_kernel_map(const int32_t *q, int64_t nq, const int32_t *off,
     return CG3D_OK;
 }
 
+// Map of a coordinate map ONTO ITSELF with a centred odd kernel (offsets symmetric: off[K-1-k] == -off[k], centre 0):
+// nbr[K-1-k][j] == i  <=>  nbr[k][i] == j, so only the first K/2 offsets are looked up in the hash table; every hit writes
+// its mirror entry too, the centre is the identity, and the mirrored half starts out as -1.  Bit-identical to
+// cg3d_kernel_map on the same inputs with half the probes.
+__global__ void k_kernel_map_self(const int32_t *__restrict__ q, int64_t n, const int32_t *__restrict__ off, int32_t K,
+                                  const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, uint64_t capm1,
+                                  int32_t *__restrict__ nbr) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = reinterpret_cast<const int4 *>(q)[i];
+    const int32_t half = K >> 1;
+    if (blockIdx.y == 0) nbr[(int64_t)half * n + i] = (int32_t)i;
+    for (int32_t k = blockIdx.y; k < half; k += gridDim.y) {
+        uint64_t key;
+        int32_t r = -1;
+        if (cg3d_pack(c.x, c.y + off[k * 3], c.z + off[k * 3 + 1], c.w + off[k * 3 + 2], &key))
+            r = cg3d_lookup(keys, vals, capm1, key);
+        nbr[(int64_t)k * n + i] = r;
+        if (r >= 0) nbr[(int64_t)(K - 1 - k) * n + r] = (int32_t)i;
+    }
+}
+extern "C" int cg3d_kernel_map_self(const int32_t *q, int64_t n, const int32_t *off, int32_t K, const uint64_t *keys,
+                                    const int32_t *vals, int64_t cap, int32_t *nbr, cg3d_stream_t stream) {
+    if (n < 0 || K < 1 || !(K & 1) || ((uintptr_t)q & 15)) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipStream_t s = cg3d_hs(stream);
+    const int32_t half = K >> 1;
+    if (half > 0 && hipMemsetAsync(nbr + (int64_t)(half + 1) * n, 0xFF, (size_t)half * n * sizeof(int32_t), s) != hipSuccess)
+        return CG3D_ERR_LAUNCH;
+    unsigned gy = (unsigned)(half < 1 ? 1 : (half < 1024 ? half : 1024));
+    hipLaunchKernelGGL(k_kernel_map_self, dim3((unsigned)cg3d_divup(n, 256), gy), dim3(256), 0, s, q, n, off, K, keys, vals,
+                       (uint64_t)(cap - 1), nbr);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
 // ------------------------------------------------------------------ interpolation map
 __global__ void k_interp_map(const float *__restrict__ q, int64_t nq, int32_t ts, const uint64_t *__restrict__ keys,
                              const int32_t *__restrict__ vals, uint64_t capm1, int32_t *__restrict__ idx,

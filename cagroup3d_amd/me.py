@@ -281,6 +281,7 @@ class KernelMap:
 
 
 SEG_XCD_ORDER = __import__("os").environ.get("CG3D_SEG_XCD", "1") != "0"
+SELF_MAP_HALF = __import__("os").environ.get("CG3D_SELF_MAP_HALF", "1") != "0"
 # Off by default: measured on MI355X (82107 rows, 128 -> 128) the row-block order cuts the memory-side traffic of the launch
 # from 3.4 x to 1.4 x the tensors' bytes (L2 hit rate of the gathers 33 % -> 68 %) but runs 97 us against 78 us -- 2.7 x more
 # workgroups, each with its 64 KB atomic epilogue and a pipeline fill; the kernel is bound by dependent latencies
@@ -417,12 +418,14 @@ class CoordinateManager:
 
     # -- kernel maps
     @staticmethod
-    def _lookup_map(q_coords, table, offsets):
+    def _lookup_map(q_coords, table, offsets, onto_itself=False):
+        """onto_itself: the queries are the table's own rows and the offsets a centred odd kernel -- half the lookups."""
         lib = _lib.get()
         K, nq = offsets.shape[0], q_coords.shape[0]
         nbr = torch.empty((K, max(nq, 1)), dtype=torch.int32, device=q_coords.device)
         lib.check(q_coords, offsets)
-        lib.call("cg3d_kernel_map", ptr(q_coords), c_int64(nq), ptr(offsets), c_int32(K), ptr(table.keys),
+        lib.call("cg3d_kernel_map_self" if (onto_itself and SELF_MAP_HALF and K % 2 == 1 and nq > 0) else "cg3d_kernel_map",
+                 ptr(q_coords), c_int64(nq), ptr(offsets), c_int32(K), ptr(table.keys),
                  ptr(table.vals), c_int64(table.cap), ptr(nbr), lib.stream())
         return nbr[:, :nq] if nq > 0 else nbr[:, :0]
 
@@ -437,7 +440,7 @@ class CoordinateManager:
             else:
                 offs = _offsets(kernel_size, dst.tensor_stride * dilation, src.coords.device)
                 fwd_off, bwd_off = (-offs).contiguous(), offs      # o - off = i   /   i + off = o
-            nbr = self._lookup_map(dst.coords, src, fwd_off)
+            nbr = self._lookup_map(dst.coords, src, fwd_off, in_key == out_key and int(kernel_size) % 2 == 1)
             # the lazy transposed map must not close over `self`: manager -> _kmaps -> KernelMap -> closure -> manager
             # is a reference cycle, and every step's coordinate structures (0.5 GB of device tensors at S50k x 4) then
             # live until the cyclic collector's next gen-2 pass -- tens of GB of garbage in a long run

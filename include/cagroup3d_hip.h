@@ -99,6 +99,12 @@ int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qstride,
 int cg3d_kernel_map(const int32_t *q_coords, int64_t nq, const int32_t *offsets, int32_t K,
                     const uint64_t *keys, const int32_t *vals, int64_t cap,
                     int32_t *nbr, cg3d_stream_t stream);
+/* The same map when the queries ARE the table's rows in table order (a coordinate map onto itself) and the offsets are a
+ * centred odd kernel (K odd, offsets[K-1-k] == -offsets[k], offsets[K/2] == 0): nbr[K-1-k][j] == i <=> nbr[k][i] == j, so
+ * only K/2 offsets are looked up and every hit writes its mirror entry.  Bit-identical output, half the hash probes. */
+int cg3d_kernel_map_self(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t K,
+                         const uint64_t *keys, const int32_t *vals, int64_t cap,
+                         int32_t *nbr, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse convolution, output-stationary implicit GEMM:

@@ -162,6 +162,12 @@ int cg3d_kernel_map(const int32_t *q, int64_t nq, const int32_t *off, int32_t K,
     return CG3D_OK;
 }
 
+int cg3d_kernel_map_self(const int32_t *q, int64_t n, const int32_t *off, int32_t K, const uint64_t *keys,
+                         const int32_t *vals, int64_t cap, int32_t *nbr, cg3d_stream_t s) {
+    if (!(K & 1)) return CG3D_ERR_ARG;
+    return cg3d_kernel_map(q, n, off, K, keys, vals, cap, nbr, s);      /* the plain lookups: the definition of the result */
+}
+
 int cg3d_interp_map(const float *q, int64_t nq, int32_t ts, const uint64_t *keys, const int32_t *vals,
                     int64_t cap, int32_t *idx, float *w, cg3d_stream_t s) {
     (void)s;

@@ -220,6 +220,21 @@ def test_oracle_bn_statistics_from_the_conv_epilogue(oracle):
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("ks,dil,n", [(3, 1, 20000), (5, 1, 6000), (3, 2, 8000), (9, 1, 1500), (3, 1, 1)])
+def test_hip_self_map_by_half_the_lookups_is_bit_identical(hip, ks, dil, n):
+    """cg3d_kernel_map_self (K/2 hash lookups + mirrored writes) == cg3d_kernel_map on the map of a coordinate map onto itself"""
+    with _lib.use_library(hip):
+        coords = surface_coords(n, batch=3, extent=max(6, int(n ** 0.5) // 3), seed=n + ks).cuda()
+        x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1, device="cuda"))
+        src = x.coordinate_manager.get(x.coordinate_map_key)
+        offs = me._offsets(ks, dil, coords.device)
+        full = me.CoordinateManager._lookup_map(src.coords, src, offs, False)
+        half = me.CoordinateManager._lookup_map(src.coords, src, offs, True)
+        assert torch.equal(full, half)
+        assert n < 100 or int((full >= 0).sum()) > full.shape[1]          # (more than the centre column)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,n", [(64, 64, 9000), (128, 128, 45000), (128, 256, 30000), (256, 512, 3000)])
 def test_hip_bn_statistics_from_the_conv_epilogue(hip, cin, cout, n):
     """The loader waves of the tile kernel sum every output channel while they store a tile (one to three tiles per
