@@ -109,7 +109,9 @@ class CAGroup3D(Detector3DTemplate):
         if getattr(self, "_side_stream", None) is None:
             # normal priority on purpose: a high-priority side stream next to a stream pair that waits on each other
             # (main <-> the RCCL stream of any in-step collective) cost 8 ms/step on MI355X
-            self._side_stream = torch.cuda.Stream(device=points.device)
+            import os as _os
+            prio = int(_os.environ.get("CG3D_SIDE_PRIORITY", "0"))
+            self._side_stream = torch.cuda.Stream(device=points.device, priority=prio)
         side = self._side_stream
         with torch.cuda.stream(side), torch.no_grad():
             coordinates = points[:, :4].clone()
