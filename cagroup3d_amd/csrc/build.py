@@ -21,6 +21,7 @@ SOURCES = {
     "sort_vertices.hip": ["-ffp-contract=off"],
     "bn_act.hip": [],
     "loss.hip": [],
+    "optim.hip": ["-ffp-contract=off"],      # same rounding as the oracle's plain C (and torch's kernel: no contraction across statements)
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

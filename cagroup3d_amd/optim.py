@@ -7,7 +7,14 @@ lists.
 and dtype, walking the param groups, checking every state entry -- 2.7 ms of host time per step on a step that is bound by the
 host.  This subclass runs the SAME torch kernels (`_foreach_norm`, `_foreach_mul_`, `_foreach_add_`,
 `_fused_adamw_`) on lists built once; state layout, `state_dict()` and the update itself are torch's."""
+import os
+from ctypes import c_float, c_int64
+
+import numpy as np
 import torch
+
+CHUNK = 1 << 15          # elements per table row of the fused step (one 256-thread workgroup each)
+FUSED_STEP = os.environ.get("CG3D_FUSED_ADAMW", "1") != "0"
 
 
 class ClippedAdamW(torch.optim.AdamW):
@@ -42,6 +49,8 @@ class ClippedAdamW(torch.optim.AdamW):
         norms = torch._foreach_norm(flat, norm_type)
         total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)      # clip_grad_norm_: always multiplied, 1.0 when below the bar
+        if self._fused_step(lean, flat, coef):
+            return total
         torch._foreach_mul_(flat, coef)
         for (group, ps, m1, m2, steps), gs in zip(lean, grads):
             beta1, beta2 = group["betas"]
@@ -51,10 +60,62 @@ class ClippedAdamW(torch.optim.AdamW):
                                 found_inf=None)
         return total
 
+    # -- one launch for the gradient scaling and the update of every parameter (cg3d_adamw_step, csrc/optim.hip)
+    def _fused_step(self, lean, flat_grads, coef):
+        """True if the step was taken by the library's kernel: device library bound, every tensor fp32 and contiguous.
+        Unlike the torch path the gradients are NOT overwritten with their clipped values (nothing reads them afterwards:
+        `zero_grad` follows); the parameters, moments and step counters end up as torch's kernel leaves them (tested)."""
+        if not FUSED_STEP:
+            return False
+        from . import _lib, me
+        lib = _lib.get()
+        dev = flat_grads[0].device
+        if not lib.is_device or dev.type != "cuda":
+            return False
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            rows, pid, k = [], [], 0
+            for group, ps, m1, m2, steps in lean:
+                for p, a, b in zip(ps, m1, m2):
+                    if not (p.dtype == a.dtype == b.dtype == torch.float32 and p.is_contiguous() and a.is_contiguous() and b.is_contiguous()):
+                        self._plan = False
+                        return False
+                    n = p.numel()
+                    for o in range(0, n, CHUNK):
+                        rows.append((p.data_ptr(), a.data_ptr(), b.data_ptr(), o, min(CHUNK, n - o)))
+                        pid.append(k)
+                    k += 1
+            plan = self._plan = (me.h2d(np.asarray(rows, dtype=np.int64), torch.int64, dev), me.h2d(np.asarray(pid, dtype=np.int32), torch.int32, dev),
+                                 len(rows), [g["params"] for g in self.param_groups])
+        if plan is False:
+            return False
+        if any(g.dtype != torch.float32 or not g.is_contiguous() for g in flat_grads):
+            return False
+        # hyper-parameters are per group in torch; the table is one launch: require them equal (they are for this model)
+        g0 = lean[0][0]
+        if any((g["lr"], g["betas"], g["eps"], g["weight_decay"]) != (g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]) for g, *_ in lean):
+            return False
+        steps = [s for *_, ss in lean for s in ss]
+        torch._foreach_add_(steps, 1)
+        t = self._host_step = getattr(self, "_host_step", None) or 0
+        if t == 0:
+            t = int(steps[0].item()) - 1                   # (first fused step after torch-managed ones / a reload: one host read)
+        t += 1
+        self._host_step = t
+        beta1, beta2 = g0["betas"]
+        gp = me.h2d(np.fromiter((g.data_ptr() for g in flat_grads), dtype=np.int64, count=len(flat_grads)), torch.int64, dev)
+        lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), coef.data_ptr(),
+                 c_float(g0["lr"]), c_float(beta1), c_float(beta2), c_float(g0["eps"]), c_float(g0["weight_decay"]),
+                 c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t), lib.stream())
+        return True
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._lean = None
+        self._plan = None
+        self._host_step = None
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
         self._lean = None
+        self._plan = None

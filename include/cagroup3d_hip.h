@@ -408,6 +408,18 @@ int cg3d_focal_loss_fwd(const float *pred, const int32_t *label, const float *ro
 int cg3d_focal_loss_bwd(const float *pred, const int32_t *label, const float *row_w, const float *gscale, int64_t n,
                         int32_t c, float gamma, float alpha, float *dpred, cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimiser step of the training loop (reference tools/train_utils/train_utils.py:40-47: clip_grad_norm_ + AdamW.step()):
+ * gradient scaling by the clip coefficient and the AdamW update of every parameter in one launch.
+ *   table int64 [nrows,5] = (param address, exp_avg address, exp_avg_sq address, first element, element count <= 2^31) --
+ *   one row per chunk of a contiguous fp32 parameter; pid int32 [nrows] = parameter id of the row; grads int64 [nparams] =
+ *   this step's gradient addresses; clip: device scalar or NULL (g <- g * *clip, not written back).
+ *   p -= lr*wd*p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),
+ *   bc1 = 1 - beta1^t, bc2 = 1 - beta2^t supplied by the caller. */
+int cg3d_adamw_step(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, const float *clip,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                    float bias_correction2, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,30 @@ int cg3d_focal_loss_bwd(const float *pred, const int32_t *label, const float *ro
         }
     return CG3D_OK;
 }
+
+/* ---- optimiser step (test infrastructure): plain-C statement of cg3d_adamw_step, the per-element arithmetic of torch's
+ * fused AdamW kernel (torch/optim/adamw.py `_fused_adamw` -> aten `_fused_adamw_`), gradient pre-scaled by *clip. */
+int cg3d_adamw_step(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, const float *clip,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                    float bias_correction2, cg3d_stream_t stream) {
+    (void)stream;
+    if (nrows < 0 || (nrows > 0 && (!table || !pid || !grads))) return CG3D_ERR_ARG;
+    if (!(bias_correction1 > 0.f) || !(bias_correction2 > 0.f)) return CG3D_ERR_ARG;
+    const float cs = clip ? *clip : 1.f;
+    const float step_size = lr / bias_correction1, omb1 = 1.f - beta1, omb2 = 1.f - beta2, lrwd = lr * weight_decay;
+    const float bc2_sqrt = sqrtf(bias_correction2);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nrows; r++) {
+        const int64_t *row = table + r * 5;
+        float *p = (float *)(intptr_t)row[0] + row[3], *m = (float *)(intptr_t)row[1] + row[3], *v = (float *)(intptr_t)row[2] + row[3];
+        const float *g = (const float *)(intptr_t)grads[pid[r]] + row[3];
+        for (int64_t i = 0; i < row[4]; i++) {
+            const float gg = g[i] * cs;
+            p[i] -= lrwd * p[i];
+            m[i] += (gg - m[i]) * omb1;
+            v[i] = beta2 * v[i] + omb2 * gg * gg;
+            p[i] -= step_size * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+        }
+    }
+    return CG3D_OK;
+}

@@ -115,3 +115,61 @@ def test_clipped_adamw_is_clip_grad_norm_plus_torch_adamw():
     o2.clip_and_step(1.0)
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(a, b)
+
+
+def _adamw_case(dev, steps=4):
+    """models with parameter sizes around the chunk / vector boundaries; returns (torch-stepped, library-stepped) params"""
+    import copy
+    from cagroup3d_amd.optim import ClippedAdamW
+    torch.manual_seed(1)
+    shapes = [(3,), (70001,), (129, 257), (27, 64, 64), (5,), (32768,), (32769,)]
+    p1 = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    o1 = torch.optim.AdamW(p1, lr=1e-2, weight_decay=0.02, fused=True)
+    o2 = ClippedAdamW(p2, lr=1e-2, weight_decay=0.02)
+    for it in range(steps):
+        gs = [torch.randn_like(p) * (30.0 if it % 2 else 0.01) for p in p1]
+        for ps in (p1, p2):
+            for p, g in zip(ps, gs):
+                p.grad = g.clone()
+        n1 = torch.nn.utils.clip_grad_norm_(p1, 1.0)
+        o1.step()
+        n2 = o2.clip_and_step(1.0)
+        assert torch.allclose(n1, n2)
+    return p1, p2, o1, o2
+
+
+def test_oracle_adamw_step_matches_torch_fused_adamw(oracle):
+    """cg3d_adamw_step (the oracle's plain-C statement) against torch's fused AdamW on host tensors, clip scalar included."""
+    from ctypes import c_float, c_int64
+    import numpy as np
+    torch.manual_seed(0)
+    n = 10007
+    p = torch.randn(n); g = torch.randn(n); m = torch.randn(n) * 0.1; v = torch.rand(n) * 0.1
+    pt = torch.nn.Parameter(p.clone()); pt.grad = g.clone() * 0.37
+    opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, fused=True)
+    opt.state[pt] = {"step": torch.tensor(6.0), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+    opt.step()
+    rows = torch.tensor([[p.data_ptr(), m.data_ptr(), v.data_ptr(), 0, 4000], [p.data_ptr(), m.data_ptr(), v.data_ptr(), 4000, n - 4000]], dtype=torch.int64)
+    pid = torch.zeros(2, dtype=torch.int32)
+    gp = torch.tensor([g.data_ptr()], dtype=torch.int64)
+    clip = torch.tensor([0.37])
+    oracle.call("cg3d_adamw_step", rows.data_ptr(), pid.data_ptr(), c_int64(2), gp.data_ptr(), clip.data_ptr(), c_float(3e-3), c_float(0.9),
+                c_float(0.999), c_float(1e-8), c_float(0.05), c_float(1 - 0.9 ** 7), c_float(1 - 0.999 ** 7), None)
+    torch.testing.assert_close(p, pt.detach(), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(m, opt.state[pt]["exp_avg"], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(v, opt.state[pt]["exp_avg_sq"], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_fused_clip_adamw_launch_matches_torch_on_device(hip):
+    """ClippedAdamW on the device takes the library's one-launch step (after torch has created the state in step 1):
+    parameters and moments follow torch.optim.AdamW(fused) + clip_grad_norm_ to fp32 rounding; the step counters agree."""
+    from cagroup3d_amd import optim
+    with _lib.use_library(hip):
+        p1, p2, o1, o2 = _adamw_case("cuda", steps=5)
+        assert o2._plan not in (None, False) and o2._host_step == 5, "the library step must have run"
+    for a, b in zip(p1, p2):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(o2.state[b]["exp_avg_sq"], o1.state[a]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+        assert float(o2.state[b]["step"]) == float(o1.state[a]["step"]) == 5.0
