@@ -1387,13 +1387,17 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_bf16(const float 
 // the requests of the fp32-row kernel; the next TWO stages are kept in flight.  A thread transposes
 // PQ pairs x 8 channels (PQ = 4 for a 128-channel operand tile, 2 for a 64-channel one) into the [channel][pair]
 // LDS layout of k_spconv_pairs_wgrad_bf16; the MFMA phase is the same.
-template <int T> struct WRows {
+// NW = 8 (512 threads, 128 x 128 tile only): the same tile and LDS budget worked by twice the waves -- each owns a 64 x 32
+// block (32 accumulator registers instead of 64) and transposes 2 pairs per stage instead of 4, so a wave needs <= 128
+// registers and FOUR fit per SIMD (two workgroups per CU as before) where the 4-wave form holds two: the kernel is bound
+// by dependent latencies (SQ_WAIT_ANY 46 % of its wave cycles), which more resident waves hide.
+template <int T, int NW> struct WRows {
     static constexpr int TPR = T / 8;              // threads per gathered row
-    static constexpr int PQ = TPR / 4;             // pairs per thread per stage (64 pairs / (256 / TPR) threads)
+    static constexpr int PQ = 64 * TPR / (NW * 64);   // pairs per thread per stage (64 pairs / (threads / TPR))
     uint4 v[PQ];
 };
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint16_t *__restrict__ X,
+template <int TM, int TN, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void k_spconv_pairs_wgrad_rows16(const uint16_t *__restrict__ X,
                                                                       const uint16_t *__restrict__ dY,
                                                                       const int32_t *__restrict__ pin,
                                                                       const int32_t *__restrict__ pout,
@@ -1402,10 +1406,11 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
                                                                       int32_t co_tiles) {
     __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
-    constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 tiles per wave
+    constexpr int WJ = NW / 2;                           // waves along the output-channel direction (2 along the input channels)
+    constexpr int MI = TM / 64, NJ = TN / (32 * WJ);     // 32 x 32 tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / WJ, wj = wave % WJ;
     // Which channel of its 32-channel block lane r feeds to the MFMA.  A ds_read_b128 is served in the lane groups
     // {0-3,12-15,20-27} / {4-11,16-19,28-31} (and the same + 32); the XOR swizzle of the transposing stores depends on
     // bit 4 of the channel row, so with channel = r a group mixes rows of both halves and 7 of its 8 row pairs share a
@@ -1427,7 +1432,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    constexpr int XTPR = WRows<TM>::TPR, XPQ = WRows<TM>::PQ, DTPR = WRows<TN>::TPR, DPQ = WRows<TN>::PQ;
+    constexpr int XTPR = WRows<TM, NW>::TPR, XPQ = WRows<TM, NW>::PQ, DTPR = WRows<TN, NW>::TPR, DPQ = WRows<TN, NW>::PQ;
     const int xc8 = (tid % XTPR) * 8, xp0 = (tid / XTPR) * XPQ;
     const int dc8 = (tid % DTPR) * 8, dp0 = (tid / DTPR) * DPQ;
     const bool xin = ci0 + xc8 < cin, din = co0 + dc8 < cout;       // cin, cout are multiples of 8 here
@@ -1449,7 +1454,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
             ix.di[i] = pout[start + (p < count ? p : count - 1)];
         }
     };
-    auto issue = [&](WRows<TM> &xr, WRows<TN> &dr, const WIdx &ix, int32_t p0) {
+    auto issue = [&](WRows<TM, NW> &xr, WRows<TN, NW> &dr, const WIdx &ix, int32_t p0) {
 #pragma unroll
         for (int i = 0; i < XPQ; i++) {
             const int32_t p = p0 + xp0 + i;
@@ -1486,7 +1491,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
             *reinterpret_cast<uint32_t *>(&Tl[(c8 + 2 * q + 1) * WB_LD + col]) = __builtin_amdgcn_perm(w1[q], w0[q], HI);
         }
     };
-    auto commit = [&](const WRows<TM> &xr, const WRows<TN> &dr, int buf) {
+    auto commit = [&](const WRows<TM, NW> &xr, const WRows<TN, NW> &dr, int buf) {
         if (XPQ == 4) put4(Xs[buf], xc8, xp0, xr.v); else put2(Xs[buf], xc8, xp0, xr.v);
         if (DPQ == 4) put4(Ds[buf], dc8, dp0, dr.v); else put2(Ds[buf], dc8, dp0, dr.v);
     };
@@ -1501,7 +1506,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
             }
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                const int row = wj * (TN / 2) + j * 32 + pr;
+                const int row = wj * (TN / WJ) + j * 32 + pr;
                 b[j] = *reinterpret_cast<const bf16x8 *>(&Ds[buf][row * WB_LD + (((kk * 2 + h) ^ ((row >> 4) & 7)) << 3)]);
             }
 #pragma unroll
@@ -1513,8 +1518,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
     };
     // stage st lives in LDS buffer st&1; register set A holds stage st+1, set B stage st+2 (roles swap every stage)
     const int nstage = (count + WB_S - 1) / WB_S;
-    WRows<TM> xa, xb;
-    WRows<TN> da, db;
+    WRows<TM, NW> xa, xb;
+    WRows<TN, NW> da, db;
     WIdx i0, i1, iA, iB;
     load_idx(i0, 0);
     load_idx(i1, WB_S);                      // past the end: clamped rows, masked to zero, never used
@@ -1550,7 +1555,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs_wgrad_rows16(const uint
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int ci = ci0 + wi * (TM / 2) + i * 32 + perm32((e & 3) + 8 * (e >> 2) + 4 * h);
-                const int co = co0 + wj * (TN / 2) + j * 32 + pr;
+                const int co = co0 + wj * (TN / WJ) + j * 32 + pr;
                 if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
             }
 }
@@ -1581,10 +1586,15 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
         if (precision == 2) {   // rows stored as bf16: 16-byte gathers need 8-channel multiples
             if (cin % 8 != 0 || cout % 8 != 0) return CG3D_ERR_ARG;
 #define LAUNCH_WR(TM, TN)                                                                                          \
-    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s,    \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN, 4>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, \
                        reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg, \
                        dW, cin, cout, ot)
-            if (m128 && n128) LAUNCH_WR(128, 128);
+            static const bool w8 = !(getenv("CG3D_WGRAD_W8") && atoi(getenv("CG3D_WGRAD_W8")) == 0);
+            if (m128 && n128 && w8)
+                hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<128, 128, 8>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(512), 0, s,
+                                   reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg,
+                                   dW, cin, cout, ot);
+            else if (m128 && n128) LAUNCH_WR(128, 128);
             else if (m128) LAUNCH_WR(128, 64);
             else if (n128) LAUNCH_WR(64, 128);
             else LAUNCH_WR(64, 64);
