@@ -181,46 +181,61 @@ __global__ void k_grid_keys(const float *__restrict__ X, int32_t n, const GridIn
     keys[i] = grid_key(grid_cell(X[i * 3], gi->lo[0], h), grid_cell(X[i * 3 + 1], gi->lo[1], h), grid_cell(X[i * 3 + 2], gi->lo[2], h));
     vals[i] = i;
 }
-__global__ __launch_bounds__(256) void k_grid_nn(const float *__restrict__ X, int32_t n, const float *__restrict__ Q, int32_t m,
-                                                 const GridInfo *__restrict__ gi, const unsigned long long *__restrict__ keys,
-                                                 const int32_t *__restrict__ vals, int32_t *__restrict__ idx,
-                                                 float *__restrict__ dist2) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= m) return;
-    const float px = Q[q * 3], py = Q[q * 3 + 1], pz = Q[q * 3 + 2];
+// SIXTEEN lanes per query: the (dy, dz) rows of the cube of radius R around the query's cell are dealt to the lanes -- each
+// its own binary search and scan -- and the (distance, index) minimum is taken across the group with shuffles; R grows
+// from 1 to 4 while the best candidate is not provably the nearest (closer than 0.99 R h).  A row of the shell is one
+// range [cx-R, cx+R]; an interior row contributes only its two end cells (two searches).  The one-thread-per-query form
+// of round 1 ran up to 165 dependent binary searches per thread on ~0.8 waves per SIMD: 199 us per 50 k-point scene,
+// all latency.
+__global__ __launch_bounds__(256) void k_grid_nn16(const float *__restrict__ X, int32_t n, const float *__restrict__ Q, int32_t m,
+                                                   const GridInfo *__restrict__ gi, const unsigned long long *__restrict__ keys,
+                                                   const int32_t *__restrict__ vals, int32_t *__restrict__ idx,
+                                                   float *__restrict__ dist2) {
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), s = threadIdx.x & 15;
+    const int qq = q < m ? q : m - 1;
+    const float px = Q[qq * 3], py = Q[qq * 3 + 1], pz = Q[qq * 3 + 2];
     const float h = gi->h;
     const int cx = grid_cell(px, gi->lo[0], h), cy = grid_cell(py, gi->lo[1], h), cz = grid_cell(pz, gi->lo[2], h);
     float bd = 1e10f;
-    int bx = 0;
+    int bx = 0x7fffffff;
+    auto scan = [&](unsigned long long k0, unsigned long long k1) {
+        int lo = 0, hi = n;
+        while (lo < hi) {                         // first position with key >= k0 (x neighbours are consecutive keys)
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < k0) lo = mid + 1; else hi = mid;
+        }
+        for (int t = lo; t < n && keys[t] <= k1; t++) {
+            const int pi = vals[t];
+            const float x = X[pi * 3], y = X[pi * 3 + 1], z = X[pi * 3 + 2];
+            const float d2 = (px - x) * (px - x) + (py - y) * (py - y) + (pz - z) * (pz - z);
+            if (d2 < bd || (d2 == bd && pi < bx)) { bd = d2; bx = pi; }
+        }
+    };
     bool exact = false;
-    // cube of radius R cells around the query's cell; if the best candidate is closer than 0.99 R h the true nearest
-    // neighbour cannot lie outside the cube.  Almost every query is settled at R = 1; sparse regions widen to R = 4.
     for (int R = 1; R <= 4 && !exact; R++) {
-        for (int dz = -R; dz <= R; dz++)
-            for (int dy = -R; dy <= R; dy++) {
-                const bool shell = (dz == -R || dz == R || dy == -R || dy == R);     // rows not covered by the previous radius
-                const unsigned long long k0 = grid_key(cx - R, cy + dy, cz + dz), k1 = grid_key(cx + R, cy + dy, cz + dz);
-                int lo = 0, hi = n;
-                while (lo < hi) {                     // first position with key >= k0 (x neighbours are consecutive keys)
-                    const int mid = (lo + hi) >> 1;
-                    if (keys[mid] < k0) lo = mid + 1; else hi = mid;
-                }
-                for (int t = lo; t < n && keys[t] <= k1; t++) {
-                    if (R > 1 && !shell) {            // interior row: only its two new end cells are unseen
-                        const unsigned long long kx = keys[t] & 0x1fffffULL;
-                        if (kx != (unsigned long long)(cx - R) && kx != (unsigned long long)(cx + R)) continue;
-                    }
-                    const int pi = vals[t];
-                    const float x = X[pi * 3], y = X[pi * 3 + 1], z = X[pi * 3 + 2];
-                    const float d2 = (px - x) * (px - x) + (py - y) * (py - y) + (pz - z) * (pz - z);
-                    if (d2 < bd || (d2 == bd && pi < bx)) { bd = d2; bx = pi; }
-                }
+        const int side = 2 * R + 1;
+        for (int row = s; row < side * side; row += 16) {
+            const int dy = row / side - R, dz = row % side - R;
+            const bool shell = (dz == -R || dz == R || dy == -R || dy == R) || R == 1;
+            if (shell) scan(grid_key(cx - R, cy + dy, cz + dz), grid_key(cx + R, cy + dy, cz + dz));
+            else {                                 // interior row: only its two end cells are new at this radius
+                scan(grid_key(cx - R, cy + dy, cz + dz), grid_key(cx - R, cy + dy, cz + dz));
+                scan(grid_key(cx + R, cy + dy, cz + dz), grid_key(cx + R, cy + dy, cz + dz));
             }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float od = __shfl_xor(bd, o, 16);
+            const int ox = __shfl_xor(bx, o, 16);
+            if (od < bd || (od == bd && ox < bx)) { bd = od; bx = ox; }
+        }
         const float r = 0.99f * h * (float)R;
-        exact = bd <= r * r;
+        exact = bd <= r * r;                       // (uniform across the 16 lanes: they all hold the group minimum)
     }
-    idx[q] = exact ? bx : -1;                     // -1: not provably exact, k_knn1_fix redoes it exhaustively
-    dist2[q] = bd;
+    if (s == 0 && q < m) {
+        idx[q] = exact ? bx : -1;                  // -1: not provably exact, k_knn1_fix redoes it exhaustively
+        dist2[q] = bd;
+    }
 }
 __global__ __launch_bounds__(256) void k_knn1_fix(const float *__restrict__ X, int32_t n, const float *__restrict__ Q, int32_t m,
                                                   int32_t *__restrict__ idx, float *__restrict__ dist2) {
@@ -290,7 +305,7 @@ extern "C" int cg3d_knn(int32_t b, int32_t n, int32_t m, int32_t k, const float 
             hipLaunchKernelGGL(k_grid_keys, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, s, X, n, gi, keys, vals);
             if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 63, s) != hipSuccess)
                 return CG3D_ERR_LAUNCH;
-            hipLaunchKernelGGL(k_grid_nn, dim3((unsigned)cg3d_divup(m, 256)), dim3(256), 0, s, X, n, Q, m, gi, keys_s, vals_s,
+            hipLaunchKernelGGL(k_grid_nn16, dim3((unsigned)cg3d_divup(m, 16)), dim3(256), 0, s, X, n, Q, m, gi, keys_s, vals_s,
                                idx + (int64_t)bi * m, dist2 + (int64_t)bi * m);
             hipLaunchKernelGGL(k_knn1_fix, dim3((unsigned)cg3d_divup(m, 256)), dim3(256), 0, s, X, n, Q, m,
                                idx + (int64_t)bi * m, dist2 + (int64_t)bi * m);
