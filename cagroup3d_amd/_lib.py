@@ -32,6 +32,7 @@ _SIGNATURES = {
     "cg3d_morton_order_ws_bytes": (c_int64, [c_int64]),
     "cg3d_morton_order": (c_int32, [P, c_int64, P, P, P]),
     "cg3d_kernel_map": (c_int32, [P, c_int64, P, c_int32, P, P, c_int64, P, P]),
+    "cg3d_kernel_map_transpose": (c_int32, [P, c_int32, c_int64, c_int64, P, P]),
     "cg3d_kernel_map_self": (c_int32, [P, c_int64, P, c_int32, P, P, c_int64, P, P]),
     "cg3d_spconv_fwd": (c_int32, [P, P, P, P, P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, P]),
     "cg3d_spconv_fwd_tiled": (c_int32, [P, P, P, P, c_int64, P, P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, P]),

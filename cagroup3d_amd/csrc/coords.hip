@@ -304,6 +304,28 @@ extern "C" int cg3d_kernel_map_self(const int32_t *q, int64_t n, const int32_t *
     return CG3D_OK;
 }
 
+// Transposed kernel map by scattering the map itself: nbrT[k][i] = o  <=>  nbr[k][o] = i (a kernel map is injective per
+// offset), so the transposed map of a strided / transposed convolution needs no hash lookups -- K x n_out coalesced reads
+// and one 4-byte write per pair instead of K x n_in probes on the (larger) fine side.  nbrT starts out as -1.
+__global__ void k_kernel_map_transpose(const int32_t *__restrict__ nbr, int64_t total, int64_t n_out, int64_t n_in,
+                                       int32_t *__restrict__ nbrT) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int32_t i = nbr[t];
+    if (i >= 0) nbrT[(t / n_out) * n_in + i] = (int32_t)(t % n_out);
+}
+extern "C" int cg3d_kernel_map_transpose(const int32_t *nbr, int32_t K, int64_t n_out, int64_t n_in, int32_t *nbrT,
+                                         cg3d_stream_t stream) {
+    if (K < 1 || n_out < 0 || n_in < 0 || (int64_t)K * n_out >= (1ll << 40)) return CG3D_ERR_ARG;
+    hipStream_t s = cg3d_hs(stream);
+    if (n_in > 0 && hipMemsetAsync(nbrT, 0xFF, (size_t)K * n_in * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    const int64_t total = (int64_t)K * n_out;
+    if (total == 0 || n_in == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_kernel_map_transpose, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, s, nbr, total, n_out, n_in, nbrT);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
 // ------------------------------------------------------------------ interpolation map
 __global__ void k_interp_map(const float *__restrict__ q, int64_t nq, int32_t ts, const uint64_t *__restrict__ keys,
                              const int32_t *__restrict__ vals, uint64_t capm1, int32_t *__restrict__ idx,

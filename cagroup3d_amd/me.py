@@ -345,6 +345,15 @@ def _build_map(coords_i32, qstride):
 MORTON_ROWS = __import__("os").environ.get("CG3D_MORTON_ROWS", "1") != "0"
 
 
+def _transpose_map(nbr, n_in):
+    """nbrT [K, n_in] from nbr [K, n_out] by scattering (cg3d_kernel_map_transpose): no hash lookups."""
+    lib = _lib.get()
+    K, n_out = nbr.shape
+    out = torch.empty((K, max(n_in, 1)), dtype=torch.int32, device=nbr.device)
+    lib.call("cg3d_kernel_map_transpose", ptr(nbr), c_int32(K), c_int64(n_out), c_int64(n_in), ptr(out), lib.stream())
+    return out[:, :n_in].contiguous() if n_in > 0 else out[:, :0]
+
+
 def _morton_order(coords_i32):
     """int64 [n]: input row of the i-th row in (batch, Morton) order."""
     lib = _lib.get()
@@ -444,9 +453,9 @@ class CoordinateManager:
             # the lazy transposed map must not close over `self`: manager -> _kmaps -> KernelMap -> closure -> manager
             # is a reference cycle, and every step's coordinate structures (0.5 GB of device tensors at S50k x 4) then
             # live until the cyclic collector's next gen-2 pass -- tens of GB of garbage in a long run
-            lookup = CoordinateManager._lookup_map
-            km = KernelMap(nbr.contiguous(), offs.shape[0], src.n, dst.n,
-                           lambda: lookup(src.coords, dst, bwd_off).contiguous())
+            nbr = nbr.contiguous()
+            n_src = src.n
+            km = KernelMap(nbr, offs.shape[0], src.n, dst.n, lambda: _transpose_map(nbr, n_src))
             km.same_map = in_key == out_key          # row groups of the output are row groups of the input
             # a map onto itself with a centred odd kernel: off[K-1-k] == -off[k], hence nbrT[k] == nbr[K-1-k] -- no second
             # hash lookup for the transposed map, and the tile kernel's data gradient reuses the forward plan (wrev)

@@ -105,6 +105,10 @@ int cg3d_kernel_map(const int32_t *q_coords, int64_t nq, const int32_t *offsets,
 int cg3d_kernel_map_self(const int32_t *coords, int64_t n, const int32_t *offsets, int32_t K,
                          const uint64_t *keys, const int32_t *vals, int64_t cap,
                          int32_t *nbr, cg3d_stream_t stream);
+/* The transposed map (data gradient of a strided / transposed convolution) from the map itself, without the hash table:
+ * nbrT int32 [K, n_in], nbrT[k][i] = o  <=>  nbr[k][o] = i, -1 elsewhere (a kernel map is injective per offset). */
+int cg3d_kernel_map_transpose(const int32_t *nbr, int32_t K, int64_t n_out, int64_t n_in, int32_t *nbrT,
+                              cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse convolution, output-stationary implicit GEMM:

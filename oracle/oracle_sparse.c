@@ -168,6 +168,18 @@ int cg3d_kernel_map_self(const int32_t *q, int64_t n, const int32_t *off, int32_
     return cg3d_kernel_map(q, n, off, K, keys, vals, cap, nbr, s);      /* the plain lookups: the definition of the result */
 }
 
+int cg3d_kernel_map_transpose(const int32_t *nbr, int32_t K, int64_t n_out, int64_t n_in, int32_t *nbrT, cg3d_stream_t s) {
+    (void)s;
+    if (K < 1 || n_out < 0 || n_in < 0) return CG3D_ERR_ARG;
+    for (int64_t t = 0; t < (int64_t)K * n_in; t++) nbrT[t] = -1;
+    for (int32_t k = 0; k < K; k++)
+        for (int64_t o = 0; o < n_out; o++) {
+            const int32_t i = nbr[(int64_t)k * n_out + o];
+            if (i >= 0) nbrT[(int64_t)k * n_in + i] = (int32_t)o;
+        }
+    return CG3D_OK;
+}
+
 int cg3d_interp_map(const float *q, int64_t nq, int32_t ts, const uint64_t *keys, const int32_t *vals,
                     int64_t cap, int32_t *idx, float *w, cg3d_stream_t s) {
     (void)s;

@@ -135,6 +135,25 @@ def test_map_onto_itself_transposes_by_flipping_the_offsets(oracle):
         assert not km2.symmetric
 
 
+def _transposed_by_lookup(coords, ks, stride):
+    x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1, device=coords.device))
+    mgr = x.coordinate_manager
+    out_key = mgr.stride(x.coordinate_map_key, stride)
+    km = mgr.kernel_map(x.coordinate_map_key, out_key, ks, 1, False)
+    src, dst = mgr.get(x.coordinate_map_key), mgr.get(out_key)
+    offs = me._offsets(ks, src.tensor_stride, coords.device)
+    by_lookup = me.CoordinateManager._lookup_map(src.coords, dst, (-offs).contiguous())          # i - off = o
+    return km, by_lookup
+
+
+def test_oracle_transposed_map_by_scatter_equals_lookup(oracle):
+    """cg3d_kernel_map_transpose (nbrT scattered from nbr) == the transposed map found through the hash table, strided maps"""
+    with _lib.use_library(oracle):
+        for ks, stride, n in ((3, 2, 1500), (2, 2, 900), (5, 2, 700)):
+            km, by_lookup = _transposed_by_lookup(surface_coords(n, batch=2, extent=9, seed=ks + n), ks, stride)
+            assert not km.symmetric and torch.equal(km.nbrT, by_lookup)
+
+
 @pytest.mark.parametrize("ks,cin,cout", [(3, 64, 64), (5, 64, 128)])
 def test_oracle_data_gradient_on_the_forward_plan_with_reversed_weights(oracle, ks, cin, cout):
     """wrev: conv(dY, W^T) through the plan of the transposed map == the same call on the FORWARD plan with weight slot
@@ -219,6 +238,14 @@ def test_oracle_bn_statistics_from_the_conv_epilogue(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks,stride,n", [(3, 2, 20000), (2, 2, 9000), (5, 2, 3000), (3, 2, 1)])
+def test_hip_transposed_map_by_scatter_equals_lookup(hip, ks, stride, n):
+    with _lib.use_library(hip):
+        km, by_lookup = _transposed_by_lookup(surface_coords(n, batch=3, extent=max(6, int(n ** 0.5) // 3), seed=ks + n).cuda(), ks, stride)
+        assert torch.equal(km.nbrT, by_lookup)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ks,dil,n", [(3, 1, 20000), (5, 1, 6000), (3, 2, 8000), (9, 1, 1500), (3, 1, 1)])
 def test_hip_self_map_by_half_the_lookups_is_bit_identical(hip, ks, dil, n):
