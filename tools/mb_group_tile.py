@@ -72,6 +72,9 @@ def main():
         npass = plan.npass.cpu().numpy()
         print(f"  plan build {t_plan:.0f} us; passes/tile mean {npass.mean():.2f} max {npass.max()}; staged rows {int(plan.cursor[0])}"
               f" ({int(plan.cursor[0]) / max(km.n_out, 1):.2f} per output row)")
+        lv = plan.live.cpu().numpy()
+        bits = sum(((lv >> b) & 1).sum() for b in range(4))
+        print(f"  live offsets per tile {float((lv > 0).sum(1).mean()):.0f} of {K}; live 32-row blocks among them {bits / max(int((lv > 0).sum()), 1) / 4:.2f}")
         wft, wfp = me._prep_bf16_group(ws, True, True), me._prep_bf16_group(ws, False, True)
         for ksplit in (1, 2, 4, 8):
             if ksplit > 1 and plan.ntile * ksplit > 1024:
