@@ -109,6 +109,10 @@ class ClippedAdamW(torch.optim.AdamW):
                  c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t), lib.stream())
         return True
 
+    def step(self, closure=None):
+        self._host_step = None            # torch advances the step counters itself here: re-read them at the next fused step
+        return super().step(closure)
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._lean = None
