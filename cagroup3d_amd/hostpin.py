@@ -4,11 +4,12 @@ A training step here is ~3000 kernel launches issued by ONE Python thread whose 
 the GPU's, so every migration of that thread across a 256-core host shows up in the step time: unpinned 45.7-48.7 ms per
 step (52 on a busy box), pinned to 2-4 cores 44.2-44.9 ms (measured with taskset on the same box, five runs each).
 `pin_host_threads` narrows the affinity of the calling thread -- and of every thread created after it (the autograd
-engine, HIP's helpers) -- to a small block of the CPUs the process is allowed to use, a different block per local rank."""
+engine, the coordinate-prefetch worker, HIP's and RCCL's helpers) -- to a small block of the CPUs the process is allowed to
+use, a different block per local rank (six CPUs since round 2: the prefetch worker is a third busy thread)."""
 import os
 
 
-def pin_host_threads(local_rank=0, width=4, stride=8):
+def pin_host_threads(local_rank=0, width=6, stride=8):
     """Returns (original affinity set, pinned set), or (None, None) where the OS has no affinity call.
     CG3D_HOST_PIN=0 switches it off; CG3D_HOST_PIN="a-b" (a cpu list, e.g. "8-11") overrides the choice."""
     if not hasattr(os, "sched_setaffinity"):

@@ -21,16 +21,16 @@ def _layout(ncpu, nlocal, env=None):
 
 def test_blocks_are_distinct_per_rank():
     got = _layout(256, 8)
-    assert got[0] == [8, 9, 10, 11] and got[7] == [64, 65, 66, 67]
+    assert got[0] == [8, 9, 10, 11, 12, 13] and got[7] == [64, 65, 66, 67, 68, 69]
     flat = [c for b in got for c in b]
-    assert len(flat) == len(set(flat)) == 32
-    got = _layout(40, 8)                       # not enough room for the wide stride: blocks back to back
-    assert len(got) == 8 and len({c for b in got for c in b}) == 32
+    assert len(flat) == len(set(flat)) == 48
+    got = _layout(60, 8)                       # not enough room for the wide stride: blocks back to back
+    assert len(got) == 8 and len({c for b in got for c in b}) == 48
 
 
 def test_scarce_cpus_are_left_alone():
-    assert _layout(16, 8) == []                # 8 ranks x 4 CPUs do not fit: no pinning
-    assert _layout(4, 1) == []                 # nothing to narrow
+    assert _layout(16, 8) == []                # 8 ranks x 6 CPUs do not fit: no pinning
+    assert _layout(6, 1) == []                 # nothing to narrow
 
 
 def test_overrides():
