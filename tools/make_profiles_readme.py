@@ -71,7 +71,8 @@ for tag in ("bf16", "fp32"):
 for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc_sq_tile_128.txt" % RN, "SQ counters, tile kernel, 128->128 @ 82 107 rows"),
                    ("%s_pmc_sq_wgrad_128.txt" % RN, "SQ counters, weight gradient, same layer"), ("%s_pmc_l2_wgrad_128.txt" % RN, "L2 / memory-side counters, weight gradient"),
                    ("%s_tile_vs_dense_map.txt" % RN, "tile kernel vs the dense-map kernel per layer shape"), ("%s_bn_shapes.txt" % RN, "BatchNorm launches per shape"),
-                   ("%s_host_issue.txt" % RN, "host issue time vs step time")):
+                   ("%s_host_issue.txt" % RN, "host issue time vs step time"),
+                   ("%s_other_configs.txt" % RN, "bench lines of the other configurations and inference")):
     if os.path.exists(os.path.join(P, name)):
         out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
 open(os.path.join(P, "README.md"), "w").write("".join(out))
