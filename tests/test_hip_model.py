@@ -49,13 +49,15 @@ def test_full_detector_hip_matches_oracle(oracle, hip, dataset, cfgname):
     n0 = sum(x0[3][c][s].shape[0] for c in range(len(x0[3])) for s in range(2))
     n1 = sum(x1[3][c][s].shape[0] for c in range(len(x1[3])) for s in range(2))
     assert abs(n0 - n1) <= max(3, 0.005 * n0), (n0, n1)
-    for k in tb0:
-        assert abs(tb0[k] - tb1[k]) <= 2e-2 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    print("loss terms oracle vs hip:", {k: (round(tb0[k], 6), round(tb1[k], 6)) for k in tb0})
+    for k in tb0:                                       # end-to-end loss within 1 %
+        assert abs(tb0[k] - tb1[k]) <= 1e-2 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
     p0, p1 = [len(p[0]) for p in b0["pred_bbox_list"]], [len(p[0]) for p in b1["pred_bbox_list"]]
     assert all(abs(a - b) <= max(3, 0.05 * a) for a, b in zip(p0, p1)), (p0, p1)
     # backbone gradients (independent of the vote quantisation noise up to the loss terms it feeds)
     num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
     den = sum(float(g0[n].pow(2).sum()) for n in g0)
+    print("whole-model gradient, hip vs oracle, relative L2: %.3e" % (num / den) ** 0.5)
     assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
 
 
@@ -326,7 +328,7 @@ def test_bf16_per_stage_features_and_backbone_gradients(oracle, hip):
     print("backbone gradient deviations (relative L2):", report)
     # fp32: the two implementations differ by summation order only (1e-7 per operation) -- and the gradients already by
     # 3e-3: the net amplifies a perturbation ~10^4-fold on its way back through ~60 layers and their BatchNorms
-    assert fp32_pair < 1e-2, report
+    assert fp32_pair < 5e-3, report          # measured 2.3e-3
     assert dev_hip < 0.35 and dev_or < 0.35 and abs(dev_hip - dev_or) < 0.08, report
     assert bf16_pair < max(dev_hip, dev_or), report              # two bf16 implementations are closer to each other than to fp32
 
