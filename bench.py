@@ -171,21 +171,27 @@ def cpu_baseline(args, forced):
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r02_pmc_{FETCH,WRITE}_SIZE.csv; separate runs, as the profiling guide prescribes).
-    gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  NOT measured by this run: PMC counters
+    need their own rocprofv3 passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, as the profiling
+    guide prescribes), so the figure is read from the newest pair of CSVs committed under profiles/ and `traffic_source`
+    names them.  gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
     import csv
-    try:
-        tot = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.csv" % c)))
-                    if kernel_substr in r["Kernel_Name"]]
-            if not rows:
-                return None
-            tot[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / len(rows)
-        return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
-    except Exception:
-        return None
+    for rnd in ("r03", "r02"):
+        names = [os.path.join("profiles", "%s_pmc_%s.csv" % (rnd, c)) for c in ("FETCH_SIZE", "WRITE_SIZE")]
+        if not all(os.path.exists(os.path.join(ROOT, n)) for n in names):
+            continue
+        try:
+            tot = []
+            for n in names:
+                rows = [r for r in csv.DictReader(open(os.path.join(ROOT, n))) if kernel_substr in r["Kernel_Name"]]
+                if not rows:
+                    raise KeyError(kernel_substr)
+                tot.append(sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / len(rows))
+            return 2.0 * tot[0] + tot[1], ("%s + %s (committed rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1`, builder-side; "
+                                           "2 x FETCH_SIZE + WRITE_SIZE averaged over the kernel's launches)" % tuple(names))
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline_subprocess(args, threads=None, sample=None, budget=45):
@@ -336,7 +342,7 @@ def main():
                                       "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
                                       "gbytes_per_s_8d": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None}
                                   for k, v in kinds.items()})
-        roof["traffic"] = pmc_traffic(KNAMES[kind][1]) if bf16 else None      # bytes per launch, from profiles/ (separate --pmc runs)
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(KNAMES[kind][1]) if bf16 else (None, None)
         bound_all = sum(v[0] for v in per_kind.values())
         meas_all = sum(v[1] for v in per_kind.values())
         # every sparse convolution of the step (forward, data and weight gradient): their 8(d) bounds over their measured
@@ -373,7 +379,7 @@ def main():
                "config": {"workload": "%s CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
                    {"scannet": "ScanNetV2", "sunrgbd": "SUN RGB-D"}.get(args.dataset, args.dataset), args.batch, args.config, "forced GT selection (replaces the net's own selection: sizes independent of the weights) + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
-                          "scenes_per_gpu": args.batch, "points_per_scene": 50000 if args.config == "S50k" else args.config,
+                          "scenes_per_gpu": args.batch, "points_per_scene": int("".join(ch for ch in args.config.split("-")[0] if ch.isdigit())) * 1000,
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
                           "precision": ("bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
                                         "backbone, class branches and RoI pooling; forward, data gradient AND weight gradient "
@@ -389,10 +395,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline_subprocess(args)
-                try:        # one thread: the same step on a smaller scene (a 50 k-point step takes minutes on one core)
-                    out["cpu_baseline"]["single_thread"] = cpu_baseline_subprocess(args, threads=1, sample=args.cpu_sample_1t, budget=40)
+                # One thread, on a 10 x SMALLER scene (a 50 k-point step takes minutes on one core): its own key and its own
+                # unit -- an S5k scene per second is not the unit of `value` (S50k scenes) and must not be read next to it.
+                # Thread scaling of the S50k step itself: profiles/r03_cpu_thread_scaling.txt (tools/cpu_thread_scaling.py).
+                try:
+                    st = cpu_baseline_subprocess(args, threads=1, sample=args.cpu_sample_1t, budget=40)
+                    st["unit"] = "%s-scenes/s (NOT the unit of cpu_baseline.value)" % args.cpu_sample_1t.split(":")[0]
+                    out["cpu_baseline"]["single_thread_small_scene"] = st
                 except Exception as e:
-                    out["cpu_baseline"]["single_thread"] = {"value": None, "sample": "failed: %r" % (e,)}
+                    out["cpu_baseline"]["single_thread_small_scene"] = {"value": None, "sample": "failed: %r" % (e,)}
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -57,6 +57,7 @@ extern "C" int cg3d_interp_fwd(const float *F, const int32_t *idx, const float *
 // the kernel runs at the rate of the atomics themselves (84-168 M per launch = 2.2 TB/s of payload), and this divides
 // their number.  (In arrival order the same merging measured no gain -- 141 vs 150 us -- there were no runs.)
 #define IB_RPT 16
+template <bool VEC>     // VEC: idx / w 16-byte aligned (torch allocations are); otherwise the same loads as scalars (offset views)
 __global__ void k_interp_bwd(const float *__restrict__ dout, const int32_t *__restrict__ idx,
                              const float *__restrict__ w, float *__restrict__ dF, int64_t nq, int32_t c) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -71,10 +72,17 @@ __global__ void k_interp_bwd(const float *__restrict__ dout, const int32_t *__re
     for (int q = 0; q < n; q++) {
         const int64_t i = i0 + q;
         const float d = dout[i * c + a];
-        const int4 r0 = *reinterpret_cast<const int4 *>(idx + i * 8), r1 = *reinterpret_cast<const int4 *>(idx + i * 8 + 4);
-        const float4 w0 = *reinterpret_cast<const float4 *>(w + i * 8), w1 = *reinterpret_cast<const float4 *>(w + i * 8 + 4);
-        const int32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        int32_t rr[8];
+        float ww[8];
+        if (VEC) {
+            const int4 r0 = *reinterpret_cast<const int4 *>(idx + i * 8), r1 = *reinterpret_cast<const int4 *>(idx + i * 8 + 4);
+            const float4 w0 = *reinterpret_cast<const float4 *>(w + i * 8), w1 = *reinterpret_cast<const float4 *>(w + i * 8 + 4);
+            rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { rr[j] = idx[i * 8 + j]; ww[j] = w[i * 8 + j]; }
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (rr[j] != cur[j]) {
@@ -91,10 +99,13 @@ __global__ void k_interp_bwd(const float *__restrict__ dout, const int32_t *__re
 }
 extern "C" int cg3d_interp_bwd(const float *dout, const int32_t *idx, const float *w, float *dF, int64_t nq,
                                int32_t c, cg3d_stream_t stream) {
-    if (nq < 0 || c < 1 || (((uintptr_t)idx | (uintptr_t)w) & 15)) return CG3D_ERR_ARG;
+    if (nq < 0 || c < 1) return CG3D_ERR_ARG;
     if (nq == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_interp_bwd, dim3((unsigned)cg3d_divup(cg3d_divup(nq, IB_RPT) * c, 256)), dim3(256), 0, cg3d_hs(stream), dout,
-                       idx, w, dF, nq, c);
+    const dim3 grid((unsigned)cg3d_divup(cg3d_divup(nq, IB_RPT) * c, 256));
+    if ((((uintptr_t)idx | (uintptr_t)w) & 15) == 0)
+        hipLaunchKernelGGL(k_interp_bwd<true>, grid, dim3(256), 0, cg3d_hs(stream), dout, idx, w, dF, nq, c);
+    else        // an offset view (idx[1:], w[1:]): no alignment precondition on this entry point
+        hipLaunchKernelGGL(k_interp_bwd<false>, grid, dim3(256), 0, cg3d_hs(stream), dout, idx, w, dF, nq, c);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

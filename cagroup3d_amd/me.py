@@ -549,6 +549,10 @@ def _tile_grid(lib, ntile, cout):
     return min(ntile * max(cout // 128, 1), ncu)
 
 _STATS = {}         # data_ptr of a conv output of THIS forward -> (partials, chunks, rows, channels, output); cleared with _ROWS16
+# Whether a training-mode BatchNorm may follow the convolutions of the current forward (set by the detector's forward from
+# `self.training`): in evaluation nobody consumes the partial sums, so they are neither computed nor kept (every entry
+# holds its conv output alive)
+WANT_BN_STATS = True
 TILE_ROWS = 128
 TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS rows per pass: (ucap+1) x 128 B = 64 KB
 
@@ -594,7 +598,7 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
     lib.check(x16, wf, bias)
     y = torch.empty((plan.n_out, cout), dtype=torch.float32, device=x16.device)
     stats = None
-    if want_stats and FUSED_BN_STATS and ksplit == 1 and plan.tiles is None and cout <= 512 and plan.ntile > 0:
+    if want_stats and WANT_BN_STATS and FUSED_BN_STATS and ksplit == 1 and plan.tiles is None and cout <= 512 and plan.ntile > 0:
         # per-workgroup sum / sum of squares of the output channels, accumulated while the tiles are stored: the BatchNorm
         # that follows finalises these instead of reading Y again (cg3d_bn_stats_from_partials)
         grid = _tile_grid(lib, plan.ntile, cout)

@@ -5,8 +5,14 @@ lists.
 `torch.nn.utils.clip_grad_norm_` + `torch.optim.AdamW(fused=True).step()` are already multi-tensor on the device (two sets of
 ~14 launches for the detector's 432 parameters), but each call re-derives its tensor lists in Python -- grouping by device
 and dtype, walking the param groups, checking every state entry -- 2.7 ms of host time per step on a step that is bound by the
-host.  This subclass runs the SAME torch kernels (`_foreach_norm`, `_foreach_mul_`, `_foreach_add_`,
-`_fused_adamw_`) on lists built once; state layout, `state_dict()` and the update itself are torch's."""
+host.  State layout and `state_dict()` are torch's.  The update itself:
+
+* default (`CG3D_FUSED_ADAMW=1`, device library bound, fp32 contiguous tensors, equal hyper-parameters and equal step
+  counters over all parameters): ONE launch of the library's `cg3d_adamw_step` (csrc/optim.hip) -- gradient x clip
+  coefficient and the AdamW update in the arithmetic of torch's fused kernel (bit-identical parameters, tested).  Unlike
+  `clip_grad_norm_` it does NOT write the clipped gradients back to `p.grad` (nothing reads them: `zero_grad` follows);
+* otherwise: torch's own kernels (`_foreach_norm`, `_foreach_mul_`, `_foreach_add_`, `_fused_adamw_`) on lists built once,
+  or plain `clip_grad_norm_` + `step()` when a gradient is missing or the state does not exist yet."""
 import os
 from ctypes import c_float, c_int64
 
@@ -73,6 +79,12 @@ class ClippedAdamW(torch.optim.AdamW):
         if not lib.is_device or dev.type != "cuda":
             return False
         plan = getattr(self, "_plan", None)
+        if plan not in (None, False):
+            # the table holds raw addresses: rebuild it when a parameter or a moment has moved (model.to(), .data reassigned,
+            # state reloaded into new tensors) -- 432 integer compares, no device work
+            cur = [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts]
+            if cur != plan[4]:
+                plan = self._plan = None
         if plan is None:
             rows, pid, k = [], [], 0
             for group, ps, m1, m2, steps in lean:
@@ -86,7 +98,8 @@ class ClippedAdamW(torch.optim.AdamW):
                         pid.append(k)
                     k += 1
             plan = self._plan = (me.h2d(np.asarray(rows, dtype=np.int64), torch.int64, dev), me.h2d(np.asarray(pid, dtype=np.int32), torch.int32, dev),
-                                 len(rows), [g["params"] for g in self.param_groups])
+                                 len(rows), [g["params"] for g in self.param_groups],
+                                 [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts])
         if plan is False:
             return False
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in flat_grads):
@@ -96,10 +109,17 @@ class ClippedAdamW(torch.optim.AdamW):
         if any((g["lr"], g["betas"], g["eps"], g["weight_decay"]) != (g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]) for g, *_ in lean):
             return False
         steps = [s for *_, ss in lean for s in ss]
-        torch._foreach_add_(steps, 1)
         t = self._host_step = getattr(self, "_host_step", None) or 0
         if t == 0:
-            t = int(steps[0].item()) - 1                   # (first fused step after torch-managed ones / a reload: one host read)
+            # first fused step after torch-managed ones / a reload: ONE host read.  The launch applies a single bias correction
+            # to every parameter, torch keeps a step counter per parameter: they must all agree (a parameter that joined late,
+            # a state loaded with unequal steps, a step() that skipped gradient-less parameters) or torch's kernels take over
+            st = torch.stack([x.reshape(()) for x in steps]).cpu()
+            if not bool((st == st[0]).all()):
+                self._host_step = None
+                return False
+            t = int(st[0].item())
+        torch._foreach_add_(steps, 1)
         t += 1
         self._host_step = t
         beta1, beta2 = g0["betas"]

@@ -49,9 +49,26 @@ class _PrefetchWorker:
         atexit.register(self.close)
 
     def close(self):
+        """Stop the worker: pending jobs are dropped (their handles report the shutdown), the sentinel is queued and the
+        thread joined.  A worker that does not come back within the timeout is still inside a launch or a device wait --
+        tearing the runtime down under it is what corrupted the heap -- so that is reported loudly instead of ignored."""
+        if not self.thread.is_alive():
+            return
+        import queue
+        try:
+            while True:
+                job = self.jobs.get_nowait()
+                if job is not None:
+                    job[1].error = RuntimeError("coordinate prefetch worker closed before this job ran")
+                    job[1].done.set()
+        except queue.Empty:
+            pass
+        self.jobs.put(None)
+        self.thread.join(timeout=30)
         if self.thread.is_alive():
-            self.jobs.put(None)
-            self.thread.join(timeout=30)
+            import sys
+            print("cagroup3d_amd: the coordinate-prefetch worker did not stop within 30 s (a hung device wait?); "
+                  "the interpreter may not exit cleanly", file=sys.stderr, flush=True)
 
     def submit(self, batch):
         h = _Pending()
@@ -142,7 +159,12 @@ class CAGroup3D(Detector3DTemplate):
 
     def prefetch_coordinates_async(self, batch_dict):
         """`prefetch_coordinates` on a worker thread: returns a handle whose `.result()` is what `prefetch_coordinates`
-        returns.  Submit the NEXT batch before starting the current step: the dry run is Python glue, short launches and
+        returns.  What the dry run may touch (and nothing else): the backbone's modules READ-ONLY (no parameter, buffer or
+        attribute is written: `COORDS_ONLY` is a per-thread flag and BatchNorm / convolutions return placeholders under it),
+        `dense_head.data_targets` / `_forced_selection` (pure functions of the batch), its own side stream, and the
+        host-side caches of `me.py` (`_offset_cache`, `_chunk_cache`, `_ident_cache`, the pinned staging rings -- keyed per
+        stream), whose get-or-insert updates are single dict operations under the GIL; their size-triggered `clear()`s only
+        drop entries that are rebuilt on the next miss.  A worker exception surfaces at `.result()`, i.e. one step late.  Submit the NEXT batch before starting the current step: the dry run is Python glue, short launches and
         ~30 host reads of device counters (each a wait for the side stream); on its own thread those waits and every
         GIL-free stretch (launches, ATen calls, the autograd engine's C++ side) overlap with the issue path of the
         current step, which is what bounds the step once the kernels are fast (host path)."""
@@ -158,12 +180,15 @@ class CAGroup3D(Detector3DTemplate):
         assert cur_epoch is not None
         ME._ROWS16.clear()
         ME._STATS.clear()
+        ME.WANT_BN_STATS = bool(self.training)      # evaluation: no BatchNorm takes the conv epilogue's partial sums
         # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
         ME.prepare_weights(self.training)
         try:
             return self._forward(batch_dict, cur_epoch)
         finally:
             ME.finish_weights()
+            ME._STATS.clear()                       # partial sums no BatchNorm asked for must not keep conv outputs alive
+            ME.WANT_BN_STATS = True
 
     def _forward(self, batch_dict, cur_epoch):
         object.__setattr__(self.module_list[1], "semantic_threshold",

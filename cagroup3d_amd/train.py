@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 from . import build_model, synthetic
 from .pcdet.datasets.indoor_eval import indoor_eval
 from .pcdet.models import load_data_to_gpu, model_fn_decorator
+from .pcdet.models.detectors.detector3d_template import CHECKPOINT_VERSION
 
 
 def shard_ids(ids, rank, world):
@@ -157,7 +158,7 @@ def build_scheduler(optimizer, iters_per_epoch, optim_cfg, last_it=-1):
 def checkpoint_state(model, optimizer, epoch, it):
     m = model.module if hasattr(model, "module") else model
     return {"epoch": epoch, "it": it, "model_state": {k: v.cpu() for k, v in m.state_dict().items()},
-            "optimizer_state": optimizer.state_dict() if optimizer is not None else None, "version": "cagroup3d_amd"}
+            "optimizer_state": optimizer.state_dict() if optimizer is not None else None, "version": CHECKPOINT_VERSION}
 
 
 _FROZEN = [False]

@@ -108,16 +108,17 @@ def _class_map_case(coords, B, G, ks, seed, vs):
     """The 9^3 class-branch convolution (cagroup_head.py:259) on a benchmark-shaped class map: the stride-2 voxels, every
     class c re-quantised at its own voxel size into batch index c*B + b of ONE coordinate map, grouped weights."""
     dev = coords.device
-    x = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1, device=dev))
-    mgr = x.coordinate_manager
-    c2 = mgr.get(mgr.stride(x.coordinate_map_key, 2)).coords                    # [N2, 4] int32, tensor stride 2
+    # the class coordinates are made on the host for both sides (a float division by a scalar is a multiplication by its
+    # reciprocal on the device: floor() of it can differ from the host's in the last voxel)
+    ch = coords.cpu()
+    c2 = torch.unique(torch.cat([ch[:, :1], torch.div(ch[:, 1:], 2, rounding_mode="floor") * 2], 1), dim=0)     # tensor stride 2
     xyz = c2[:, 1:].float() * 0.02
     rows = []
     for c in range(G):
         sel = (torch.div(c2[:, 1], 16, rounding_mode="floor") + 5 * torch.div(c2[:, 2], 16, rounding_mode="floor")) % G == c   # 32 cm columns
         q = torch.floor(xyz[sel] / vs[c])
         rows.append(torch.cat([(c * B + c2[sel, :1]).float(), q], 1))
-    fine = torch.cat(rows).int().contiguous()
+    fine = torch.cat(rows).int().contiguous().to(dev)
     cls_map = me.SparseTensor(coordinates=fine, features=torch.zeros(fine.shape[0], 1, device=dev))
     key = cls_map.coordinate_map_key
     cm = cls_map.coordinate_manager

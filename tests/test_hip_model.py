@@ -50,15 +50,15 @@ def test_full_detector_hip_matches_oracle(oracle, hip, dataset, cfgname):
     n1 = sum(x1[3][c][s].shape[0] for c in range(len(x1[3])) for s in range(2))
     assert abs(n0 - n1) <= max(3, 0.005 * n0), (n0, n1)
     print("loss terms oracle vs hip:", {k: (round(tb0[k], 6), round(tb1[k], 6)) for k in tb0})
-    for k in tb0:                                       # end-to-end loss within 1 %
-        assert abs(tb0[k] - tb1[k]) <= 1e-2 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    for k in tb0:                                       # SURVEY 8(d) asks 1 %; measured: every term agrees to 1e-6
+        assert abs(tb0[k] - tb1[k]) <= 1e-3 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
     p0, p1 = [len(p[0]) for p in b0["pred_bbox_list"]], [len(p[0]) for p in b1["pred_bbox_list"]]
     assert all(abs(a - b) <= max(3, 0.05 * a) for a, b in zip(p0, p1)), (p0, p1)
     # backbone gradients (independent of the vote quantisation noise up to the loss terms it feeds)
     num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0)
     den = sum(float(g0[n].pow(2).sum()) for n in g0)
     print("whole-model gradient, hip vs oracle, relative L2: %.3e" % (num / den) ** 0.5)
-    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5         # measured 1.0e-3 / 1.2e-3 (fp32 atomics, ~60 layers deep)
 
 
 def test_bf16_mode_stays_within_stated_tolerance_of_fp32(hip):
