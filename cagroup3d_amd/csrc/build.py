@@ -15,6 +15,7 @@ SOURCES = {
     "coords.hip": ["-ffp-contract=off"],
     "spconv.hip": ["-munsafe-fp-atomics"],
     "spconv_tile.hip": ["-munsafe-fp-atomics"],
+    "spconv_tile2.hip": ["-munsafe-fp-atomics"],
     "gather_scatter.hip": ["-munsafe-fp-atomics"],
     "iou3d_nms.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
@@ -23,7 +24,8 @@ SOURCES = {
     "loss.hip": [],
     "optim.hip": ["-ffp-contract=off"],      # same rounding as the oracle's plain C (and torch's kernel: no contraction across statements)
 }
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CG3D_HIPCC_EXTRA", "").split()
+# (CG3D_HIPCC_EXTRA: dev builds on the GPU box, e.g. -DCG3D_TILE_TRACE; the shipped library is built without it)
 
 
 def _hipcc():

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(512, 2) void k_spconv_tile(
     }
 }
 
-extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
+int64_t cg3d_tile_v1_lds_bytes(int32_t ucap) {
     const int64_t a = (int64_t)(ucap + 1) * 128;
     const int64_t buf = (a > 65536 ? a : 65536) + TP_KB * TP_TM * 2 + (TP_KB + 2) * 2 + 12 + (int64_t)sizeof(StageDesc);
     return 2 * buf + 96 + 4096;     // two stage buffers (the A tile doubles as the 64 KB exchange buffer) + flags + BN partial sums [2][<=512]
@@ -764,14 +764,14 @@ static int tile_ncu() {
     return ncu;
 }
 // number of (persistent) workgroups cg3d_spconv_tile_fwd launches = rows of its `stats` output
-extern "C" int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
+int32_t cg3d_tile_v1_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
     const int ncu = tile_ncu();
     if (ncu <= 0 || ntile < 0 || cout < 64 || ksplit < 1) return -1;
     const int64_t nunit = ntile * (cout >= 128 ? cout / 128 : 1) * ksplit;
     return (int32_t)(nunit < ncu ? nunit : ncu);
 }
 
-extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
+int cg3d_tile_v1_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                                     const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist,
                                     int32_t maxpass, int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias,
                                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
@@ -784,7 +784,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     hipStream_t s = cg3d_hs(stream);
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     static const int ldspad = getenv("CG3D_TILE_LDSPAD") ? atoi(getenv("CG3D_TILE_LDSPAD")) : 0;   // dev aid: occupancy experiments
-    const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap) + (size_t)ldspad;
+    const size_t lds = (size_t)cg3d_tile_v1_lds_bytes(ucap) + (size_t)ldspad;
     const int ncu = tile_ncu();
     if (ncu <= 0) return CG3D_ERR_LAUNCH;
     // persistent workgroups, one per CU (two 64 KB stage buffers fill the LDS)

@@ -538,15 +538,9 @@ BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 
 
 # ----------------------------------------------------------------------------- tile plans (cg3d_spconv_tile_fwd)
 FUSED_BN_STATS = __import__("os").environ.get("CG3D_FUSED_BN_STATS", "1") != "0"
-_tile_ncu = {}
-
-
 def _tile_grid(lib, ntile, cout):
-    """Workgroups cg3d_spconv_tile_fwd launches at ksplit 1 (= cg3d_spconv_tile_grid; the CU count is asked once per library)."""
-    ncu = _tile_ncu.get(lib.path)
-    if ncu is None:
-        ncu = _tile_ncu[lib.path] = int(lib.raw("cg3d_spconv_tile_grid")(1 << 40, 64, 1))
-    return min(ntile * max(cout // 128, 1), ncu)
+    """Rows of the `stats` output of cg3d_spconv_tile_fwd at ksplit 1 (= cg3d_spconv_tile_grid: one partial per tile)."""
+    return int(lib.raw("cg3d_spconv_tile_grid")(c_int64(ntile), c_int32(cout), c_int32(1)))
 
 _STATS = {}         # data_ptr of a conv output of THIS forward -> (partials, chunks, rows, channels, output); cleared with _ROWS16
 # Whether a training-mode BatchNorm may follow the convolutions of the current forward (set by the detector's forward from
