@@ -113,7 +113,6 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
     // consumer identity
     const int r = lane & 31, kg = lane >> 5;
     const int g = wave / NCO, h = wave % NCO;
-    const uint32_t cg[4] = {(uint32_t)kg, 2u + kg, 4u + kg, 6u + kg};        // channel granule of (ks, this lane's half)
     const int nt0 = (yb * NCO + h) * 2;                 // this wave's first 32-channel output block
     const int first = zi * KG + g, stride = gz * KG;    // this wave's share of the live offsets
     f32x16 acc[4][2];
@@ -192,7 +191,10 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
                                 const int row = row8 + q;
-                                slot_s[kk * T2_TM + (row & 31) * 4 + (row >> 5)] = (uint16_t)(w4[q >> 1] >> ((q & 1) * 16));
+                                // stored as the BYTE ADDRESS of the row's granule for (ks 0, kg 0): slot * 128 | swizzle << 4
+                                // (<= 65520: ucap <= 511); the multiply loop then needs one XOR per fragment read
+                                const uint32_t sl = (w4[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+                                slot_s[kk * T2_TM + (row & 31) * 4 + (row >> 5)] = (uint16_t)((sl << 7) | (((sl >> 1) & 7u) << 4));
                             }
                         }
                     }
@@ -216,38 +218,27 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
                                             (int64_t)c * 4 * 512 + lane * 8;
                     const int64_t wstride = (wrev ? -1 : 1) * (int64_t)nt_total * ks_total * 512;       // per offset
                     const int64_t wn = (int64_t)ks_total * 512;                        // per 32-channel output block
-                    struct Rows { uint32_t base[4], sw[4]; };                          // LDS row address / swizzle of the 4 row blocks
+                    // LDS byte address of (row block m, ks = 0) for this lane's channel half; granule g of slot s sits at
+                    // g ^ ((s >> 1) & 7) and g = 2 ks + kg, so the address of ks is  a0 ^ (kg << 4) ^ (ks << 5)
+                    struct Rows { uint32_t a[4]; };
                     // this wave's offsets of the block, one per lane of ONE register (a single LDS read): the offset of step st
                     // is a v_readlane away -- a scalar, so the weight addresses are scalar arithmetic and no step starts with
                     // the LDS round trip list -> slot row -> A fragments
-                    const int kreg = klist[first + (lane < nstep ? lane : nstep - 1) * stride] & 0xff;
-                    auto kk_of = [&](int st) -> int { return __builtin_amdgcn_readlane(kreg, st < nstep ? st : nstep - 1); };
+                    const int kreg = klist[first + (lane < nstep ? lane : nstep - 1) * stride];       // offset | live bits << 8
+                    auto kk_of = [&](int st) -> int { return __builtin_amdgcn_readlane(kreg, st < nstep ? st : nstep - 1) & 0xff; };
                     const uint16_t *slot_lane = slot_s + r * 4;
+                    const uint32_t kg16 = (uint32_t)kg << 4;
                     auto slot_raw = [&](int kk) -> uint2 { return *reinterpret_cast<const uint2 *>(slot_lane + kk * T2_TM); };
                     auto rows_from = [&](const uint2 s2) -> Rows {
-                        const uint32_t s4[4] = {s2.x & 0xffffu, s2.x >> 16, s2.y & 0xffffu, s2.y >> 16};
                         Rows R;
-#pragma unroll
-                        for (int m = 0; m < 4; m++) { R.base[m] = s4[m] * 128u; R.sw[m] = (s4[m] >> 1) & 7u; }
+                        R.a[0] = (s2.x & 0xffffu) ^ kg16; R.a[1] = (s2.x >> 16) ^ kg16;
+                        R.a[2] = (s2.y & 0xffffu) ^ kg16; R.a[3] = (s2.y >> 16) ^ kg16;
                         return R;
-                    };
-                    auto read_a = [&](bf16x8 (&a)[4], const Rows &R, int ks) {
-#pragma unroll
-                        for (int m = 0; m < 4; m++)
-                            a[m] = *reinterpret_cast<const bf16x8 *>(As + R.base[m] + ((cg[ks] ^ R.sw[m]) << 4));
                     };
                     auto load_b = [&](uint4 (&b)[2], int kk, int ks) {
                         const uint16_t *wk = wbase + kk * wstride + ks * 512;
                         b[0] = *reinterpret_cast<const uint4 *>(wk);
                         b[1] = *reinterpret_cast<const uint4 *>(wk + wn);
-                    };
-                    auto mma = [&](const bf16x8 (&a)[4], const uint4 (&b)[2]) {
-                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]);
-#pragma unroll
-                        for (int m = 0; m < 4; m++) {
-                            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b0, acc[m][0], 0, 0, 0);
-                            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b1, acc[m][1], 0, 0, 0);
-                        }
                     };
                     uint4 b[4][2];
                     bf16x8 aA[4], aB[4];
@@ -260,50 +251,82 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
 #pragma unroll
                         for (int ks = 0; ks < 4; ks++) { load_b(b[ks], kcur, ks); __builtin_amdgcn_sched_barrier(0); }
                         const Rows R0 = rows_from(slot_raw(kcur));
-                        read_a(aA, R0, 0);
+#pragma unroll
+                        for (int m = 0; m < 4; m++) aA[m] = *reinterpret_cast<const bf16x8 *>(As + R0.a[m]);
                     }
                     Rows R = rows_from(slot_raw(kk_of(0)));
                     uint2 sraw_n = slot_raw(knext);      // the NEXT offset's slot row, requested a whole step before it is decoded
-                    // One scheduling region per (offset, 16 channels): its 8 MFMAs, the 4 LDS reads of the NEXT one's A
-                    // fragments and the 2 weight-fragment loads of the next offset, interleaved by rule.
-#define T2_UNIT_SCHED()                                                                         \
-    do {                                                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* MFMA */                      \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  /* VALU (address) */            \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  /* DS read */                   \
-        }                                                                                       \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
-            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);  /* VALU / SALU */               \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* VMEM read */                 \
-        }                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    } while (0)
-                    for (int st = 0; st < nstep; st++) {
-                        const int knn = kk_of(st + 2);                                // past the end: the last offset again, unused
-                        read_a(aB, R, 1);
+                    // One step = one offset x 64 input channels = 4 sub-steps of 16 channels.  The body is specialised on the
+                    // offset's LIVE MASK (bit m: some row of the tile's 32-row block m has a neighbour at this offset; the plan's
+                    // `live` bits ANDed with the row blocks this unit owns): a dead block costs neither its two MFMAs nor its
+                    // fragment read.  Per sub-step: the MFMAs of the live blocks, the LDS reads of the NEXT sub-step's A fragments
+                    // (the last sub-step requests all four blocks of the next offset: its mask selects among them) and the two
+                    // weight-fragment loads of the next offset, interleaved by rule.
+                    auto step = [&](auto MASK_, const int knn) {
+                        constexpr int MASK = decltype(MASK_)::value;
+                        constexpr int NM = ((MASK >> 0) & 1) + ((MASK >> 1) & 1) + ((MASK >> 2) & 1) + ((MASK >> 3) & 1);
+                        auto read_live = [&](bf16x8 (&a)[4], const Rows &Rr, auto KS_) {
+                            constexpr uint32_t kx = (uint32_t)decltype(KS_)::value << 5;
+#pragma unroll
+                            for (int m = 0; m < 4; m++)
+                                if ((MASK >> m) & 1) a[m] = *reinterpret_cast<const bf16x8 *>(As + (Rr.a[m] ^ kx));
+                        };
+                        auto mma = [&](const bf16x8 (&a)[4], const uint4 (&bb)[2]) {
+                            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bb[0]), b1 = __builtin_bit_cast(bf16x8, bb[1]);
+#pragma unroll
+                            for (int m = 0; m < 4; m++)
+                                if ((MASK >> m) & 1) {
+                                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b0, acc[m][0], 0, 0, 0);
+                                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b1, acc[m][1], 0, 0, 0);
+                                }
+                        };
+                        auto sched = [&](auto NDS_) {                          // 2 NM MFMAs, NDS LDS reads, 2 weight loads
+                            constexpr int NDS = decltype(NDS_)::value, NMF = 2 * NM;
+                            constexpr int per = NMF > 0 ? (NDS + NMF - 1) / NMF : 0;       // LDS reads behind each of the first MFMAs
+                            constexpr int lead = NMF > 0 && per > 0 ? (NDS + per - 1) / per : 0;
+#pragma unroll
+                            for (int q_ = 0; q_ < lead; q_++) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU (address)
+                                __builtin_amdgcn_sched_group_barrier(0x100, per, 0);    // DS read
+                            }
+#pragma unroll
+                            for (int q_ = lead; q_ < NMF; q_++) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);      // VALU / SALU
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+                        using K3 = std::integral_constant<int, 3>;
+                        read_live(aB, R, K1{});
                         mma(aA, b[0]);
                         load_b(b[0], knext, 0);
-                        T2_UNIT_SCHED();
-                        read_a(aA, R, 2);
+                        sched(std::integral_constant<int, NM>{});
+                        read_live(aA, R, K2{});
                         mma(aB, b[1]);
                         load_b(b[1], knext, 1);
-                        T2_UNIT_SCHED();
-                        read_a(aB, R, 3);
+                        sched(std::integral_constant<int, NM>{});
+                        read_live(aB, R, K3{});
                         const Rows Rn = rows_from(sraw_n);
                         mma(aA, b[2]);
                         load_b(b[2], knext, 2);
-                        T2_UNIT_SCHED();
-                        read_a(aA, Rn, 0);
+                        sched(std::integral_constant<int, NM>{});
+#pragma unroll
+                        for (int m = 0; m < 4; m++) aA[m] = *reinterpret_cast<const bf16x8 *>(As + Rn.a[m]);
                         sraw_n = slot_raw(knn);
                         mma(aB, b[3]);
                         load_b(b[3], knext, 3);
-                        T2_UNIT_SCHED();
+                        sched(std::integral_constant<int, 5>{});
                         R = Rn;
                         knext = knn;
-                    }
-#undef T2_UNIT_SCHED
+                    };
+                    // (Skipping the dead blocks was tried and is not kept: one loop switching between 15 mask-specialised bodies, or
+                    // branching around each block's MFMAs, made the register allocator spill 700-900 registers at the joins; 15
+                    // plain loops in a row over the offsets grouped by mask kept the hot loops clean but paid ~120 scratch
+                    // operations per stage at the transitions -- 7.6 vs 4.4 ms over the step's layers.  DESIGN.md section 5.)
+                    for (int st = 0; st < nstep; st++) step(std::integral_constant<int, 15>{}, kk_of(st + 2));
                 }
                 T2_STAMP();                             // multiplied
             }

@@ -124,6 +124,13 @@ class TwoBucketGradSync:
     # (a rank whose RoI head saw no proposal has no gradient for it -> zeros), or the ranks would issue their
     # collectives in different orders.
     def _on_stem_output_grad(self, grad):
+        # ORDER: early -> mid -> late on every rank, whichever hooks fired.  If the backbone-output hook did not run on this
+        # rank (the tensor was not hooked, or no loss term reached it) the early bucket leaves here, before the mid one --
+        # never after it from finish(), which would swap two collectives against the peers' order (a deadlock on RCCL).
+        if self.early and not self._early_sent:
+            flat_e, _ = self._pack("early", self.early)
+            self._work = self._reduce(flat_e, True)
+            self._early_sent = True
         flat, _ = self._pack("mid", self.mid)
         self._mid_work = self._reduce(flat, True)
         self._mid_sent = True

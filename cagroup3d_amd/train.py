@@ -54,6 +54,13 @@ class SyntheticIndoorDataset:
     def __len__(self):
         return (len(self.scene_ids) + self.batch_size - 1) // self.batch_size
 
+    def n_total(self):
+        return len(self.all_ids)
+
+    def eval_positions(self):
+        """Dataset positions of the scenes `batches()` (unshuffled) yields on this rank, in order (padding included)."""
+        return shard_ids(range(len(self.all_ids)), self.rank, self.world)
+
     _cache = {}
 
     def _scene(self, s):
@@ -108,6 +115,12 @@ class DiskIndoorDataset:
 
     def gt_annos(self):
         return [self.data.gt_annos()[i] for i in shard_ids(range(len(self.data)), self.rank, self.world)]
+
+    def n_total(self):
+        return len(self.data)
+
+    def eval_positions(self):
+        return shard_ids(range(len(self.data)), self.rank, self.world)
 
     def batches(self, epoch=0, shuffle=False):
         ids = np.arange(len(self.data))
@@ -216,9 +229,33 @@ def train_one_epoch(model, optimizer, scheduler, dataset, epoch, it, clip, rank=
     return it
 
 
+def merge_eval_shards(det_annos, gt_annos, indices, n_total, group=None):
+    """Collect every rank's per-scene results on all ranks and put them back in dataset order
+    (pcdet/utils/common_utils.py:202-223 `merge_results_dist`, tools/eval_utils/eval_utils.py:44-48: the reference gathers
+    through pickle files in a shared tmpdir, interleaves the ranks' lists and cuts the sampler's padding off; here the
+    lists travel through the process group and every scene is placed by its own index, so the padding duplicates of
+    `shard_ids` simply overwrite themselves).  EVERY rank must call this (a collective)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world <= 1:
+        parts = [(list(indices), det_annos, gt_annos)]
+    else:
+        parts = [None] * world
+        dist.all_gather_object(parts, (list(indices), det_annos, gt_annos), group=group)
+    det, gt = [None] * n_total, [None] * n_total
+    for idx, d, g in parts:
+        assert len(idx) == len(d) == len(g), "a rank evaluated %d scenes for %d indices" % (len(d), len(idx))
+        for i, di, gi in zip(idx, d, g):
+            det[i], gt[i] = di, gi
+    missing = [i for i in range(n_total) if det[i] is None]
+    assert not missing, "scenes %s were evaluated by no rank" % missing[:8]
+    return det, gt
+
+
 @torch.no_grad()
-def eval_one_epoch(model, dataset, class_names, device, metric=(0.25, 0.5), log=print):
-    """Detections of every scene of this rank's shard -> indoor_eval (test.py / eval_utils.py / scannet_dataset.py:88-150)."""
+def eval_one_epoch(model, dataset, class_names, device, metric=(0.25, 0.5), log=print, rank=0, world=1):
+    """Detections of every scene of THIS rank's shard, merged over the ranks, -> indoor_eval (test.py / eval_utils.py /
+    scannet_dataset.py:88-150).  With world > 1 every rank evaluates its own shard of `dataset` (scene i -> rank
+    i mod W, as in training) and all of them must call this; the metric dict is returned on rank 0, None elsewhere."""
     model.eval()
     det_annos, gt_annos = [], []
     for batch in dataset.batches():
@@ -229,6 +266,10 @@ def eval_one_epoch(model, dataset, class_names, device, metric=(0.25, 0.5), log=
         for p in pred_dicts:
             det_annos.append({"boxes_3d": p["pred_boxes"].cpu().numpy(), "scores_3d": p["pred_scores"].cpu().numpy(),
                               "labels_3d": p["pred_labels"].cpu().numpy().astype(np.int64)})
+    if world > 1:
+        det_annos, gt_annos = merge_eval_shards(det_annos, gt_annos, dataset.eval_positions(), dataset.n_total())
+        if rank != 0:
+            return None
     return indoor_eval(gt_annos, det_annos, list(metric), {i: c for i, c in enumerate(class_names)},
                        logger=type("L", (), {"info": staticmethod(log)}))
 
@@ -287,11 +328,14 @@ def main(argv=None):
     if rank == 0:
         print("trained %d iterations in %.1f s" % (it, time.time() - t0))
     result = None
-    if args.eval and rank == 0:
-        val = (DiskIndoorDataset(args.dataset, args.data_root, cfg.CLASS_NAMES, bs, False, workers=args.workers) if args.data_root
-               else SyntheticIndoorDataset(args.config, args.scenes, bs))
-        result = eval_one_epoch(model, val, cfg.CLASS_NAMES, dev)
+    if args.eval:
+        # every rank evaluates its shard of the validation set; the detections meet on rank 0 (tools/test.py with
+        # --launcher pytorch: eval_utils.py:44-48)
+        val = (DiskIndoorDataset(args.dataset, args.data_root, cfg.CLASS_NAMES, bs, False, rank, world, workers=args.workers)
+               if args.data_root else SyntheticIndoorDataset(args.config, args.scenes, bs, rank, world))
+        result = eval_one_epoch(model, val, cfg.CLASS_NAMES, dev, rank=rank, world=world)
     if world > 1:
+        dist.barrier()                       # nobody tears the group down while a peer is still inside a collective
         dist.destroy_process_group()
     return result
 

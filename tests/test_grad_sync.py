@@ -75,6 +75,59 @@ def test_two_bucket_sync_matches_ddp(tmp_path):
     assert open(out).read() == "ok"
 
 
+def _worker_uneven(rank, world, port, out):
+    """The collectives must leave in the same order (early, mid, late) on every rank whichever hooks fire.  Rank 1 plays a
+    rank whose heads got nothing to do: its backbone output is never hooked (the early bucket cannot leave from its hook)
+    and in the second step its loss does not reach the roi head at all (zero gradients travel instead).  With the early
+    bucket sent from finish() -- after the mid bucket from ITS hook -- rank 1 would issue (mid, early, late) against rank
+    0's (early, mid, late): mismatched all-reduces, i.e. wrong sums on gloo and a hang on RCCL."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    ref = Toy()
+    torch.manual_seed(0)
+    mine = Toy()
+    mine.grad_sync = TwoBucketGradSync(mine)
+    gs = mine.grad_sync
+    order = []
+    real_reduce = gs._reduce
+    gs._reduce = lambda flat, async_op: (order.append(next(k for k, v in gs._buf.items() if v[0] is flat)), real_reduce(flat, async_op))[1]
+    if rank == 1:
+        gs.attach = lambda tensor: (setattr(gs, "_early_sent", False), setattr(gs, "_work", None))      # never hooks the tensor
+    for step in range(2):
+        xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(world)]
+
+        def loss_of(m, r, x):
+            f = m.backbone_3d(x)
+            if m.grad_sync is not None:
+                m.grad_sync.attach(f)
+            out = m.dense_head(f).pow(2).sum()
+            return out if (r == 1 and step == 1) else out + m.roi_head(f).abs().sum()
+        ref.zero_grad(set_to_none=True)
+        for r, x in enumerate(xs):                      # the average over ranks, computed locally
+            (loss_of(ref, r, x) / world).backward()
+        mine.zero_grad(set_to_none=True)
+        del order[:]
+        loss_of(mine, rank, xs[rank]).backward()
+        gs.finish()
+        assert order == ["early", "mid", "late"], (rank, step, order)
+        for (n, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
+            if a.grad is None:
+                assert b.grad is None or float(b.grad.abs().max()) == 0.0, n
+            else:
+                torch.testing.assert_close(b.grad, a.grad, rtol=1e-5, atol=1e-6, msg=lambda m: "%s step %d: %s" % (n, step, m))
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_order_does_not_depend_on_which_hooks_fire(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_uneven, args=(2, 29536, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
 def _worker_gpu(rank, world, port, out):
     """Both ranks on cuda:0 over gloo (RCCL refuses two ranks on one device): the bucket packing, the asynchronous
     exchange started inside backward and finish() run on device tensors and streams."""

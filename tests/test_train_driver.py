@@ -177,3 +177,46 @@ def test_fused_clip_adamw_launch_matches_torch_on_device(hip):
         torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(o2.state[b]["exp_avg_sq"], o1.state[a]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
         assert float(o2.state[b]["step"]) == float(o1.state[a]["step"]) == 5.0
+
+
+def _worker_eval(rank, world, port, out):
+    """Two gloo ranks evaluate their shards of 5 scenes (uneven: rank 0 gets scenes 0,2,4, rank 1 gets 1,3 and the padding
+    duplicate 0); the merged result on rank 0 must be exactly the single-process evaluation, and the non-zero rank gets
+    None after taking part in the gather."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import _build_oracle
+    oracle = _lib.bind(_build_oracle())
+    with _lib.use_library(oracle):
+        model, cfg = build_model.build_cagroup3d("scannet", seed=0)
+        names = cfg.CLASS_NAMES
+        full = train.eval_one_epoch(model, train.SyntheticIndoorDataset("S5k", 5, 2), names, "cpu", log=lambda *a: None) if rank == 0 else None
+        ds = train.SyntheticIndoorDataset("S5k", 5, 2, rank, world)
+        assert ds.eval_positions() == ([0, 2, 4] if rank == 0 else [1, 3, 0]) and ds.n_total() == 5
+        res = train.eval_one_epoch(model, ds, names, "cpu", log=lambda *a: None, rank=rank, world=world)
+    if rank == 0:
+        assert res is not None and set(res) == set(full)
+        for k in full:
+            a, b = full[k], res[k]
+            assert (a == b) or (a != a and b != b) or abs(a - b) < 1e-9, (k, a, b)
+        open(out, "w").write("ok")
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_merges_to_the_single_process_result(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_eval, args=(2, 29541, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_merge_eval_shards_places_scenes_by_index():
+    # single process: identity; the multi-rank path is the spawn test above
+    det, gt = train.merge_eval_shards(["a", "b", "c"], ["x", "y", "z"], [0, 1, 2], 3)
+    assert det == ["a", "b", "c"] and gt == ["x", "y", "z"]
+    with pytest.raises(AssertionError):
+        train.merge_eval_shards(["a"], ["x"], [0], 2)             # a scene nobody evaluated

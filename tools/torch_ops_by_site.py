@@ -16,6 +16,11 @@ from cagroup3d_amd import build_model, me  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+VIEWS = ("aten.view.", "aten.detach.", "aten.select.", "aten.slice.", "aten.empty", "aten.alias.", "aten.expand.", "aten.unsqueeze.",
+         "aten.t.", "aten.lift_fresh.", "aten.record_stream.", "aten.unbind.", "aten.split", "aten.squeeze.", "aten.permute.",
+         "aten.transpose.", "aten._unsafe_view", "aten.reshape", "aten.as_strided", "aten.is_pinned", "aten._local_scalar_dense")
+
+
 class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
@@ -27,9 +32,15 @@ class Count(TorchDispatchMode):
             if fr.filename.startswith(ROOT) and "tools/" not in fr.filename:
                 site = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)
                 break
+        name = str(func)
+        if any(k in name for k in VIEWS):
+            return func(*args, **(kwargs or {}))               # no kernel behind these
+        if site == "?":
+            node = torch._C._current_autograd_node()
+            if node is not None:
+                site = "autograd: " + node.name()
         self.sites[site] += 1
         self.ops[str(func)] += 1
-        name = str(func)
         if any(k in name for k in ("_to_copy", "zeros", "fill_", "copy_", "clone", "zero_", "ones", "full")):
             self.fills[(name.split(".")[1], site)] += 1
         return func(*args, **(kwargs or {}))
