@@ -1,7 +1,7 @@
 // spconv_tile2.hip -- sparse convolution forward / data gradient on LDS-staged neighbour tiles, round 3 (gfx950).
 //
-// Same operator, plan and operand layouts as spconv_tile.hip (cg3d_tile_plan_build, cg3d_spconv_prep_weights_frag);
-// replaces its persistent loader/consumer kernel.  Call sites: pcdet/models/backbones_3d/biresnet.py:358-406 (every
+// The convolution on the plans / operand layouts of spconv_tile.hip (cg3d_tile_plan_build, cg3d_spconv_prep_weights_frag);
+// replaces round 2's persistent loader/consumer kernel (one workgroup per CU).  Call sites: pcdet/models/backbones_3d/biresnet.py:358-406 (every
 // K > 1 convolution of BiResNet), dense_heads/cagroup_head.py:259-275 (the grouped class-branch convolutions);
 // MinkowskiEngine's ConvolutionForwardGPU / ConvolutionBackwardGPU (un-vendored).
 //
@@ -29,18 +29,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define T2_KB 32             // offsets whose slot table is resident in LDS at a time
 #define T2_NLV 16            // row granules a thread stages per pass and chunk: 256 threads x 16 = 4096 = 512 rows x 8
 
-// the round-2 kernel (spconv_tile.hip), kept for A/B runs: CG3D_TILE_V1=1
-int64_t cg3d_tile_v1_lds_bytes(int32_t ucap);
-int32_t cg3d_tile_v1_grid(int64_t ntile, int32_t cout, int32_t ksplit);
-int cg3d_tile_v1_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
-                     const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass, int32_t ucap,
-                     const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K,
-                     int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t stream);
-static bool use_v1() {
-    static const int v1 = getenv("CG3D_TILE_V1") ? atoi(getenv("CG3D_TILE_V1")) : 0;
-    return v1 != 0;
-}
-
 #ifdef CG3D_TILE_TRACE
 // dev build only (CG3D_HIPCC_EXTRA=-DCG3D_TILE_TRACE): per workgroup {shader-clock start, end, 100 MHz start, end, HW_ID | XCC_ID << 32, unit}
 __device__ unsigned long long *g_t2_trace;
@@ -65,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
     const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf, const uint16_t *__restrict__ slots,
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
     const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,
-    const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
+    const int32_t *__restrict__ order, const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
     int32_t nunit, int32_t ny, int32_t gz, int32_t wrev, float *__restrict__ stats, int32_t stagger) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
@@ -413,14 +401,15 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
         const int col0 = (yb * NCO + h) * 64 + c4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias && zi == 0) bv = *reinterpret_cast<const float4 *>(bias + col0);
-        float *ybase = Y + (row0 + g * rows_per + rq) * (int64_t)cout + col0;
         float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
 #pragma unroll
         for (int i = 0; i < rows_per / 4; i++) {
             float4 v = *reinterpret_cast<const float4 *>(tb + (i * 4 + rq) * 64 + c4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (g * rows_per + i * 4 + rq < rows) {
-                float *dst = ybase + (int64_t)i * 4 * cout;
+            const int pos = g * rows_per + i * 4 + rq;   // position in the tile -> output row (permuted tiles: `order`)
+            if (pos < rows) {
+                const int64_t orow = order ? (int64_t)order[row0 + pos] : row0 + pos;
+                float *dst = Y + orow * cout + col0;
                 if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
                 else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
@@ -451,27 +440,22 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
 }
 
 extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
-    if (use_v1()) return cg3d_tile_v1_lds_bytes(ucap);
     return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES + T2_IDX_BYTES + 2 * 128 * sizeof(float);
 }
 
 // rows of the `stats` output of cg3d_spconv_tile_fwd: one [2][cout] partial per tile (every workgroup of a tile fills its
 // own channel block of it)
 extern "C" int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
-    if (use_v1()) return cg3d_tile_v1_grid(ntile, cout, ksplit);
     if (ntile < 0 || ntile > 0x7fffffffll || cout < 64 || ksplit < 1) return -1;
     return (int32_t)ntile;
 }
 
 extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                                     const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist,
-                                    int32_t maxpass, int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias,
-                                    float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-                                    int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t stream) {
-    if (use_v1())
-        return cg3d_tile_v1_fwd(X, Wf, slots, live, pass_tab, npass, ulist, maxpass, ucap, tiles, ntile, bias, Y, n_in, n_out, K,
-                                cin, cout, ksplit, wrev, stats, stream);
-    if (stats && (ksplit != 1 || tiles || cout > 512)) return CG3D_ERR_ARG;
+                                    int32_t maxpass, int32_t ucap, const int32_t *tiles, int64_t ntile, const int32_t *order,
+                                    const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin,
+                                    int32_t cout, int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t stream) {
+    if ((stats && (ksplit != 1 || tiles || cout > 512)) || (order && tiles)) return CG3D_ERR_ARG;
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
         return CG3D_ERR_ARG;
     if (ucap < T2_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
@@ -500,7 +484,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
             }                                                                                                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spconv_tile2<NW>), dim3(grid), dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist,    \
-                           maxpass, ucap, tiles, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev ? 1 : 0, stats, stagger); \
+                           maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev ? 1 : 0, stats, stagger); \
     } while (0)
     if (cout >= 128) T2_LAUNCH(2); else T2_LAUNCH(1);
 #undef T2_LAUNCH

@@ -241,7 +241,12 @@ class KernelMap:
         if pl is None:
             _, _, _, P = self.pairs(row_bounds)
             nbr = self.nbrT if transposed else self.nbr
-            pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds))
+            # sparse maps (the transposed map of a strided convolution, the map of a transposed one: a row has neighbours
+            # only at the offsets of its parity class, occupancy 0.10-0.13): tiles cut from rows grouped by their set of
+            # live offsets multiply 2-3 x the rows they need instead of 7-8 x (cg3d_tile_row_order)
+            sort_rows = (TILE_SORT_ROWS and row_bounds is None and not self.symmetric and self.K <= 32
+                         and P < TILE_SORT_MAX_OCCUPANCY * self.K * max(nbr.shape[1], 1))
+            pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds), sort_rows=sort_rows)
             self._segs[ck] = pl
         return pl
 
@@ -551,17 +556,22 @@ TILE_ROWS = 128
 TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS rows per pass: (ucap+1) x 128 B = 64 KB
 
 
+TILE_SORT_ROWS = __import__("os").environ.get("CG3D_TILE_SORT_ROWS", "1") != "0"
+TILE_SORT_MAX_OCCUPANCY = 0.2       # pairs / (K * rows) below which a map's tiles are cut from signature-sorted rows
+
+
 class TilePlan:
     """A kernel map re-encoded per tile of 128 output rows (include/cagroup3d_hip.h, cg3d_tile_plan_build)."""
-    __slots__ = ("slots", "live", "pass_tab", "npass", "ulist", "cursor", "maxpass", "ucap", "ntile", "tiles", "K", "n_out")
+    __slots__ = ("slots", "live", "pass_tab", "npass", "ulist", "cursor", "maxpass", "ucap", "ntile", "tiles", "K", "n_out", "order")
 
     def tensors(self):
-        return [self.slots, self.live, self.pass_tab, self.npass, self.ulist, self.cursor, self.tiles]
+        return [self.slots, self.live, self.pass_tab, self.npass, self.ulist, self.cursor, self.tiles, self.order]
 
 
-def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None):
+def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None, sort_rows=False):
     """nbr int32 [K, n_out] (k-major) -> TilePlan.  `n_pairs` (host int, >= the number of nbr >= 0) sizes `ulist`;
-    tiles: None or (device int32 [ntile,3], ntile)."""
+    tiles: None or (device int32 [ntile,3], ntile); sort_rows: cut the tiles from the rows permuted by
+    cg3d_tile_row_order (plan.order: position -> output row)."""
     lib = _lib.get()
     lib.check(nbr)
     K, n_out = nbr.shape
@@ -579,9 +589,13 @@ def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None):
     p.npass = torch.empty(nt, dtype=torch.int32, device=dev)
     p.ulist = torch.empty(max(int(n_pairs), 1), dtype=torch.int32, device=dev)
     p.cursor = torch.empty(2, dtype=torch.int32, device=dev)
+    p.order = None
+    if sort_rows and tiles is None and K <= 32 and n_out > 0:
+        p.order = torch.empty(n_out, dtype=torch.int32, device=dev)
+        lib.call("cg3d_tile_row_order", ptr(nbr), c_int32(K), c_int64(n_out), ptr(p.order), lib.stream())
     lib.call("cg3d_tile_plan_build", ptr(nbr), c_int32(K), c_int64(n_out), ptr(p.tiles), c_int64(p.ntile), c_int32(p.ucap),
              c_int32(p.maxpass), ptr(p.slots), ptr(p.live), ptr(p.pass_tab), ptr(p.npass), ptr(p.ulist),
-             c_int64(p.ulist.shape[0]), ptr(p.cursor), lib.stream())
+             c_int64(p.ulist.shape[0]), ptr(p.cursor), ptr(p.order), lib.stream())
     return p
 
 
@@ -605,7 +619,7 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     lib.call("cg3d_spconv_tile_fwd", ptr(x16), ptr(wf), ptr(plan.slots), ptr(plan.live), ptr(plan.pass_tab), ptr(plan.npass),
-             ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(bias), ptr(y),
+             ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(plan.order), ptr(bias), ptr(y),
              c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit),
              c_int32(1 if wrev else 0), ptr(stats), lib.stream())
     if prof:

@@ -209,6 +209,13 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
  *            [0] = entries used, [1] != 0 = ulist / pass_tab overflowed (the plan is unusable)
  * The slot numbering inside a pass is the implementation's choice (tests check the plan by decoding it).
  * 128 <= ucap <= 1023; maxpass >= K is always enough.
+ * `order` (optional, tiles == NULL only): int32 [n_out], a permutation of the output rows; position p of tile t is then
+ *   output row order[128 t + p] -- in the plan's slot table and where cg3d_spconv_tile_fwd stores its rows.
+ *
+ * cg3d_tile_row_order: the permutation that sorts the rows inside every window of CG3D_TILE_WINDOW consecutive rows
+ *   by their set of live offsets (bit k = nbr[k][row] >= 0; K <= 32), ties in row order.  For the transposed map of a
+ *   strided convolution and the map of a transposed convolution (a row has neighbours only at the offsets of its parity
+ *   class) the tiles cut from it multiply 2-3 x the rows they need instead of 7-8 x.
  *
  * cg3d_spconv_prep_weights_frag: fp32 [slot][cin][cout] (one tensor W0, or G tensors Ws like
  *   cg3d_spconv_prep_weights_bf16_multi) -> bf16 in MFMA B-fragment order,
@@ -226,20 +233,23 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
  *   Launch needs cg3d_spconv_tile_lds_bytes(ucap) <= 160 KB of LDS per workgroup.
  * ---------------------------------------------------------------------------------------- */
 #define CG3D_TILE_ROWS 128
+#define CG3D_TILE_WINDOW 1024
+int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t *order, cg3d_stream_t stream);
 int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
                          int32_t ucap, int32_t maxpass, uint16_t *slots, uint8_t *live, int32_t *pass_tab,
-                         int32_t *npass, int32_t *ulist, int64_t ulist_cap, int32_t *cursor, cg3d_stream_t stream);
+                         int32_t *npass, int32_t *ulist, int64_t ulist_cap, int32_t *cursor, const int32_t *order,
+                         cg3d_stream_t stream);
 int cg3d_spconv_prep_weights_frag(const float *W0, const float *const *Ws, uint16_t *Wf_t, uint16_t *Wf, int32_t G,
                                   int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t stream);
 int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap);
 int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
-                         int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
-                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev,
-                         float *stats, cg3d_stream_t stream);
+                         int32_t ucap, const int32_t *tiles, int64_t ntile, const int32_t *order, const float *bias,
+                         float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit,
+                         int32_t wrev, float *stats, cg3d_stream_t stream);
 /* stats (optional; needs ksplit == 1, tiles == NULL, cout <= 512): float32 [cg3d_spconv_tile_grid(ntile, cout, ksplit)][2][cout],
- * per launched workgroup the sum and the sum of squares of every output channel over the rows it stored -- the chunk
- * partials cg3d_bn_stats would compute in a pass of its own over Y; finalise them with cg3d_bn_stats_from_partials. */
+ * partial sums (one row per tile on the device) of every output channel and of its square over the rows stored -- the
+ * chunk partials cg3d_bn_stats would compute in a pass of its own over Y; finalise them with cg3d_bn_stats_from_partials. */
 int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit);
 
 /* ------------------------------------------------------------------------------------------

@@ -48,12 +48,37 @@ int cg3d_spconv_prep_weights_frag(const float *W0, const float *const *Ws, uint1
     return CG3D_OK;
 }
 
+/* Rows sorted by (set of live offsets, row) inside windows of CG3D_TILE_WINDOW rows (spconv_tile.hip, k_tile_row_order). */
+typedef struct { uint32_t sig; int32_t row; } ot_key;
+static int ot_key_cmp(const void *a, const void *b) {
+    const ot_key *x = (const ot_key *)a, *y = (const ot_key *)b;
+    if (x->sig != y->sig) return x->sig < y->sig ? -1 : 1;
+    return x->row < y->row ? -1 : (x->row > y->row);
+}
+int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t *order, cg3d_stream_t s) {
+    (void)s;
+    if (K < 1 || K > 32 || n_out < 0) return CG3D_ERR_ARG;
+    ot_key *keys = (ot_key *)malloc(sizeof(ot_key) * CG3D_TILE_WINDOW);
+    for (int64_t w0 = 0; w0 < n_out; w0 += CG3D_TILE_WINDOW) {
+        const int n = (int)(n_out - w0 < CG3D_TILE_WINDOW ? n_out - w0 : CG3D_TILE_WINDOW);
+        for (int i = 0; i < n; i++) {
+            uint32_t sig = 0;
+            for (int k = 0; k < K; k++) sig |= (nbr[(int64_t)k * n_out + w0 + i] >= 0 ? 1u : 0u) << k;
+            keys[i].sig = sig; keys[i].row = (int32_t)(w0 + i);
+        }
+        qsort(keys, (size_t)n, sizeof(ot_key), ot_key_cmp);
+        for (int i = 0; i < n; i++) order[w0 + i] = keys[i].row;
+    }
+    free(keys);
+    return CG3D_OK;
+}
+
 /* Greedy passes in offset order; a row's slot = 1 + its rank of first appearance within the pass. */
 int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile, int32_t ucap,
                          int32_t maxpass, uint16_t *slots, uint8_t *live, int32_t *pass_tab, int32_t *npass,
-                         int32_t *ulist, int64_t ulist_cap, int32_t *cursor, cg3d_stream_t s) {
+                         int32_t *ulist, int64_t ulist_cap, int32_t *cursor, const int32_t *order, cg3d_stream_t s) {
     (void)s;
-    if (K < 1 || n_out < 0 || ntile < 0 || ucap < TP_TM || ucap > 1023 || maxpass < 1) return CG3D_ERR_ARG;
+    if (K < 1 || n_out < 0 || ntile < 0 || ucap < TP_TM || ucap > 1023 || maxpass < 1 || (order && tiles)) return CG3D_ERR_ARG;
     if (!tiles && ntile != (n_out + TP_TM - 1) / TP_TM) return CG3D_ERR_ARG;
     cursor[0] = cursor[1] = 0;
     int32_t *ul = (int32_t *)malloc(sizeof(int32_t) * 1024);
@@ -67,7 +92,7 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
             int newc = 0;
             if (k < K)
                 for (int r = 0; r < rows; r++) {
-                    const int32_t g = nbr[(int64_t)k * n_out + row0 + r];
+                    const int32_t g = nbr[(int64_t)k * n_out + (order ? order[row0 + r] : row0 + r)];
                     if (g < 0) continue;
                     int found = 0;
                     for (int u = 0; u < ucount && !found; u++) found = ul[u] == g;
@@ -85,7 +110,7 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
             }
             int lv = 0;
             for (int r = 0; r < TP_TM; r++) {
-                const int32_t g = r < rows ? nbr[(int64_t)k * n_out + row0 + r] : -1;
+                const int32_t g = r < rows ? nbr[(int64_t)k * n_out + (order ? order[row0 + r] : row0 + r)] : -1;
                 int sl = 0;
                 if (g >= 0) {
                     lv |= 1 << (r >> 5);
@@ -104,10 +129,11 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
 
 int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,
                          const int32_t *pass_tab, const int32_t *npass, const int32_t *ulist, int32_t maxpass,
-                         int32_t ucap, const int32_t *tiles, int64_t ntile, const float *bias, float *Y, int64_t n_in,
-                         int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t s) {
+                         int32_t ucap, const int32_t *tiles, int64_t ntile, const int32_t *order, const float *bias, float *Y,
+                         int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit, int32_t wrev,
+                         float *stats, cg3d_stream_t s) {
     (void)s; (void)n_in; (void)ucap;
-    if (stats && (ksplit != 1 || tiles || cout > 512)) return CG3D_ERR_ARG;
+    if ((stats && (ksplit != 1 || tiles || cout > 512)) || (order && tiles)) return CG3D_ERR_ARG;
     if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127))) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t t = 0; t < ntile; t++) {
@@ -116,7 +142,7 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
         const int64_t wslot0 = tiles ? (int64_t)tiles[t * 3] * K : 0;
         float *xq = (float *)malloc(sizeof(float) * (size_t)cin);
         for (int r = 0; r < rows; r++) {
-            float *y = Y + (row0 + r) * cout;
+            float *y = Y + (order ? (int64_t)order[row0 + r] : row0 + r) * cout;       /* position r of the tile -> output row */
             for (int c = 0; c < cout; c++) y[c] = bias ? bias[c] : 0.f;
         }
         for (int p = 0; p < npass[t]; p++) {
@@ -129,7 +155,7 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
                     if (!sl || !((lv >> (r >> 5)) & 1)) continue;     /* a dead block is skipped by the kernel: its slots must be 0 */
                     const int64_t g = ulist[pt[2] + sl - 1];
                     for (int a = 0; a < cin; a++) xq[a] = ot_bf16_bits(X[g * cin + a]);
-                    float *y = Y + (row0 + r) * cout;
+                    float *y = Y + (order ? (int64_t)order[row0 + r] : row0 + r) * cout;
                     for (int c = 0; c < cout; c++) {
                         float acc = 0.f;
                         for (int a = 0; a < cin; a++) acc += xq[a] * ot_bf16_bits(wk[ot_frag_index(c, a, cin)]);

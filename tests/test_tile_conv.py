@@ -28,6 +28,9 @@ def decode_plan(plan):
     live = plan.live.cpu().numpy()
     ptab, npass, ulist, cursor = plan.pass_tab.cpu().numpy(), plan.npass.cpu().numpy(), plan.ulist.cpu().numpy(), plan.cursor.cpu().numpy()
     tiles = plan.tiles.cpu().numpy() if plan.tiles is not None else None
+    order = plan.order.cpu().numpy() if getattr(plan, "order", None) is not None else None
+    if order is not None:
+        assert sorted(order.tolist()) == list(range(n_out)), "order must be a permutation of the output rows"
     assert cursor[1] == 0, "plan overflowed"
     nbr = np.full((K, n_out), -1, np.int32)
     used = 0
@@ -46,7 +49,8 @@ def decode_plan(plan):
             assert s.max(initial=0) <= ucnt
             assert (s[:, rows:] == 0).all()
             dec = np.where(s > 0, ul[np.maximum(s.astype(np.int64) - 1, 0)] if ucnt else -1, -1).astype(np.int32)
-            nbr[k0:k1, row0:row0 + rows] = dec[:, :rows]
+            out_rows = np.arange(row0, row0 + rows) if order is None else order[row0:row0 + rows]      # position -> output row
+            nbr[k0:k1, out_rows] = dec[:, :rows]
             lv = np.stack([(s[:, m * 32:(m + 1) * 32] > 0).any(1) for m in range(4)], 1)
             lv_plan = (live[t, k0:k1, None] >> np.arange(4)[None]) & 1
             assert (lv == lv_plan.astype(bool)).all(), "liveness bits"
@@ -55,8 +59,8 @@ def decode_plan(plan):
     return nbr
 
 
-def _plan_roundtrip(nbr, P, ucap, tiles=None):
-    plan = me.build_tile_plan(nbr, P, tiles=tiles, ucap=ucap)
+def _plan_roundtrip(nbr, P, ucap, tiles=None, sort_rows=False):
+    plan = me.build_tile_plan(nbr, P, tiles=tiles, ucap=ucap, sort_rows=sort_rows)
     dec = decode_plan(plan)
     return plan, dec
 
@@ -84,6 +88,39 @@ def test_oracle_plan_empty_map_and_grouped_tiles(oracle):
         tiles = km.tiles(bounds)
         plan, dec = _plan_roundtrip(km.nbr.contiguous(), int((km.nbr >= 0).sum()), 511, tiles)
         assert np.array_equal(dec, km.nbr.numpy())
+
+
+def _row_order_reference(nbr, window=1024):
+    """numpy restatement of cg3d_tile_row_order: inside every window rows sorted by (set of live offsets, row)."""
+    nbr = np.asarray(nbr)
+    K, n = nbr.shape
+    sig = ((nbr >= 0).astype(np.uint64) << np.arange(K, dtype=np.uint64)[:, None]).sum(0)
+    order = np.empty(n, np.int32)
+    for w0 in range(0, n, window):
+        idx = np.arange(w0, min(n, w0 + window))
+        order[idx] = idx[np.lexsort((idx, sig[idx]))]
+    return order
+
+
+@pytest.mark.parametrize("n,ks,stride,transposed", [(5000, 3, 2, True), (3000, 2, 2, True), (2600, 3, 1, False), (1, 3, 2, True)])
+def test_oracle_sorted_rows_plan_is_the_same_map_with_fewer_live_offsets(oracle, n, ks, stride, transposed):
+    """cg3d_tile_row_order + a plan on the permuted rows: decodes to the same kernel map; on the transposed map of a strided
+    convolution the tiles have far fewer live (tile, offset) entries than in arrival order."""
+    with _lib.use_library(oracle):
+        km = _kernel_map(surface_coords(n, batch=2, extent=max(6, int(n ** 0.5) // 3), seed=n + ks), ks, stride)
+        nbr = (km.nbrT if transposed else km.nbr).contiguous()
+        P = int((nbr >= 0).sum())
+        plain, dec0 = _plan_roundtrip(nbr, P, 511)
+        plan, dec = _plan_roundtrip(nbr, P, 511, sort_rows=True)
+        assert plan.order is not None and np.array_equal(plan.order.numpy(), _row_order_reference(nbr.numpy()))
+        assert np.array_equal(dec, nbr.numpy()) and np.array_equal(dec0, nbr.numpy())
+        live_sorted, live_plain = int((plan.live.numpy() != 0).sum()), int((plain.live.numpy() != 0).sum())
+        if stride == 2 and n >= 2000:
+            assert live_sorted < 0.6 * live_plain, (live_sorted, live_plain)
+        # the policy: sparse non-symmetric maps only
+        assert km.tile_plan(True).order is (None if stride == 1 else km.tile_plan(True).order)
+        if stride == 1:
+            assert km.tile_plan(False).order is None, "a map onto itself keeps the arrival order"
 
 
 def _tile_conv(coords, x, w, bias, ks, stride, ucap, ksplit, transposed):
@@ -324,6 +361,39 @@ def test_hip_tile_conv_matches_oracle(oracle, hip, cin, cout, n, ks, stride, uca
         scale = max(float(ref.abs().max()), 1.0)
         torch.testing.assert_close(y.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
         torch.testing.assert_close(ydense.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ks,stride,cin,cout", [(30000, 3, 2, 128, 64), (20000, 2, 2, 64, 128), (9000, 3, 2, 256, 128), (700, 3, 2, 64, 64)])
+def test_hip_sorted_rows_plan_and_convolution(oracle, hip, n, ks, stride, cin, cout):
+    """Device row order == the oracle's (bit-exact); the plan on the permuted rows decodes to the map; the convolution
+    through it (rows stored at order[position]) == the oracle's dense-map bf16 emulation == the unpermuted plan."""
+    coords = surface_coords(n, batch=3, extent=max(6, int(n ** 0.5) // 3), seed=n + ks)
+    torch.manual_seed(n)
+    w = torch.randn(ks ** 3, cin, cout) / (cin * 8) ** 0.5          # the data-gradient problem: dY [n_out, cout] -> dX [n_in, cin]
+    with _lib.use_library(oracle):
+        km0 = _kernel_map(coords, ks, stride)
+        ref_order = me.build_tile_plan(km0.nbrT.contiguous(), int((km0.nbrT >= 0).sum()), sort_rows=True).order
+        dy = torch.randn(km0.n_out, cout)
+        ref = me._conv_implicit_bf16(me._to_bf16(dy), me._prep_bf16_both(w)[1], km0.nbrT.contiguous(), None, km0.n_in, cout, cin,
+                                     int((km0.nbrT >= 0).sum()))
+    with _lib.use_library(hip):
+        km = _kernel_map(coords.cuda(), ks, stride)
+        nbrT = km.nbrT.contiguous()
+        P = int((nbrT >= 0).sum())
+        plan, dec = _plan_roundtrip(nbrT, P, 511, sort_rows=True)
+        assert torch.equal(plan.order.cpu(), ref_order)
+        assert np.array_equal(dec, nbrT.cpu().numpy())
+        plain = me.build_tile_plan(nbrT, P)
+        assert int((plan.live != 0).sum()) < int((plain.live != 0).sum())
+        _, wp = me._prep_frag(w.cuda(), False, True)
+        dy16 = me._to_bf16(dy.cuda())
+        y = me._conv_tile(dy16, wp, plan, None, cout, cin, km.n_out, P)
+        y0 = me._conv_tile(dy16, wp, plain, None, cout, cin, km.n_out, P)
+        assert km.tile_plan(True).order is not None, "the autograd path must pick the sorted plan for this map"
+    scale = max(float(ref.abs().max()), 1.0)
+    torch.testing.assert_close(y.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
+    torch.testing.assert_close(y0.cpu(), ref, rtol=RTOL, atol=ATOL * scale)
 
 
 @pytest.mark.gpu
