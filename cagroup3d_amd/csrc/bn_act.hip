@@ -95,42 +95,44 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
     }
 }
 
-// fp64 reduction over the group's chunks: a 256-thread block owns 16 channels of one group; its 16
-// chunk-lanes stride the group's chunks, then combine through LDS.
+// fp64 reduction over the group's chunks: a 1024-thread block owns 16 channels of one group; its 64 chunk-lanes stride
+// the group's chunks (four loads in flight each), then combine through LDS.  (Round 3: 64 lanes instead of 16 -- the tile
+// convolution now leaves one partial per TILE, up to 1 500 of them, and with 16 lanes every thread walked ~100 chunks
+// one L2 round trip after the other: 11 us per launch, 130 launches per step.)
 // MODE 0: out0 = mean, out1 = biased variance (row count from the chunk table)
 // MODE 1: out0 = sum0 (dbeta), out1 = sum1 (dgamma)
+#define BN_FL 64
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
-                                                     const int32_t *__restrict__ gco, int32_t G, int32_t c,
-                                                     float *__restrict__ out0, float *__restrict__ out1,
-                                                     float *__restrict__ run0, float *__restrict__ run1,
-                                                     long long *__restrict__ nbt, float momentum,
-                                                     long long rows_arg, int nchunk_arg) {
-    __shared__ double r0[256], r1[256];
-    __shared__ long long rr[256];
+__global__ __launch_bounds__(16 * BN_FL) void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
+                                                            const int32_t *__restrict__ gco, int32_t G, int32_t c,
+                                                            float *__restrict__ out0, float *__restrict__ out1,
+                                                            float *__restrict__ run0, float *__restrict__ run1,
+                                                            long long *__restrict__ nbt, float momentum,
+                                                            long long rows_arg, int nchunk_arg) {
+    __shared__ double r0[16 * BN_FL], r1[16 * BN_FL];
+    __shared__ long long rr[16 * BN_FL];
     const int cblocks = (c + 15) / 16;
     const int g = blockIdx.x / cblocks, a = (blockIdx.x % cblocks) * 16 + (threadIdx.x & 15), lanek = threadIdx.x >> 4;
     double s0 = 0.0, s1 = 0.0;
     long long rows = 0;
     if (a < c) {
-        // four chunks per trip, every load issued before the first add: with one dependent load per trip the whole
-        // kernel was a chain of ~40 L2 round trips (11 us for a few hundred KB)
+        // four chunks per trip, every load issued before the first add
         // (no chunk table: one group, chunks [0, nchunk_arg), rows_arg rows -- partial sums produced by another kernel)
         int k = (gco ? gco[g] : 0) + lanek;
         const int kend = gco ? gco[g + 1] : nchunk_arg;
-        for (; k + 48 < kend; k += 64) {
+        for (; k + 3 * BN_FL < kend; k += 4 * BN_FL) {
             float p0[4], p1[4];
             int pr[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                p0[u] = ws[(int64_t)(k + 16 * u) * 2 * c + a];
-                p1[u] = ws[(int64_t)(k + 16 * u) * 2 * c + c + a];
-                pr[u] = (MODE == 0 && chunks) ? chunks[(k + 16 * u) * 3 + 2] : 0;
+                p0[u] = ws[(int64_t)(k + BN_FL * u) * 2 * c + a];
+                p1[u] = ws[(int64_t)(k + BN_FL * u) * 2 * c + c + a];
+                pr[u] = (MODE == 0 && chunks) ? chunks[(k + BN_FL * u) * 3 + 2] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) { s0 += (double)p0[u]; s1 += (double)p1[u]; rows += pr[u]; }
         }
-        for (; k < kend; k += 16) {
+        for (; k < kend; k += BN_FL) {
             s0 += (double)ws[(int64_t)k * 2 * c + a];
             s1 += (double)ws[(int64_t)k * 2 * c + c + a];
             if (MODE == 0 && chunks) rows += chunks[k * 3 + 2];
@@ -138,8 +140,17 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ w
     }
     r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; rr[threadIdx.x] = rows;
     __syncthreads();
+    // tree over the chunk lanes (64 -> 1), 16 channels side by side
+    for (int half = BN_FL / 2; half >= 1; half >>= 1) {
+        if (lanek < half) {
+            r0[threadIdx.x] += r0[threadIdx.x + half * 16];
+            r1[threadIdx.x] += r1[threadIdx.x + half * 16];
+            rr[threadIdx.x] += rr[threadIdx.x + half * 16];
+        }
+        __syncthreads();
+    }
     if (lanek == 0 && a < c) {
-        for (int j = 1; j < 16; j++) { s0 += r0[j * 16 + threadIdx.x]; s1 += r1[j * 16 + threadIdx.x]; rows += rr[j * 16 + threadIdx.x]; }
+        s0 = r0[threadIdx.x]; s1 = r1[threadIdx.x]; rows = rr[threadIdx.x];
         const int64_t t = (int64_t)g * c + a;
         if (MODE == 0) {
             if (!chunks) rows = rows_arg;
@@ -171,7 +182,7 @@ extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchu
     if (nchunk > 0)
         hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, c,
                            nullptr, nullptr, 0.f, 0, ws);
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(16 * BN_FL), 0, s, ws, chunks,
                        group_chunk_off, G, c, mean, var, running_mean, running_var,
                        reinterpret_cast<long long *>(num_batches_tracked), momentum, 0ll, 0);
     CG3D_CHECK_LAUNCH();
@@ -181,7 +192,7 @@ extern "C" int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int6
                                            float *running_mean, float *running_var, int64_t *num_batches_tracked,
                                            float momentum, cg3d_stream_t stream) {
     if (nchunk < 1 || nchunk > 0x7fffffffll || rows < 0 || c < 1 || !ws) return CG3D_ERR_ARG;
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, cg3d_hs(stream), ws, nullptr, nullptr, 1, c,
+    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)((c + 15) / 16)), dim3(16 * BN_FL), 0, cg3d_hs(stream), ws, nullptr, nullptr, 1, c,
                        mean, var, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), momentum,
                        (long long)rows, (int)nchunk);
     CG3D_CHECK_LAUNCH();
@@ -196,7 +207,7 @@ extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *
     if (nchunk > 0)
         hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
                            act, ws);
-    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(256), 0, s, ws, chunks,
+    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(16 * BN_FL), 0, s, ws, chunks,
                        group_chunk_off, G, c, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0ll, 0);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
