@@ -59,7 +59,7 @@ _SIGNATURES = {
     "cg3d_spconv_prep_weights_bf16_multi": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, P]),
     "cg3d_spconv_prep_weights_bf16_table": (c_int32, [P, c_int64, P]),
     "cg3d_spconv_prep_weights_frag": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, P]),
-    "cg3d_tile_row_order": (c_int32, [P, c_int32, c_int64, P, P]),
+    "cg3d_tile_row_order": (c_int32, [P, c_int32, c_int64, c_int32, P, P]),
     "cg3d_tile_plan_build": (c_int32, [P, c_int32, c_int64, P, c_int64, c_int32, c_int32, P, P, P, P, P, c_int64, P, P, P]),
     "cg3d_spconv_tile_lds_bytes": (c_int64, [c_int32]),
     "cg3d_spconv_tile_fwd": (c_int32, [P, P, P, P, P, P, P, c_int32, c_int32, P, c_int64, P, P, P, c_int64, c_int64, c_int32,

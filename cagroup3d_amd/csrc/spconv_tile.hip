@@ -209,8 +209,8 @@ extern "C" int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out
 __global__ __launch_bounds__(TP_WINDOW) void k_tile_row_order(const int32_t *__restrict__ nbr, int32_t K, int64_t n_out,
                                                               int32_t *__restrict__ order) {
     __shared__ unsigned long long key[TP_WINDOW];
-    const int t = threadIdx.x;
-    const int64_t row = (int64_t)blockIdx.x * TP_WINDOW + t;
+    const int t = threadIdx.x, window = blockDim.x;
+    const int64_t row = (int64_t)blockIdx.x * window + t;
     unsigned long long kv = ~0ull;                       // rows past the end sort behind every real row
     if (row < n_out) {
         uint32_t sig = 0;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(TP_WINDOW) void k_tile_row_order(const int32_t *__r
     }
     key[t] = kv;
     __syncthreads();
-    for (int size = 2; size <= TP_WINDOW; size <<= 1)
+    for (int size = 2; size <= window; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             const int partner = t ^ stride;
             if (partner > t) {
@@ -229,12 +229,13 @@ __global__ __launch_bounds__(TP_WINDOW) void k_tile_row_order(const int32_t *__r
             }
             __syncthreads();
         }
-    if (row < n_out) order[row] = (int32_t)((int64_t)blockIdx.x * TP_WINDOW + (int64_t)(key[t] & 0xffffffffull));
+    if (row < n_out) order[row] = (int32_t)((int64_t)blockIdx.x * window + (int64_t)(key[t] & 0xffffffffull));
 }
-extern "C" int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t *order, cg3d_stream_t stream) {
-    if (K < 1 || K > 32 || n_out < 0) return CG3D_ERR_ARG;
+extern "C" int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t window, int32_t *order,
+                                   cg3d_stream_t stream) {
+    if (K < 1 || K > 32 || n_out < 0 || window < 128 || window > TP_WINDOW || (window & (window - 1))) return CG3D_ERR_ARG;
     if (n_out == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_tile_row_order, dim3((unsigned)cg3d_divup(n_out, TP_WINDOW)), dim3(TP_WINDOW), 0, cg3d_hs(stream), nbr, K,
+    hipLaunchKernelGGL(k_tile_row_order, dim3((unsigned)cg3d_divup(n_out, window)), dim3((unsigned)window), 0, cg3d_hs(stream), nbr, K,
                        n_out, order);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;

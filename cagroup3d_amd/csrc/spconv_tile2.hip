@@ -310,10 +310,16 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
                         R = Rn;
                         knext = knn;
                     };
-                    // (Skipping the dead blocks was tried and is not kept: one loop switching between 15 mask-specialised bodies, or
-                    // branching around each block's MFMAs, made the register allocator spill 700-900 registers at the joins; 15
-                    // plain loops in a row over the offsets grouped by mask kept the hot loops clean but paid ~120 scratch
-                    // operations per stage at the transitions -- 7.6 vs 4.4 ms over the step's layers.  DESIGN.md section 5.)
+                    // Skipping the dead 32-row blocks of an offset (the plan's `live` bits; rows sorted by their live offsets inside
+                    // the tile make 16 % of the blocks of a 3^3 map onto itself dead) was tried three ways and is not kept:
+                    //  * one loop switching between 15 mask-specialised bodies, or C++ branches around each block's MFMAs: the
+                    //    register allocator spills 700-900 registers at the joins;
+                    //  * 15 plain loops in a row over the offsets grouped by mask: clean hot loops, ~120 scratch operations per
+                    //    stage between them -- 7.6 vs 4.4 ms over the step's layers;
+                    //  * the two MFMAs of a block behind s_bitcmp1 / s_cbranch_scc0 INSIDE one asm statement (straight-line code
+                    //    to the compiler, no spills): correct, but a branch per 64 cycles of MFMA and no sched_group_barrier
+                    //    interleave cost as much as the skipped blocks save (128 -> 128: 87 vs 88 us, 256 -> 256: 98 vs 88 us).
+                    // `MASK` stays a template parameter of the body for that reason only.  
                     for (int st = 0; st < nstep; st++) step(std::integral_constant<int, 15>{}, kk_of(st + 2));
                 }
                 T2_STAMP();                             // multiplied

@@ -244,8 +244,14 @@ class KernelMap:
             # sparse maps (the transposed map of a strided convolution, the map of a transposed one: a row has neighbours
             # only at the offsets of its parity class, occupancy 0.10-0.13): tiles cut from rows grouped by their set of
             # live offsets multiply 2-3 x the rows they need instead of 7-8 x (cg3d_tile_row_order)
-            sort_rows = (TILE_SORT_ROWS and row_bounds is None and not self.symmetric and self.K <= 32
-                         and P < TILE_SORT_MAX_OCCUPANCY * self.K * max(nbr.shape[1], 1))
+            sort_rows = 0
+            if TILE_SORT_ROWS and row_bounds is None and self.K <= 32:
+                if not self.symmetric and P < TILE_SORT_MAX_OCCUPANCY * self.K * max(nbr.shape[1], 1):
+                    sort_rows = 1024
+                elif TILE_SORT_IN_TILE:
+                    # every other map: the tiles keep their rows (and the distinct input rows they stage), but inside a tile
+                    # rows with the same live offsets share 32-row blocks, whose dead (offset, block) pairs the kernel skips
+                    sort_rows = 128
             pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds), sort_rows=sort_rows)
             self._segs[ck] = pl
         return pl
@@ -558,6 +564,8 @@ TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS 
 
 TILE_SORT_ROWS = __import__("os").environ.get("CG3D_TILE_SORT_ROWS", "1") != "0"
 TILE_SORT_MAX_OCCUPANCY = 0.2       # pairs / (K * rows) below which a map's tiles are cut from signature-sorted rows
+# (window 128 = inside the tile: only useful to a kernel that skips dead 32-row blocks -- tried, not kept: spconv_tile2.hip)
+TILE_SORT_IN_TILE = __import__("os").environ.get("CG3D_TILE_SORT_IN_TILE", "0") != "0"
 
 
 class TilePlan:
@@ -570,8 +578,8 @@ class TilePlan:
 
 def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None, sort_rows=False):
     """nbr int32 [K, n_out] (k-major) -> TilePlan.  `n_pairs` (host int, >= the number of nbr >= 0) sizes `ulist`;
-    tiles: None or (device int32 [ntile,3], ntile); sort_rows: cut the tiles from the rows permuted by
-    cg3d_tile_row_order (plan.order: position -> output row)."""
+    tiles: None or (device int32 [ntile,3], ntile); sort_rows: 0 / False, or the window (True = 1024, or 128) of
+    cg3d_tile_row_order: the tiles are cut from the permuted rows (plan.order: position -> output row)."""
     lib = _lib.get()
     lib.check(nbr)
     K, n_out = nbr.shape
@@ -592,7 +600,8 @@ def build_tile_plan(nbr, n_pairs, tiles=None, ucap=None, sort_rows=False):
     p.order = None
     if sort_rows and tiles is None and K <= 32 and n_out > 0:
         p.order = torch.empty(n_out, dtype=torch.int32, device=dev)
-        lib.call("cg3d_tile_row_order", ptr(nbr), c_int32(K), c_int64(n_out), ptr(p.order), lib.stream())
+        lib.call("cg3d_tile_row_order", ptr(nbr), c_int32(K), c_int64(n_out), c_int32(1024 if sort_rows is True else int(sort_rows)),
+                 ptr(p.order), lib.stream())
     lib.call("cg3d_tile_plan_build", ptr(nbr), c_int32(K), c_int64(n_out), ptr(p.tiles), c_int64(p.ntile), c_int32(p.ucap),
              c_int32(p.maxpass), ptr(p.slots), ptr(p.live), ptr(p.pass_tab), ptr(p.npass), ptr(p.ulist),
              c_int64(p.ulist.shape[0]), ptr(p.cursor), ptr(p.order), lib.stream())

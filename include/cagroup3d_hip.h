@@ -212,10 +212,12 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
  * `order` (optional, tiles == NULL only): int32 [n_out], a permutation of the output rows; position p of tile t is then
  *   output row order[128 t + p] -- in the plan's slot table and where cg3d_spconv_tile_fwd stores its rows.
  *
- * cg3d_tile_row_order: the permutation that sorts the rows inside every window of CG3D_TILE_WINDOW consecutive rows
- *   by their set of live offsets (bit k = nbr[k][row] >= 0; K <= 32), ties in row order.  For the transposed map of a
- *   strided convolution and the map of a transposed convolution (a row has neighbours only at the offsets of its parity
- *   class) the tiles cut from it multiply 2-3 x the rows they need instead of 7-8 x.
+ * cg3d_tile_row_order: the permutation that sorts the rows inside every window of `window` consecutive rows (a power of
+ *   two, 128 <= window <= CG3D_TILE_WINDOW) by their set of live offsets (bit k = nbr[k][row] >= 0; K <= 32), ties in row
+ *   order.  window 1024, sparse maps: for the transposed map of a strided convolution and the map of a transposed convolution
+ *   (a row has neighbours only at the offsets of its parity class) the tiles cut from it multiply 2-3 x the rows they need
+ *   instead of 7-8 x.  window 128 (= one tile): the tiles keep their rows, but rows with the same live offsets share 32-row
+ *   blocks, whose dead (offset, block) pairs cg3d_spconv_tile_fwd skips (the plan's `live` bits).
  *
  * cg3d_spconv_prep_weights_frag: fp32 [slot][cin][cout] (one tensor W0, or G tensors Ws like
  *   cg3d_spconv_prep_weights_bf16_multi) -> bf16 in MFMA B-fragment order,
@@ -234,7 +236,8 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
  * ---------------------------------------------------------------------------------------- */
 #define CG3D_TILE_ROWS 128
 #define CG3D_TILE_WINDOW 1024
-int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t *order, cg3d_stream_t stream);
+int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t window, int32_t *order,
+                        cg3d_stream_t stream);
 int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *tiles, int64_t ntile,
                          int32_t ucap, int32_t maxpass, uint16_t *slots, uint8_t *live, int32_t *pass_tab,
                          int32_t *npass, int32_t *ulist, int64_t ulist_cap, int32_t *cursor, const int32_t *order,

@@ -55,12 +55,12 @@ static int ot_key_cmp(const void *a, const void *b) {
     if (x->sig != y->sig) return x->sig < y->sig ? -1 : 1;
     return x->row < y->row ? -1 : (x->row > y->row);
 }
-int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t *order, cg3d_stream_t s) {
+int cg3d_tile_row_order(const int32_t *nbr, int32_t K, int64_t n_out, int32_t window, int32_t *order, cg3d_stream_t s) {
     (void)s;
-    if (K < 1 || K > 32 || n_out < 0) return CG3D_ERR_ARG;
+    if (K < 1 || K > 32 || n_out < 0 || window < 128 || window > CG3D_TILE_WINDOW || (window & (window - 1))) return CG3D_ERR_ARG;
     ot_key *keys = (ot_key *)malloc(sizeof(ot_key) * CG3D_TILE_WINDOW);
-    for (int64_t w0 = 0; w0 < n_out; w0 += CG3D_TILE_WINDOW) {
-        const int n = (int)(n_out - w0 < CG3D_TILE_WINDOW ? n_out - w0 : CG3D_TILE_WINDOW);
+    for (int64_t w0 = 0; w0 < n_out; w0 += window) {
+        const int n = (int)(n_out - w0 < window ? n_out - w0 : window);
         for (int i = 0; i < n; i++) {
             uint32_t sig = 0;
             for (int k = 0; k < K; k++) sig |= (nbr[(int64_t)k * n_out + w0 + i] >= 0 ? 1u : 0u) << k;

@@ -117,10 +117,17 @@ def test_oracle_sorted_rows_plan_is_the_same_map_with_fewer_live_offsets(oracle,
         live_sorted, live_plain = int((plan.live.numpy() != 0).sum()), int((plain.live.numpy() != 0).sum())
         if stride == 2 and n >= 2000:
             assert live_sorted < 0.6 * live_plain, (live_sorted, live_plain)
-        # the policy: sparse non-symmetric maps only
-        assert km.tile_plan(True).order is (None if stride == 1 else km.tile_plan(True).order)
-        if stride == 1:
-            assert km.tile_plan(False).order is None, "a map onto itself keeps the arrival order"
+        # the policy: windows of 1024 rows on sparse non-symmetric maps, arrival order everywhere else
+        pol = km.tile_plan(transposed)
+        if stride == 2 and P < 0.2 * nbr.shape[0] * nbr.shape[1]:
+            assert pol.order is not None and np.array_equal(pol.order.numpy(), _row_order_reference(nbr.numpy(), 1024))
+        else:
+            assert pol.order is None
+        assert np.array_equal(decode_plan(pol), nbr.numpy())
+        # window 128: every tile keeps its rows (a permutation inside the tile)
+        p128, dec128 = _plan_roundtrip(nbr, P, 511, sort_rows=128)
+        assert np.array_equal(p128.order.numpy(), _row_order_reference(nbr.numpy(), 128)) and np.array_equal(dec128, nbr.numpy())
+        assert (p128.order.numpy() // 128 == np.arange(p128.n_out) // 128).all()
 
 
 def _tile_conv(coords, x, w, bias, ks, stride, ucap, ksplit, transposed):
