@@ -66,10 +66,11 @@ _SIGNATURES = {
                                        c_int32, c_int32, c_int32, c_int32, P, P]),
     "cg3d_spconv_tile_grid": (c_int32, [c_int64, c_int32, c_int32]),
     "cg3d_adamw_step": (c_int32, [P, P, c_int64, P, P, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
-    "cg3d_bn_stats_from_partials": (c_int32, [P, c_int64, c_int64, c_int32, P, P, P, P, P, c_float, P]),
-    "cg3d_bn_stats": (c_int32, [P, P, c_int64, P, c_int32, c_int32, P, P, P, P, P, P, c_float, P]),
+    "cg3d_bn_sums": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P]),
+    "cg3d_bn_apply_sums": (c_int32, [P, P, P, c_int64, c_int32, c_int32, P, P, c_float, P, P, c_int32, P, P, P, P, P, P, P, c_float, P]),
     "cg3d_bn_apply": (c_int32, [P, P, P, c_int64, c_int32, P, P, c_float, P, P, c_int32, P, P, P]),
-    "cg3d_bn_bwd_reduce": (c_int32, [P, P, P, P, c_int64, P, c_int32, c_int32, P, P, c_float, c_int32, P, P, P, P]),
+    "cg3d_bn_bwd_sums": (c_int32, [P, P, P, P, c_int64, c_int32, c_int32, P, P, c_float, c_int32, P, P]),
+    "cg3d_bn_bwd_apply_sums": (c_int32, [P, P, P, P, c_int64, c_int32, c_int32, P, P, c_float, P, P, P, c_int32, c_int32, P, P, P, P, P, P]),
     "cg3d_bn_bwd_apply": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, c_float, P, P, P, P, c_int32, c_int32, P, P, P, P]),
     "cg3d_boxes_overlap_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
     "cg3d_boxes_iou_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),

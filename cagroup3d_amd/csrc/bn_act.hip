@@ -6,8 +6,13 @@
 // normalise in ONE launch.  HBM-bound: X is read twice in the forward (statistics, apply) and dY/X/Y once
 // each per backward kernel; every access is a 16-byte vector per lane, a row (C*4 bytes) is covered by
 // C/4 consecutive lanes, so each wave reads whole 128-byte lines.
-// Statistics: fp32 partial sums per <=256-row chunk (plain stores, no atomics), then a finalise kernel
-// reduces the chunks of every group in fp64.
+// Statistics (round 3): every workgroup adds its chunk's partial sums into ONE zero-filled fp32 table per layer,
+// sums[CG3D_BN_SLOTS][2][G][C] (sum, sum of squares -- or sum dz, sum dz * xhat in the backward), with fp32 atomics into
+// slot (workgroup index % CG3D_BN_SLOTS); the kernels that need mean / variance / dbeta / dgamma add the slots up and derive
+// them themselves (in fp64, a few channels per thread).  The per-chunk partials + fp64 finalise kernel of rounds 1-2 cost
+// 130 launches of ~10 us per step for a few hundred KB of work.  (One slot was measured first: the ~1 200 workgroups of a
+// layer then queue on the same 2 C addresses at the L2 atomic unit -- 17 -> 70 us per launch.)
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include "cg3d_common.h"
 
 __device__ static inline float act_fwd(float v, int act) {
@@ -28,14 +33,15 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
                                                     const float *__restrict__ Yv, const int32_t *__restrict__ chunks,
                                                     int32_t c, const float *__restrict__ mean,
                                                     const float *__restrict__ var, float eps, int act,
-                                                    float *__restrict__ ws) {
+                                                    float *__restrict__ sums, int G) {
     __shared__ float4 red0[256], red1[256];
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
     const int tpr = cq < 256 ? cq : 256;          // threads per row
     const int rpb = 256 / tpr;                    // rows per block pass
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-    float *w0 = ws + (int64_t)blockIdx.x * 2 * c, *w1 = w0 + c;
+    const int slot = blockIdx.x % CG3D_BN_SLOTS;
+    float *w0 = sums + ((int64_t)(slot * 2) * G + g) * c, *w1 = sums + ((int64_t)(slot * 2 + 1) * G + g) * c;    // rows g of sums[slot][0] / [1]
     for (int q = tq; q < cq; q += tpr) {
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, mu = s0, is = s0;
         if (BWD) {
@@ -88,127 +94,35 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
                 s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
                 s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
             }
-            reinterpret_cast<float4 *>(w0)[q] = s0;
-            reinterpret_cast<float4 *>(w1)[q] = s1;
+            unsafeAtomicAdd(w0 + 4 * q, s0.x); unsafeAtomicAdd(w0 + 4 * q + 1, s0.y);
+            unsafeAtomicAdd(w0 + 4 * q + 2, s0.z); unsafeAtomicAdd(w0 + 4 * q + 3, s0.w);
+            unsafeAtomicAdd(w1 + 4 * q, s1.x); unsafeAtomicAdd(w1 + 4 * q + 1, s1.y);
+            unsafeAtomicAdd(w1 + 4 * q + 2, s1.z); unsafeAtomicAdd(w1 + 4 * q + 3, s1.w);
         }
         __syncthreads();
-    }
-}
-
-// fp64 reduction over the group's chunks: a 1024-thread block owns 16 channels of one group; its 64 chunk-lanes stride
-// the group's chunks (four loads in flight each), then combine through LDS.  (Round 3: 64 lanes instead of 16 -- the tile
-// convolution now leaves one partial per TILE, up to 1 500 of them, and with 16 lanes every thread walked ~100 chunks
-// one L2 round trip after the other: 11 us per launch, 130 launches per step.)
-// MODE 0: out0 = mean, out1 = biased variance (row count from the chunk table)
-// MODE 1: out0 = sum0 (dbeta), out1 = sum1 (dgamma)
-#define BN_FL 64
-template <int MODE>
-__global__ __launch_bounds__(16 * BN_FL) void k_bn_finalize(const float *__restrict__ ws, const int32_t *__restrict__ chunks,
-                                                            const int32_t *__restrict__ gco, int32_t G, int32_t c,
-                                                            float *__restrict__ out0, float *__restrict__ out1,
-                                                            float *__restrict__ run0, float *__restrict__ run1,
-                                                            long long *__restrict__ nbt, float momentum,
-                                                            long long rows_arg, int nchunk_arg) {
-    __shared__ double r0[16 * BN_FL], r1[16 * BN_FL];
-    __shared__ long long rr[16 * BN_FL];
-    const int cblocks = (c + 15) / 16;
-    const int g = blockIdx.x / cblocks, a = (blockIdx.x % cblocks) * 16 + (threadIdx.x & 15), lanek = threadIdx.x >> 4;
-    double s0 = 0.0, s1 = 0.0;
-    long long rows = 0;
-    if (a < c) {
-        // four chunks per trip, every load issued before the first add
-        // (no chunk table: one group, chunks [0, nchunk_arg), rows_arg rows -- partial sums produced by another kernel)
-        int k = (gco ? gco[g] : 0) + lanek;
-        const int kend = gco ? gco[g + 1] : nchunk_arg;
-        for (; k + 3 * BN_FL < kend; k += 4 * BN_FL) {
-            float p0[4], p1[4];
-            int pr[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                p0[u] = ws[(int64_t)(k + BN_FL * u) * 2 * c + a];
-                p1[u] = ws[(int64_t)(k + BN_FL * u) * 2 * c + c + a];
-                pr[u] = (MODE == 0 && chunks) ? chunks[(k + BN_FL * u) * 3 + 2] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { s0 += (double)p0[u]; s1 += (double)p1[u]; rows += pr[u]; }
-        }
-        for (; k < kend; k += BN_FL) {
-            s0 += (double)ws[(int64_t)k * 2 * c + a];
-            s1 += (double)ws[(int64_t)k * 2 * c + c + a];
-            if (MODE == 0 && chunks) rows += chunks[k * 3 + 2];
-        }
-    }
-    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; rr[threadIdx.x] = rows;
-    __syncthreads();
-    // tree over the chunk lanes (64 -> 1), 16 channels side by side
-    for (int half = BN_FL / 2; half >= 1; half >>= 1) {
-        if (lanek < half) {
-            r0[threadIdx.x] += r0[threadIdx.x + half * 16];
-            r1[threadIdx.x] += r1[threadIdx.x + half * 16];
-            rr[threadIdx.x] += rr[threadIdx.x + half * 16];
-        }
-        __syncthreads();
-    }
-    if (lanek == 0 && a < c) {
-        s0 = r0[threadIdx.x]; s1 = r1[threadIdx.x]; rows = rr[threadIdx.x];
-        const int64_t t = (int64_t)g * c + a;
-        if (MODE == 0) {
-            if (!chunks) rows = rows_arg;
-            const double n = rows > 0 ? (double)rows : 1.0;
-            const double m = s0 / n;
-            double v = s1 / n - m * m;
-            out0[t] = (float)m;
-            out1[t] = (float)(v > 0.0 ? v : 0.0);
-            if (run0 && run1) {     // running statistics, as nn.BatchNorm1d updates them (unbiased variance)
-                const float unb = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
-                run0[t] = (1.f - momentum) * run0[t] + momentum * (float)m;
-                run1[t] = (1.f - momentum) * run1[t] + momentum * ((float)(v > 0.0 ? v : 0.0) * unb);
-            }
-            if (nbt && a == 0) nbt[g] += 1;
-        } else {
-            out0[t] = (float)s0;
-            out1[t] = (float)s1;
-        }
     }
 }
 
 static bool bad(const void *p) { return ((uintptr_t)p & 15) != 0; }
 
-extern "C" int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off,
-                             int32_t G, int32_t c, float *ws, float *mean, float *var, float *running_mean,
-                             float *running_var, int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream) {
-    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(ws)) return CG3D_ERR_ARG;
-    hipStream_t s = cg3d_hs(stream);
-    if (nchunk > 0)
-        hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, s, X, nullptr, nullptr, chunks, c,
-                           nullptr, nullptr, 0.f, 0, ws);
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(16 * BN_FL), 0, s, ws, chunks,
-                       group_chunk_off, G, c, mean, var, running_mean, running_var,
-                       reinterpret_cast<long long *>(num_batches_tracked), momentum, 0ll, 0);
+// sums[slot][0][g][:] += sum over the rows of group g of x, sums[slot][1][g][:] += sum of x^2 (the caller zero-fills `sums`)
+extern "C" int cg3d_bn_sums(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, float *sums,
+                            cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || !sums) return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_bn_partial<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, nullptr, nullptr, chunks, c,
+                       nullptr, nullptr, 0.f, 0, sums, G);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
-extern "C" int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
-                                           float *running_mean, float *running_var, int64_t *num_batches_tracked,
-                                           float momentum, cg3d_stream_t stream) {
-    if (nchunk < 1 || nchunk > 0x7fffffffll || rows < 0 || c < 1 || !ws) return CG3D_ERR_ARG;
-    hipLaunchKernelGGL(k_bn_finalize<0>, dim3((unsigned)((c + 15) / 16)), dim3(16 * BN_FL), 0, cg3d_hs(stream), ws, nullptr, nullptr, 1, c,
-                       mean, var, running_mean, running_var, reinterpret_cast<long long *>(num_batches_tracked), momentum,
-                       (long long)rows, (int)nchunk);
-    CG3D_CHECK_LAUNCH();
-    return CG3D_OK;
-}
-extern "C" int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                                  const int32_t *group_chunk_off, int32_t G, int32_t c, const float *mean,
-                                  const float *var, float eps, int32_t act, float *ws, float *dbeta, float *dgamma,
-                                  cg3d_stream_t stream) {
-    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(ws)) return CG3D_ERR_ARG;
-    hipStream_t s = cg3d_hs(stream);
-    if (nchunk > 0)
-        hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, s, dY, X, Y, chunks, c, mean, var, eps,
-                           act, ws);
-    hipLaunchKernelGGL(k_bn_finalize<1>, dim3((unsigned)(G * ((c + 15) / 16))), dim3(16 * BN_FL), 0, s, ws, chunks,
-                       group_chunk_off, G, c, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0ll, 0);
+// dsums[slot][0][g][:] += sum dz (dbeta), dsums[slot][1][g][:] += sum dz * xhat (dgamma); dz = dy * act'(y)
+extern "C" int cg3d_bn_bwd_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G,
+                                int32_t c, const float *mean, const float *var, float eps, int32_t act, float *dsums,
+                                cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || !dsums) return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var, eps,
+                       act, dsums, G);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
@@ -222,21 +136,62 @@ __device__ static inline uint2 bn_pack4bf(float4 v) {
                       __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bn_bf16x2)));
 }
 
+// SUMS: mean / variance are not inputs but derived from the zero-based statistics table sums[2][G][C] of the layer
+// (cg3d_bn_sums, or the producing convolution's epilogue) and the group's row count -- in fp64, per thread, for its own
+// channel quad; the first chunk of every group also writes them to mean / var (the backward pass reads them) and updates
+// the running statistics like nn.BatchNorm1d (momentum, unbiased variance).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, const float *__restrict__ R,
                                                   const int32_t *__restrict__ chunks, int32_t c,
-                                                  const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                                                  float *__restrict__ mean, float *__restrict__ var, float eps,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, int act,
-                                                  float *__restrict__ Y, uint2 *__restrict__ Y16) {
+                                                  float *__restrict__ Y, uint2 *__restrict__ Y16,
+                                                  const float *__restrict__ sums, const float *__restrict__ group_n, int G,
+                                                  float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                  long long *__restrict__ nbt, float momentum) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
+    const bool first_of_group = SUMS && (blockIdx.x == 0 || chunks[(blockIdx.x - 1) * 3] != g);
     // thread = (channel quad tq, row lane tr): the per-channel constants are loaded and inverted ONCE per thread, rows
     // are walked four at a time with all loads issued before the first use (memory-level parallelism)
     const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
     if (tr >= rpb) return;
     for (int q = tq; q < cq; q += tpr) {
-        const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
-        const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
+        float4 mu, vv;
+        if (SUMS) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+            for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+                const float4 u0 = reinterpret_cast<const float4 *>(sums + ((int64_t)(sl * 2) * G + g) * c)[q];
+                const float4 u1 = reinterpret_cast<const float4 *>(sums + ((int64_t)(sl * 2 + 1) * G + g) * c)[q];
+                a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w;
+                a1.x += u1.x; a1.y += u1.y; a1.z += u1.z; a1.w += u1.w;
+            }
+            const double n = group_n[g] > 0.f ? (double)group_n[g] : 1.0;
+            const double m0 = a0.x / n, m1 = a0.y / n, m2 = a0.z / n, m3 = a0.w / n;
+            const double v0 = a1.x / n - m0 * m0, v1 = a1.y / n - m1 * m1, v2 = a1.z / n - m2 * m2, v3 = a1.w / n - m3 * m3;
+            mu = make_float4((float)m0, (float)m1, (float)m2, (float)m3);
+            vv = make_float4((float)(v0 > 0 ? v0 : 0), (float)(v1 > 0 ? v1 : 0), (float)(v2 > 0 ? v2 : 0), (float)(v3 > 0 ? v3 : 0));
+            if (first_of_group && tr == 0) {
+                reinterpret_cast<float4 *>(mean + (int64_t)g * c)[q] = mu;
+                reinterpret_cast<float4 *>(var + (int64_t)g * c)[q] = vv;
+                if (run_mean && run_var) {
+                    const float unb = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
+                    float4 *rm = reinterpret_cast<float4 *>(run_mean + (int64_t)g * c) + q, *rvp = reinterpret_cast<float4 *>(run_var + (int64_t)g * c) + q;
+                    float4 a = *rm, b = *rvp;
+                    a.x = (1.f - momentum) * a.x + momentum * mu.x; a.y = (1.f - momentum) * a.y + momentum * mu.y;
+                    a.z = (1.f - momentum) * a.z + momentum * mu.z; a.w = (1.f - momentum) * a.w + momentum * mu.w;
+                    b.x = (1.f - momentum) * b.x + momentum * (vv.x * unb); b.y = (1.f - momentum) * b.y + momentum * (vv.y * unb);
+                    b.z = (1.f - momentum) * b.z + momentum * (vv.z * unb); b.w = (1.f - momentum) * b.w + momentum * (vv.w * unb);
+                    *rm = a; *rvp = b;
+                }
+                if (nbt && q == 0) nbt[g] += 1;
+            }
+        } else {
+            mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
+            vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
+        }
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         const float4 be = reinterpret_cast<const float4 *>(beta + (int64_t)g * c)[q];
         const float4 is = make_float4(rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps));
@@ -272,22 +227,43 @@ extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_
                              int32_t act, float *Y, uint16_t *Y16, cg3d_stream_t stream) {
     if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual) || ((uintptr_t)Y16 & 7)) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean, var,
-                       eps, gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16));
+    hipLaunchKernelGGL(k_bn_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c,
+                       const_cast<float *>(mean), const_cast<float *>(var), eps, gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16),
+                       nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0.f);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_bn_apply_sums(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t G,
+                                  int32_t c, const float *sums, const float *group_n, float eps, const float *gamma,
+                                  const float *beta, int32_t act, float *Y, uint16_t *Y16, float *mean, float *var,
+                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                                  cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual) || ((uintptr_t)Y16 & 7) || bad(sums) || bad(mean) ||
+        bad(var) || bad(running_mean) || bad(running_var) || !sums || !group_n || !mean || !var)
+        return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_bn_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean, var, eps,
+                       gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16), sums, group_n, G, running_mean, running_var,
+                       reinterpret_cast<long long *>(num_batches_tracked), momentum);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
 
+// SUMS: dbeta / dgamma are not inputs but the slot sums of the backward statistics table dsums[CG3D_BN_SLOTS][2][G][C]
+// (cg3d_bn_bwd_sums); the first chunk of every group writes them to dbeta / dgamma (the parameters' gradients).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, const float *__restrict__ X,
                                                       const float *__restrict__ Yv, const int32_t *__restrict__ chunks,
                                                       int32_t c, const float *__restrict__ mean,
                                                       const float *__restrict__ var, float eps,
-                                                      const float *__restrict__ gamma, const float *__restrict__ dbeta,
-                                                      const float *__restrict__ dgamma, const float *__restrict__ group_n,
+                                                      const float *__restrict__ gamma, float *__restrict__ dbeta,
+                                                      float *__restrict__ dgamma, const float *__restrict__ group_n,
                                                       int act, int use_batch, float *__restrict__ dX,
-                                                      uint2 *__restrict__ dX16, float *__restrict__ dR) {
+                                                      uint2 *__restrict__ dX16, float *__restrict__ dR,
+                                                      const float *__restrict__ dsums, int G) {
     const int cq = c >> 2;
     const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
+    const bool first_of_group = SUMS && (blockIdx.x == 0 || chunks[(blockIdx.x - 1) * 3] != g);
     const float inv_n = use_batch ? 1.f / group_n[g] : 0.f;
     const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
@@ -296,8 +272,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
         const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
-        const float4 sb = reinterpret_cast<const float4 *>(dbeta + (int64_t)g * c)[q];
-        const float4 sg = reinterpret_cast<const float4 *>(dgamma + (int64_t)g * c)[q];
+        float4 sb, sg;
+        if (SUMS) {
+            sb = make_float4(0.f, 0.f, 0.f, 0.f); sg = sb;
+#pragma unroll
+            for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+                const float4 u0 = reinterpret_cast<const float4 *>(dsums + ((int64_t)(sl * 2) * G + g) * c)[q];
+                const float4 u1 = reinterpret_cast<const float4 *>(dsums + ((int64_t)(sl * 2 + 1) * G + g) * c)[q];
+                sb.x += u0.x; sb.y += u0.y; sb.z += u0.z; sb.w += u0.w;
+                sg.x += u1.x; sg.y += u1.y; sg.z += u1.z; sg.w += u1.w;
+            }
+            if (first_of_group && tr == 0) {
+                reinterpret_cast<float4 *>(dbeta + (int64_t)g * c)[q] = sb;
+                reinterpret_cast<float4 *>(dgamma + (int64_t)g * c)[q] = sg;
+            }
+        } else {
+            sb = reinterpret_cast<const float4 *>(dbeta + (int64_t)g * c)[q];
+            sg = reinterpret_cast<const float4 *>(dgamma + (int64_t)g * c)[q];
+        }
         const float4 is = make_float4(rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps));
         for (int r = tr; r < nr; r += 4 * rpb) {
             float4 dv[4], xv[4], yv[4];
@@ -340,8 +332,23 @@ extern "C" int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y
     if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes) || ((uintptr_t)dX16 & 7))
         return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var,
-                       eps, gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, reinterpret_cast<uint2 *>(dX16), dRes);
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var,
+                       eps, gamma, const_cast<float *>(dbeta), const_cast<float *>(dgamma), group_n, act, use_batch_stats, dX,
+                       reinterpret_cast<uint2 *>(dX16), dRes, nullptr, 1);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_bn_bwd_apply_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                                      int32_t G, int32_t c, const float *mean, const float *var, float eps, const float *gamma,
+                                      const float *dsums, const float *group_n, int32_t act, int32_t use_batch_stats,
+                                      float *dX, uint16_t *dX16, float *dRes, float *dbeta, float *dgamma,
+                                      cg3d_stream_t stream) {
+    if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes) || ((uintptr_t)dX16 & 7) ||
+        bad(dsums) || bad(dbeta) || bad(dgamma) || !dsums || !dbeta || !dgamma)
+        return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var, eps,
+                       gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, reinterpret_cast<uint2 *>(dX16), dRes, dsums, G);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

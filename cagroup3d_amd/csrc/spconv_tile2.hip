@@ -424,12 +424,15 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
         }
         if (stats) {
             // per-channel sum / sum of squares of the rows this workgroup stored (BatchNorm statistics of the layer's
-            // output): 4 lanes x KG waves share a column quad -> LDS atomics, then one [2][NC] slice per workgroup
+            // output): 4 lanes x KG waves share a column quad -> LDS atomics, then 2 NC global atomics per workgroup into
+            // slot (workgroup % CG3D_BN_SLOTS) of the layer's zero-based table stats[slots][2][cout] (cg3d_bn_apply_sums
+            // adds the slots up and derives mean / variance)
             float *a0 = sacc + h * 64 + c4, *a1 = sacc + NC + h * 64 + c4;
             unsafeAtomicAdd(a0, t0.x); unsafeAtomicAdd(a0 + 1, t0.y); unsafeAtomicAdd(a0 + 2, t0.z); unsafeAtomicAdd(a0 + 3, t0.w);
             unsafeAtomicAdd(a1, t1.x); unsafeAtomicAdd(a1 + 1, t1.y); unsafeAtomicAdd(a1 + 2, t1.z); unsafeAtomicAdd(a1 + 3, t1.w);
             __syncthreads();
-            if (tid < 2 * NC) stats[(tile * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC] = sacc[tid];
+            if (tid < 2 * NC)
+                unsafeAtomicAdd(&stats[((blockIdx.x % CG3D_BN_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);
         }
     }
 #ifdef CG3D_TILE_TRACE
@@ -449,11 +452,10 @@ extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
     return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES + T2_IDX_BYTES + 2 * 128 * sizeof(float);
 }
 
-// rows of the `stats` output of cg3d_spconv_tile_fwd: one [2][cout] partial per tile (every workgroup of a tile fills its
-// own channel block of it)
+// rows of [2][cout] floats of the `stats` table of cg3d_spconv_tile_fwd (accumulated with atomics; the caller zero-fills it)
 extern "C" int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
     if (ntile < 0 || ntile > 0x7fffffffll || cout < 64 || ksplit < 1) return -1;
-    return (int32_t)ntile;
+    return CG3D_BN_SLOTS;
 }
 
 extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *slots, const uint8_t *live,

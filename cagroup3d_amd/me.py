@@ -549,9 +549,39 @@ BF16_ROWS = __import__("os").environ.get("CG3D_BF16_ROWS", "1") != "0"   # bf16 
 
 # ----------------------------------------------------------------------------- tile plans (cg3d_spconv_tile_fwd)
 FUSED_BN_STATS = __import__("os").environ.get("CG3D_FUSED_BN_STATS", "1") != "0"
-def _tile_grid(lib, ntile, cout):
-    """Rows of the `stats` output of cg3d_spconv_tile_fwd at ksplit 1 (= cg3d_spconv_tile_grid: one partial per tile)."""
-    return int(lib.raw("cg3d_spconv_tile_grid")(c_int64(ntile), c_int32(cout), c_int32(1)))
+class _ZeroArena:
+    """Zero-filled fp32 scratch for the per-layer statistics tables (BatchNorm sums, their backward counterparts): ONE
+    `torch.zeros` per step and thread instead of a fill launch per layer.  `take(n)` hands out 16-byte aligned slices of the
+    current block; a new block is opened when it is used up or at `reset()` (the detector's forward).  Blocks are never
+    written back to zero: a slice is handed out once, and whoever holds it (an autograd context, a parameter gradient that
+    is a view of it) keeps its block alive."""
+    BLOCK = 1 << 21             # floats (8 MB: the step's ~130 tables of BN_SLOTS x 2 x G x C)
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def reset(self):
+        self.buf, self.off = None, 0
+
+    def take(self, n, device):
+        n4 = -(-int(n) // 4) * 4
+        if self.buf is None or self.buf.device != device or self.off + n4 > self.buf.numel():
+            self.buf = torch.zeros(max(self.BLOCK, n4), dtype=torch.float32, device=device)
+            self.off = 0
+        out = self.buf[self.off:self.off + int(n)]
+        self.off += n4
+        return out
+
+
+BN_SLOTS = 16          # CG3D_BN_SLOTS of include/cagroup3d_hip.h: slots of a statistics table
+
+
+def zero_arena():
+    a = getattr(_TLS, "arena", None)
+    if a is None:
+        a = _TLS.arena = _ZeroArena()
+    return a
+
 
 _STATS = {}         # data_ptr of a conv output of THIS forward -> (partials, chunks, rows, channels, output); cleared with _ROWS16
 # Whether a training-mode BatchNorm may follow the convolutions of the current forward (set by the detector's forward from
@@ -617,12 +647,11 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
     stats = None
     if want_stats and WANT_BN_STATS and FUSED_BN_STATS and ksplit == 1 and plan.tiles is None and cout <= 512 and plan.ntile > 0:
         # per-workgroup sum / sum of squares of the output channels, accumulated while the tiles are stored: the BatchNorm
-        # that follows finalises these instead of reading Y again (cg3d_bn_stats_from_partials)
-        grid = _tile_grid(lib, plan.ntile, cout)
-        stats = torch.empty((grid, 2, cout), dtype=torch.float32, device=x16.device)
+        # that follows derives mean / variance from this table instead of reading Y again (cg3d_bn_apply_sums)
+        stats = zero_arena().take(BN_SLOTS * 2 * cout, x16.device)       # the layer's zero-based statistics table [slots][2][cout]
         if len(_STATS) > 64:
             _STATS.clear()
-        _STATS[y.data_ptr()] = (stats, grid, plan.n_out, cout, y)        # holds y: its address cannot be reused while the entry lives
+        _STATS[y.data_ptr()] = (stats, 1, plan.n_out, cout, y)           # holds y: its address cannot be reused while the entry lives
     prof = KernelProfile.enabled and lib.is_device
     if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1490,29 +1519,34 @@ class FusedBNActFunction(torch.autograd.Function):
         gamma, beta = gamma.contiguous().view(G, C), beta.contiguous().view(G, C)
         res = residual.contiguous() if residual is not None else None
         lib.check(x, gamma, beta, res, chunks)
-        if use_batch:
-            ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
-            mean = torch.empty((G, C), dtype=torch.float32, device=x.device)
-            var = torch.empty((G, C), dtype=torch.float32, device=x.device)
-            rm, rv, nbt, mom = running if running is not None else (None, None, None, 0.0)
-            lib.check(rm, rv, nbt)
-            pre = _STATS.pop(x.data_ptr(), None) if G == 1 else None
-            if pre is not None and pre[2] == N and pre[3] == C:
-                # the producing convolution already summed its output per channel (tile kernel epilogue)
-                lib.call("cg3d_bn_stats_from_partials", ptr(pre[0]), c_int64(pre[1]), c_int64(N), c_int32(C), ptr(mean), ptr(var),
-                         ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
-            else:
-                lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G), c_int32(C), ptr(ws),
-                         ptr(mean), ptr(var), ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
-        else:
-            mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
         y = torch.empty_like(x)
         # bf16 mode: the apply kernels also write the bf16 row copy the neighbouring convolution gathers from
         # (forward: y16 -> its input; backward: dx16 -> its output gradient), instead of separate cg3d_to_bf16 passes
         want16 = BF16_ROWS and _use_bf16(C)
         y16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want16 else None
-        lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean), ptr(var),
-                 c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), lib.stream())
+        if use_batch:
+            # (from the zero block: an EMPTY group has no chunk, hence no workgroup that writes its mean / variance)
+            mv = zero_arena().take(2 * G * C, x.device).view(2, G, C)
+            mean, var = mv[0], mv[1]
+            rm, rv, nbt, mom = running if running is not None else (None, None, None, 0.0)
+            lib.check(rm, rv, nbt)
+            pre = _STATS.pop(x.data_ptr(), None) if G == 1 else None
+            if pre is not None and pre[2] == N and pre[3] == C:
+                sums = pre[0]            # the producing convolution already summed its output per channel (tile kernel epilogue)
+            else:
+                sums = zero_arena().take(BN_SLOTS * 2 * G * C, x.device)
+                lib.call("cg3d_bn_sums", ptr(x), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(sums), lib.stream())
+            # mean / variance are derived from the table inside the apply launch (and written out for the backward pass)
+            lib.call("cg3d_bn_apply_sums", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(G), c_int32(C), ptr(sums),
+                     ptr(group_n), c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), ptr(mean), ptr(var),
+                     ptr(rm), ptr(rv), ptr(nbt), c_float(mom), lib.stream())
+            # the backward pass's table (sum dz, sum dz * xhat), reserved now: the block is zero and nobody else gets this slice
+            ctx.dsums = zero_arena().take(BN_SLOTS * 2 * G * C, x.device) if any(ctx.needs_input_grad[:3]) else None
+        else:
+            mean, var = mean_in.contiguous().view(G, C), var_in.contiguous().view(G, C)
+            lib.call("cg3d_bn_apply", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean), ptr(var),
+                     c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), lib.stream())
+            ctx.dsums = None
         ctx.want16 = want16
         if want16:
             _ROWS16[y.data_ptr()] = (y, y16)
@@ -1530,17 +1564,19 @@ class FusedBNActFunction(torch.autograd.Function):
             return (None,) * 11
         lib = _lib.get()
         dy = dy.contiguous()
-        ws = torch.empty(max(nchunk, 1) * 2 * C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty((G, C), dtype=torch.float32, device=x.device)
-        dgamma = torch.empty((G, C), dtype=torch.float32, device=x.device)
-        lib.call("cg3d_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(G),
-                 c_int32(C), ptr(mean), ptr(var), c_float(eps), c_int32(act), ptr(ws), ptr(dbeta), ptr(dgamma), lib.stream())
+        dsums = ctx.dsums if getattr(ctx, "dsums", None) is not None else torch.zeros(BN_SLOTS * 2 * G * C, dtype=torch.float32, device=x.device)
+        ctx.dsums = None                                  # (a second backward through the same node gets a fresh table)
+        lib.call("cg3d_bn_bwd_sums", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(mean),
+                 ptr(var), c_float(eps), c_int32(act), ptr(dsums), lib.stream())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dx16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if ctx.want16 else None
-        lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean),
-                 ptr(var), c_float(eps), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
-                 c_int32(1 if use_batch else 0), ptr(dx), ptr(dx16), ptr(dres), lib.stream())
+        dpar = zero_arena().take(2 * G * C, x.device).view(2, G, C)          # zeros: an empty group's gradients stay 0
+        dbeta, dgamma = dpar[0], dpar[1]
+        # dbeta / dgamma: the slot sums of the table, added up inside the apply launch (and written out as the gradients)
+        lib.call("cg3d_bn_bwd_apply_sums", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(G), c_int32(C), ptr(mean),
+                 ptr(var), c_float(eps), ptr(gamma), ptr(dsums), ptr(group_n), c_int32(act), c_int32(1 if use_batch else 0),
+                 ptr(dx), ptr(dx16), ptr(dres), ptr(dbeta), ptr(dgamma), lib.stream())
         if dx16 is not None:
             _ROWS16[dx.data_ptr()] = (dx, dx16)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None

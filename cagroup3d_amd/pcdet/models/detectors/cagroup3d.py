@@ -180,6 +180,7 @@ class CAGroup3D(Detector3DTemplate):
         assert cur_epoch is not None
         ME._ROWS16.clear()
         ME._STATS.clear()
+        ME.zero_arena().reset()                     # a fresh zero block for this step's statistics tables
         ME.WANT_BN_STATS = bool(self.training)      # evaluation: no BatchNorm takes the conv epilogue's partial sums
         # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
         ME.prepare_weights(self.training)

@@ -250,9 +250,10 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
                          int32_t ucap, const int32_t *tiles, int64_t ntile, const int32_t *order, const float *bias,
                          float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout, int32_t ksplit,
                          int32_t wrev, float *stats, cg3d_stream_t stream);
-/* stats (optional; needs ksplit == 1, tiles == NULL, cout <= 512): float32 [cg3d_spconv_tile_grid(ntile, cout, ksplit)][2][cout],
- * partial sums (one row per tile on the device) of every output channel and of its square over the rows stored -- the
- * chunk partials cg3d_bn_stats would compute in a pass of its own over Y; finalise them with cg3d_bn_stats_from_partials. */
+/* stats (optional; needs ksplit == 1, tiles == NULL, cout <= 512): float32 [CG3D_BN_SLOTS][2][cout], ZERO-FILLED by the
+ * caller: the sum of every output channel and of its square over the rows stored are ADDED to it (fp32 atomics) -- the
+ * statistics table cg3d_bn_sums would fill in a pass of its own over Y; hand it to cg3d_bn_apply_sums.
+ * (cg3d_spconv_tile_grid = its number of [2][cout] rows, CG3D_BN_SLOTS.) */
 int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit);
 
 /* ------------------------------------------------------------------------------------------
@@ -310,40 +311,52 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  * per class branch in cagroup_head.py:117-127).  Rows are split into contiguous groups by the chunk
  * table `chunks` int32 [nchunk,3] = (group, first row, row count); a chunk never straddles two groups.
  *   act: 0 none, 1 ReLU, 2 ELU(alpha=1).
- *   `group_chunk_off` int32 [G+1]: chunks of group g are [group_chunk_off[g], group_chunk_off[g+1]).
- *   `ws` float32 [nchunk*2*C] scratch for per-chunk partial sums (no atomics; the per-group reduction over
- *   chunks runs in fp64 inside the finalise kernel).
- * cg3d_bn_stats:  mean, var (biased) float32 [G,C] of every group.  When `running_mean`/`running_var`
- *                 (float32 [G,C]) are not NULL they are updated in the same launch like nn.BatchNorm1d does:
- *                 r = (1-momentum)*r + momentum*stat, the variance unbiased (n/(n-1)); `num_batches_tracked`
- *                 (int64 [G], may be NULL) is incremented.
- * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL);
+ *   Statistics live in ONE zero-based fp32 table per layer, sums float32 [CG3D_BN_SLOTS][2][G][C]; every producer ADDS
+ *   its partial sums to one of the slots with fp32 atomics (a workgroup picks slot = its index % CG3D_BN_SLOTS: with a
+ *   single slot the ~1 200 workgroups of a layer queue on 2 C addresses), the consumers add the slots up, and the caller
+ *   zero-fills the table (round 3: the per-chunk partials + fp64 finalise kernel of rounds 1-2 were 130 launches of ~10 us
+ *   per step).  Below, sums[0] / sums[1] stand for the slot sums:
+ * cg3d_bn_sums:       sums[0][g] += sum of the rows of group g, sums[1][g] += sum of their squares.  For G == 1 the producing
+ *                     convolution fills the same table in its epilogue (`stats` of cg3d_spconv_tile_fwd).
+ * cg3d_bn_apply_sums: cg3d_bn_apply with mean = sums[0]/n, var (biased) = sums[1]/n - mean^2 (derived in fp64 by every
+ *                     thread for its own channels; n = group_n[g]); also WRITES mean / var float32 [G,C] (the backward pass
+ *                     reads them) and, when `running_mean`/`running_var` (float32 [G,C]) are not NULL, updates them like
+ *                     nn.BatchNorm1d: r = (1-momentum)*r + momentum*stat, the variance unbiased (n/(n-1));
+ *                     `num_batches_tracked` (int64 [G], may be NULL) is incremented.
+ * cg3d_bn_apply:  y = act(gamma[g]*(x - mean[g])*rsqrt(var[g]+eps) + beta[g] + residual)   (residual may be NULL), mean /
+ *                 var given (evaluation: the running statistics);
  *                 Y16 / dX16 (may be NULL): the same rows again as bf16 (RNE) -- the copy the next convolution (forward:
  *                 its input, backward: its output gradient) gathers from at precision 2, written while the fp32 values
  *                 are in registers instead of by a separate cg3d_to_bf16 pass
- * cg3d_bn_bwd_reduce: with dz = dy * act'(y), xhat = (x-mean)*rsqrt(var+eps):
- *                 dbeta = sum(dz), dgamma = sum(dz * xhat)   float32 [G,C]
+ * cg3d_bn_bwd_sums: with dz = dy * act'(y), xhat = (x-mean)*rsqrt(var+eps):
+ *                 dsums[0][g] += sum(dz) (= dbeta), dsums[1][g] += sum(dz * xhat) (= dgamma); the same slot table layout,
+ *                 zero-filled by the caller
  * cg3d_bn_bwd_apply:  dx = gamma*invstd*(dz - (dbeta + xhat*dgamma)/n[g])  (batch statistics;
  *                 use_batch_stats == 0: dx = gamma*invstd*dz), dres (may be NULL) = dz;  group_n float32 [G]
+ * cg3d_bn_bwd_apply_sums: the same with dbeta / dgamma taken from the table `dsums` (slot sums) and WRITTEN to dbeta /
+ *                 dgamma float32 [G,C] (the parameters' gradients)
  * ---------------------------------------------------------------------------------------- */
-int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *group_chunk_off, int32_t G,
-                  int32_t c, float *ws, float *mean, float *var, float *running_mean, float *running_var,
-                  int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream);
-/* cg3d_bn_stats of ONE group from partial sums somebody else produced (cg3d_spconv_tile_fwd's `stats`): ws float32
- * [nchunk][2][C] (sum, sum of squares per chunk), `rows` = number of rows the partials cover. */
-int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
-                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
-                                cg3d_stream_t stream);
+#define CG3D_BN_SLOTS 16
+int cg3d_bn_sums(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, float *sums,
+                 cg3d_stream_t stream);
+int cg3d_bn_apply_sums(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c,
+                       const float *sums, const float *group_n, float eps, const float *gamma, const float *beta,
+                       int32_t act, float *Y, uint16_t *Y16, float *mean, float *var, float *running_mean,
+                       float *running_var, int64_t *num_batches_tracked, float momentum, cg3d_stream_t stream);
 int cg3d_bn_apply(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t c,
                   const float *mean, const float *var, float eps, const float *gamma, const float *beta, int32_t act,
                   float *Y, uint16_t *Y16, cg3d_stream_t stream);
-int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                       const int32_t *group_chunk_off, int32_t G, int32_t c, const float *mean, const float *var,
-                       float eps, int32_t act, float *ws, float *dbeta, float *dgamma, cg3d_stream_t stream);
+int cg3d_bn_bwd_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G,
+                     int32_t c, const float *mean, const float *var, float eps, int32_t act, float *dsums,
+                     cg3d_stream_t stream);
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
                       int32_t c, const float *mean, const float *var, float eps, const float *gamma,
                       const float *dbeta, const float *dgamma, const float *group_n, int32_t act,
                       int32_t use_batch_stats, float *dX, uint16_t *dX16, float *dRes, cg3d_stream_t stream);
+int cg3d_bn_bwd_apply_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
+                           int32_t G, int32_t c, const float *mean, const float *var, float eps, const float *gamma,
+                           const float *dsums, const float *group_n, int32_t act, int32_t use_batch_stats, float *dX,
+                           uint16_t *dX16, float *dRes, float *dbeta, float *dgamma, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * iou3d_nms (boxes are float32 [n,7] = x,y,z,dx,dy,dz,heading, contiguous).

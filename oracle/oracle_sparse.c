@@ -400,51 +400,26 @@ static inline uint16_t os_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-int cg3d_bn_stats(const float *X, const int32_t *chunks, int64_t nchunk, const int32_t *gco, int32_t G, int32_t c,
-                  float *ws, float *mean, float *var, float *running_mean, float *running_var,
-                  int64_t *num_batches_tracked, float momentum, cg3d_stream_t s) {
-    (void)s; (void)ws;
-    double *sums = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
-    os_bn_sums(0, X, NULL, NULL, chunks, nchunk, G, c, NULL, NULL, 0.f, 0, sums);
-    for (int32_t g = 0; g < G; g++) {
-        double n = 0;
-        for (int32_t k = gco[g]; k < gco[g + 1]; k++) n += chunks[k * 3 + 2];
-        if (n < 1) n = 1;
-        for (int32_t a = 0; a < c; a++) {
-            double m = sums[(int64_t)g * c + a] / n, v = sums[(int64_t)(G + g) * c + a] / n - m * m;
-            mean[(int64_t)g * c + a] = (float)m;
-            var[(int64_t)g * c + a] = (float)(v > 0 ? v : 0);
-            if (running_mean && running_var) {   /* nn.BatchNorm1d: unbiased variance into the running buffer */
-                float unb = (float)(n / (n > 1 ? n - 1 : 1));
-                float *rm = running_mean + (int64_t)g * c + a, *rv = running_var + (int64_t)g * c + a;
-                *rm = (1.f - momentum) * *rm + momentum * (float)m;
-                *rv = (1.f - momentum) * *rv + momentum * ((float)(v > 0 ? v : 0) * unb);
-            }
-        }
-        if (num_batches_tracked) num_batches_tracked[g] += 1;
-    }
-    free(sums);
+/* The statistics tables are float32 [CG3D_BN_SLOTS][2][G][C] (include/cagroup3d_hip.h); this restatement adds everything to
+ * slot 0 and the consumers add the slots up.
+ * sums[0][g][:] += sum x, sums[1][g][:] += sum x^2 over the rows of group g (the caller zero-fills `sums`) */
+int cg3d_bn_sums(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, float *sums, cg3d_stream_t s) {
+    (void)s;
+    if (nchunk < 0 || G < 1 || c < 1 || !sums) return CG3D_ERR_ARG;
+    double *d = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
+    os_bn_sums(0, X, NULL, NULL, chunks, nchunk, G, c, NULL, NULL, 0.f, 0, d);
+    for (int64_t i = 0; i < 2 * (int64_t)G * c; i++) sums[i] += (float)d[i];
+    free(d);
     return CG3D_OK;
 }
-int cg3d_bn_stats_from_partials(const float *ws, int64_t nchunk, int64_t rows, int32_t c, float *mean, float *var,
-                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
-                                cg3d_stream_t s) {
+int cg3d_bn_bwd_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c,
+                     const float *mean, const float *var, float eps, int32_t act, float *dsums, cg3d_stream_t s) {
     (void)s;
-    if (nchunk < 1 || rows < 0 || c < 1 || !ws) return CG3D_ERR_ARG;
-    const double n = rows > 0 ? (double)rows : 1.0;
-    for (int32_t a = 0; a < c; a++) {
-        double s0 = 0, s1 = 0;
-        for (int64_t k = 0; k < nchunk; k++) { s0 += ws[k * 2 * c + a]; s1 += ws[k * 2 * c + c + a]; }
-        const double m = s0 / n, v = s1 / n - m * m;
-        mean[a] = (float)m;
-        var[a] = (float)(v > 0 ? v : 0);
-        if (running_mean && running_var) {
-            const float unb = (float)(n / (n > 1 ? n - 1 : 1));
-            running_mean[a] = (1.f - momentum) * running_mean[a] + momentum * (float)m;
-            running_var[a] = (1.f - momentum) * running_var[a] + momentum * ((float)(v > 0 ? v : 0) * unb);
-        }
-    }
-    if (num_batches_tracked) num_batches_tracked[0] += 1;
+    if (nchunk < 0 || G < 1 || c < 1 || !dsums) return CG3D_ERR_ARG;
+    double *d = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
+    os_bn_sums(1, dY, X, Y, chunks, nchunk, G, c, mean, var, eps, act, d);
+    for (int64_t i = 0; i < 2 * (int64_t)G * c; i++) dsums[i] += (float)d[i];
+    free(d);
     return CG3D_OK;
 }
 int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t c, const float *mean,
@@ -465,15 +440,55 @@ int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t
     }
     return CG3D_OK;
 }
-int cg3d_bn_bwd_reduce(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
-                       const int32_t *gco, int32_t G, int32_t c, const float *mean, const float *var, float eps,
-                       int32_t act, float *ws, float *dbeta, float *dgamma, cg3d_stream_t s) {
-    (void)s; (void)ws; (void)gco;
-    double *sums = (double *)malloc(sizeof(double) * 2 * (size_t)G * c);
-    os_bn_sums(1, dY, X, Y, chunks, nchunk, G, c, mean, var, eps, act, sums);
-    for (int64_t i = 0; i < (int64_t)G * c; i++) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[(int64_t)G * c + i]; }
-    free(sums);
-    return CG3D_OK;
+/* cg3d_bn_apply with mean / variance derived from the statistics table (fp64), written to mean / var, running statistics
+ * updated like nn.BatchNorm1d */
+int cg3d_bn_apply_sums(const float *X, const float *R, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c,
+                       const float *sums, const float *group_n, float eps, const float *gamma, const float *beta, int32_t act,
+                       float *Y, uint16_t *Y16, float *mean, float *var, float *running_mean, float *running_var,
+                       int64_t *num_batches_tracked, float momentum, cg3d_stream_t s) {
+    if (nchunk < 0 || G < 1 || c < 1 || !sums || !group_n || !mean || !var) return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    for (int32_t g = 0; g < G; g++) {
+        const double n = group_n[g] > 0.f ? (double)group_n[g] : 1.0;
+        for (int32_t a = 0; a < c; a++) {
+            double s0 = 0, s1 = 0;
+            for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+                s0 += sums[((int64_t)(sl * 2) * G + g) * c + a];
+                s1 += sums[((int64_t)(sl * 2 + 1) * G + g) * c + a];
+            }
+            const double m = s0 / n, v = s1 / n - m * m;
+            mean[(int64_t)g * c + a] = (float)m;
+            var[(int64_t)g * c + a] = (float)(v > 0 ? v : 0);
+            if (running_mean && running_var) {
+                const float unb = (float)(n / (n > 1 ? n - 1 : 1));
+                float *rm = running_mean + (int64_t)g * c + a, *rv = running_var + (int64_t)g * c + a;
+                *rm = (1.f - momentum) * *rm + momentum * (float)m;
+                *rv = (1.f - momentum) * *rv + momentum * ((float)(v > 0 ? v : 0) * unb);
+            }
+        }
+        if (num_batches_tracked) num_batches_tracked[g] += 1;
+    }
+    return cg3d_bn_apply(X, R, chunks, nchunk, c, mean, var, eps, gamma, beta, act, Y, Y16, s);
+}
+int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t c,
+                      const float *mean, const float *var, float eps, const float *gamma, const float *dbeta,
+                      const float *dgamma, const float *group_n, int32_t act, int32_t use_batch, float *dX,
+                      uint16_t *dX16, float *dR, cg3d_stream_t s);
+int cg3d_bn_bwd_apply_sums(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t G,
+                           int32_t c, const float *mean, const float *var, float eps, const float *gamma, const float *dsums,
+                           const float *group_n, int32_t act, int32_t use_batch, float *dX, uint16_t *dX16, float *dR,
+                           float *dbeta, float *dgamma, cg3d_stream_t s) {
+    if (nchunk < 0 || G < 1 || c < 1 || !dsums || !dbeta || !dgamma) return CG3D_ERR_ARG;
+    if (nchunk == 0) return CG3D_OK;
+    for (int64_t i = 0; i < (int64_t)G * c; i++) {
+        double b = 0, gm = 0;
+        for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+            b += dsums[(int64_t)(sl * 2) * G * c + i];
+            gm += dsums[(int64_t)(sl * 2 + 1) * G * c + i];
+        }
+        dbeta[i] = (float)b; dgamma[i] = (float)gm;
+    }
+    return cg3d_bn_bwd_apply(dY, X, Y, chunks, nchunk, c, mean, var, eps, gamma, dbeta, dgamma, group_n, act, use_batch, dX, dX16, dR, s);
 }
 int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk, int32_t c,
                       const float *mean, const float *var, float eps, const float *gamma, const float *dbeta,

@@ -166,14 +166,16 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
         }
         free(xq);
     }
-    if (stats) {        /* one "workgroup": row 0 holds the sums over all rows (the grid of this restatement is 1) */
-        for (int c = 0; c < 2 * cout; c++) stats[c] = 0.f;
+    if (stats) {        /* the zero-based table [2][cout]: += sum and sum of squares over all rows (fp64, then added) */
+        double *acc = (double *)calloc(2 * (size_t)cout, sizeof(double));
         for (int64_t o = 0; o < n_out; o++)
             for (int c = 0; c < cout; c++) {
-                const float v = Y[o * cout + c];
-                stats[c] += v;
-                stats[cout + c] += v * v;
+                const double v = Y[o * cout + c];
+                acc[c] += v;
+                acc[cout + c] += v * v;
             }
+        for (int c = 0; c < 2 * cout; c++) stats[c] += (float)acc[c];
+        free(acc);
     }
     return CG3D_OK;
 }

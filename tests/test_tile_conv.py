@@ -269,7 +269,7 @@ def _conv_then_bn(coords, cin, cout, dev, fused):
 
 
 def test_oracle_bn_statistics_from_the_conv_epilogue(oracle):
-    """cg3d_spconv_tile_fwd(stats=...) + cg3d_bn_stats_from_partials == cg3d_bn_stats over the stored rows."""
+    """cg3d_spconv_tile_fwd(stats=...) fills the same statistics table as cg3d_bn_sums over the stored rows."""
     with _lib.use_library(oracle):
         coords = surface_coords(1500, batch=2, extent=10, seed=5)
         y1, o1, rm1, rv1 = _conv_then_bn(coords, 64, 128, "cpu", True)

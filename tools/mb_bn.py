@@ -41,12 +41,11 @@ def main():
             dres = torch.empty_like(x) if res else None
             dbeta, dgamma = torch.empty(1, C, device="cuda"), torch.empty(1, C, device="cuda")
             S = lib.stream
-            f_stats = lambda: lib.call("cg3d_bn_stats", ptr(x), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(1), c_int32(C), ptr(ws),
-                                       ptr(mean), ptr(var), ptr(None), ptr(None), ptr(None), c_float(0.1), S())
+            f_stats = lambda: lib.call("cg3d_bn_sums", ptr(x), ptr(chunks), c_int64(nchunk), c_int32(1), c_int32(C), ptr(ws), S())
             f_apply = lambda: lib.call("cg3d_bn_apply", ptr(x), ptr(r), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean), ptr(var),
                                        c_float(1e-5), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), S())
-            f_red = lambda: lib.call("cg3d_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), ptr(gco), c_int32(1),
-                                     c_int32(C), ptr(mean), ptr(var), c_float(1e-5), c_int32(act), ptr(ws), ptr(dbeta), ptr(dgamma), S())
+            f_red = lambda: lib.call("cg3d_bn_bwd_sums", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(1), c_int32(C),
+                                     ptr(mean), ptr(var), c_float(1e-5), c_int32(act), ptr(ws), S())
             f_bapp = lambda: lib.call("cg3d_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(mean),
                                       ptr(var), c_float(1e-5), ptr(gamma), ptr(dbeta), ptr(dgamma), ptr(group_n), c_int32(act),
                                       c_int32(1), ptr(dx), ptr(dx16), ptr(dres), S())
