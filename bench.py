@@ -195,10 +195,11 @@ def pmc_traffic(kernel_substr):
 
 
 def cpu_baseline_subprocess(args, threads=None, sample=None, budget=45):
-    """The cpu_baseline leg in a child process (this process runs torch's host ops on one thread): all host cores
-    (the oracle stops scaling beyond 64 threads) or `threads`."""
+    """The cpu_baseline leg in a child process (this process runs torch's host ops on one thread), on `threads` or
+    min(host cores, 16) threads: measured on the 256-thread GPU host the oracle's step takes 2.9 / 2.1 / 2.8 / 5.3 / 14.1 s
+    at 8 / 16 / 32 / 64 / 128 threads (profiles/r03_cpu_thread_scaling.txt, tools/cpu_thread_scaling.py) -- 16 is its best."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads or min(os.cpu_count() or 1, 64)), CG3D_CPU_BUDGET_S=str(budget))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads or min(os.cpu_count() or 1, 16)), CG3D_CPU_BUDGET_S=str(budget))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", sample or args.cpu_sample,

@@ -65,6 +65,11 @@ _SIGNATURES = {
     "cg3d_spconv_tile_fwd": (c_int32, [P, P, P, P, P, P, P, c_int32, c_int32, P, c_int64, P, P, P, c_int64, c_int64, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, P, P]),
     "cg3d_spconv_tile_grid": (c_int32, [c_int64, c_int32, c_int32]),
+    "cg3d_pos_loss_nblocks": (c_int32, [c_int64]),
+    "cg3d_pos_loss_fwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P]),
+    "cg3d_pos_loss_bwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, P]),
+    "cg3d_smooth_l1_rows_fwd": (c_int32, [P, P, P, c_int64, c_int32, c_float, P, P]),
+    "cg3d_smooth_l1_rows_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, P, P]),
     "cg3d_adamw_step": (c_int32, [P, P, c_int64, P, P, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "cg3d_bn_sums": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P]),
     "cg3d_bn_apply_sums": (c_int32, [P, P, P, c_int64, c_int32, c_int32, P, P, c_float, P, P, c_int32, P, P, P, P, P, P, P, c_float, P]),

@@ -29,6 +29,9 @@ SUNRGBD_CLASS_SIZES = [[0.6343, 0.4861, 0.2782], [0.2373, 0.3839, 0.2155], [0.27
                        [0.2298, 0.4195, 0.1418]]
 
 
+FUSED_LOSSES = __import__("os").environ.get("CG3D_FUSED_LOSSES", "1") != "0"
+
+
 def _conv_bn_elu(cin, cout, k):
     return ME.Sequential(ME.MinkowskiConvolution(cin, cout, kernel_size=k, dimension=3),
                          ME.MinkowskiBatchNorm(cout), ME.MinkowskiELU())
@@ -456,23 +459,31 @@ class CAGroup3DHead(nn.Module):
         else:
             w = (off_m / n_vox + 1e-6).unsqueeze(1)         # the reference's precedence quirk (:518): +1e-6 on every weight
             pred_v, tgt_v = voxel_offset.F, off_t
-        d = torch.abs(pred_v - tgt_v)
         beta = self.loss_offset.beta
-        el = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
-        loss_vote = self.loss_offset.loss_weight * (el * w).sum() / B
-        # centerness + box losses over the positives
         pos_inds = torch.nonzero(pos).squeeze(1)
-        ps = pt_scene[pos_inds]
-        pc, pb = m["centerness"][pos_inds], m["bbox_pred"][pos_inds]
-        ct = centerness_targets[pos_inds].unsqueeze(1)
-        bce = torch.nn.functional.binary_cross_entropy_with_logits(pc, ct, reduction="none")
         eps = torch.finfo(torch.float32).eps
-        loss_centerness = self.loss_centerness.loss_weight * (bce.squeeze(1) / ((n_pos[ps] + eps) * B)).sum()
-        boxes = self._bbox_pred_to_bbox(m["points"][pos_inds], pb)
-        # IoU3DLoss returns pred.sum()*weight.sum() (== 0) for a scene whose weights are all zero (iou3d_loss.py:31);
-        # with positives the weights (centerness targets) are > 0, so the plain weighted form is identical
-        iou_el = self.loss_bbox.loss_function(boxes, bbox_targets[pos_inds], None, reduction="none")
-        loss_bbox = self.loss_bbox.loss_weight * (iou_el * ct.squeeze(1) / (ctr_denorm[ps] * B)).sum()
+        if FUSED_LOSSES and not self.with_yaw and m["bbox_pred"].shape[1] == 6:
+            # vote loss, centerness loss and box loss as fused ops (one pass forward, one backward each: ops/fused_losses.py)
+            from ....ops.fused_losses import positives_loss, smooth_l1_rows
+            loss_vote = self.loss_offset.loss_weight * smooth_l1_rows(pred_v, tgt_v, w, beta) / B
+            lp = positives_loss(m["centerness"], m["bbox_pred"], m["points"], centerness_targets, bbox_targets, pt_scene, n_pos,
+                                ctr_denorm, pos_inds, self.loss_centerness.loss_weight / B, self.loss_bbox.loss_weight / B, eps)
+            loss_centerness, loss_bbox = lp[0], lp[1]
+        else:
+            d = torch.abs(pred_v - tgt_v)
+            el = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+            loss_vote = self.loss_offset.loss_weight * (el * w).sum() / B
+            # centerness + box losses over the positives
+            ps = pt_scene[pos_inds]
+            pc, pb = m["centerness"][pos_inds], m["bbox_pred"][pos_inds]
+            ct = centerness_targets[pos_inds].unsqueeze(1)
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(pc, ct, reduction="none")
+            loss_centerness = self.loss_centerness.loss_weight * (bce.squeeze(1) / ((n_pos[ps] + eps) * B)).sum()
+            boxes = self._bbox_pred_to_bbox(m["points"][pos_inds], pb)
+            # IoU3DLoss returns pred.sum()*weight.sum() (== 0) for a scene whose weights are all zero (iou3d_loss.py:31);
+            # with positives the weights (centerness targets) are > 0, so the plain weighted form is identical
+            iou_el = self.loss_bbox.loss_function(boxes, bbox_targets[pos_inds], None, reduction="none")
+            loss_bbox = self.loss_bbox.loss_weight * (iou_el * ct.squeeze(1) / (ctr_denorm[ps] * B)).sum()
         losses = [loss_centerness, loss_bbox, loss_cls, loss_sem, loss_vote]
         loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         names = ("loss_centerness", "loss_bbox", "loss_cls", "loss_sem", "loss_vote")

@@ -438,6 +438,36 @@ int cg3d_focal_loss_fwd(const float *pred, const int32_t *label, const float *ro
 int cg3d_focal_loss_bwd(const float *pred, const int32_t *label, const float *row_w, const float *gscale, int64_t n,
                         int32_t c, float gamma, float alpha, float *dpred, cg3d_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Centerness BCE + axis-aligned IoU loss over the positive points of the class maps, fused.
+ * Replaces: dense_heads/cagroup_head.py:532-546 (loss_centerness :532-536, loss_bbox :537-546) with `_bbox_pred_to_bbox`
+ *   :654-668, iou3d_loss.py:14-95 (axis-aligned form) and axis_aligned_bbox_overlaps_3d, loss_utils.py:419-538 -- ~45
+ *   element-wise launches forward, ~80 backward.  ScanNet form (no yaw: 6 face distances per point).
+ *   centerness float32 [N], bbox_pred float32 [N,6] = (dx-,dx+,dy-,dy+,dz-,dz+), points float32 [N,3],
+ *   ctr_t float32 [N] centerness targets, bbox_t float32 [N,tstride] target boxes (x,y,z,w,l,h,...), scene int64 [N],
+ *   n_pos / ctr_denorm float32 [B] per-scene normalisers, pos int64 [npos] rows of the positives.
+ *   fwd: partial float32 [cg3d_pos_loss_nblocks(npos)][2]: per block
+ *        [0] = sum wc / (n_pos[scene] + eps) * BCE(centerness, ctr_t),
+ *        [1] = sum wb * ctr_t / ctr_denorm[scene] * (1 - IoU(box(points, bbox_pred), bbox_t))      (the caller adds the blocks)
+ *   bwd: dcenterness[r], dbbox_pred[r, 0:6] for r in pos only (the caller zero-fills both); gscale float32 [2] = the two
+ *        upstream scalars (device).
+ * cg3d_smooth_l1_rows: sum_i w[i] * sum_j smooth_l1(pred[i,j] - target[i,j]; beta) (SmoothL1Loss reduction 'sum',
+ *   loss_utils.py:1042-1123: the vote loss cagroup_head.py:512-519); partial float32 [cg3d_focal_loss_nblocks(n,d)].
+ * ---------------------------------------------------------------------------------------- */
+int32_t cg3d_pos_loss_nblocks(int64_t npos);
+int cg3d_pos_loss_fwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                      const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                      const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                      float *partial, cg3d_stream_t stream);
+int cg3d_pos_loss_bwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                      const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                      const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                      const float *gscale, float *dcenterness, float *dbbox_pred, cg3d_stream_t stream);
+int cg3d_smooth_l1_rows_fwd(const float *pred, const float *target, const float *w, int64_t n, int32_t d, float beta,
+                            float *partial, cg3d_stream_t stream);
+int cg3d_smooth_l1_rows_bwd(const float *pred, const float *target, const float *w, const float *gscale, int64_t n,
+                            int32_t d, float beta, float *dpred, cg3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser step of the training loop (reference tools/train_utils/train_utils.py:40-47: clip_grad_norm_ + AdamW.step()):
  * gradient scaling by the clip coefficient and the AdamW update of every parameter in one launch.

@@ -78,3 +78,96 @@ int cg3d_adamw_step(const int64_t *table, const int32_t *pid, int64_t nrows, con
     }
     return CG3D_OK;
 }
+
+/* ---- positives of the class maps (test infrastructure): centerness BCE + axis-aligned IoU loss, restated in the
+ * REFERENCE's parametrisation -- `_bbox_pred_to_bbox` (dense_heads/cagroup_head.py:654-668: centre = p + (d+ - d-)/2,
+ * size = d- + d+), corners = centre -/+ size/2 (iou3d_loss.py:_corners), axis_aligned_bbox_overlaps_3d
+ * (loss_utils.py:419-538: max / min of the corners, clamp(min=0), union clamped at eps 1e-6), loss 1 - IoU weighted by the
+ * centerness target / (sum of centerness targets of the scene * B) (cagroup_head.py:537-546), centerness loss
+ * BCE-with-logits / ((positives of the scene + eps) * B) (:532-536) -- in double precision, derivatives by the chain rule
+ * through (centre, size).  Pinned against the torch mirror of those lines (itself pinned by the reference's fixtures) in
+ * tests/test_fused_losses.py. */
+typedef struct { double bce, dbce, loss_b, dd[6]; } ol_pos;
+static ol_pos ol_pos_terms(float pc, float ct, const float *p, const float *d, const float *t) {
+    ol_pos r;
+    const double x = pc, sg = 1.0 / (1.0 + exp(-x));
+    r.bce = fmax(x, 0.0) - x * ct + log1p(exp(-fabs(x)));
+    r.dbce = sg - ct;
+    double lo[3], hi[3], tlo[3], thi[3], wh[3], s[3], a1 = 1, a2 = 1, ov = 1;
+    for (int a = 0; a < 3; a++) {
+        const double c = (double)p[a] + ((double)d[2 * a + 1] - (double)d[2 * a]) / 2, sz = (double)d[2 * a] + (double)d[2 * a + 1];
+        lo[a] = c - sz / 2; hi[a] = c + sz / 2;
+        tlo[a] = (double)t[a] - (double)t[3 + a] / 2; thi[a] = (double)t[a] + (double)t[3 + a] / 2;
+        s[a] = hi[a] - lo[a];
+        const double w = fmin(hi[a], thi[a]) - fmax(lo[a], tlo[a]);
+        wh[a] = w > 0 ? w : 0;
+        a1 *= s[a]; a2 *= thi[a] - tlo[a]; ov *= wh[a];
+    }
+    const double ub = a1 + a2 - ov, un = ub < 1e-6 ? 1e-6 : ub;
+    r.loss_b = 1.0 - ov / un;
+    for (int a = 0; a < 3; a++) {
+        const double ov_o = wh[(a + 1) % 3] * wh[(a + 2) % 3], a1_o = s[(a + 1) % 3] * s[(a + 2) % 3];
+        const double dov_hi = (wh[a] > 0 && hi[a] < thi[a]) ? ov_o : 0, dov_lo = (wh[a] > 0 && lo[a] > tlo[a]) ? -ov_o : 0;
+        const double dun_hi = ub < 1e-6 ? 0 : a1_o - dov_hi, dun_lo = ub < 1e-6 ? 0 : -a1_o - dov_lo;
+        const double dl_hi = -(dov_hi * un - ov * dun_hi) / (un * un), dl_lo = -(dov_lo * un - ov * dun_lo) / (un * un);
+        /* lo = c - s/2, hi = c + s/2; c = p + (d+ - d-)/2, s = d- + d+ */
+        const double dl_c = dl_lo + dl_hi, dl_s = (dl_hi - dl_lo) / 2;
+        r.dd[2 * a] = -dl_c / 2 + dl_s;
+        r.dd[2 * a + 1] = dl_c / 2 + dl_s;
+    }
+    return r;
+}
+int32_t cg3d_pos_loss_nblocks(int64_t npos) { (void)npos; return 1; }
+int cg3d_pos_loss_fwd(const float *cent, const float *bbox, const float *points, const float *ctr_t, const float *bbox_t,
+                      int32_t tstride, const int64_t *scene, const float *n_pos, const float *ctr_den, const int64_t *pos,
+                      int64_t npos, float wc, float wb, float eps, float *partial, cg3d_stream_t stream) {
+    (void)stream;
+    if (npos < 0 || tstride < 6) return CG3D_ERR_ARG;
+    double s0 = 0, s1 = 0;
+    for (int64_t i = 0; i < npos; i++) {
+        const int64_t r = pos[i], sc = scene[r];
+        const ol_pos T = ol_pos_terms(cent[r], ctr_t[r], points + r * 3, bbox + r * 6, bbox_t + r * tstride);
+        s0 += T.bce * ((double)wc / ((double)n_pos[sc] + eps));
+        s1 += T.loss_b * ((double)wb * ctr_t[r] / ctr_den[sc]);
+    }
+    partial[0] = (float)s0; partial[1] = (float)s1;
+    return CG3D_OK;
+}
+int cg3d_pos_loss_bwd(const float *cent, const float *bbox, const float *points, const float *ctr_t, const float *bbox_t,
+                      int32_t tstride, const int64_t *scene, const float *n_pos, const float *ctr_den, const int64_t *pos,
+                      int64_t npos, float wc, float wb, float eps, const float *gscale, float *dcent, float *dbbox,
+                      cg3d_stream_t stream) {
+    (void)stream;
+    if (npos < 0 || tstride < 6) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < npos; i++) {
+        const int64_t r = pos[i], sc = scene[r];
+        const ol_pos T = ol_pos_terms(cent[r], ctr_t[r], points + r * 3, bbox + r * 6, bbox_t + r * tstride);
+        dcent[r] = (float)(gscale[0] * T.dbce * ((double)wc / ((double)n_pos[sc] + eps)));
+        const double gb = (double)gscale[1] * ((double)wb * ctr_t[r] / ctr_den[sc]);
+        for (int j = 0; j < 6; j++) dbbox[r * 6 + j] = (float)(gb * T.dd[j]);
+    }
+    return CG3D_OK;
+}
+/* ---- smooth-L1 with row weights, reduction 'sum' (SmoothL1Loss, loss_utils.py:1042-1123; the vote loss cagroup_head.py:512-519) */
+int cg3d_smooth_l1_rows_fwd(const float *pred, const float *target, const float *w, int64_t n, int32_t d, float beta,
+                            float *partial, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || d < 1 || !(beta > 0.f)) return CG3D_ERR_ARG;
+    double s = 0;
+    for (int64_t t = 0; t < n * d; t++) {
+        const double e = fabs((double)pred[t] - (double)target[t]);
+        s += (e < beta ? 0.5 * e * e / beta : e - 0.5 * beta) * w[t / d];
+    }
+    partial[0] = (float)s;
+    return CG3D_OK;
+}
+int cg3d_smooth_l1_rows_bwd(const float *pred, const float *target, const float *w, const float *gscale, int64_t n, int32_t d,
+                            float beta, float *dpred, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || d < 1 || !(beta > 0.f)) return CG3D_ERR_ARG;
+    for (int64_t t = 0; t < n * d; t++) {
+        const float df = pred[t] - target[t], e = fabsf(df);
+        dpred[t] = gscale[0] * w[t / d] * (e < beta ? df / beta : (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)));
+    }
+    return CG3D_OK;
+}
