@@ -138,7 +138,7 @@ def test_hip_smooth_l1_rows_matches_oracle(oracle, hip):
     res = []
     for lib, dev in ((oracle, "cpu"), (hip, "cuda")):
         with _lib.use_library(lib):
-            p = pred.to(dev).requires_grad_(True)
+            p = pred.detach().clone().to(dev).requires_grad_(True)       # a fresh leaf on either device
             out = fused_losses.smooth_l1_rows(p, tgt.to(dev), w.to(dev), 0.04)
             (out * 0.5).backward()
             res.append((out.detach().cpu(), p.grad.cpu()))

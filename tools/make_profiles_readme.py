@@ -4,14 +4,14 @@ import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-RN = os.environ.get("ROUND", "r02")
+RN = os.environ.get("ROUND", "r03")
 
 
 def rd(name):
     return open(os.path.join(P, name)).read()
 
 
-out = ["# profiles/ — round 2 (MI355X, 1 GPU, ROCm 7.2)\n\n",
+out = ["# profiles/ — round %s (MI355X, 1 GPU, ROCm 7.2)\n\n" % RN[1:].lstrip("0"),
        "Everything here is produced by `tools/refresh_profiles.sh` in one `gpurun` call (`cd /tmp && export TMPDIR=/tmp` first) and copied "
        "from `gpurun_out/refresh/`:\n\n```\n"
        "rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o bench -- python bench.py --no-cpu-baseline --no-fp32 [--precision fp32]\n"
@@ -21,7 +21,7 @@ out = ["# profiles/ — round 2 (MI355X, 1 GPU, ROCm 7.2)\n\n",
        "bash tools/pmc_sq.sh k_spconv_tile tools/mb_tile_one.py 4 128 128     # SQ counters, 128->128 layer (82 107 rows)\n"
        "bash tools/pmc_sq.sh wgrad_rows16 tools/mb_wgrad_one.py 4 128 128; bash tools/pmc_wgrad.sh 4 128 128   # weight gradient: SQ and L2 / memory-side counters\n"
        "python tools/mb_tile.py; python tools/mb_bn.py; python tools/host_profile.py; python tools/stream_bw.py\n```\n\n" % (RN, RN),
-       "Round-1 files (`r01_*`) are kept for comparison.  `%s_synthetic_convergence.json`, `..._64.json`: `tools/synthetic_convergence.py` (fp32 / bf16 / fp32 repeat from one seed; 40 scenes x 400 iterations evaluated on 8 held-out scenes, and 64 scenes x 480 iterations on 32; indoor_eval mAP / recall and the loss curves).\n\n" % RN,
+       "Earlier rounds' files (`r01_*`, `r02_*`) are kept for comparison; `r02_synthetic_convergence*.json`: `tools/synthetic_convergence.py` (fp32 / bf16 / fp32 repeat from one seed; indoor_eval mAP / recall and the loss curves).\n\n",
        "Device copy rate on the box: " + rd("%s_stream_bw.txt" % RN).strip().splitlines()[-1] + ".\n\n"]
 import bench as _b
 for tag in ("bf16", "fp32"):
@@ -44,7 +44,7 @@ for tag in ("bf16", "fp32"):
                   100 * r["kernel_time_share"], 100 * r.get("conv_bound_over_conv_time", 0), 100 * r.get("conv_bound_over_step_time", 0)))
     if tag == "bf16":
         for kn in ("k_spconv_tile", "k_spconv_implicit_bf16", "k_spconv_pairs_wgrad_rows16"):
-            t = _b.pmc_traffic(kn)
+            t, _src = _b.pmc_traffic(kn)
             if t:
                 out.append("PMC `%s`: %.0f MB memory-side traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes, averaged over the step's launches of that kernel; "
                            "FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)%s.\n\n"
@@ -73,6 +73,11 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_pmc_sq_wgrad_128.txt" % RN, "SQ counters, weight gradient, same layer"), ("%s_pmc_l2_wgrad_128.txt" % RN, "L2 / memory-side counters, weight gradient"),
                    ("%s_tile_vs_dense_map.txt" % RN, "tile kernel vs the dense-map kernel per layer shape"), ("%s_bn_shapes.txt" % RN, "BatchNorm launches per shape"),
                    ("%s_host_issue.txt" % RN, "host issue time vs step time"),
+                   ("%s_tile_trace.txt" % RN, "per-workgroup trace of the tile kernel (dev build): effective clock, co-residency, time per phase, for 256 / 512 / 642 units"),
+                   ("%s_tile_units_scaling.txt" % RN, "tile kernel time against the number of units in flight (one / two workgroups per CU, the tail round)"),
+                   ("%s_tile_v1_knockout.txt" % RN, "round 2's tile kernel with its pieces knocked out (what motivated the rewrite)"),
+                   ("%s_cpu_thread_scaling.txt" % RN, "thread scaling of the cpu_baseline leg (the oracle's S50k step) on the GPU host"),
+                   ("%s_pmc_mem_tile_128.txt" % RN, "memory-side counters of the tile kernel, 128->128 @ 82 107 rows"),
                    ("%s_other_configs.txt" % RN, "bench lines of the other configurations and inference")):
     if os.path.exists(os.path.join(P, name)):
         out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
