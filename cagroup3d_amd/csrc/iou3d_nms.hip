@@ -413,3 +413,89 @@ extern "C" int cg3d_points_in_boxes(const float *points, int64_t n, const float 
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ---------------------------------------------------------------- FCOS-style assignment of the class-map points
+// CAGroup3DAssigner.assign (pcdet/models/dense_heads/target_assigner/cagroup3d_assigner.py:62-130; compute_centerness
+// :39-46), all classes and scenes of the batch at once: a point of class map c competes for the GT boxes of class c of
+// its own scene; it is positive for the smallest-volume such box it lies strictly inside AND among whose top-k most
+// central points it is.  The reference (and the torch mirror) materialise [n, m, 7] face distances and five [n, m]
+// companions through ~70 tensor launches; here
+//   k_fcos_centerness  one thread per (point, box): the face distances in the reference's operation order (as
+//                      k_points_in_boxes), centerness = sqrt(min/max * min/max * min/max) evaluated left to right like the
+//                      tensor expression, -1 where the pair does not compete (outside / other class / other scene);
+//   (the k-th largest centerness of every box column is taken by the caller: one top-k over the [n, m] table)
+//   k_fcos_assign      one thread per point: smallest-volume box among those whose centerness beats the column's k-th
+//                      value (ties -> the lower box index, as one min() over the row does), label, centerness and box targets.
+__device__ static inline float fcos_centerness_of(const float *p, const float *b, bool *inside) {
+    const float cx = b[0], cy = b[1], cz = b[2];
+    const float sx = p[0] - cx, sy = p[1] - cy, sz = p[2] - cz;
+    const float c = dg_cosf(-b[6]), s = dg_sinf(-b[6]);
+    const float rx = sx * c + sy * s, ry = sy * c - sx * s;
+    const float qx = cx + rx, qy = cy + ry, qz = cz + sz;
+    const float hx = b[3] / 2, hy = b[4] / 2, hz = b[5] / 2;
+    const float x0 = qx - cx + hx, x1 = cx + hx - qx, y0 = qy - cy + hy, y1 = cy + hy - qy, z0 = qz - cz + hz, z1 = cz + hz - qz;
+    float m = x0;
+    m = fminf(m, x1); m = fminf(m, y0); m = fminf(m, y1); m = fminf(m, z0); m = fminf(m, z1);
+    *inside = m > 0.f;
+    // x.min / x.max * y.min / y.max * z.min / z.max, left to right
+    float v = fminf(x0, x1) / fmaxf(x0, x1);
+    v = v * fminf(y0, y1);
+    v = v / fmaxf(y0, y1);
+    v = v * fminf(z0, z1);
+    v = v / fmaxf(z0, z1);
+    return sqrtf(v);
+}
+__global__ void k_fcos_centerness(const float *__restrict__ pts, const int64_t *__restrict__ pt_cls,
+                                  const int64_t *__restrict__ pt_scene, int64_t n, const float *__restrict__ gt,
+                                  const int64_t *__restrict__ gt_cls, const int64_t *__restrict__ gt_scene, int32_t m,
+                                  float *__restrict__ cness) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * m) return;
+    const int64_t i = t / m;
+    const int j = (int)(t % m);
+    bool inside;
+    const float v = fcos_centerness_of(pts + i * 3, gt + (int64_t)j * 7, &inside);
+    const bool compete = inside && pt_cls[i] == gt_cls[j] && (!pt_scene || pt_scene[i] == gt_scene[j]);
+    cness[t] = compete ? v : -1.f;
+}
+__global__ void k_fcos_assign(const float *__restrict__ cness, const float *__restrict__ kth, int64_t n,
+                              const float *__restrict__ gt, const int64_t *__restrict__ gt_cls, int32_t m,
+                              float *__restrict__ ctr_t, float *__restrict__ box_t, int64_t *__restrict__ labels) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float best = 1e8f;                       // FLOAT_MAX of the reference
+    int bj = 0;
+    for (int j = 0; j < m; j++) {
+        const float c = cness[i * m + j];
+        if (c > kth[j] && c >= 0.f) {        // competes (>= 0) and is among the top k of the column
+            const float *b = gt + (int64_t)j * 7;
+            const float vol = b[3] * b[4] * b[5];
+            if (vol < best) { best = vol; bj = j; }
+        }
+    }
+    const bool pos = best != 1e8f;
+    labels[i] = pos ? gt_cls[bj] : -1;
+    const float cb = cness[i * m + bj];
+    ctr_t[i] = cb;                           // (rows with label -1: unspecified, never read -- as in assign_all_classes)
+#pragma unroll
+    for (int q = 0; q < 7; q++) box_t[i * 7 + q] = gt[(int64_t)bj * 7 + q];
+}
+extern "C" int cg3d_fcos_centerness(const float *points, const int64_t *pt_cls, const int64_t *pt_scene, int64_t n, const float *gt,
+                                    const int64_t *gt_cls, const int64_t *gt_scene, int32_t m, float *cness,
+                                    cg3d_stream_t stream) {
+    if (n < 0 || m < 0 || (!pt_scene) != (!gt_scene)) return CG3D_ERR_ARG;
+    if (n == 0 || m == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_fcos_centerness, dim3((unsigned)cg3d_divup(n * m, 256)), dim3(256), 0, cg3d_hs(stream), points, pt_cls,
+                       pt_scene, n, gt, gt_cls, gt_scene, m, cness);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_fcos_assign(const float *cness, const float *kth, int64_t n, const float *gt, const int64_t *gt_cls, int32_t m,
+                                float *ctr_t, float *box_t, int64_t *labels, cg3d_stream_t stream) {
+    if (n < 0 || m < 1) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_fcos_assign, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, cg3d_hs(stream), cness, kth, n, gt, gt_cls, m,
+                       ctr_t, box_t, labels);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

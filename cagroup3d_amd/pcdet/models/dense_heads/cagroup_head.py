@@ -431,7 +431,7 @@ class CAGroup3DHead(nn.Module):
             pt_cls, pt_scene = seg // B, seg % B
             per = ME.h2d(m["per_scene"], torch.long, dev)                      # points of map (class c, scene b) at c*B+b
             centerness_targets, bbox_targets, labels = self.assigner.assign_all_classes(
-                [m["points"]], gt, gl, pt_cls=pt_cls, same=pt_scene.view(-1, 1) == gt_scene.view(1, -1),
+                [m["points"]], gt, gl, pt_cls=pt_cls, pt_scene=pt_scene, gt_scene=gt_scene,
                 n_map=per[gl.clamp(max=self.n_classes - 1) * B + gt_scene])
             # ---- per-scene normalisers, one all-reduce (the reference: 3 per scene, cagroup_head.py:523,530,538)
             pos = labels >= 0

@@ -5,6 +5,7 @@ import torch
 from ...model_utils.cagroup_utils import rotation_3d_in_axis
 
 FLOAT_MAX = 1e8
+FUSED_ASSIGN = __import__("os").environ.get("CG3D_FUSED_ASSIGN", "1") != "0"
 
 
 def volume(boxes):
@@ -93,12 +94,42 @@ class CAGroup3DAssigner(object):
             lab_all.append(labels)
         return torch.cat(ctr_all), torch.cat(box_all), torch.cat(lab_all)
 
-    def assign_all_classes(self, points_list, gt_bboxes_ori, gt_labels_ori, pt_cls=None, same=None, n_map=None):
+    def _assign_fused(self, points, pt_cls, pt_scene, gt, gt_labels, gt_scene, k):
+        """`assign_all_classes` through the C-ABI (cg3d_fcos_centerness -> one top-k over the [n, m] table ->
+        cg3d_fcos_assign): three launches instead of ~70."""
+        from ctypes import c_int32, c_int64
+        from ..... import _lib
+        from ....._lib import ptr
+        lib = _lib.get()
+        dev = points.device
+        n, m = points.shape[0], gt.shape[0]
+        pts = points[:, :3].to(torch.float32).contiguous()
+        gtc = gt[:, :7].to(torch.float32).contiguous()
+        pc, gc = pt_cls.to(torch.int64).contiguous(), gt_labels.to(torch.int64).contiguous()
+        ps = pt_scene.to(torch.int64).contiguous() if pt_scene is not None else None
+        gs = gt_scene.to(torch.int64).contiguous() if gt_scene is not None else None
+        lib.check(pts, gtc, pc, gc, ps, gs)
+        cness = torch.empty((n, m), dtype=torch.float32, device=dev)
+        lib.call("cg3d_fcos_centerness", ptr(pts), ptr(pc), ptr(ps), c_int64(n), ptr(gtc), ptr(gc), ptr(gs), c_int32(m), ptr(cness),
+                 lib.stream())
+        top = torch.topk(cness, min(self.topk + 1, n), dim=0).values                      # [K, m], descending
+        kth = top.gather(0, (k - 1).clamp(max=top.shape[0] - 1).unsqueeze(0)).squeeze(0).contiguous()
+        ctr = torch.empty(n, dtype=torch.float32, device=dev)
+        box = torch.empty((n, 7), dtype=torch.float32, device=dev)
+        labels = torch.empty(n, dtype=torch.int64, device=dev)
+        lib.call("cg3d_fcos_assign", ptr(cness), ptr(kth), c_int64(n), ptr(gtc), ptr(gc), c_int32(m), ptr(ctr), ptr(box), ptr(labels),
+                 lib.stream())
+        return ctr, box, labels
+
+    def assign_all_classes(self, points_list, gt_bboxes_ori, gt_labels_ori, pt_cls=None, same=None, n_map=None, pt_scene=None,
+                           gt_scene=None):
         """`assign` for all classes (and, with `same`, all scenes) in one pass: a point of class map c only
         competes for GT boxes of class c (and of its own scene).  Same positives / targets as `assign` for every
         labelled point; rows with label -1 carry unspecified (unused) box / centerness values.
           pt_cls : class of every point (default: list position);  same : bool [n, m] extra pair mask;
-          n_map  : [m] number of points on the map each GT box competes on (default: its class's point count)."""
+          n_map  : [m] number of points on the map each GT box competes on (default: its class's point count);
+          pt_scene / gt_scene : int [n] / [m], the pair mask `same` as two id vectors (same = pt_scene[:, None] == gt_scene[None])
+          -- the form the fused path (`_assign_fused`) takes."""
         points = torch.cat(points_list)
         dev = points.device
         n, m = len(points), len(gt_bboxes_ori)
@@ -118,6 +149,10 @@ class CAGroup3DAssigner(object):
         # sizes: 28 k points x 80 boxes); larger batches walk the boxes in column chunks -- the reference's per-class,
         # per-scene loop bounds its memory the same way (cagroup3d_assigner.py:62-130)
         k = torch.clamp(n_map, max=self.topk + 1).clamp(min=1)
+        if FUSED_ASSIGN and gt.shape[1] >= 7 and n * m <= self.PAIR_CHUNK and n > 0 and (same is None or pt_scene is not None):
+            return self._assign_fused(points, pt_cls, pt_scene, gt, gt_labels, gt_scene, k)
+        if same is None and pt_scene is not None:
+            same = pt_scene.view(-1, 1) == gt_scene.view(1, -1)
         vol_all = volume(gt)
         mc = m if n * m <= self.PAIR_CHUNK else max(1, self.PAIR_CHUNK // max(n, 1))
         min_vol = min_ind = None

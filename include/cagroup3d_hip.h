@@ -424,6 +424,25 @@ int cg3d_points_in_boxes(const float *points, int64_t n, const float *boxes, int
                          const int32_t *box_seg, uint8_t *inside, cg3d_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
+ * FCOS-style target assignment of the class-map points, all classes (and scenes) at once.
+ * Replaces: CAGroup3DAssigner.assign, dense_heads/target_assigner/cagroup3d_assigner.py:62-130 with compute_centerness
+ *   :39-46 (the per-class loop of [n, m, 7] face-distance tensors and their [n, m] companions: ~70 tensor launches).
+ *   points float32 [n,3]; pt_cls / pt_scene int64 [n] (class map / scene of every point; pt_scene and gt_scene both NULL =
+ *   one scene); gt float32 [m,7] boxes, gt_cls / gt_scene int64 [m].
+ * cg3d_fcos_centerness: cness float32 [n,m] = centerness of point i in box j -- sqrt(min/max * min/max * min/max) of the
+ *   face distances in the box frame, the reference's operation order -- where the pair competes (strictly inside, same
+ *   class, same scene), -1 elsewhere.
+ * cg3d_fcos_assign: with kth float32 [m] = the k-th largest value of every column of `cness` (k = min(points on the box's
+ *   map, TOPK + 1); taken by the caller), point i is positive for the smallest-volume box j with cness[i,j] > kth[j]
+ *   (ties -> the lower j): labels int64 [n] (class of the box, -1 = negative), ctr_t float32 [n] and box_t float32 [n,7]
+ *   its centerness / box targets (unspecified for negatives).
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_fcos_centerness(const float *points, const int64_t *pt_cls, const int64_t *pt_scene, int64_t n, const float *gt,
+                         const int64_t *gt_cls, const int64_t *gt_scene, int32_t m, float *cness, cg3d_stream_t stream);
+int cg3d_fcos_assign(const float *cness, const float *kth, int64_t n, const float *gt, const int64_t *gt_cls, int32_t m,
+                     float *ctr_t, float *box_t, int64_t *labels, cg3d_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------
  * Fused sigmoid focal loss with per-row weights.
  * Replaces: py_sigmoid_focal_loss, pcdet/utils/loss_utils.py:903-961 (the element-wise torch chain FocalLoss :964-1040
  *   runs for cagroup_head.py:520-531), including the -1 -> background rewrite of FocalLoss.forward :1024.

@@ -437,3 +437,63 @@ int cg3d_points_in_boxes(const float *pts, int64_t n, const float *boxes, int32_
         }
     return CG3D_OK;
 }
+
+/* FCOS-style assignment of the class-map points (cagroup3d_assigner.py:62-130, compute_centerness :39-46), restated per
+ * (point, box) pair in the operation order of the reference's tensor expressions (face distances as find_points_in_boxes
+ * above; centerness = sqrt(x.min / x.max * y.min / y.max * z.min / z.max) evaluated left to right), compiled with
+ * -ffp-contract=off like the rest of this file.  Pinned through CAGroup3DAssigner.assign_all_classes against the fixture the
+ * reference's own assigner produced (tests/test_golden.py::test_assigner_matches_reference). */
+static float og_fcos_centerness(const float *p, const float *b, int *inside) {
+    float cx = b[0], cy = b[1], cz = b[2];
+    float sx = p[0] - cx, sy = p[1] - cy, sz = p[2] - cz;
+    float c = og_cosf(-b[6]), s = og_sinf(-b[6]);
+    float rx = sx * c + sy * s, ry = sy * c - sx * s;
+    float qx = cx + rx, qy = cy + ry, qz = cz + sz;
+    float hx = b[3] / 2, hy = b[4] / 2, hz = b[5] / 2;
+    float x0 = qx - cx + hx, x1 = cx + hx - qx, y0 = qy - cy + hy, y1 = cy + hy - qy, z0 = qz - cz + hz, z1 = cz + hz - qz;
+    float m = x0;
+    m = fminf(m, x1); m = fminf(m, y0); m = fminf(m, y1); m = fminf(m, z0); m = fminf(m, z1);
+    *inside = m > 0.f;
+    float v = fminf(x0, x1) / fmaxf(x0, x1);
+    v = v * fminf(y0, y1);
+    v = v / fmaxf(y0, y1);
+    v = v * fminf(z0, z1);
+    v = v / fmaxf(z0, z1);
+    return sqrtf(v);
+}
+int cg3d_fcos_centerness(const float *points, const int64_t *pt_cls, const int64_t *pt_scene, int64_t n, const float *gt,
+                         const int64_t *gt_cls, const int64_t *gt_scene, int32_t m, float *cness, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || m < 0 || (!pt_scene) != (!gt_scene)) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int32_t j = 0; j < m; j++) {
+            int inside;
+            const float v = og_fcos_centerness(points + i * 3, gt + (int64_t)j * 7, &inside);
+            const int compete = inside && pt_cls[i] == gt_cls[j] && (!pt_scene || pt_scene[i] == gt_scene[j]);
+            cness[i * m + j] = compete ? v : -1.f;
+        }
+    return CG3D_OK;
+}
+int cg3d_fcos_assign(const float *cness, const float *kth, int64_t n, const float *gt, const int64_t *gt_cls, int32_t m,
+                     float *ctr_t, float *box_t, int64_t *labels, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || m < 1) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float best = 1e8f;
+        int bj = 0;
+        for (int32_t j = 0; j < m; j++) {
+            const float c = cness[i * m + j];
+            if (c > kth[j] && c >= 0.f) {
+                const float *b = gt + (int64_t)j * 7;
+                const float vol = b[3] * b[4] * b[5];
+                if (vol < best) { best = vol; bj = j; }
+            }
+        }
+        labels[i] = best != 1e8f ? gt_cls[bj] : -1;
+        ctr_t[i] = cness[i * m + bj];
+        for (int q = 0; q < 7; q++) box_t[i * 7 + q] = gt[(int64_t)bj * 7 + q];
+    }
+    return CG3D_OK;
+}

@@ -144,3 +144,62 @@ def test_hip_smooth_l1_rows_matches_oracle(oracle, hip):
             res.append((out.detach().cpu(), p.grad.cpu()))
     torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(res[1][1], res[0][1], rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------- fused FCOS assignment
+def _assign_case(n=6000, m=40, n_cls=6, B=3, seed=0, yaw=True):
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.cat([(torch.rand(m, 3, generator=g) - 0.5) * 6, torch.rand(m, 3, generator=g) * 2.0 + 0.3,
+                    ((torch.rand(m, 1, generator=g) - 0.5) * 6.0) if yaw else torch.zeros(m, 1)], 1)
+    gl = torch.randint(0, n_cls, (m,), generator=g)
+    gs = torch.randint(0, B, (m,), generator=g)
+    # points: half of them inside some box of their class / scene, the rest anywhere
+    pick = torch.randint(0, m, (n,), generator=g)
+    pts = gt[pick, :3] + (torch.rand(n, 3, generator=g) - 0.5) * gt[pick, 3:6] * 1.3
+    pts[n // 2:] = (torch.rand(n - n // 2, 3, generator=g) - 0.5) * 8
+    pc, ps = gl[pick].clone(), gs[pick].clone()
+    pc[n // 2:] = torch.randint(0, n_cls, (n - n // 2,), generator=g)
+    ps[n // 2:] = torch.randint(0, B, (n - n // 2,), generator=g)
+    n_map = torch.full((m,), n // (n_cls * B), dtype=torch.long)
+    n_map[::7] = 5                                         # a few boxes compete on tiny maps: k = 5 < TOPK + 1
+    return pts, pc, ps, gt, gl, gs, n_map
+
+
+def _assign(dev, fused, pts, pc, ps, gt, gl, gs, n_map):
+    from cagroup3d_amd.pcdet.models.dense_heads.target_assigner import cagroup3d_assigner as A
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    a = A.CAGroup3DAssigner(Cfg(LIMIT=27, TOPK=18, N_SCALES=4))
+    old, A.FUSED_ASSIGN = A.FUSED_ASSIGN, fused
+    try:
+        out = a.assign_all_classes([pts.to(dev)], gt.to(dev), gl.to(dev), pt_cls=pc.to(dev), pt_scene=ps.to(dev), gt_scene=gs.to(dev),
+                                   n_map=n_map.to(dev))
+    finally:
+        A.FUSED_ASSIGN = old
+    return [o.cpu() for o in out]
+
+
+@pytest.mark.parametrize("yaw,seed", [(False, 0), (True, 1), (True, 2)])
+def test_oracle_fused_assignment_equals_the_torch_chain(oracle, yaw, seed):
+    c = _assign_case(seed=seed, yaw=yaw)
+    with _lib.use_library(oracle):
+        ctr1, box1, lab1 = _assign("cpu", True, *c)
+        ctr0, box0, lab0 = _assign("cpu", False, *c)
+    assert torch.equal(lab1, lab0) and int((lab0 >= 0).sum()) > 200
+    pos = lab0 >= 0
+    torch.testing.assert_close(ctr1[pos], ctr0[pos], rtol=1e-5, atol=1e-6)
+    assert torch.equal(box1[pos], box0[pos])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("yaw,seed,n,m", [(False, 0, 28000, 80), (True, 1, 6000, 40), (True, 2, 700, 3)])
+def test_hip_fused_assignment_is_bit_identical_to_the_oracle(oracle, hip, yaw, seed, n, m):
+    c = _assign_case(n=n, m=m, seed=seed, yaw=yaw)
+    with _lib.use_library(oracle):
+        ref = _assign("cpu", True, *c)
+    with _lib.use_library(hip):
+        out = _assign("cuda", True, *c)
+    assert torch.equal(out[2], ref[2])
+    pos = ref[2] >= 0
+    assert torch.equal(out[0][pos], ref[0][pos]) and torch.equal(out[1][pos], ref[1][pos])
