@@ -16,6 +16,7 @@ SOURCES = {
     "spconv.hip": ["-munsafe-fp-atomics"],
     "spconv_tile.hip": ["-munsafe-fp-atomics"],
     "spconv_tile2.hip": ["-munsafe-fp-atomics"],
+    "linear.hip": ["-munsafe-fp-atomics"],
     "gather_scatter.hip": ["-munsafe-fp-atomics"],
     "iou3d_nms.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],

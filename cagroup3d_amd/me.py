@@ -977,11 +977,9 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
     else:
         K, cin, cout = w3.shape
     lib.check(x, w3, pin, pout, seg, bias, w_bf16_t)
-    # Y initialised here (torch fill / broadcast copy) so that the C call launches exactly one kernel
-    if bias is None:
-        y = torch.zeros((n_out, cout), dtype=torch.float32, device=x.device)
-    else:
-        y = bias.view(1, -1).expand(n_out, cout).contiguous()
+    # Y is initialised inside the C call (accumulate = 0: a memset, or a bias broadcast kernel, on the same stream): one
+    # host-side op fewer per launch than a torch fill -- 34 of them per step
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     prec = 1 if _use_bf16(cin) else 0
     wptr = w3
     if prec == 1:
@@ -995,8 +993,8 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rows16 = x.dtype == torch.int16
-    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(wptr), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(None), ptr(y),
-             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else prec), c_int32(1), lib.stream())
+    lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(wptr), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(bias), ptr(y),
+             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else prec), c_int32(0), lib.stream())
     if prof:
         ev1.record()
         # algorithmic work of one launch: 2*P*cin*cout flops; bytes = every gathered input row and every
@@ -1035,6 +1033,7 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
 
 
 TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
+LINEAR_KERNEL = __import__("os").environ.get("CG3D_LINEAR_KERNEL", "1") != "0"
 TILE_KERNEL = __import__("os").environ.get("CG3D_TILE_KERNEL", "1") != "0"
 GROUP_TILE_KERNEL = __import__("os").environ.get("CG3D_GROUP_TILE_KERNEL", "1") != "0"
 
@@ -1291,6 +1290,7 @@ class LinearFunction(torch.autograd.Function):
     the library runs on a handful of workgroups -- it goes through the split-over-rows wgrad kernel instead
     (cg3d_spconv_pairs_wgrad on the identity pair list)."""
     MIN_ROWS = 8192
+    OWN_MIN_ROWS = 1024
 
     @staticmethod
     def _skinny(n, a, b):
@@ -1305,19 +1305,57 @@ class LinearFunction(torch.autograd.Function):
         return _conv_pairs(x.contiguous(), w.contiguous().view(1, cin, cout), ar, ar, seg, nseg, bias, n, n)
 
     @staticmethod
+    def _own(n, cin, cout):
+        """The hand-written streaming kernel (cg3d_linear_fwd, csrc/linear.hip): bench precision, bf16 row copies, channel
+        counts in multiples of 64 on both sides (the data gradient is the same kernel with the roles swapped)."""
+        return (LINEAR_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
+                and cin % 64 == 0 and cout % 64 == 0 and cin >= 64 and cout >= 64)
+
+    @staticmethod
+    def _own_gemm(x16, wf, bias, n, cin, cout, want_stats=False):
+        lib = _lib.get()
+        y = torch.empty((n, cout), dtype=torch.float32, device=x16.device)
+        stats = None
+        if want_stats and WANT_BN_STATS and FUSED_BN_STATS and cout <= 1024:
+            stats = zero_arena().take(BN_SLOTS * 2 * cout, x16.device)
+            if len(_STATS) > 64:
+                _STATS.clear()
+            _STATS[y.data_ptr()] = (stats, 1, n, cout, y)
+        lib.check(x16, wf, bias)
+        lib.call("cg3d_linear_fwd", ptr(x16), ptr(wf), ptr(bias), ptr(y), c_int64(n), c_int32(cin), c_int32(cout), c_int32(1),
+                 ptr(stats), lib.stream())
+        return y
+
+    @staticmethod
     def forward(ctx, x, w, bias):
-        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        n, (cin, cout) = x.shape[0], w.shape
+        ctx.own = LinearFunction._own(n, cin, cout)
+        if ctx.own:
+            x = x.contiguous()
+            x16 = _to_bf16(x, keep=True)
+            wt, wp = _prep_frag(w.contiguous().view(1, cin, cout), True, ctx.needs_input_grad[0])
+            ctx.save_for_backward(x, w, x16, wp)
+            return LinearFunction._own_gemm(x16, wt, bias.contiguous() if bias is not None else None, n, cin, cout, want_stats=True)
+        ctx.save_for_backward(x, w, None, None)
         if LinearFunction._skinny(x.shape[0], w.shape[0], w.shape[1]):
             return LinearFunction._rows_gemm(x, w, bias.contiguous() if bias is not None else None)
         return torch.addmm(bias, x, w) if bias is not None else x @ w
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, x16, wp = ctx.saved_tensors
         dx = dw = db = None
+        dy16 = None
+        if ctx.own:
+            dy = dy.contiguous()
+            dy16 = _to_bf16(dy)
         if ctx.needs_input_grad[0]:
-            if LinearFunction._skinny(x.shape[0], w.shape[0], w.shape[1]):
+            if ctx.own:
+                if wp is None:
+                    _, wp = _prep_frag(w.contiguous().view(1, w.shape[0], w.shape[1]), False, True)
+                dx = LinearFunction._own_gemm(dy16, wp, None, x.shape[0], w.shape[1], w.shape[0])
+            elif LinearFunction._skinny(x.shape[0], w.shape[0], w.shape[1]):
                 dx = LinearFunction._rows_gemm(dy, w.t(), None)
             else:
                 dx = dy @ w.t()
@@ -1329,7 +1367,9 @@ class LinearFunction(torch.autograd.Function):
             else:
                 xc, dyc = x.contiguous(), dy.contiguous()
                 wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
-                ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, wprec, 1), x.device)
+                if wprec and x16 is not None and dy16 is not None and cout % 8 == 0:
+                    xc, dyc, wprec = x16, dy16, 2           # both operands as bf16 rows: half the gather traffic
+                ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1), x.device)
                 dw = torch.empty_like(w)
                 lib.check(xc, dyc, ar, seg, dw)
                 lib.call("cg3d_spconv_pairs_wgrad", ptr(xc), ptr(dyc), ptr(ar), ptr(ar), ptr(seg), c_int64(nseg), ptr(dw),

@@ -257,6 +257,22 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
 int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit);
 
 /* ------------------------------------------------------------------------------------------
+ * Y = X @ W (+ bias) on bf16 rows, fp32 accumulation: the kernel-size-1 convolutions (ME: a plain matrix product per
+ * sparse tensor; call sites backbones_3d/biresnet.py:270-280,308-315, dense_heads/cagroup_head.py:163-188) forward and
+ * data gradient, and with ksplit the per-RoI 7^3 -> centre contraction (roi_heads/cagroup_roi_head.py:74-91).
+ *   X uint16 [n, cin] bf16 rows (cg3d_to_bf16 / the BatchNorm kernels' Y16); Wf = ONE slot of
+ *   cg3d_spconv_prep_weights_frag: the transposed copy Wf_t of W [cin, cout] for Y = X @ W, the plain copy Wf for the data
+ *   gradient dX = dY @ W^T (then cin / cout below are the gradient's: contraction = W's cout, outputs = W's cin);
+ *   cin % 64 == 0, cout % 64 == 0; bias float32 [cout] or NULL; Y float32 [n, cout].
+ *   ksplit > 1: the contraction is cut into that many ranges of 64-channel chunks whose partial products meet in Y through
+ *   fp32 atomics (the callee zero-fills Y); ksplit <= cin / 64.
+ *   stats (optional, ksplit == 1): the layer's BatchNorm statistics table, float32 [CG3D_BN_SLOTS][2][cout], zero-filled by
+ *   the caller, filled like `stats` of cg3d_spconv_tile_fwd.
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin, int32_t cout,
+                    int32_t ksplit, float *stats, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates
  * (SparseTensor.features_at_coordinates; reference call sites biresnet.py:182-197,376,389,394).
  *   q float32 [nq,4] (batch, x, y, z) in input-grid units.

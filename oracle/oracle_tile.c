@@ -183,3 +183,43 @@ int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
     if (ntile < 0 || cout < 64 || ksplit < 1) return -1;
     return 1;
 }
+
+/* Y = X @ W (+ bias) on bf16 rows, fp32 accumulate: the 1x1x1 convolutions (reference call sites biresnet.py:270-280,
+ * 308-315, cagroup_head.py:163-188; ME's kernel-size-1 convolution is a plain matrix product).  Wf = the weights in MFMA
+ * fragment order (cg3d_spconv_prep_weights_frag, one slot): element (output n, contraction k) at ot_frag_index(n, k, cin).
+ * stats: += sum / sum of squares per output channel into slot 0 of the statistics table. */
+int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin, int32_t cout,
+                    int32_t ksplit, float *stats, cg3d_stream_t s) {
+    (void)s;
+    if (n < 0 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || ksplit < 1 || ksplit > 256 || ksplit > (cin >> 6)) return CG3D_ERR_ARG;
+    if (stats && ksplit != 1) return CG3D_ERR_ARG;
+    float *w = (float *)malloc(sizeof(float) * (size_t)cin * cout);          /* [cout][cin] */
+    for (int c = 0; c < cout; c++)
+        for (int a = 0; a < cin; a++) w[(size_t)c * cin + a] = ot_bf16_bits(Wf[ot_frag_index(c, a, cin)]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float xq[1024];
+        for (int a = 0; a < cin && a < 1024; a++) xq[a] = ot_bf16_bits(X[i * cin + a]);
+        for (int c = 0; c < cout; c++) {
+            float acc = 0.f;
+            const float *wc = w + (size_t)c * cin;
+            if (cin <= 1024)
+                for (int a = 0; a < cin; a++) acc += xq[a] * wc[a];
+            else
+                for (int a = 0; a < cin; a++) acc += ot_bf16_bits(X[i * cin + a]) * wc[a];
+            Y[i * cout + c] = acc + (bias ? bias[c] : 0.f);
+        }
+    }
+    free(w);
+    if (stats) {
+        double *acc = (double *)calloc(2 * (size_t)cout, sizeof(double));
+        for (int64_t o = 0; o < n; o++)
+            for (int c = 0; c < cout; c++) {
+                const double v = Y[o * cout + c];
+                acc[c] += v; acc[cout + c] += v * v;
+            }
+        for (int c = 0; c < 2 * cout; c++) stats[c] += (float)acc[c];
+        free(acc);
+    }
+    return CG3D_OK;
+}

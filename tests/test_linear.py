@@ -1,0 +1,111 @@
+"""cg3d_linear_fwd: the streaming bf16 MFMA product behind the kernel-size-1 convolutions (csrc/linear.hip).
+
+CPU (-m "not gpu"): the oracle's restatement against a torch product of the bf16-rounded operands (pins the fragment order
+of the weights as the kernel reads them).  -m gpu: the HIP kernel against the oracle -- ragged row counts, both channel
+widths of a workgroup, the split contraction, the BatchNorm statistics epilogue -- and LinearFunction end to end."""
+import ctypes
+
+import pytest
+import torch
+
+from cagroup3d_amd import _lib, me
+from cagroup3d_amd._lib import ptr
+
+RTOL, ATOL = 1e-4, 1e-5          # same operands, fp32 accumulation: only the summation order differs
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _run(lib, x, w, bias, ksplit=1, stats=False, transposed_product=False):
+    """Y = X @ W through cg3d_linear_fwd on `lib` (transposed_product: dX = X @ W^T on the plain fragment copy)."""
+    dev = x.device
+    n, cin = x.shape
+    K, wi, wo = 1, w.shape[0], w.shape[1]
+    with _lib.use_library(lib):
+        x16 = me._to_bf16(x.contiguous())
+        wt = torch.empty((K, wo, wi), dtype=torch.int16, device=dev)
+        wp = torch.empty((K, wi, wo), dtype=torch.int16, device=dev)
+        w3 = w.contiguous().view(1, wi, wo)
+        lib.call("cg3d_spconv_prep_weights_frag", ptr(w3), ptr(None), ptr(wt), ptr(wp), ctypes.c_int32(1), ctypes.c_int64(K),
+                 ctypes.c_int32(wi), ctypes.c_int32(wo), lib.stream())
+        cout = wi if transposed_product else wo
+        y = torch.full((n, cout), float("nan"), dtype=torch.float32, device=dev)
+        st = torch.zeros((me.BN_SLOTS, 2, cout), dtype=torch.float32, device=dev) if stats else None
+        lib.call("cg3d_linear_fwd", ptr(x16), ptr(wp if transposed_product else wt), ptr(bias), ptr(y), ctypes.c_int64(n),
+                 ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(ksplit), ptr(st), lib.stream())
+    return y, st
+
+
+def _case(n, cin, cout, seed, dev="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cin, cout, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    return x.to(dev), w.to(dev), b.to(dev)
+
+
+@pytest.mark.parametrize("n,cin,cout", [(1, 64, 64), (130, 64, 128), (257, 192, 64), (300, 128, 256)])
+def test_oracle_linear_is_the_product_of_the_bf16_rounded_operands(oracle, n, cin, cout):
+    x, w, b = _case(n, cin, cout, 0)
+    y, st = _run(oracle, x, w, b, stats=True)
+    ref = _bf16(x).double() @ _bf16(w).double() + b.double()
+    torch.testing.assert_close(y.double(), ref, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(st.sum(0)[0].double(), ref.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st.sum(0)[1].double(), (ref * ref).sum(0), rtol=1e-4, atol=1e-3)
+    # the data-gradient form: the plain fragment copy, roles of the channel counts swapped
+    dy = torch.randn(n, cout, generator=torch.Generator().manual_seed(1))
+    dx, _ = _run(oracle, dy, w, None, transposed_product=True)
+    torch.testing.assert_close(dx.double(), _bf16(dy).double() @ _bf16(w).double().t(), rtol=RTOL, atol=ATOL)
+
+
+def test_oracle_linear_rejects_what_the_kernel_rejects(oracle):
+    x, w, b = _case(16, 64, 64, 0)
+    for bad in ((48, 64, 1), (64, 96, 1), (64, 64, 2)):
+        with pytest.raises(_lib.CG3DError):
+            oracle.call("cg3d_linear_fwd", ptr(torch.zeros(16, bad[0], dtype=torch.int16)), ptr(torch.zeros(64 * 64, dtype=torch.int16)),
+                        ptr(None), ptr(torch.zeros(16, bad[1])), ctypes.c_int64(16), ctypes.c_int32(bad[0]), ctypes.c_int32(bad[1]),
+                        ctypes.c_int32(bad[2]), ptr(None), oracle.stream())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,ksplit", [(1, 64, 64, 1), (127, 64, 128, 1), (1000, 128, 64, 1), (4099, 256, 256, 1),
+                                               (20000, 64, 64, 1), (20000, 512, 128, 1), (20000, 128, 192, 1), (0, 64, 64, 1),
+                                               (300, 1024, 128, 4), (64, 43904, 128, 49)])
+def test_hip_linear_matches_oracle(oracle, hip, n, cin, cout, ksplit):
+    x, w, b = _case(n, cin, cout, 2)
+    want, want_st = _run(oracle, x, w, b, ksplit=ksplit, stats=ksplit == 1)
+    got, got_st = _run(hip, x.cuda(), w.cuda(), b.cuda(), ksplit=ksplit, stats=ksplit == 1)
+    tol = dict(rtol=RTOL, atol=ATOL) if cin <= 1024 else dict(rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(got.cpu(), want, **tol)
+    if ksplit == 1:
+        scale = max(1.0, float(n)) ** 0.5
+        torch.testing.assert_close(got_st.sum(0).cpu(), want_st.sum(0), rtol=1e-4, atol=1e-3 * scale)
+    if n:
+        dy = torch.randn(n, cout, generator=torch.Generator().manual_seed(3))
+        if cin <= 1024:
+            want_dx, _ = _run(oracle, dy, w, None, transposed_product=True)
+            got_dx, _ = _run(hip, dy.cuda(), w.cuda(), None, transposed_product=True)
+            torch.testing.assert_close(got_dx.cpu(), want_dx, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout", [(5000, 64, 128), (20000, 128, 64)])
+def test_linear_function_own_kernel_against_the_library_path(hip, monkeypatch, n, cin, cout):
+    """me.linear forward / dX / dW / db with the streaming kernel == the library path on bf16-rounded operands."""
+    x, w, b = _case(n, cin, cout, 4, "cuda")
+    x, w, gy = _bf16(x), _bf16(w), _bf16(torch.randn(n, cout, device="cuda"))      # operands both paths represent exactly
+    out = {}
+    with _lib.use_library(hip):
+        monkeypatch.setattr(me, "PRECISION", 1)
+        for own in (True, False):
+            monkeypatch.setattr(me, "LINEAR_KERNEL", own)
+            xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = me.linear(xs, ws, bs)
+            y.backward(gy)
+            out[own] = (y.detach(), xs.grad, ws.grad, bs.grad)
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out[True][2], out[False][2], rtol=1e-3, atol=1e-2)      # n-row contraction, different split
+    torch.testing.assert_close(out[True][3], gy.sum(0), rtol=1e-4, atol=1e-3)

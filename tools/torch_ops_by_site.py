@@ -33,6 +33,8 @@ class Count(TorchDispatchMode):
                 site = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)
                 break
         name = str(func)
+        if "_local_scalar_dense" in name:
+            self.fills[("item", site)] += 1                    # a device -> host read (one copyBuffer + a sync)
         if any(k in name for k in VIEWS):
             return func(*args, **(kwargs or {}))               # no kernel behind these
         if site == "?":
@@ -56,14 +58,29 @@ for _ in range(3):
     bench.train_step(model, opt, batch, 10.0)
 torch.cuda.synchronize()
 c = Count()
+from cagroup3d_amd import _lib  # noqa: E402
+entries = collections.Counter()
+_call = _lib.Library.call
+
+
+def counted(self, name, *a):
+    entries[name] += 1
+    return _call(self, name, *a)
+
+
+_lib.Library.call = counted
 with c:
     bench.train_step(model, opt, batch, 10.0)
 torch.cuda.synchronize()
+_lib.Library.call = _call
+print("C-ABI calls in one step:", sum(entries.values()))
+for s, n in entries.most_common(60):
+    print("%5d  %s" % (n, s))
 print("ops in one step:", sum(c.sites.values()))
 for s, n in c.sites.most_common(90):
     print("%5d  %s" % (n, s))
 print("--- fills / copies / casts by site")
-for (op, site), n in c.fills.most_common(45):
+for (op, site), n in c.fills.most_common(90):
     print("%5d  %-10s %s" % (n, op, site))
 print("--- by op")
 for s, n in c.ops.most_common(40):
