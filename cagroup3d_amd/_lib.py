@@ -65,7 +65,7 @@ _SIGNATURES = {
     "cg3d_spconv_tile_fwd": (c_int32, [P, P, P, P, P, P, P, c_int32, c_int32, P, c_int64, P, P, P, c_int64, c_int64, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, P, P]),
     "cg3d_spconv_tile_grid": (c_int32, [c_int64, c_int32, c_int32]),
-    "cg3d_linear_fwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P, P]),
+    "cg3d_linear_fwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P, P, P]),
     "cg3d_fcos_centerness": (c_int32, [P, P, P, c_int64, P, P, P, c_int32, P, P]),
     "cg3d_fcos_assign": (c_int32, [P, P, c_int64, P, P, c_int32, P, P, P, P]),
     "cg3d_pos_loss_nblocks": (c_int32, [c_int64]),

@@ -27,7 +27,7 @@ template <int NCO>                  // output channels of a workgroup = NCO * 64
 __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf,
                                                         const float *__restrict__ bias, float *__restrict__ Y, int64_t n,
                                                         int32_t cin, int32_t cout, int32_t ny, int32_t gz,
-                                                        float *__restrict__ stats) {
+                                                        float *__restrict__ stats, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NB = NCO * 2;                          // 32-channel output blocks of the workgroup
     constexpr int NC = NCO * 64;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
         // (the wave reads back what it wrote itself: LDS operations of one wave execute in order)
         const int col0 = yb * NC + h * 64 + c4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias && zi == 0) bv = *reinterpret_cast<const float4 *>(bias + col0);
+        if (bias && zi == 0 && !part) bv = *reinterpret_cast<const float4 *>(bias + col0);
         float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
             float4 v = *reinterpret_cast<const float4 *>(tb + rr * 64 + c4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (wave * 32 + rr < rows) {
-                float *dst = Y + (row0 + wave * 32 + rr) * (int64_t)cout + col0;
-                if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
+                float *dst = (part ? part + (int64_t)zi * n * cout : Y) + (row0 + wave * 32 + rr) * (int64_t)cout + col0;
+                if (gz == 1 || part) *reinterpret_cast<float4 *>(dst) = v;
                 else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
                 t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
@@ -128,13 +128,35 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
     }
 }
 
+// Y = bias + sum_z part[z]: the second half of a split contraction whose partial products were stored, not added atomically.
+// A workgroup owns 64 float4 columns; its four 64-thread groups each sum a quarter of the ranges, LDS joins them.
+__global__ __launch_bounds__(256) void k_linear_reduce(const float4 *__restrict__ part, const float *__restrict__ bias,
+                                                       float4 *__restrict__ Y, int64_t total4, int32_t cout4, int32_t gz) {
+    __shared__ float4 sh[3][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4)
+        for (int z = q; z < gz; z += 4) {
+            const float4 v = part[(int64_t)z * total4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    if (q) sh[q - 1][col] = a;
+    __syncthreads();
+    if (q || i >= total4) return;
+    for (int k = 0; k < 3; k++) { const float4 v = sh[k][col]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (bias) { const float4 v = reinterpret_cast<const float4 *>(bias)[i % cout4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    Y[i] = a;
+}
+
 extern "C" int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin,
-                               int32_t cout, int32_t ksplit, float *stats, cg3d_stream_t stream) {
+                               int32_t cout, int32_t ksplit, float *stats, float *partials, cg3d_stream_t stream) {
     if (n < 0 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || ksplit < 1 || ksplit > 256 || ksplit > (cin >> 6)) return CG3D_ERR_ARG;
-    if (((uintptr_t)X & 15) || ((uintptr_t)Wf & 15) || ((uintptr_t)Y & 15) || (stats && ksplit != 1)) return CG3D_ERR_ARG;
+    if (((uintptr_t)X & 15) || ((uintptr_t)Wf & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)partials & 15) || (stats && ksplit != 1)) return CG3D_ERR_ARG;
     if (n == 0) return CG3D_OK;
     hipStream_t s = cg3d_hs(stream);
-    if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (ksplit == 1) partials = nullptr;
+    if (ksplit > 1 && !partials && hipMemsetAsync(Y, 0, (size_t)n * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     const int nco = (cout % 128 == 0) ? 2 : 1;
     const int32_t ny = cout / (nco * 64);
     const int64_t nunit = cg3d_divup(n, LN_TM) * ny * ksplit;
@@ -149,10 +171,16 @@ extern "C" int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const floa
             attr = true;                                                                                                          \
         }                                                                                                                         \
         hipLaunchKernelGGL((k_linear_tile<NCO>), dim3((unsigned)nunit), dim3(256), LN_LDS, s, X, Wf, bias, Y, n, cin, cout, ny,   \
-                           ksplit, stats);                                                                                        \
+                           ksplit, stats, partials);                                                                              \
     } while (0)
     if (nco == 2) LN_LAUNCH(2); else LN_LAUNCH(1);
 #undef LN_LAUNCH
     CG3D_CHECK_LAUNCH();
+    if (partials) {
+        const int64_t total4 = n * cout / 4;
+        hipLaunchKernelGGL(k_linear_reduce, dim3((unsigned)cg3d_divup(total4, 64)), dim3(256), 0, s,
+                           reinterpret_cast<const float4 *>(partials), bias, reinterpret_cast<float4 *>(Y), total4, cout / 4, ksplit);
+        CG3D_CHECK_LAUNCH();
+    }
     return CG3D_OK;
 }

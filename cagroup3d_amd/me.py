@@ -1323,7 +1323,7 @@ class LinearFunction(torch.autograd.Function):
             _STATS[y.data_ptr()] = (stats, 1, n, cout, y)
         lib.check(x16, wf, bias)
         lib.call("cg3d_linear_fwd", ptr(x16), ptr(wf), ptr(bias), ptr(y), c_int64(n), c_int32(cin), c_int32(cout), c_int32(1),
-                 ptr(stats), lib.stream())
+                 ptr(stats), ptr(None), lib.stream())
         return y
 
     @staticmethod
@@ -1412,6 +1412,102 @@ class GatherRowsFunction(torch.autograd.Function):
 
 def gather_rows(feats, idx):
     return GatherRowsFunction.apply(feats, idx)
+
+
+ROI_CONTRACT = __import__("os").environ.get("CG3D_ROI_CONTRACT", "1") != "0"
+ROI_CONTRACT_PARTIALS = __import__("os").environ.get("CG3D_ROI_CONTRACT_PARTIALS", "1") != "0"
+ROI_CONTRACT_UNITS = int(__import__("os").environ.get("CG3D_ROI_CONTRACT_UNITS", "256"))      # workgroups of the split contraction (measured: 256 = 23 + 6 us, 512 = 18 + 10 us)
+_roi_pair_cache = {}
+
+
+def _roi_pairs(R, G, seglen, device):
+    """Pair list of the per-RoI contraction's weight gradient: offset g pairs row r * G + g of the gathered grid rows
+    with output row r.  int32 in [G * R], out [G * R] (offset-major), segment table (g, start, count <= seglen); cached."""
+    ck = (R, G, seglen, str(device))
+    hit = _roi_pair_cache.get(ck)
+    if hit is None:
+        r, g = np.arange(R, dtype=np.int64), np.arange(G, dtype=np.int64)
+        pin = (r[None, :] * G + g[:, None]).reshape(-1).astype(np.int32)
+        pout = np.tile(r, G).astype(np.int32)
+        starts = np.arange(0, R, seglen, dtype=np.int64)
+        tab = np.stack([np.repeat(g, len(starts)), (g[:, None] * R + starts[None, :]).reshape(-1),
+                        np.tile(np.minimum(seglen, R - starts), G)], 1).astype(np.int32)
+        hit = (h2d(torch.from_numpy(pin), torch.int32, device), h2d(torch.from_numpy(pout), torch.int32, device),
+               h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
+        if len(_roi_pair_cache) > 16:
+            _roi_pair_cache.clear()
+        _roi_pair_cache[ck] = hit
+    return hit
+
+
+class RoiContractFunction(torch.autograd.Function):
+    """pooled[r] = sum_g feats[idx[r * G + g]] @ W[g]: the per-RoI G = 7^3 grid -> centre convolution of the RoI head
+    (reference roi_heads/cagroup_roi_head.py:74-91 builds a fake 7^3 sparse tensor per RoI and convolves it with a
+    kernel-size-7 MinkowskiConvolution evaluated at the centre; as a product it is [R, G C] x [G C, C2]).
+
+    bench precision: the grid rows are gathered as bf16 (half the bytes of the fp32 gather they replace), the contraction
+    runs on cg3d_linear_fwd with the G C = 43 904 channels split over the chip (ksplit), the data gradient is the same
+    kernel on the other fragment-ordered copy of the weights followed by the scatter-add of the gather, the weight gradient
+    the bf16-rows pair kernel on the (r G + g, r) pair list."""
+
+    @staticmethod
+    def available(feats, w):
+        G, C, C2 = w.shape
+        return ROI_CONTRACT and PRECISION == 1 and BF16_ROWS and C % 64 == 0 and C2 % 64 == 0 and feats.shape[1] == C
+
+    @staticmethod
+    def forward(ctx, feats, idx, w):
+        lib = _lib.get()
+        G, C, C2 = w.shape
+        feats = feats.contiguous()
+        idx = idx.to(torch.int32).contiguous()
+        R = idx.shape[0] // G
+        x16 = _to_bf16(feats, keep=True)
+        g16 = torch.empty((R * G, C), dtype=torch.int16, device=feats.device)
+        lib.check(x16, idx, g16)
+        # a bf16 row of C channels moves as a row of C / 2 four-byte words
+        lib.call("cg3d_gather_rows", ptr(x16), ptr(idx), ptr(g16), c_int64(R * G), c_int32(C // 2), lib.stream())
+        wt, wp = _prep_frag(w.contiguous().view(1, G * C, C2), True, ctx.needs_input_grad[0])
+        tiles, ny, nchunk = -(-R // 128), C2 // (128 if C2 % 128 == 0 else 64), G * C // 64
+        ksplit = max(1, min(256, nchunk, ROI_CONTRACT_UNITS // max(tiles * ny, 1)))
+        y = torch.empty((R, C2), dtype=torch.float32, device=feats.device)
+        part = torch.empty((ksplit, R, C2), dtype=torch.float32, device=feats.device) if ksplit > 1 and ROI_CONTRACT_PARTIALS else None
+        lib.call("cg3d_linear_fwd", ptr(g16), ptr(wt), ptr(None), ptr(y), c_int64(R), c_int32(G * C), c_int32(C2), c_int32(ksplit),
+                 ptr(None), ptr(part), lib.stream())
+        ctx.save_for_backward(g16, idx, w, wp)
+        ctx.n_src = feats.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g16, idx, w, wp = ctx.saved_tensors
+        lib = _lib.get()
+        G, C, C2 = w.shape
+        R = dy.shape[0]
+        dy16 = _to_bf16(dy.contiguous())
+        dfeats = dw = None
+        if ctx.needs_input_grad[0]:
+            if wp is None:
+                _, wp = _prep_frag(w.contiguous().view(1, G * C, C2), False, True)
+            dflat = torch.empty((R, G * C), dtype=torch.float32, device=dy.device)
+            lib.call("cg3d_linear_fwd", ptr(dy16), ptr(wp), ptr(None), ptr(dflat), c_int64(R), c_int32(C2), c_int32(G * C), c_int32(1),
+                     ptr(None), ptr(None), lib.stream())
+            dfeats = torch.zeros((ctx.n_src, C), dtype=torch.float32, device=dy.device)
+            lib.call("cg3d_scatter_add_rows", ptr(dflat), ptr(idx), ptr(dfeats), c_int64(R * G), c_int32(C), lib.stream())
+        if ctx.needs_input_grad[2]:
+            pin, pout, seg, nseg = _roi_pairs(R, G, 512 if lib.is_device else 1 << 30, dy.device)
+            dw = torch.empty_like(w)
+            lib.call("cg3d_spconv_pairs_wgrad", ptr(g16), ptr(dy16), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
+                     c_int32(G), c_int32(C), c_int32(C2), c_int32(2), lib.stream())
+        return dfeats, None, dw
+
+
+def roi_contract(feats, idx, w):
+    """sum_g feats[idx[r G + g]] @ w[g] -> [R, C2] (w [G, C, C2]); the fp32 form gathers and multiplies with the library."""
+    if RoiContractFunction.available(feats, w):
+        return RoiContractFunction.apply(feats, idx, w)
+    G, C, C2 = w.shape
+    return gather_rows(feats, idx).view(-1, G * C) @ w.view(G * C, C2)
 
 
 class ImplicitConvFunction(torch.autograd.Function):

@@ -52,12 +52,10 @@ class SimplePoolingLayer(nn.Module):
                           (unq // gs[2]) % gs[1] - half, unq % gs[2] - half), dim=1)
         uc[:, 1:4] *= self.coord_key
         feat = self.grid_bn(self.grid_conv(sp_tensor, uc.int()), act=ME.ACT_ELU).F      # BN + ELU fused
-        new_features = ME.gather_rows(feat, inv)   # scatter-add backward (atomics), not torch's sort-based index_put
         if not self.pooling:
-            return new_features
-        g3 = self.grid_num ** 3
-        flat = new_features.view(-1, g3 * new_features.shape[1])      # one row per RoI, (grid, channel) order
-        pooled = flat @ self.pooling_conv.kernel.view(g3 * self.pooling_conv.in_channels, -1)
+            return ME.gather_rows(feat, inv)       # scatter-add backward (atomics), not torch's sort-based index_put
+        # one row per RoI, (grid, channel) order, times the kernel as a [G C, C2] matrix (ME.roi_contract)
+        pooled = ME.roi_contract(feat, inv, self.pooling_conv.kernel)
         return self.pooling_bn.bn(pooled)
 
 

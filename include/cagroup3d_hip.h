@@ -264,13 +264,15 @@ int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit);
  *   cg3d_spconv_prep_weights_frag: the transposed copy Wf_t of W [cin, cout] for Y = X @ W, the plain copy Wf for the data
  *   gradient dX = dY @ W^T (then cin / cout below are the gradient's: contraction = W's cout, outputs = W's cin);
  *   cin % 64 == 0, cout % 64 == 0; bias float32 [cout] or NULL; Y float32 [n, cout].
- *   ksplit > 1: the contraction is cut into that many ranges of 64-channel chunks whose partial products meet in Y through
- *   fp32 atomics (the callee zero-fills Y); ksplit <= cin / 64.
+ *   ksplit > 1: the contraction is cut into that many ranges of 64-channel chunks (ksplit <= cin / 64).  With `partials`
+ *   (caller-owned scratch, float32 [ksplit, n, cout], 16-byte aligned) every range stores its product there and a second
+ *   launch of the same call sums them (+ bias) into Y; with partials == NULL the ranges meet in Y through fp32 atomics
+ *   (the callee zero-fills Y) -- many ranges on few rows serialise on the same addresses, so give the scratch then.
  *   stats (optional, ksplit == 1): the layer's BatchNorm statistics table, float32 [CG3D_BN_SLOTS][2][cout], zero-filled by
  *   the caller, filled like `stats` of cg3d_spconv_tile_fwd.
  * ---------------------------------------------------------------------------------------- */
 int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin, int32_t cout,
-                    int32_t ksplit, float *stats, cg3d_stream_t stream);
+                    int32_t ksplit, float *stats, float *partials, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear interpolation of a tensor-stride-`ts` map at continuous coordinates

@@ -189,8 +189,8 @@ int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
  * fragment order (cg3d_spconv_prep_weights_frag, one slot): element (output n, contraction k) at ot_frag_index(n, k, cin).
  * stats: += sum / sum of squares per output channel into slot 0 of the statistics table. */
 int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin, int32_t cout,
-                    int32_t ksplit, float *stats, cg3d_stream_t s) {
-    (void)s;
+                    int32_t ksplit, float *stats, float *partials, cg3d_stream_t s) {
+    (void)s; (void)partials;          /* scratch of the device's split contraction: the restatement sums in one pass */
     if (n < 0 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || ksplit < 1 || ksplit > 256 || ksplit > (cin >> 6)) return CG3D_ERR_ARG;
     if (stats && ksplit != 1) return CG3D_ERR_ARG;
     float *w = (float *)malloc(sizeof(float) * (size_t)cin * cout);          /* [cout][cin] */

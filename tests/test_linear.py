@@ -18,7 +18,7 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def _run(lib, x, w, bias, ksplit=1, stats=False, transposed_product=False):
+def _run(lib, x, w, bias, ksplit=1, stats=False, transposed_product=False, partials=False):
     """Y = X @ W through cg3d_linear_fwd on `lib` (transposed_product: dX = X @ W^T on the plain fragment copy)."""
     dev = x.device
     n, cin = x.shape
@@ -33,8 +33,9 @@ def _run(lib, x, w, bias, ksplit=1, stats=False, transposed_product=False):
         cout = wi if transposed_product else wo
         y = torch.full((n, cout), float("nan"), dtype=torch.float32, device=dev)
         st = torch.zeros((me.BN_SLOTS, 2, cout), dtype=torch.float32, device=dev) if stats else None
+        part = torch.full((ksplit, n, cout), float("nan"), dtype=torch.float32, device=dev) if partials else None
         lib.call("cg3d_linear_fwd", ptr(x16), ptr(wp if transposed_product else wt), ptr(bias), ptr(y), ctypes.c_int64(n),
-                 ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(ksplit), ptr(st), lib.stream())
+                 ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(ksplit), ptr(st), ptr(part), lib.stream())
     return y, st
 
 
@@ -66,7 +67,7 @@ def test_oracle_linear_rejects_what_the_kernel_rejects(oracle):
         with pytest.raises(_lib.CG3DError):
             oracle.call("cg3d_linear_fwd", ptr(torch.zeros(16, bad[0], dtype=torch.int16)), ptr(torch.zeros(64 * 64, dtype=torch.int16)),
                         ptr(None), ptr(torch.zeros(16, bad[1])), ctypes.c_int64(16), ctypes.c_int32(bad[0]), ctypes.c_int32(bad[1]),
-                        ctypes.c_int32(bad[2]), ptr(None), oracle.stream())
+                        ctypes.c_int32(bad[2]), ptr(None), ptr(None), oracle.stream())
 
 
 @pytest.mark.gpu
@@ -79,6 +80,9 @@ def test_hip_linear_matches_oracle(oracle, hip, n, cin, cout, ksplit):
     got, got_st = _run(hip, x.cuda(), w.cuda(), b.cuda(), ksplit=ksplit, stats=ksplit == 1)
     tol = dict(rtol=RTOL, atol=ATOL) if cin <= 1024 else dict(rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(got.cpu(), want, **tol)
+    if ksplit > 1:                                  # the same split through the scratch of stored partial products
+        got_p, _ = _run(hip, x.cuda(), w.cuda(), b.cuda(), ksplit=ksplit, partials=True)
+        torch.testing.assert_close(got_p.cpu(), want, **tol)
     if ksplit == 1:
         scale = max(1.0, float(n)) ** 0.5
         torch.testing.assert_close(got_st.sum(0).cpu(), want_st.sum(0), rtol=1e-4, atol=1e-3 * scale)
@@ -109,3 +113,48 @@ def test_linear_function_own_kernel_against_the_library_path(hip, monkeypatch, n
     torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out[True][2], out[False][2], rtol=1e-3, atol=1e-2)      # n-row contraction, different split
     torch.testing.assert_close(out[True][3], gy.sum(0), rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------ the per-RoI 7^3 -> centre contraction (me.roi_contract)
+def _roi_case(n_src, R, G, C, C2, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = _bf16(torch.randn(n_src, C, generator=g))
+    idx = torch.randint(0, n_src, (R * G,), generator=g)
+    idx[:G] = 7                                              # a degenerate RoI: every grid point on one voxel row
+    w = _bf16(torch.randn(G, C, C2, generator=g) * 0.02)
+    dy = _bf16(torch.randn(R, C2, generator=g))
+    return feats, idx, w, dy
+
+
+def _roi_run(feats, idx, w, dy, fused):
+    prec, me.PRECISION = me.PRECISION, 1 if fused else 0
+    try:
+        f, k = feats.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        assert me.RoiContractFunction.available(f, k) == fused
+        y = me.roi_contract(f, idx, k)
+        (y * dy).sum().backward()
+        return y.detach(), f.grad, k.grad
+    finally:
+        me.PRECISION = prec
+
+
+@pytest.mark.parametrize("n_src,R,G,C,C2", [(500, 5, 27, 64, 64), (800, 130, 8, 128, 64), (300, 3, 343, 128, 128)])
+def test_oracle_roi_contraction_is_gather_times_kernel(oracle, n_src, R, G, C, C2):
+    """bf16-exact operands: the fused form (bf16 gather, split contraction, pair-list weight gradient) == the fp32 form."""
+    case = _roi_case(n_src, R, G, C, C2, 5)
+    with _lib.use_library(oracle):
+        got, want = _roi_run(*case, True), _roi_run(*case, False)
+    for name, a, b in zip(("pooled", "d features", "d kernel"), got, want):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())), msg=lambda m: name + ": " + m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_src,R,G,C,C2", [(500, 5, 27, 64, 64), (3000, 130, 8, 128, 64), (20000, 512, 343, 128, 128), (2000, 1, 343, 128, 128)])
+def test_hip_roi_contraction_matches_oracle(oracle, hip, n_src, R, G, C, C2):
+    case = _roi_case(n_src, R, G, C, C2, 6)
+    with _lib.use_library(oracle):
+        want = _roi_run(*case, True)
+    with _lib.use_library(hip):
+        got = _roi_run(*[t.cuda() for t in case], True)
+    for name, a, b in zip(("pooled", "d features", "d kernel"), got, want):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())), msg=lambda m: name + ": " + m)
