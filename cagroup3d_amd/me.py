@@ -1034,6 +1034,7 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
 
 TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
 LINEAR_KERNEL = __import__("os").environ.get("CG3D_LINEAR_KERNEL", "1") != "0"
+LINEAR_WGRAD_SMALL = __import__("os").environ.get("CG3D_LINEAR_WGRAD_SMALL", "1") != "0"   # 1 k - 8 k rows: bf16-rows pair kernel, not the library
 TILE_KERNEL = __import__("os").environ.get("CG3D_TILE_KERNEL", "1") != "0"
 GROUP_TILE_KERNEL = __import__("os").environ.get("CG3D_GROUP_TILE_KERNEL", "1") != "0"
 
@@ -1308,7 +1309,7 @@ class LinearFunction(torch.autograd.Function):
     def _own(n, cin, cout):
         """The hand-written streaming kernel (cg3d_linear_fwd, csrc/linear.hip): bench precision, bf16 row copies, channel
         counts in multiples of 64 on both sides (the data gradient is the same kernel with the roles swapped)."""
-        return (LINEAR_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
+        return (LINEAR_KERNEL and PRECISION == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and cin >= 64 and cout >= 64)
 
     @staticmethod
@@ -1362,7 +1363,7 @@ class LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n, (cin, cout) = x.shape[0], w.shape
             lib = _lib.get()
-            if n < LinearFunction.MIN_ROWS or not lib.is_device:
+            if (n < LinearFunction.MIN_ROWS and not (ctx.own and LINEAR_WGRAD_SMALL)) or not lib.is_device:
                 dw = x.t() @ dy
             else:
                 xc, dyc = x.contiguous(), dy.contiguous()
@@ -1645,8 +1646,9 @@ class FusedBNActFunction(torch.autograd.Function):
     Returns (y, batch_mean [G,C], batch_var_biased [G,C])."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps, running=None):
+    def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps, running=None, sync=None):
         # running: None or (running_mean [G*C], running_var, num_batches_tracked, momentum), updated in the statistics launch
+        # sync: None or (process group,): statistics over every rank's rows (--sync_bn; reference tools/train.py:118-119)
         lib = _lib.get()
         x = x.contiguous()
         N, C = x.shape
@@ -1672,6 +1674,11 @@ class FusedBNActFunction(torch.autograd.Function):
             else:
                 sums = zero_arena().take(BN_SLOTS * 2 * G * C, x.device)
                 lib.call("cg3d_bn_sums", ptr(x), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(sums), lib.stream())
+            if sync is not None:
+                # (the cached group_n holds max(rows, 1): a group that is empty HERE must add 0 rows to the global count)
+                rows = h2d(torch.from_numpy(np.diff(np.asarray(bounds, dtype=np.int64)).astype(np.float32)), torch.float32, x.device)
+                sums, group_n = _all_ranks_sums(sums, rows, G * C, sync[0])
+                _SYNC_ROWS[0] = group_n                  # (the caller's running-variance update needs the global row counts)
             # mean / variance are derived from the table inside the apply launch (and written out for the backward pass)
             lib.call("cg3d_bn_apply_sums", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(G), c_int32(C), ptr(sums),
                      ptr(group_n), c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), ptr(mean), ptr(var),
@@ -1684,6 +1691,7 @@ class FusedBNActFunction(torch.autograd.Function):
                      c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), lib.stream())
             ctx.dsums = None
         ctx.want16 = want16
+        ctx.sync = sync if use_batch else None
         if want16:
             _ROWS16[y.data_ptr()] = (y, y16)
         ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n, achunks)
@@ -1697,13 +1705,19 @@ class FusedBNActFunction(torch.autograd.Function):
         x, y, mean, var, gamma, chunks, gco, group_n, achunks = ctx.saved_tensors
         nchunk, G, C, act, use_batch, has_res, eps, nachunk = ctx.meta
         if dy is None:
-            return (None,) * 11
+            return (None,) * 12
         lib = _lib.get()
         dy = dy.contiguous()
         dsums = ctx.dsums if getattr(ctx, "dsums", None) is not None else torch.zeros(BN_SLOTS * 2 * G * C, dtype=torch.float32, device=x.device)
         ctx.dsums = None                                  # (a second backward through the same node gets a fresh table)
         lib.call("cg3d_bn_bwd_sums", ptr(dy), ptr(x), ptr(y), ptr(chunks), c_int64(nchunk), c_int32(G), c_int32(C), ptr(mean),
                  ptr(var), c_float(eps), c_int32(act), ptr(dsums), lib.stream())
+        local = None
+        if ctx.sync is not None:
+            # dx needs the sums over every rank's rows (group_n already holds the global row counts); the parameters'
+            # gradients stay this rank's own sums, which the gradient exchange averages like every other gradient
+            local = dsums.view(BN_SLOTS, 2, G, C).sum(0)
+            dsums, _ = _all_ranks_sums(dsums, None, G * C, ctx.sync[0])
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dx16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if ctx.want16 else None
@@ -1715,7 +1729,35 @@ class FusedBNActFunction(torch.autograd.Function):
                  ptr(dx), ptr(dx16), ptr(dres), ptr(dbeta), ptr(dgamma), lib.stream())
         if dx16 is not None:
             _ROWS16[dx.data_ptr()] = (dx, dx16)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        if local is not None:
+            dbeta, dgamma = local[0], local[1]
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+_SYNC_ROWS = [None]
+
+
+def _all_ranks_sums(table, group_n, gc, group):
+    """A statistics table [CG3D_BN_SLOTS][2][G][C] (and the groups' row counts) summed over the ranks of `group`: one
+    all-reduce of 2 G C (+ G) floats.  Returns a fresh table holding the totals in slot 0, and the global row counts."""
+    import torch.distributed as dist
+    tot = table.view(BN_SLOTS, 2 * gc).sum(0)
+    buf = torch.cat([tot, group_n.to(tot.dtype)]) if group_n is not None else tot
+    dist.all_reduce(buf, group=group)
+    out = torch.zeros_like(table)
+    out[:2 * gc] = buf[:2 * gc]
+    return out, (buf[2 * gc:].clamp(min=1).contiguous() if group_n is not None else None)
+
+
+def _sync_group_of(bn):
+    """(process group,) when `bn` is a torch.nn.SyncBatchNorm in training mode inside an initialised job of > 1 ranks."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not bn.training:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return (group,) if dist.get_world_size(group) > 1 else None
 
 
 def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
@@ -1746,12 +1788,17 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     running = None
     if track and G == 1 and b0.momentum is not None:
         running = (b0.running_mean, b0.running_var, b0.num_batches_tracked, float(b0.momentum))
+    sync = _sync_group_of(b0) if use_batch else None
     y, mean, var = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in,
-                                            b0.eps, running)
+                                            b0.eps, running, sync)
     if track and running is None:
         with torch.no_grad():
             m = b0.momentum
-            unb = var * _bn_chunks(tuple(bounds), feats.device, C)[6]
+            if sync is not None:
+                n_all = _SYNC_ROWS[0].view(-1, 1)
+                unb = var * (n_all / (n_all - 1).clamp(min=1))
+            else:
+                unb = var * _bn_chunks(tuple(bounds), feats.device, C)[6]
             rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
             torch._foreach_mul_(rms, 1 - m)
             torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)

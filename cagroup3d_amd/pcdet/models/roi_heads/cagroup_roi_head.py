@@ -56,7 +56,7 @@ class SimplePoolingLayer(nn.Module):
             return ME.gather_rows(feat, inv)       # scatter-add backward (atomics), not torch's sort-based index_put
         # one row per RoI, (grid, channel) order, times the kernel as a [G C, C2] matrix (ME.roi_contract)
         pooled = ME.roi_contract(feat, inv, self.pooling_conv.kernel)
-        return self.pooling_bn.bn(pooled)
+        return ME.fused_bn_act(pooled, [self.pooling_bn.bn])       # (the fused rows form: also the cross-rank statistics of --sync_bn)
 
 
 class CAGroup3DRoIHead(nn.Module):
@@ -160,7 +160,24 @@ class CAGroup3DRoIHead(nn.Module):
     def _refine(self, input_dict):
         pooled = self.roi_grid_pool(input_dict)
         pooled = pooled.view(pooled.shape[0], -1)
-        return self.reg_pred_layer(self.reg_fc_layers(pooled))
+        return self.reg_pred_layer(self._fc(pooled))
+
+    def _fc(self, x):
+        """reg_fc_layers (Linear, BatchNorm1d, ReLU[, Dropout]) with BatchNorm + ReLU as the fused rows form (ME.fused_bn_act):
+        two launches instead of torch's chain, and the same cross-rank statistics path as every other BatchNorm of the model
+        under --sync_bn (torch's own SyncBatchNorm refuses host tensors, so the gloo tests could not run it)."""
+        mods = list(self.reg_fc_layers)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and x.shape[1] % 4 == 0 and x.shape[0] > 0:
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = ME.fused_bn_act(x, [m], act=ME.ACT_RELU if relu else ME.ACT_NONE)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x
 
     def forward_train(self, input_dict):
         res = self.reoder_rois_for_refining(input_dict["pred_bbox_list"])

@@ -288,6 +288,7 @@ def main(argv=None):
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32")
+    ap.add_argument("--sync_bn", action="store_true", help="BatchNorm statistics over every rank's rows (reference tools/train.py:33,118-119)")
     args = ap.parse_args(argv)
     from . import me
     me.PRECISION = 1 if args.precision == "bf16" else 0
@@ -302,6 +303,11 @@ def main(argv=None):
         torch.cuda.set_device(dev)
     model, cfg = build_model.build_cagroup3d(args.dataset, seed=0)
     model = model.to(dev)
+    if args.sync_bn and world > 1:
+        # every nn.BatchNorm1d (the ones inside ME.MinkowskiBatchNorm included) becomes a SyncBatchNorm: me.fused_bn_act then
+        # all-reduces its statistics tables (2 C floats forward, 2 C backward per layer); the RoI head's plain FC BatchNorms
+        # run torch's SyncBatchNorm itself
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     oc = cfg.OPTIMIZATION
     epochs = args.epochs if args.epochs is not None else oc.NUM_EPOCHS
     bs = args.batch or oc.BATCH_SIZE_PER_GPU

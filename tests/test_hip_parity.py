@@ -194,7 +194,8 @@ def test_spconv_output_stationary_bf16_matches_pair_form_oracle(oracle, hip, cin
 
 @pytest.mark.parametrize("cin,cout,prec", [(64, 64, 0), (64, 3, 0), (128, 18, 0), (64, 64, 1), (256, 128, 1)])
 def test_linear_split_row_weight_gradient(oracle, hip, cin, cout, prec):
-    """1x1x1 convolutions: library GEMMs forward, the split-over-rows wgrad kernel backward == x^T @ dy."""
+    """1x1x1 convolutions: forward / data gradient (fp32: library GEMMs; bench precision with 64-multiple channels:
+    cg3d_linear_fwd on bf16 rows, on both sides), the split-over-rows wgrad kernel backward == x^T @ dy."""
     torch.manual_seed(cin + cout)
     n = 20000
     x, w, b, dy = torch.randn(n, cin), torch.randn(cin, cout) / cin ** 0.5, torch.randn(cout), torch.randn(n, cout)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from cagroup3d_amd import _lib, build_model, train
+from cagroup3d_amd import _lib, build_model, me, train
 from cagroup3d_amd.pcdet.config import cfg_from_yaml_file
 
 
@@ -220,3 +220,27 @@ def test_merge_eval_shards_places_scenes_by_index():
     assert det == ["a", "b", "c"] and gt == ["x", "y", "z"]
     with pytest.raises(AssertionError):
         train.merge_eval_shards(["a"], ["x"], [0], 2)             # a scene nobody evaluated
+
+
+def _worker_sync_bn(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from conftest import _build_oracle
+    oracle = _lib.bind(_build_oracle())
+    calls = []
+    orig = me._all_ranks_sums
+    me._all_ranks_sums = lambda *a: (calls.append(1), orig(*a))[1]
+    with _lib.use_library(oracle):
+        train.main(["--config", "S5k", "--scenes", "4", "--batch", "2", "--epochs", "1", "--device", "cpu", "--sync_bn"])
+    assert len(calls) > 100, len(calls)          # every BatchNorm of the step, forward and backward
+    if rank == 0:
+        open(out, "w").write("ok")
+
+
+def test_two_rank_training_with_sync_bn(tmp_path):
+    """train.main --sync_bn on two gloo ranks (oracle kernels): every BatchNorm -- backbone, class branches, RoI pooling, the
+    RoI head's FC layers -- exchanges its statistics tables; the step runs through and both ranks leave together."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_sync_bn, args=(2, 29551, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

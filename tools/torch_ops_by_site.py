@@ -24,7 +24,7 @@ VIEWS = ("aten.view.", "aten.detach.", "aten.select.", "aten.slice.", "aten.empt
 class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
-        self.sites, self.ops, self.fills = collections.Counter(), collections.Counter(), collections.Counter()
+        self.sites, self.ops, self.fills, self.gemms = collections.Counter(), collections.Counter(), collections.Counter(), collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         site = "?"
@@ -43,6 +43,9 @@ class Count(TorchDispatchMode):
                 site = "autograd: " + node.name()
         self.sites[site] += 1
         self.ops[str(func)] += 1
+        if any(k in name for k in ("aten.mm.", "aten.addmm.", "aten.bmm.", "aten.baddbmm.", "aten.matmul.")):
+            shp = " x ".join(str(tuple(a.shape)) for a in args if torch.is_tensor(a))
+            self.gemms[(name.split(".")[1], shp, site)] += 1
         if any(k in name for k in ("_to_copy", "zeros", "fill_", "copy_", "clone", "zero_", "ones", "full")):
             self.fills[(name.split(".")[1], site)] += 1
         return func(*args, **(kwargs or {}))
@@ -82,6 +85,9 @@ for s, n in c.sites.most_common(90):
 print("--- fills / copies / casts by site")
 for (op, site), n in c.fills.most_common(90):
     print("%5d  %-10s %s" % (n, op, site))
+print("--- library GEMMs by site")
+for (op, shp, site), n in c.gemms.most_common(60):
+    print("%5d  %-8s %-40s %s" % (n, op, shp, site))
 print("--- by op")
 for s, n in c.ops.most_common(40):
     print("%5d  %s" % (n, s))
