@@ -1384,6 +1384,15 @@ def linear(x, w, bias=None):
     return LinearFunction.apply(x, w, bias)
 
 
+def count_ids(ids, m):
+    """torch.bincount(ids, minlength=m) for ids known to lie in [0, m): one comparison against the m bins and a row sum --
+    bincount first scans its input for min and max (two single-workgroup-chain reductions, 14 + 23 us on 150 k ids)."""
+    n = ids.numel()
+    if n == 0 or m * n > (1 << 27) or not ids.is_cuda:
+        return torch.bincount(ids.reshape(-1), minlength=m)[:m] if n else torch.zeros(m, dtype=torch.int64, device=ids.device)
+    return (torch.arange(m, device=ids.device, dtype=ids.dtype).view(-1, 1) == ids.view(1, -1)).sum(1)
+
+
 class GatherRowsFunction(torch.autograd.Function):
     """out = F[idx] with a scatter-add backward (atomics) instead of torch's sort-based index_put."""
 

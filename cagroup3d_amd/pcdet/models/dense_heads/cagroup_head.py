@@ -114,8 +114,11 @@ class CAGroup3DHead(nn.Module):
         pad_id = torch.stack([p[0] for p in semantic_scores.decomposition_permutations]).long()  # first row of every scene
         ts = out.coordinate_map_key.get_key()[0][0]
         xyz_vox = out.C[:, 1:]
-        max_bound = (xyz_vox.max(0)[0] + ts) * self.voxel_size
-        min_bound = (xyz_vox.min(0)[0] - ts) * self.voxel_size
+        # (column reductions of the strided [N, 3] view run one workgroup chain per column: 100 + 52 us on 156 k rows;
+        # the same numbers as row reductions of a contiguous [3, N] copy: 3 x 5 us)
+        xyz_t = xyz_vox.t().contiguous()
+        max_bound = (xyz_t.amax(1) + ts) * self.voxel_size
+        min_bound = (xyz_t.amin(1) - ts) * self.voxel_size
 
         voxel_offsets = self.offset_block(out)
         offset_features = self.feature_offset(out).F
@@ -231,7 +234,7 @@ class CAGroup3DHead(nn.Module):
             order = torch.argsort(all_cls * (N + B) + all_pos)
             e_cls, e_row = all_cls[order], all_row[order]
             E = e_cls.shape[0]
-            n_c = torch.bincount(e_cls, minlength=C)
+            n_c = ME.count_ids(e_cls, C)
             start_c = torch.cumsum(n_c, 0) - n_c
             j = torch.arange(E, device=dev) - start_c[e_cls]
             base = start_c[e_cls] * (n_vote + 1)
@@ -261,8 +264,8 @@ class CAGroup3DHead(nn.Module):
         fine_C = cls_map.C
         with torch.no_grad():                                             # ONE host read for all group sizes
             fb, cb = fine_C[:, 0].long(), cls_exp.C[:, 0].long()
-            sizes = torch.cat([torch.bincount(fb // B, minlength=C), torch.bincount(cb // B, minlength=C),
-                               torch.bincount(fb, minlength=C * B)]).cpu().numpy()
+            per = ME.count_ids(fb, C * B)                                 # (class, scene) sizes; a class's size is their sum
+            sizes = torch.cat([per.view(C, B).sum(1), ME.count_ids(cb // B, C), per]).cpu().numpy()
         fine_bounds = (0,) + tuple(np.cumsum(sizes[:C]).tolist())
         coarse_bounds = (0,) + tuple(np.cumsum(sizes[C:2 * C]).tolist())
         per_scene = sizes[2 * C:].tolist()
@@ -387,7 +390,7 @@ class CAGroup3DHead(nn.Module):
             n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1      # one host read for all scenes
         if not self.with_yaw and equal_pts:
             order = torch.sort(vox_scene, stable=True)[1]
-            counts = torch.bincount(vox_scene, minlength=B)
+            counts = ME.count_ids(vox_scene, B)
             perms = list(torch.split(order, counts.cpu().tolist()))
             t, mk = self._vote_targets_masks_batched(vox_xyz, vox_scene, perms, gt_bboxes, scene_points, sem_masks, ins_masks, n_ins)
             off_t, off_m = t, mk.float()
@@ -682,7 +685,7 @@ class CAGroup3DHead(nn.Module):
         e_score = c_scores[j, i]
         o = self._sort_seg_desc(e_seg, e_score)
         j, i, e_seg, e_score = j[o], i[o], e_seg[o], e_score[o]
-        counts = torch.bincount(e_seg, minlength=B * C).cpu().numpy()                  # host read 2
+        counts = ME.count_ids(e_seg, B * C).cpu().numpy()                  # host read 2
         seg_off = np.zeros(B * C + 1, dtype=np.int64)
         seg_off[1:] = np.cumsum(counts)
         e_boxes = boxes[j].contiguous()

@@ -63,7 +63,8 @@ def test_full_detector_hip_matches_oracle(oracle, hip, dataset, cfgname):
 
 def test_bf16_mode_stays_within_stated_tolerance_of_fp32(hip):
     """The bench precision (bf16 MFMA operands, fp32 accumulate/storage) against the fp32 parity configuration on
-    the same weights and scenes: backbone/shared-head features within 2e-2 of their scale, every loss term within
+    the same weights and scenes: shared-head features within 1e-2 (semantic) / 4e-2 (offset) of their scale at the worst
+    row, 2e-3 / 4e-2 relative RMS, every loss term within
     2 % (the build's own tolerance -- the reference has no bf16 behaviour)."""
     outs = []
     for prec in (0, 1):
@@ -79,8 +80,15 @@ def test_bf16_mode_stays_within_stated_tolerance_of_fp32(hip):
             me.PRECISION = 0
         outs.append((b["one_stage_results"][1].F.detach(), b["one_stage_results"][2].F.detach(), tb, g))
     (sem0, off0, tb0, g0), (sem1, off1, tb1, g1) = outs
-    assert float((sem1 - sem0).abs().max()) <= 2e-2 * float(sem0.abs().max())
-    assert float((off1 - off0).abs().max()) <= 2e-2 * max(float(off0.abs().max()), 1.0)
+    def rel(a, b):
+        scale = max(float(b.abs().max()), 1.0)
+        return float((a - b).abs().max()) / scale, float((a - b).pow(2).mean().sqrt()) / float(b.pow(2).mean().sqrt())
+    (sem_max, sem_rms), (off_max, off_rms) = rel(sem1, sem0), rel(off1, off0)
+    print("bf16 vs fp32 features: semantic max %.2e rms %.2e, offset max %.2e rms %.2e" % (sem_max, sem_rms, off_max, off_rms))
+    # measured over 8 runs (round 3: every convolution incl. the 1x1x1 ones on bf16 operands): semantic max 1.9-2.6e-3;
+    # offset max 1.6-2.3e-2 of the largest offset (one row out of 5 k decides it; fp32 atomics move it run to run)
+    assert sem_max <= 1e-2 and off_max <= 4e-2, (sem_max, off_max)
+    assert sem_rms <= 2e-3 and off_rms <= 4e-2, (sem_rms, off_rms)      # measured 1.6e-4 / 1.8e-2 (offsets at initialisation are small numbers)
     print("loss terms fp32 vs bf16:", {k: (round(tb0[k], 5), round(tb1[k], 5)) for k in tb0})
     for k in tb0:
         assert abs(tb0[k] - tb1[k]) <= 2e-2 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
@@ -92,6 +100,7 @@ def test_bf16_mode_stays_within_stated_tolerance_of_fp32(hip):
     den = sum(float(g0[n].pow(2).sum()) for n in g0)
     # gradients: a sanity bound, not a precision claim -- bf16 rounding moves some votes across class-voxel
     # boundaries (discrete changes of the class maps), which dominates this number (0.16 measured on S5k)
+    print("bf16 vs fp32 whole-model gradient, relative L2: %.3f" % (num / den) ** 0.5)
     assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
 
 

@@ -41,6 +41,7 @@ buf.zero_()
 me._conv_tile(xin, wf, plan, None, cin, cout, km.n_in, P, 1)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(nwg, 16).astype(np.uint64)
+bidx = np.nonzero(t[:, 1] > 0)[0]                     # row of the trace buffer = blockIdx.x
 t = t[t[:, 1] > 0]
 c0, c1, r0, r1 = (t[:, i].astype(np.float64) for i in range(4))
 hw = t[:, 4]
@@ -56,6 +57,17 @@ print("workgroup duration: mean %.1f us, min %.1f, max %.1f;  shader cycles / us
 cuid = (xcc.astype(np.int64) * 64 + se.astype(np.int64) * 16 + sh.astype(np.int64) * 16 * 8 + cu.astype(np.int64))
 ids, counts = np.unique(cuid, return_counts=True)
 print("distinct CUs seen: %d; workgroups per CU: min %d max %d" % (len(ids), counts.min(), counts.max()))
+# which blockIdx values share a CU in the first round (the hardware's placement, not ours)
+first = (r0 - r0.min()) / 100.0 < 5.0
+diffs = []
+for c in ids:
+    b = np.sort(bidx[(cuid == c) & first])
+    if len(b) == 2:
+        diffs.append(int(b[1] - b[0]))
+if diffs:
+    vals, cnt = np.unique(np.asarray(diffs), return_counts=True)
+    top = np.argsort(-cnt)[:6]
+    print("first-round pairs on one CU: blockIdx difference -> count:", ", ".join("%d: %d" % (vals[i], cnt[i]) for i in top))
 # concurrency: for every CU, the time during which >= 2 of its workgroups overlap
 ov = tot = 0.0
 for c in ids:

@@ -43,6 +43,9 @@ class Count(TorchDispatchMode):
                 site = "autograd: " + node.name()
         self.sites[site] += 1
         self.ops[str(func)] += 1
+        if any(k in name for k in ("aten.max.", "aten.min.", "aten.amax.", "aten.amin.", "aten.aminmax.", "aten.sum.", "aten.any.", "aten.all.", "aten.argmax", "aten.argmin", "aten.topk", "aten.sort", "aten.unique", "aten._unique", "aten.nonzero", "aten.cumsum")):
+            shp = " ".join(str(tuple(a.shape)) + ("s" if not a.is_contiguous() else "") for a in args if torch.is_tensor(a))
+            self.gemms[(name.split(".")[1] + "." + name.split(".")[2], shp + " " + " ".join(str(a) for a in args[1:] if isinstance(a, (int, bool))), site)] += 1
         if any(k in name for k in ("aten.mm.", "aten.addmm.", "aten.bmm.", "aten.baddbmm.", "aten.matmul.")):
             shp = " x ".join(str(tuple(a.shape)) for a in args if torch.is_tensor(a))
             self.gemms[(name.split(".")[1], shp, site)] += 1
@@ -85,9 +88,9 @@ for s, n in c.sites.most_common(90):
 print("--- fills / copies / casts by site")
 for (op, site), n in c.fills.most_common(90):
     print("%5d  %-10s %s" % (n, op, site))
-print("--- library GEMMs by site")
-for (op, shp, site), n in c.gemms.most_common(60):
-    print("%5d  %-8s %-40s %s" % (n, op, shp, site))
+print("--- library GEMMs, reductions, sorts by site")
+for (op, shp, site), n in c.gemms.most_common(150):
+    print("%5d  %-16s %-44s %s" % (n, op, shp, site))
 print("--- by op")
 for s, n in c.ops.most_common(40):
     print("%5d  %s" % (n, s))
