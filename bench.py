@@ -290,9 +290,10 @@ def main():
         return dt_, profiled, tb_
 
     KNAMES = {
-        "tile_bf16": ("k_spconv_tile (sparse conv fwd + dgrad on LDS-staged neighbour tiles: persistent workgroups, loader waves "
-                      "gather the tile's distinct rows into LDS, consumer waves run bf16 MFMA from LDS with fragment-ordered "
-                      "weights streamed from L2, one store per output row)", "k_spconv_tile"),
+        "tile_bf16": ("k_spconv_tile2 (sparse conv fwd + dgrad on LDS-staged neighbour tiles: one 4-wave workgroup per "
+                      "(128-row tile, 128/64 output channels), two per CU; the tile's distinct input rows reach LDS by LDS-DMA, "
+                      "bf16 MFMA from LDS with fragment-ordered weights streamed from L2, one store per output row, BatchNorm "
+                      "statistics in the store phase)", "k_spconv_tile"),
         "implicit_bf16": ("k_spconv_implicit_bf16_ad (sparse conv fwd + dgrad, output-stationary: neighbour rows -> "
                           "registers -> bf16 MFMA -> one store per output row)", "k_spconv_implicit_bf16"),
         "pairs_bf16": ("k_spconv_pairs_bf16 (sparse conv fwd + dgrad: gather -> bf16 MFMA -> atomic scatter)", "k_spconv_pairs_bf16"),

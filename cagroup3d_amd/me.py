@@ -1384,6 +1384,31 @@ def linear(x, w, bias=None):
     return LinearFunction.apply(x, w, bias)
 
 
+def rows_by_batch(b, n_batch=None):
+    """Per-batch row index lists (ascending) of a batch-index column: torch.split(stable argsort, counts) with ONE host
+    read.  Rows of every map of this build are batch-major ((batch, Morton) order, strided maps in first-occurrence order
+    of their parents), so the sort is normally the identity: the number of descents rides along with the counts and the
+    ~10 merge-sort launches are only paid when it is not zero."""
+    b = b.reshape(-1).long()
+    if b.numel() == 0:
+        return []
+    if not b.is_cuda:
+        order = torch.sort(b, stable=True)[1]
+        return list(torch.split(order, torch.bincount(b, minlength=n_batch or 0).tolist()))
+    desc = (b[1:] < b[:-1]).sum().view(1)
+    if n_batch is None:
+        host = torch.cat([desc, b[-1:]]).tolist()          # batch-major: the last row holds the largest index
+        if host[0] == 0:
+            counts = count_ids(b, host[1] + 1).tolist()    # (second read only on this path without a known batch size)
+            return list(torch.split(torch.arange(b.numel(), device=b.device), counts))
+    else:
+        host = torch.cat([desc, count_ids(b, n_batch)]).tolist()
+        if host[0] == 0:
+            return list(torch.split(torch.arange(b.numel(), device=b.device), host[1:]))
+    order = torch.sort(b, stable=True)[1]
+    return list(torch.split(order, torch.bincount(b, minlength=n_batch or 0).tolist()))
+
+
 def count_ids(ids, m):
     """torch.bincount(ids, minlength=m) for ids known to lie in [0, m): one comparison against the m bins and a row sum --
     bincount first scans its input for min and max (two single-workgroup-chain reductions, 14 + 23 us on 150 k ids)."""
@@ -1880,16 +1905,13 @@ class SparseTensor:
 
     @property
     def decomposition_permutations(self):
-        """Per-scene row index lists (ascending), one stable sort + ONE host read for all scenes."""
+        """Per-scene row index lists (ascending): `rows_by_batch`."""
         m = self._map
         if m._perms is None:
             if m.n == 0:
                 m._perms = []
             else:
-                b = m.coords[:, 0].long()
-                order = torch.sort(b, stable=True)[1]
-                counts = torch.bincount(b).cpu().numpy()
-                m._perms = list(torch.split(order, counts.tolist()))
+                m._perms = rows_by_batch(m.coords[:, 0])
         return m._perms
 
     @property

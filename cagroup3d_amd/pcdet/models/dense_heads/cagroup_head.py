@@ -389,9 +389,8 @@ class CAGroup3DHead(nn.Module):
         if not self.with_yaw:
             n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1      # one host read for all scenes
         if not self.with_yaw and equal_pts:
-            order = torch.sort(vox_scene, stable=True)[1]
-            counts = ME.count_ids(vox_scene, B)
-            perms = list(torch.split(order, counts.cpu().tolist()))
+            perms = ME.rows_by_batch(vox_scene, B)
+            counts = ME.h2d([p.shape[0] for p in perms], torch.long, dev)
             t, mk = self._vote_targets_masks_batched(vox_xyz, vox_scene, perms, gt_bboxes, scene_points, sem_masks, ins_masks, n_ins)
             off_t, off_m = t, mk.float()
             n_vox = counts.float()[vox_scene]

@@ -28,3 +28,6 @@ ls -la $O
 bash $R/tools/pmc_mem.sh k_spconv_tile tools/mb_tile_one.py 4 128 128 > /dev/null 2>&1; cp $R/gpurun_out/pmc_mem_k_spconv_tile.txt $O/${RN}_pmc_mem_tile_128.txt
 bash $R/tools/pmc_calibrate.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_calibrate.txt $O/${RN}_pmc_calibrate.txt
 ls -la $O
+python $R/tools/mb_roi_contract.py > $O/${RN}_roi_contract.txt 2>&1
+python $R/tools/torch_ops_by_site.py > $O/${RN}_ops_by_site.txt 2>&1
+ls -la $O
