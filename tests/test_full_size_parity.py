@@ -156,3 +156,44 @@ def test_benchmark_class_map_convolution_matches_oracle(oracle, hip, monkeypatch
     for nm, r, o in zip(("y", "dx", "dw"), ref[:3], out[:3]):
         scale = max(float(r.abs().max()), 1.0)
         torch.testing.assert_close(o.cpu(), r, rtol=RTOL, atol=ATOL * scale, msg=lambda m: "%s (K=%d): %s" % (nm, ks ** 3, m))
+
+
+# ------------------------------------------------------------------ the 1x1x1 convolutions (cg3d_linear_fwd) at the benchmark's row counts
+@pytest.mark.parametrize("n,cin,cout", [(155773, 64, 64), (82107, 128, 256), (23015, 256, 128), (155773, 64, 128)])
+def test_benchmark_linear_layer_matches_oracle(oracle, hip, n, cin, cout):
+    """me.linear in the bench precision on the row counts of the S50k x 4 maps: forward (bf16 rows x fragment-ordered weights
+    + bias), data gradient (the other weight copy), weight gradient (bf16-rows pair kernel on the identity list) and the
+    BatchNorm statistics the kernel leaves in its epilogue, all against the oracle's restatement of the same arithmetic."""
+    g = torch.Generator().manual_seed(n + cin)
+    x, w, b = torch.randn(n, cin, generator=g), torch.randn(cin, cout, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    dy = torch.randn(n, cout, generator=g)
+    # operands that bf16 represents exactly: the oracle side's weight gradient is the fp32 product x^T dy
+    x, w, dy = (t.to(torch.bfloat16).float() for t in (x, w, dy))
+
+    def run(lib, dev):
+        old = me.PRECISION, me.WANT_BN_STATS
+        me.PRECISION, me.WANT_BN_STATS = 1, True
+        calls = []
+        orig = lib.call
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            with _lib.use_library(lib):
+                me.zero_arena().reset()
+                xs, ws, bs = (t.to(dev).clone().requires_grad_(True) for t in (x, w, b))
+                y = me.linear(xs, ws, bs)
+                st = me._STATS.pop(y.data_ptr(), None)
+                sums = st[0].view(me.BN_SLOTS, 2, cout).sum(0).cpu() if st is not None else None
+                y.backward(dy.to(dev))
+                return [y.detach().cpu(), xs.grad.cpu(), ws.grad.cpu(), bs.grad.cpu(), sums], calls
+        finally:
+            lib.call = orig
+            me.PRECISION, me.WANT_BN_STATS = old
+            me._STATS.clear()
+    want, _ = run(oracle, "cpu")
+    got, calls = run(hip, "cuda") if hip is not None else run(oracle, "cpu")      # (CG3D_PARITY_SELFTEST: the test code alone)
+    assert calls.count("cg3d_linear_fwd") == 2, calls               # forward + dX on the own kernel
+    assert hip is None or "cg3d_spconv_pairs_wgrad" in calls, calls
+    for name, a, r in zip(("y", "dx", "dw", "db", "statistics"), got, want):
+        assert a is not None and r is not None, name
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-5 * scale * (30 if name in ("dw", "db", "statistics") else 1), msg=lambda m: name + ": " + m)
