@@ -182,7 +182,7 @@ class KernelMap:
                 G = nb
             rb = h2d(blocks if blocks is not None else row_bounds, torch.int32, dev) if (blocks is not None or row_bounds is not None) else None
             ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
-            off = torch.zeros(self.K * G + 1, dtype=torch.int32, device=dev)
+            off = torch.empty(self.K * G + 1, dtype=torch.int32, device=dev)      # (zero-filled by the call)
             lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
                      ptr(off), lib.stream())
             any_hit = next(iter(self._pairs.values()), None)
@@ -339,7 +339,7 @@ def _build_map(coords_i32, qstride):
     out_coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    n_out = torch.zeros(2, dtype=torch.int32, device=dev)          # [row count, status]
+    n_out = torch.empty(2, dtype=torch.int32, device=dev)          # [row count, status], both written by the call
     lib.call("cg3d_coord_map_build", ptr(coords_i32), c_int64(n), c_int32(qstride), ptr(keys), ptr(vals),
              c_int64(cap), ptr(ws), ptr(out_coords), ptr(uniq), ptr(inv), ptr(n_out), lib.stream())
     m, status = n_out.tolist()  # host sync: the row count sizes every later tensor on this map
@@ -1384,6 +1384,17 @@ def linear(x, w, bias=None):
     return LinearFunction.apply(x, w, bias)
 
 
+def sorted_batch_counts(b, n_batch):
+    """Rows per batch index (host list of n_batch ints) when the batch-index column `b` is non-decreasing with values in
+    [0, n_batch), else None; one host read."""
+    b = b.reshape(-1)
+    if b.numel() == 0:
+        return [0] * n_batch
+    bad = ((b[1:] < b[:-1]).sum() + (b[-1] >= n_batch) + (b[0] < 0)).view(1).long()
+    host = torch.cat([bad, count_ids(b.long(), n_batch)]).tolist()
+    return host[1:] if host[0] == 0 else None
+
+
 def rows_by_batch(b, n_batch=None):
     """Per-batch row index lists (ascending) of a batch-index column: torch.split(stable argsort, counts) with ONE host
     read.  Rows of every map of this build are batch-major ((batch, Morton) order, strided maps in first-occurrence order
@@ -1834,10 +1845,8 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
             else:
                 unb = var * _bn_chunks(tuple(bounds), feats.device, C)[6]
             rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
-            torch._foreach_mul_(rms, 1 - m)
-            torch._foreach_add_(rms, list(mean.unbind(0)), alpha=m)
-            torch._foreach_mul_(rvs, 1 - m)
-            torch._foreach_add_(rvs, list(unb.unbind(0)), alpha=m)
+            torch._foreach_lerp_(rms, list(mean.unbind(0)), m)            # r += m * (stat - r)
+            torch._foreach_lerp_(rvs, list(unb.unbind(0)), m)
             torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
     return y
 

@@ -815,8 +815,13 @@ def split_gt_boxes(gt_boxes, label_dtype=torch.long):
     (cagroup_head.py:298-318, cagroup3d.py:118-135)."""
     boxes, labels = [], []
     valid = ~(gt_boxes == 0.).all(dim=-1)
+    v = valid.cpu().numpy()                        # ONE host read (a boolean-mask selection per scene is a sync per scene)
     for b in range(gt_boxes.shape[0]):
-        g = gt_boxes[b][valid[b]]
+        idx = np.nonzero(v[b])[0]
+        if len(idx) == 0 or idx[-1] == len(idx) - 1:           # the padding rows come last (collate_batch): a prefix slice
+            g = gt_boxes[b, :len(idx)]
+        else:
+            g = gt_boxes[b][ME.h2d(idx, torch.long, gt_boxes.device)]
         boxes.append(g[:, :7].contiguous())
         labels.append(g[:, 7].to(label_dtype))
     return boxes, labels

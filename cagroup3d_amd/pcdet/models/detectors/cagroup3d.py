@@ -219,8 +219,19 @@ class CAGroup3D(Detector3DTemplate):
 
     @staticmethod
     def convert2list(points, batch_size=None):
+        """(N, 1 + C) rows with a leading scene index -> per-scene (n_i, C) tensors (reference cagroup3d.py:76-80).  Collated
+        batches are scene-major, so the scenes are row RANGES: views, and one host read for their sizes instead of one
+        boolean-mask selection (a host sync each) per scene; a column that is not sorted takes the reference's masks."""
         if batch_size is None:
             batch_size = int(points[:, 0].max().int()) + 1
+        if points.is_cuda and points.shape[0] > 0:
+            counts = ME.sorted_batch_counts(points[:, 0], batch_size)
+            if counts is not None:
+                out, r0 = [], 0
+                for c in counts:
+                    out.append(points[r0:r0 + c, 1:])
+                    r0 += c
+                return out
         return [points[points[:, 0] == i, 1:] for i in range(batch_size)]
 
     def get_training_loss(self, batch_dict):
