@@ -10,6 +10,7 @@ from .... import me as ME
 from ....ops.iou3d_nms_utils import nms_batched_sorted, nms_gpu, nms_normal_gpu
 from ....ops.knn import knn
 from ...config import AttrDict
+from ...utils.common_utils import DeferredLog
 from ...utils.iou3d_loss import IoU3DLoss
 from ...utils.loss_utils import CrossEntropy, FocalLoss, SmoothL1Loss
 from ..model_utils.cagroup_utils import Scale, bias_init_with_prob, parse_params, reduce_mean
@@ -361,9 +362,7 @@ class CAGroup3DHead(nn.Module):
         names = ("loss_centerness", "loss_bbox", "loss_cls", "loss_sem", "loss_vote")
         means = [torch.mean(torch.stack([t[j] for t in terms])) for j in range(5)]
         loss = means[0] + means[1] + means[2] + means[3] + means[4]
-        vals = torch.stack(means + [loss]).detach().cpu().tolist()      # ONE device->host copy for the log
-        tb_dict = dict(zip(names + ("one_stage_loss",), vals))
-        return loss, tb_dict
+        return loss, DeferredLog(names + ("one_stage_loss",), torch.stack(means + [loss]))      # ONE device->host copy, when the log is read
 
     @torch.no_grad()
     def data_targets(self, vox_C, gt_bboxes, gt_labels, scene_points, sem_masks, ins_masks):
@@ -489,8 +488,8 @@ class CAGroup3DHead(nn.Module):
         losses = [loss_centerness, loss_bbox, loss_cls, loss_sem, loss_vote]
         loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         names = ("loss_centerness", "loss_bbox", "loss_cls", "loss_sem", "loss_vote")
-        vals = torch.stack(losses + [loss]).detach().cpu().tolist()
-        return loss, dict(zip(names + ("one_stage_loss",), vals))
+        # (the terms stay on the device until the log is read: common_utils.DeferredLog)
+        return loss, DeferredLog(names + ("one_stage_loss",), torch.stack(losses + [loss]))
 
     def _vote_targets_yaw(self, original_points, gt_bboxes, gt_labels):
         """SUN RGB-D: up to gt_per_seed box-centre votes per voxel (cagroup_head.py:418-452)."""

@@ -4,6 +4,7 @@ packaging.  Same forward(batch_dict) contract as the reference."""
 import torch
 
 from .... import me as ME
+from ...utils.common_utils import DeferredLog
 from ..dense_heads.cagroup_head import split_gt_boxes
 from .detector3d_template import Detector3DTemplate
 
@@ -251,8 +252,8 @@ class CAGroup3D(Detector3DTemplate):
             batch_dict["gt_bboxes_3d"], batch_dict["gt_labels_3d"], self.convert2list(batch_dict["points"], bs),
             [None] * bs, masks("semantic_mask"), masks("instance_mask"))
         loss_two, tb_two = self.roi_head.loss(batch_dict)
-        tb_dict.update(tb_two)
-        disp_dict = dict(tb_dict)
         loss_all = loss_one + loss_two
-        tb_dict = {"loss_all": tb_dict["one_stage_loss"] + tb_dict["loss_two_stage"], **tb_dict}
-        return loss_all, tb_dict, disp_dict
+        # every number of the log stays on the device until somebody reads the dict (common_utils.DeferredLog)
+        tb_all = DeferredLog(("loss_all",), loss_all.view(1)).absorb(tb_dict).absorb(tb_two)
+        disp_dict = DeferredLog().absorb(tb_dict).absorb(tb_two)
+        return loss_all, tb_all, disp_dict

@@ -13,6 +13,7 @@ import torch.nn as nn
 from .... import me as ME
 from ....ops.iou3d_nms_utils import nms_gpu, nms_normal_gpu
 from ...utils import common_utils
+from ...utils.common_utils import DeferredLog
 from ...utils.iou3d_loss import IoU3DLoss
 from ...utils.loss_utils import WeightedSmoothL1Loss
 from ..model_utils.cagroup_utils import CAGroupResidualCoder as ResidualCoder
@@ -294,9 +295,7 @@ class CAGroup3DRoIHead(nn.Module):
                 parts = {"rcnn_loss_reg": reg, "rcnn_loss_iou": iou}
         total = sum(parts.values())
         keys = list(parts)
-        vals = torch.stack([parts[k] for k in keys] + [total]).detach().cpu().tolist()
-        tb = dict(zip(keys + ["loss_two_stage"], vals))
-        return total, tb
+        return total, DeferredLog(keys + ["loss_two_stage"], torch.stack([parts[k] for k in keys] + [total]))
 
     def get_box_reg_layer_loss(self, d):
         """Smooth-L1 on encoded residuals of foreground RoIs (+ rotated IoU loss) (:551-615)."""

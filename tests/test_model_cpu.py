@@ -180,3 +180,17 @@ def test_checkpoint_loader_converts_foreign_checkpoints_and_refuses_their_optimi
         fresh.load_params_with_optimizer(f_me, to_cpu=True, optimizer=opt)
     it, ep = fresh.load_params_with_optimizer(f_native, to_cpu=True, optimizer=None)
     assert (it, ep) == (7, 2)
+
+
+def test_deferred_log_reads_the_device_once_and_behaves_like_a_dict():
+    import json
+    from cagroup3d_amd.pcdet.utils.common_utils import DeferredLog
+    one = DeferredLog(("loss_a", "loss_b", "one_stage_loss"), torch.tensor([1.0, 2.0, 3.0]))
+    two = DeferredLog(["rcnn", "loss_two_stage"], torch.tensor([0.5, 0.5]))
+    tb = DeferredLog(("loss_all",), torch.tensor([3.5])).absorb(one).absorb(two).absorb({"extra": 7})
+    assert len(tb._pend) == 3 and dict.__len__(tb) == 1              # nothing read yet
+    assert tb["loss_all"] == 3.5 and not tb._pend                     # the first look materialises everything
+    assert list(tb) == ["extra", "loss_all", "loss_a", "loss_b", "one_stage_loss", "rcnn", "loss_two_stage"]
+    assert dict(tb)["rcnn"] == 0.5 and {**tb}["loss_b"] == 2.0 and tb.get("missing", -1) == -1 and "loss_a" in tb
+    assert json.loads(json.dumps(tb))["one_stage_loss"] == 3.0 and isinstance(tb, dict) and len(tb) == 7
+    assert one["loss_a"] == 1.0                                       # the absorbed log can still be read on its own
