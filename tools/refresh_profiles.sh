@@ -31,3 +31,4 @@ ls -la $O
 python $R/tools/mb_roi_contract.py > $O/${RN}_roi_contract.txt 2>&1
 python $R/tools/torch_ops_by_site.py > $O/${RN}_ops_by_site.txt 2>&1
 ls -la $O
+python $R/tools/host_sections.py > $O/${RN}_host_sections.txt 2>&1; BATCH=4 python $R/tools/host_sections.py >> $O/${RN}_host_sections.txt 2>&1
