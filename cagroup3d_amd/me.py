@@ -1291,7 +1291,7 @@ class LinearFunction(torch.autograd.Function):
     the library runs on a handful of workgroups -- it goes through the split-over-rows wgrad kernel instead
     (cg3d_spconv_pairs_wgrad on the identity pair list)."""
     MIN_ROWS = 8192
-    OWN_MIN_ROWS = 1024
+    OWN_MIN_ROWS = int(__import__("os").environ.get("CG3D_LINEAR_MIN_ROWS", "1"))      # (1 024 until late in round 3: below it the library GEMM's host cost, 25-60 us per call, is the larger part)
 
     @staticmethod
     def _skinny(n, a, b):
@@ -1316,15 +1316,21 @@ class LinearFunction(torch.autograd.Function):
     def _own_gemm(x16, wf, bias, n, cin, cout, want_stats=False):
         lib = _lib.get()
         y = torch.empty((n, cout), dtype=torch.float32, device=x16.device)
-        stats = None
-        if want_stats and WANT_BN_STATS and FUSED_BN_STATS and cout <= 1024:
+        # few rows x a long contraction (DAPPM: 32-284 rows x 1024 channels): one workgroup would walk 16 chunks one latency
+        # at a time -- the chunks go to separate workgroups instead, partial products stored and summed by the same call
+        units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin // 64
+        ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
+        stats = part = None
+        if ksplit > 1:
+            part = torch.empty((ksplit, n, cout), dtype=torch.float32, device=x16.device)
+        elif want_stats and WANT_BN_STATS and FUSED_BN_STATS and cout <= 1024:
             stats = zero_arena().take(BN_SLOTS * 2 * cout, x16.device)
             if len(_STATS) > 64:
                 _STATS.clear()
             _STATS[y.data_ptr()] = (stats, 1, n, cout, y)
         lib.check(x16, wf, bias)
-        lib.call("cg3d_linear_fwd", ptr(x16), ptr(wf), ptr(bias), ptr(y), c_int64(n), c_int32(cin), c_int32(cout), c_int32(1),
-                 ptr(stats), ptr(None), lib.stream())
+        lib.call("cg3d_linear_fwd", ptr(x16), ptr(wf), ptr(bias), ptr(y), c_int64(n), c_int32(cin), c_int32(cout), c_int32(max(ksplit, 1)),
+                 ptr(stats), ptr(part), lib.stream())
         return y
 
     @staticmethod
@@ -1382,6 +1388,52 @@ class LinearFunction(torch.autograd.Function):
 
 def linear(x, w, bias=None):
     return LinearFunction.apply(x, w, bias)
+
+
+class LinearTFunction(torch.autograd.Function):
+    """y = x @ w^T (+ bias) with w stored [cout, cin] like nn.Linear (the RoI head's FC layers, reference
+    roi_heads/cagroup_roi_head.py:37-55) on the same kernel as `linear`: for the [cout, cin] tensor the PLAIN fragment copy is
+    the forward operand (contraction over its second index) and the transposed copy the data gradient's; the weight
+    gradient dy^T x is the pair kernel with the operands swapped.  The library GEMM costs the host 25-70 us per call."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        n, (cout, cin) = x.shape[0], w.shape
+        x = x.contiguous()
+        x16 = _to_bf16(x, keep=True)
+        wt, wp = _prep_frag(w.contiguous().view(1, cout, cin), ctx.needs_input_grad[0], True)
+        ctx.save_for_backward(x16, w, wt)
+        ctx.has_bias = bias is not None
+        return LinearFunction._own_gemm(x16, wp, bias.contiguous() if bias is not None else None, n, cin, cout, want_stats=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w, wt = ctx.saved_tensors
+        n, (cout, cin) = dy.shape[0], w.shape
+        dy = dy.contiguous()
+        dy16 = _to_bf16(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if wt is None:
+                wt, _ = _prep_frag(w.contiguous().view(1, cout, cin), True, False)
+            dx = LinearFunction._own_gemm(dy16, wt, None, n, cout, cin)
+        if ctx.needs_input_grad[1]:
+            lib = _lib.get()
+            ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cout, cin, 1, 1), dy.device)
+            dw = torch.empty_like(w)
+            lib.check(x16, dy16, ar, seg, dw)
+            lib.call("cg3d_spconv_pairs_wgrad", ptr(dy16), ptr(x16), ptr(ar), ptr(ar), ptr(seg), c_int64(nseg), ptr(dw),
+                     c_int32(1), c_int32(cout), c_int32(cin), c_int32(2), lib.stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def linear_t(x, w, bias=None):
+    """nn.Linear's y = x @ w^T + bias (w [cout, cin]); the own kernel in the bench precision with 64-multiple channels."""
+    if x.dim() == 2 and LinearFunction._own(x.shape[0], w.shape[1], w.shape[0]):
+        return LinearTFunction.apply(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)
 
 
 def sorted_batch_counts(b, n_batch):

@@ -175,6 +175,9 @@ class CAGroup3DRoIHead(nn.Module):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = ME.fused_bn_act(x, [m], act=ME.ACT_RELU if relu else ME.ACT_NONE)
                 i += 2 if relu else 1
+            elif isinstance(m, nn.Linear):
+                x = ME.linear_t(x, m.weight, m.bias)
+                i += 1
             else:
                 x = m(x)
                 i += 1

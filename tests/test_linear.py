@@ -95,7 +95,7 @@ def test_hip_linear_matches_oracle(oracle, hip, n, cin, cout, ksplit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,cin,cout", [(5000, 64, 128), (20000, 128, 64)])
+@pytest.mark.parametrize("n,cin,cout", [(5000, 64, 128), (20000, 128, 64), (33, 1024, 128), (284, 1024, 128), (1, 64, 64), (700, 256, 512)])
 def test_linear_function_own_kernel_against_the_library_path(hip, monkeypatch, n, cin, cout):
     """me.linear forward / dX / dW / db with the streaming kernel == the library path on bf16-rounded operands."""
     x, w, b = _case(n, cin, cout, 4, "cuda")
@@ -158,3 +158,30 @@ def test_hip_roi_contraction_matches_oracle(oracle, hip, n_src, R, G, C, C2):
         got = _roi_run(*[t.cuda() for t in case], True)
     for name, a, b in zip(("pooled", "d features", "d kernel"), got, want):
         torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())), msg=lambda m: name + ": " + m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,bias", [(512, 128, 256, False), (512, 256, 256, True), (77, 64, 128, True), (3000, 256, 64, False)])
+def test_linear_with_the_weight_stored_like_nn_linear(oracle, hip, n, cin, cout, bias):
+    """me.linear_t (the RoI head's FC layers): y = x @ w^T + b, dx, dw, db on the own kernel == torch's F.linear on operands
+    bf16 represents exactly, and == the oracle running the same path."""
+    g = torch.Generator().manual_seed(n + cin)
+    x, w, dy = _bf16(torch.randn(n, cin, generator=g)), _bf16(torch.randn(cout, cin, generator=g) / cin ** 0.5), _bf16(torch.randn(n, cout, generator=g))
+    b = torch.randn(cout, generator=g) if bias else None
+
+    def run(lib, dev, own):
+        prec, me.PRECISION = me.PRECISION, 1 if own else 0
+        try:
+            with _lib.use_library(lib):
+                xs, ws = x.to(dev).clone().requires_grad_(True), w.to(dev).clone().requires_grad_(True)
+                bs = b.to(dev).clone().requires_grad_(True) if bias else None
+                y = me.linear_t(xs, ws, bs)
+                y.backward(dy.to(dev))
+                return [y.detach().cpu(), xs.grad.cpu(), ws.grad.cpu()] + ([bs.grad.cpu()] if bias else [])
+        finally:
+            me.PRECISION = prec
+    got, ref, want = run(hip, "cuda", True), run(hip, "cuda", False), run(oracle, "cpu", True)
+    for name, a, r, o in zip(("y", "dx", "dw", "db"), got, ref, want):
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * scale, msg=lambda m: name + " vs F.linear: " + m)
+        torch.testing.assert_close(a, o, rtol=1e-4, atol=1e-4 * scale, msg=lambda m: name + " vs oracle: " + m)
