@@ -97,6 +97,10 @@ class CG3DError(RuntimeError):
     pass
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None) or (lambda: torch.cuda.current_device())
+
+
 class Library:
     """A loaded shared object exporting the cg3d_* C-ABI."""
 
@@ -121,15 +125,18 @@ class Library:
     def stream(self):
         """Raw handle of torch's current stream on the current device (hipStream_t)."""
         if self.is_device:
-            return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+            # (the two C entry points directly: torch.cuda.current_device() is a Python function with a lazy-init check,
+            # ~600 calls per training step)
+            return _RAW_STREAM(_GET_DEVICE())
         return None
 
     def check(self, *tensors):
         """Every tensor must live where this library computes and be contiguous."""
+        dev_is_cuda = self.is_device
         for t in tensors:
             if t is None:
                 continue
-            if t.device.type != self.device_type:
+            if t.is_cuda != dev_is_cuda:
                 raise CG3DError(
                     "cagroup3d_amd op got a %s tensor but the bound library (%s) computes on %s; "
                     "there is no CPU fallback in the product path" % (t.device.type, self.path, self.device_type))
