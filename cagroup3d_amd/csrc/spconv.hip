@@ -1560,6 +1560,70 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void k_spconv_pairs_wgrad
             }
 }
 
+// Weight gradient with ONE narrow side (fp32): the stem (3 -> 64), the semantic / offset / per-class score, box and centerness
+// layers (64 -> 18 / 3 / 6 / 1).  A 64 x 64 MFMA tile is 5-28 % full there and the generic kernel ran 80-200 us per launch for
+// 11-110 MB of rows.  Here the WIDE operand's channels sit on the lanes (coalesced row reads), the narrow operand's <= 32
+// values ride on the first lanes of one coalesced load and reach every lane by v_readlane (as wave-uniform scalar loads
+// 4 x 18 of them spilled the scalar file: 182 us at cout = 18), a wave streams the pairs of its quarter of the segment PF at a time and
+// keeps dW[wide channel = lane][narrow channel] in registers; the waves meet in LDS, one atomic per element at the end.  Every
+// workgroup ends with wide x narrow atomics onto the SAME addresses: with 18 narrow channels 609 four-wave workgroups spent
+// most of 160 us in that queue -- 16 waves per workgroup (NW) and a quarter of the workgroups keep the parallelism.
+//   NARROW_OUT: narrow = dY (cout <= 32), wide = X;  else narrow = X (cin <= 32), wide = dY.
+template <int S, bool NARROW_OUT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_spconv_pairs_wgrad_skinny(const float *__restrict__ X, const float *__restrict__ dY,
+                                                                   const int32_t *__restrict__ pin,
+                                                                   const int32_t *__restrict__ pout,
+                                                                   const int32_t *__restrict__ seg, float *__restrict__ dW,
+                                                                   int32_t cin, int32_t cout) {
+    constexpr int PF = 8;
+    __shared__ float red[NW - 1][64][S + 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t k = seg[blockIdx.x * 3], start = seg[blockIdx.x * 3 + 1], count = seg[blockIdx.x * 3 + 2];
+    if (count <= 0) return;
+    const int wide = NARROW_OUT ? cin : cout, narrow = NARROW_OUT ? cout : cin;
+    const int w0 = blockIdx.y * 64;                              // this workgroup's 64 wide channels
+    const bool wok = w0 + lane < wide;
+    const float *Wd = NARROW_OUT ? X : dY, *Nr = NARROW_OUT ? dY : X;
+    const int32_t *wi = NARROW_OUT ? pin : pout, *ni = NARROW_OUT ? pout : pin;
+    float acc[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) acc[j] = 0.f;
+    const int nl = lane < narrow ? lane : 0;                     // the narrow row rides on the first `narrow` lanes
+    for (int32_t p0 = wave * PF; p0 < count; p0 += NW * PF) {
+        float wv[PF], nv[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int32_t p = p0 + u < count ? p0 + u : count - 1;          // clamped, unconditional loads; masked below
+            const int64_t wr = wi[start + p], nr = ni[start + p];
+            wv[u] = wok ? Wd[wr * wide + w0 + lane] : 0.f;
+            nv[u] = Nr[nr * narrow + nl];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const float x = p0 + u < count ? wv[u] : 0.f;
+#pragma unroll
+            for (int j = 0; j < S; j++)          // lane j's value to every lane (v_readlane: no memory, no long-lived scalars)
+                acc[j] += x * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nv[u]), j));
+        }
+    }
+    if (wave) {
+#pragma unroll
+        for (int j = 0; j < S; j++) red[wave - 1][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (wave || !wok) return;
+    float *dst = dW + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int j = 0; j < S; j++) {
+        if (j >= narrow) break;
+        float v = acc[j];
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) v += red[w][lane][j];
+        // dW is [cin][cout]: wide = cin -> element (w0 + lane, j); wide = cout -> element (j, w0 + lane)
+        unsafeAtomicAdd(NARROW_OUT ? &dst[(int64_t)(w0 + lane) * cout + j] : &dst[(int64_t)j * cout + w0 + lane], v);
+    }
+}
+
 extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in,
                                        const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
                                        int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
@@ -1605,6 +1669,24 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
         LAUNCH_WB_ALL(float);
 #undef LAUNCH_WB_ALL
 #undef LAUNCH_WB
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
+    static const bool skinny = !(getenv("CG3D_WGRAD_SKINNY") && atoi(getenv("CG3D_WGRAD_SKINNY")) == 0);
+    if (skinny && ((cout <= 32 && cin >= 32) || (cin <= 32 && cout >= 32))) {
+        const bool narrow_out = cout <= 32 && cin >= 32;
+        const int narrow = narrow_out ? cout : cin, wide = narrow_out ? cin : cout;
+        const dim3 grid((unsigned)nseg, (unsigned)cg3d_divup(wide, 64));
+#define LAUNCH_SK(S, NW)                                                                                                        \
+    do {                                                                                                                        \
+        if (narrow_out) hipLaunchKernelGGL((k_spconv_pairs_wgrad_skinny<S, true, NW>), grid, dim3(NW * 64), 0, s, X, dY, pair_in, pair_out, seg, dW, cin, cout); \
+        else hipLaunchKernelGGL((k_spconv_pairs_wgrad_skinny<S, false, NW>), grid, dim3(NW * 64), 0, s, X, dY, pair_in, pair_out, seg, dW, cin, cout);          \
+    } while (0)
+        if (narrow <= 4) LAUNCH_SK(4, 4);
+        else if (narrow <= 8) LAUNCH_SK(8, 4);
+        else if (narrow <= 20) LAUNCH_SK(20, 16);
+        else LAUNCH_SK(32, 16);
+#undef LAUNCH_SK
         CG3D_CHECK_LAUNCH();
         return CG3D_OK;
     }

@@ -1026,12 +1026,18 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
         slots = max(512 * rounds * _WGRAD_BF16_WGS // 2048 - K * tiles, 64)
         per = -(-P * tiles // slots)
         return max(_WGRAD_BF16_MIN, -(-per // 64) * 64)
+    if min(cin, cout) <= 32 <= max(cin, cout):
+        # k_spconv_pairs_wgrad_skinny: every workgroup ends with (wide x narrow) atomics onto the same few addresses --
+        # few, long segments worked by 16 waves when the narrow side is large, many short ones when it is 1-8 channels
+        wgs = WGRAD_SKINNY_WGS if min(cin, cout) > 8 else 1024
+        return max(256, -(-(-(-P // wgs)) // 64) * 64)
     t = 128 if (cin >= 128 and cout >= 128) else 64          # tile edge of the kernel the library will pick
     tiles = ((cin + t - 1) // t) * ((cout + t - 1) // t)
     per = -(-P * tiles // 2048)             # aim at >= 2048 workgroups
     return max(256, -(-per // 256) * 256)
 
 
+WGRAD_SKINNY_WGS = int(__import__("os").environ.get("CG3D_WGRAD_SKINNY_WGS", "64"))      # measured at cout = 18: 58 / 66 / 88 us at 64 / 128 / 256
 TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
 LINEAR_KERNEL = __import__("os").environ.get("CG3D_LINEAR_KERNEL", "1") != "0"
 LINEAR_WGRAD_SMALL = __import__("os").environ.get("CG3D_LINEAR_WGRAD_SMALL", "1") != "0"   # 1 k - 8 k rows: bf16-rows pair kernel, not the library
