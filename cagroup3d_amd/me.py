@@ -1933,7 +1933,7 @@ class SparseTensor:
             elif quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
                 self.F = ScatterMeanFunction.apply(features, inv.view(1, -1), n_out)
             else:
-                self.F = features[uniq.long()]
+                self.F = gather_rows(features, uniq) if (features.dim() == 2 and features.dtype == torch.float32) else features[uniq.long()]
         else:
             assert coordinate_map_key is not None and coordinate_manager is not None
             self.coordinate_manager, self.coordinate_map_key = coordinate_manager, coordinate_map_key

@@ -386,7 +386,7 @@ class CAGroup3DHead(nn.Module):
         N = vox_C.shape[0]
         equal_pts = len({sp.shape[0] for sp in scene_points}) == 1
         if not self.with_yaw:
-            n_ins = torch.stack([im.max() for im in ins_masks]).cpu().numpy() + 1      # one host read for all scenes
+            n_ins = (torch.stack(list(ins_masks)).amax(1) if equal_pts else torch.stack([im.max() for im in ins_masks])).cpu().numpy() + 1      # one host read for all scenes
         if not self.with_yaw and equal_pts:
             perms = ME.rows_by_batch(vox_scene, B)
             counts = ME.h2d([p.shape[0] for p in perms], torch.long, dev)

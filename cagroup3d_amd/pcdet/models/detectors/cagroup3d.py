@@ -109,8 +109,8 @@ class CAGroup3D(Detector3DTemplate):
             if targets is not None and self.training:
                 object.__setattr__(self.dense_head, "_data_targets", targets.get("loss"))
                 object.__setattr__(self.dense_head, "_forced_pre", targets.get("forced"))
-            feats = points[:, 4:][uniq.long()]          # rows are in (batch, Morton) order: always re-index
-            return ME.SparseTensor(features=feats.clone(), coordinate_map_key=key, coordinate_manager=mgr)
+            feats = points[:, 4:][uniq.long()]          # rows are in (batch, Morton) order: always re-index (a fresh tensor)
+            return ME.SparseTensor(features=feats, coordinate_map_key=key, coordinate_manager=mgr)
         coordinates = points[:, :4].clone()
         coordinates[:, 1:] /= self.voxel_size
         return ME.SparseTensor(coordinates=coordinates, features=points[:, 4:].clone())
