@@ -1909,6 +1909,68 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     return y
 
 
+_unit_cache = {}
+ADD_RELU = __import__("os").environ.get("CG3D_ADD_RELU", "1") != "0"
+
+
+def _unit_bn(C, device):
+    """(zeros, ones) float32 [1, C]: the identity BatchNorm (mean 0, variance 1, gamma 1, beta 0, eps 0)."""
+    ck = (C, str(device))
+    hit = _unit_cache.get(ck)
+    if hit is None:
+        hit = _unit_cache[ck] = (torch.zeros((1, C), dtype=torch.float32, device=device), torch.ones((1, C), dtype=torch.float32, device=device))
+    return hit
+
+
+class AddReluFunction(torch.autograd.Function):
+    """y = relu(a [+ b]) on feature rows in ONE pass that also leaves the bf16 row copy the next convolution gathers from --
+    the `x = relu(lo + down(hi))` joins of BiResNet (reference backbones_3d/biresnet.py:358-406) were an add, a ReLU and a
+    cg3d_to_bf16 launch (26 bytes per element instead of 14).  It is cg3d_bn_apply with the identity normalisation
+    (mean 0, variance 1, eps 0: rsqrt(1) = 1, so (x - 0) * 1 * 1 + 0 + b is exact) -- no new kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.get()
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        N, C = a.shape
+        zeros, ones = _unit_bn(C, a.device)
+        _, _, _, _, achunks, nachunk, _ = _bn_chunks((0, N), a.device, C)
+        y = torch.empty_like(a)
+        want16 = BF16_ROWS and _use_bf16(C)
+        y16 = torch.empty(a.shape, dtype=torch.int16, device=a.device) if want16 else None
+        lib.check(a, b, achunks)
+        lib.call("cg3d_bn_apply", ptr(a), ptr(b), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(zeros), ptr(ones), c_float(0.0),
+                 ptr(ones), ptr(zeros), c_int32(ACT_RELU), ptr(y), ptr(y16), lib.stream())
+        if want16:
+            _ROWS16[y.data_ptr()] = (y, y16)
+        ctx.save_for_backward(y)
+        ctx.two = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dz = torch.ops.aten.threshold_backward(dy, y, 0.0)
+        return dz, (dz if ctx.two else None)
+
+
+def add_relu(a, b=None):
+    """relu(a + b) (b None: relu(a)) for SparseTensors on the same map or feature rows."""
+    sp = isinstance(a, SparseTensor)
+    fa = a.F if sp else a
+    fb = (b.F if isinstance(b, SparseTensor) else b) if b is not None else None
+    if sp and isinstance(b, SparseTensor):
+        a._same_map(b)
+    if coords_only():
+        return a
+    if ADD_RELU and fa.dim() == 2 and fa.shape[1] % 4 == 0 and fa.dtype == torch.float32 and fa.shape[0] > 0:
+        out = AddReluFunction.apply(fa, fb)
+    else:
+        out = torch.relu(fa if fb is None else fa + fb)
+    return a._like(out) if sp else out
+
+
 # ----------------------------------------------------------------------------- SparseTensor
 class SparseTensor:
     """ME.SparseTensor: features [N, C] on a coordinate map.
@@ -2159,6 +2221,9 @@ class MinkowskiReLU(_Pointwise):
     def __init__(self, inplace=False):
         super().__init__()
         self.fn = nn.ReLU(inplace=False)
+
+    def forward(self, x):
+        return add_relu(x)          # one pass that also writes the bf16 row copy (AddReluFunction)
 
 
 class MinkowskiELU(_Pointwise):

@@ -174,17 +174,22 @@ class BiResNet(nn.Module):
         l2 = self.layer2(self.relu(l1))                               # ts 4
         if self.training and getattr(self, "grad_sync", None) is not None and not ME.coords_only():
             self.grad_sync.attach_mid(l2.F)          # every deeper layer's gradient is complete when this one is
-        l3 = self.layer3(self.relu(l2))                               # ts 8
-        hi = self.layer3_(self.relu(l2))                              # ts 4 (high-resolution branch)
+        r2 = self.relu(l2)                                            # (one ReLU for both consumers)
+        l3 = self.layer3(r2)                                          # ts 8
+        hi = self.layer3_(r2)                                         # ts 4 (high-resolution branch)
 
-        lo = l3 + self.down3(self.relu(hi))
-        hi = hi._like(hi.F + self.compression3(self.relu(l3)).features_at_coordinates(hi.C.float()))
+        # the joins  lo = l3 + down3(relu(hi)),  hi = hi + compression3(relu(l3))(hi.C)  are only ever read through a ReLU:
+        # ME.add_relu forms relu(a + b) in one pass (biresnet.py:378-394 in the reference: add, then relu at the consumer)
+        r3, rh = self.relu(l3), self.relu(hi)
+        lo_r = ME.add_relu(l3, self.down3(rh))
+        hi_r = ME.add_relu(hi, hi._like(self.compression3(r3).features_at_coordinates(hi.C.float())))
 
-        l4 = self.layer4(self.relu(lo))                               # ts 16
-        hi = self.layer4_(self.relu(hi))
-        lo = l4 + self.down4(self.relu(hi))
-        hi = hi._like(hi.F + self.compression4(self.relu(l4)).features_at_coordinates(hi.C.float()))
+        l4 = self.layer4(lo_r)                                        # ts 16
+        hi = self.layer4_(hi_r)
+        r4, rh = self.relu(l4), self.relu(hi)
+        lo_r = ME.add_relu(l4, self.down4(rh))
+        hi_r = ME.add_relu(hi, hi._like(self.compression4(r4).features_at_coordinates(hi.C.float())))
 
-        hi = self.layer5_(self.relu(hi))
-        hi = hi._like(hi.F + self.spp(self.layer5(self.relu(lo))).features_at_coordinates(hi.C.float()))
+        hi = self.layer5_(hi_r)
+        hi = hi._like(hi.F + self.spp(self.layer5(lo_r)).features_at_coordinates(hi.C.float()))
         return {"sp_tensor": self.out(hi)}                            # ts 2, OUT_CHANNELS

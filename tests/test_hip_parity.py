@@ -622,3 +622,28 @@ def test_weight_plan_single_launch_equals_per_layer_conversion(hip):
     finally:
         me.PRECISION = 0
         me._WeightPlan.reset()
+
+
+@pytest.mark.parametrize("n,c,two", [(5000, 64, True), (777, 128, True), (82107, 128, True), (3000, 256, False), (1, 64, True)])
+def test_add_relu_rows_is_exact(oracle, hip, n, c, two):
+    """me.add_relu (cg3d_bn_apply with the identity normalisation): relu(a + b), its bf16 row copy and the masked gradient,
+    bit for bit what torch computes, on the oracle and on the device."""
+    g = torch.Generator().manual_seed(n + c)
+    a, b, dy = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+
+    def fn(a, b, dy):
+        me.PRECISION = 1
+        try:
+            xa, xb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = me.add_relu(xa, xb if two else None)
+            y16 = me.rows16_of(y.detach() if False else y, True)
+            (y * dy).sum().backward()
+            return y.detach(), xa.grad, (xb.grad if two else xa.grad), (y16.clone() if y16 is not None else torch.zeros(1))
+        finally:
+            me.PRECISION = 0
+    ref, out = both(oracle, hip, fn, a, b, dy)
+    want = torch.relu(a + b if two else a)
+    for r, o in zip(ref, out):
+        eq(r, o)
+    assert torch.equal(out[0].cpu(), want) and torch.equal(out[1].cpu(), dy * (want > 0))
+    assert torch.equal(out[3].cpu().view(torch.bfloat16).float(), want.to(torch.bfloat16).float())
