@@ -73,6 +73,7 @@ _SIGNATURES = {
     "cg3d_pos_loss_bwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, P]),
     "cg3d_smooth_l1_rows_fwd": (c_int32, [P, P, P, c_int64, c_int32, c_float, P, P]),
     "cg3d_smooth_l1_rows_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, P, P]),
+    "cg3d_grad_norm_clip": (c_int32, [P, P, c_int64, P, c_float, P, P, P, P]),
     "cg3d_adamw_step": (c_int32, [P, P, c_int64, P, P, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "cg3d_bn_sums": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P]),
     "cg3d_bn_apply_sums": (c_int32, [P, P, P, c_int64, c_int32, c_int32, P, P, c_float, P, P, c_int32, P, P, P, P, P, P, P, c_float, P]),

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 CHUNK = 1 << 15          # elements per table row of the fused step (one 256-thread workgroup each)
+FUSED_NORM = os.environ.get("CG3D_FUSED_NORM", "1") != "0"      # gradient norm + clip coefficient by cg3d_grad_norm_clip
 FUSED_STEP = os.environ.get("CG3D_FUSED_ADAMW", "1") != "0"
 
 
@@ -52,10 +53,14 @@ class ClippedAdamW(torch.optim.AdamW):
             return total
         grads = [[p.grad for p in ps] for _, ps, _, _, _ in lean]
         flat = [g for gs in grads for g in gs]
+        if norm_type == 2.0 and FUSED_NORM:
+            total = self._fused_step(lean, flat, None, float(max_norm))      # norm, clip coefficient and update: three launches
+            if total is not None:
+                return total
         norms = torch._foreach_norm(flat, norm_type)
         total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)      # clip_grad_norm_: always multiplied, 1.0 when below the bar
-        if self._fused_step(lean, flat, coef):
+        if self._fused_step(lean, flat, coef) is not None:
             return total
         torch._foreach_mul_(flat, coef)
         for (group, ps, m1, m2, steps), gs in zip(lean, grads):
@@ -67,17 +72,19 @@ class ClippedAdamW(torch.optim.AdamW):
         return total
 
     # -- one launch for the gradient scaling and the update of every parameter (cg3d_adamw_step, csrc/optim.hip)
-    def _fused_step(self, lean, flat_grads, coef):
-        """True if the step was taken by the library's kernel: device library bound, every tensor fp32 and contiguous.
+    def _fused_step(self, lean, flat_grads, coef, max_norm=None):
+        """The total gradient norm (a device scalar; `coef` given: True) if the step was taken by the library's kernels, else
+        None: device library bound, every tensor fp32 and contiguous.  coef None: the norm and the clip coefficient come from
+        cg3d_grad_norm_clip over the same chunk table (one pass over the gradients instead of torch's _foreach_norm chain).
         Unlike the torch path the gradients are NOT overwritten with their clipped values (nothing reads them afterwards:
         `zero_grad` follows); the parameters, moments and step counters end up as torch's kernel leaves them (tested)."""
         if not FUSED_STEP:
-            return False
+            return None
         from . import _lib, me
         lib = _lib.get()
         dev = flat_grads[0].device
         if not lib.is_device or dev.type != "cuda":
-            return False
+            return None
         plan = getattr(self, "_plan", None)
         if plan not in (None, False):
             # the table holds raw addresses: rebuild it when a parameter or a moment has moved (model.to(), .data reassigned,
@@ -91,7 +98,7 @@ class ClippedAdamW(torch.optim.AdamW):
                 for p, a, b in zip(ps, m1, m2):
                     if not (p.dtype == a.dtype == b.dtype == torch.float32 and p.is_contiguous() and a.is_contiguous() and b.is_contiguous()):
                         self._plan = False
-                        return False
+                        return None
                     n = p.numel()
                     for o in range(0, n, CHUNK):
                         rows.append((p.data_ptr(), a.data_ptr(), b.data_ptr(), o, min(CHUNK, n - o)))
@@ -101,13 +108,13 @@ class ClippedAdamW(torch.optim.AdamW):
                                  len(rows), [g["params"] for g in self.param_groups],
                                  [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts])
         if plan is False:
-            return False
+            return None
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in flat_grads):
-            return False
+            return None
         # hyper-parameters are per group in torch; the table is one launch: require them equal (they are for this model)
         g0 = lean[0][0]
         if any((g["lr"], g["betas"], g["eps"], g["weight_decay"]) != (g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]) for g, *_ in lean):
-            return False
+            return None
         steps = [s for *_, ss in lean for s in ss]
         t = self._host_step = getattr(self, "_host_step", None) or 0
         if t == 0:
@@ -117,17 +124,24 @@ class ClippedAdamW(torch.optim.AdamW):
             st = torch.stack([x.reshape(()) for x in steps]).cpu()
             if not bool((st == st[0]).all()):
                 self._host_step = None
-                return False
+                return None
             t = int(st[0].item())
         torch._foreach_add_(steps, 1)
         t += 1
         self._host_step = t
         beta1, beta2 = g0["betas"]
         gp = me.h2d(np.fromiter((g.data_ptr() for g in flat_grads), dtype=np.int64, count=len(flat_grads)), torch.int64, dev)
+        total = True
+        if coef is None:
+            sc = torch.empty(4, dtype=torch.float64, device=dev)            # [sum of squares | norm, coefficient as floats]
+            nc = sc[1:2].view(torch.float32)
+            lib.call("cg3d_grad_norm_clip", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), c_float(max_norm),
+                     sc.data_ptr(), nc[0:1].data_ptr(), nc[1:2].data_ptr(), lib.stream())
+            total, coef = nc[0], nc[1:2]
         lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), coef.data_ptr(),
                  c_float(g0["lr"]), c_float(beta1), c_float(beta2), c_float(g0["eps"]), c_float(g0["weight_decay"]),
                  c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t), lib.stream())
-        return True
+        return total
 
     def step(self, closure=None):
         self._host_step = None            # torch advances the step counters itself here: re-read them at the next fused step

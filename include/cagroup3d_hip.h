@@ -513,6 +513,11 @@ int cg3d_smooth_l1_rows_bwd(const float *pred, const float *target, const float 
  *   this step's gradient addresses; clip: device scalar or NULL (g <- g * *clip, not written back).
  *   p -= lr*wd*p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),
  *   bc1 = 1 - beta1^t, bc2 = 1 - beta2^t supplied by the caller. */
+/* clip_grad_norm_ (tools/train_utils/train_utils.py:40-47) over the same chunk table, before cg3d_adamw_step:
+ *   *norm = sqrt(sum over every gradient element of g^2)  (chunk sums in double),  *coef = min(max_norm / (*norm + 1e-6), 1)
+ *   -- the `clip` argument of cg3d_adamw_step.  scratch: one caller-owned double (zeroed by the callee). */
+int cg3d_grad_norm_clip(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, float max_norm,
+                        double *scratch, float *norm, float *coef, cg3d_stream_t stream);
 int cg3d_adamw_step(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, const float *clip,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                     float bias_correction2, cg3d_stream_t stream);

@@ -79,6 +79,25 @@ int cg3d_adamw_step(const int64_t *table, const int32_t *pid, int64_t nrows, con
     return CG3D_OK;
 }
 
+/* clip_grad_norm_ over the chunk table: norm = sqrt(sum g^2) (double accumulation), coef = min(max_norm / (norm + 1e-6), 1)
+ * (torch/nn/utils/clip_grad.py: total_norm, clip_coef_clamped) */
+int cg3d_grad_norm_clip(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, float max_norm,
+                        double *scratch, float *norm, float *coef, cg3d_stream_t stream) {
+    (void)stream;
+    if (nrows < 0 || (nrows > 0 && (!table || !pid || !grads)) || !scratch || !norm || !coef) return CG3D_ERR_ARG;
+    double s = 0;
+    for (int64_t r = 0; r < nrows; r++) {
+        const int64_t *row = table + r * 5;
+        const float *g = (const float *)(intptr_t)grads[pid[r]] + row[3];
+        for (int64_t i = 0; i < row[4]; i++) s += (double)g[i] * g[i];
+    }
+    *scratch = s;
+    *norm = (float)sqrt(s);
+    const float c = max_norm / (*norm + 1e-6f);
+    *coef = c < 1.f ? c : 1.f;
+    return CG3D_OK;
+}
+
 /* ---- positives of the class maps (test infrastructure): centerness BCE + axis-aligned IoU loss, restated in the
  * REFERENCE's parametrisation -- `_bbox_pred_to_bbox` (dense_heads/cagroup_head.py:654-668: centre = p + (d+ - d-)/2,
  * size = d- + d+), corners = centre -/+ size/2 (iou3d_loss.py:_corners), axis_aligned_bbox_overlaps_3d

@@ -165,6 +165,43 @@ def test_oracle_adamw_step_matches_torch_fused_adamw(oracle):
     torch.testing.assert_close(v, opt.state[pt]["exp_avg_sq"], rtol=2e-6, atol=1e-7)
 
 
+def _norm_case(lib, dev, max_norm, scale):
+    from ctypes import c_float, c_int64
+    g = torch.Generator().manual_seed(3)
+    grads = [(torch.randn(n, generator=g) * scale).to(dev) for n in (70001, 5, 32768, 33)]
+    rows, pid = [], []
+    for k, t in enumerate(grads):
+        for o in range(0, t.numel(), 32768):
+            rows.append((0, 0, 0, o, min(32768, t.numel() - o)))          # (the parameter / moment columns are not read)
+            pid.append(k)
+    rows_t = torch.tensor(rows, dtype=torch.int64).to(dev)
+    pid_t = torch.tensor(pid, dtype=torch.int32).to(dev)
+    gp = torch.tensor([t.data_ptr() for t in grads], dtype=torch.int64).to(dev)
+    sc = torch.empty(1, dtype=torch.float64, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    with _lib.use_library(lib):
+        lib.call("cg3d_grad_norm_clip", rows_t.data_ptr(), pid_t.data_ptr(), c_int64(len(rows)), gp.data_ptr(), c_float(max_norm),
+                 sc.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), lib.stream())
+    params = [torch.nn.Parameter(torch.zeros_like(t)) for t in grads]
+    for p, t in zip(params, grads):
+        p.grad = t.clone()
+    total = torch.nn.utils.clip_grad_norm_(params, max_norm)
+    return out.cpu(), float(total), float(params[0].grad[0] / grads[0][0])
+
+
+@pytest.mark.parametrize("max_norm,scale", [(10.0, 1.0), (10.0, 1e-3), (0.5, 30.0)])
+def test_oracle_grad_norm_clip_is_clip_grad_norm(oracle, max_norm, scale):
+    out, total, coef = _norm_case(oracle, "cpu", max_norm, scale)
+    assert abs(float(out[0]) - total) <= 2e-6 * total and abs(float(out[1]) - coef) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_norm,scale", [(10.0, 1.0), (10.0, 1e-3), (0.5, 30.0)])
+def test_hip_grad_norm_clip_is_clip_grad_norm(hip, max_norm, scale):
+    out, total, coef = _norm_case(hip, "cuda", max_norm, scale)
+    assert abs(float(out[0]) - total) <= 2e-6 * total and abs(float(out[1]) - coef) <= 2e-6
+
+
 @pytest.mark.gpu
 def test_fused_clip_adamw_launch_matches_torch_on_device(hip):
     """ClippedAdamW on the device takes the library's one-launch step (after torch has created the state in step 1):
