@@ -264,12 +264,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # live HIP-event timing of every conv launch (the roofline figures) -- on at most ~6 of the timed steps, spread evenly
-    # over the timed region: two events per launch add up (20 k live events in a 100-step run slowed the run itself)
+    # live HIP-event timing of every conv launch (the roofline figures) -- on ~3 of the timed steps, spread evenly over the
+    # timed region: two events per launch add up (a profiled step records ~440 events and takes ~2 ms longer; 20 k live events
+    # in a 100-step run slowed the run itself).  3 steps x 67 launches of the dominant kernel is plenty for an average.
     def timed_run(steps):
         me.KernelProfile.reset()
         me.KernelProfile.wgrad = True               # the weight gradient is part of the step's 8(d) work
-        stride = max(1, -(-steps // 6))
+        stride = max(1, -(-steps // int(os.environ.get("CG3D_BENCH_PROFILE_STEPS", "3"))))
         profiled = 0
         barrier()
         t0 = time.perf_counter()
