@@ -78,7 +78,10 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_tile_v1_knockout.txt" % RN, "round 2's tile kernel with its pieces knocked out (what motivated the rewrite)"),
                    ("%s_cpu_thread_scaling.txt" % RN, "thread scaling of the cpu_baseline leg (the oracle's S50k step) on the GPU host"),
                    ("%s_pmc_mem_tile_128.txt" % RN, "memory-side counters of the tile kernel, 128->128 @ 82 107 rows"),
-                   ("%s_other_configs.txt" % RN, "bench lines of the other configurations and inference")):
+                   ("%s_other_configs.txt" % RN, "bench lines of the other configurations and inference"),
+                   ("%s_roi_contract.txt" % RN, "the per-RoI 7^3 contraction alone: library form vs cg3d_linear_fwd (stored partial products / atomics, by number of workgroups)"),
+                   ("%s_host_sections.txt" % RN, "host wall-clock per section of the step, batch 1 (no GPU wait) and batch 4"),
+                   ("%s_ops_by_site.txt" % RN, "framework ops, fills / copies, library GEMMs, reductions and sorts per source line; C-ABI calls per entry point (one step)")):
     if os.path.exists(os.path.join(P, name)):
         out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
 open(os.path.join(P, "README.md"), "w").write("".join(out))
