@@ -212,14 +212,48 @@ def cpu_baseline_subprocess(args, threads=None, sample=None, budget=45):
     return json.loads(lines[-1])
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, the way
+    the reference's `tools/scripts/dist_train.sh:1-18` wraps `tools/train.py` (`python -m torch.distributed.launch
+    --nproc_per_node=N train.py --launcher pytorch`, ranks picked up at `tools/train.py:59-74`).  The children see
+    WORLD_SIZE and take the normal path below; rank 0's JSON line is this process's output, its exit code ours."""
+    import subprocess
+    single = os.environ.get("CG3D_SINGLE_DEVICE") == "1"          # test aid: every rank on cuda:0 (gloo)
+    if not single:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to report a %d-GPU number from fewer devices"
+                             % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on this stack
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args, not args.natural)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the line's n_gpus would not be the number asked for "
+                         "(launch with --nproc-per-node %d, or drop the launcher and let --gpus start the ranks)"
+                         % (args.gpus, world, args.gpus))
+    if world > 1 and os.environ.get("CG3D_SINGLE_DEVICE") != "1" and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     global _ALL_CPUS
     _ALL_CPUS, _ = pin_host_threads(local_rank)        # before the runtime starts its helper threads
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -267,6 +301,8 @@ def main():
     # live HIP-event timing of every conv launch (the roofline figures) -- on ~3 of the timed steps, spread evenly over the
     # timed region: two events per launch add up (a profiled step records ~440 events and takes ~2 ms longer; 20 k live events
     # in a 100-step run slowed the run itself).  3 steps x 67 launches of the dominant kernel is plenty for an average.
+    rank_ms = []
+
     def timed_run(steps):
         me.KernelProfile.reset()
         me.KernelProfile.wgrad = True               # the weight gradient is part of the step's 8(d) work
@@ -286,8 +322,10 @@ def main():
         me.KernelProfile.enabled = False
         if use_dist:
             t = torch.tensor([dt_], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_ = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_ms[:] = [float(e.item()) / steps * 1e3 for e in every]
+            dt_ = max(float(e.item()) for e in every)            # the job is as slow as its slowest rank
         return dt_, profiled, tb_
 
     KNAMES = {
@@ -355,6 +393,7 @@ def main():
         return roof
 
     dt, profiled_steps, tb = timed_run(args.steps)
+    per_rank_ms = list(rank_ms)
     roof = roofline_of(dt, profiled_steps, args.steps, me.PRECISION) if rank == 0 else None
 
     fp32 = None
@@ -395,6 +434,8 @@ def main():
             out["fp32"] = fp32
         if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):
             out["comm"] = model.grad_sync.report()
+        if use_dist:
+            out["per_rank_ms_per_step"] = per_rank_ms
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline_subprocess(args)

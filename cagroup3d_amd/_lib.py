@@ -85,6 +85,9 @@ _SIGNATURES = {
     "cg3d_boxes_iou_bev": (c_int32, [P, c_int64, P, c_int64, P, P]),
     "cg3d_boxes_iou_bev_cpu": (c_int32, [P, c_int64, P, c_int64, P]),
     "cg3d_nms": (c_int32, [P, c_int64, c_float, c_int32, P, P, P, P]),
+    "cg3d_nms_gpu_ws_bytes": (c_int64, [c_int64]),
+    "cg3d_nms_gpu": (c_int32, [P, c_int64, P, c_float, P, P]),
+    "cg3d_nms_normal_gpu": (c_int32, [P, c_int64, P, c_float, P, P]),
     "cg3d_nms_batched": (c_int32, [P, P, P, c_int32, c_int64, c_float, c_int32, P, P, P, P]),
     "cg3d_knn_ws_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "cg3d_knn": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P]),

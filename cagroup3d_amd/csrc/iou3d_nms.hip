@@ -365,6 +365,33 @@ extern "C" int cg3d_nms(const float *boxes, int64_t n, float thresh, int32_t rot
     if (n < 0) return CG3D_ERR_ARG;
     return nms_launch(boxes, nullptr, nullptr, 1, n, thresh, rotated, mask_ws, keep, num_keep, cg3d_hs(stream));
 }
+// nms_gpu / nms_normal_gpu in the reference's own shape (iou3d_nms.h:9-12): host keep list, count returned, host blocked.
+extern "C" int64_t cg3d_nms_gpu_ws_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    return n * ((n + 63) / 64) * 8 + n * 8 + 16;
+}
+static int nms_host_keep(const float *boxes, int64_t n, int64_t *keep_host, float thresh, int rotated, void *ws, hipStream_t s) {
+    if (n < 0 || (n > 0 && (!boxes || !keep_host)) || !ws) return CG3D_ERR_ARG;
+    if (n == 0) return 0;
+    uint64_t *mask = (uint64_t *)ws;
+    int64_t *keep = (int64_t *)(mask + n * ((n + 63) / 64));
+    int32_t *num = (int32_t *)(keep + n);
+    const int rc = nms_launch(boxes, nullptr, nullptr, 1, n, thresh, rotated, mask, keep, num, s);
+    if (rc != CG3D_OK) return rc;
+    int32_t nk = 0;
+    if (hipMemcpyAsync(&nk, num, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (nk < 0 || nk > n) return CG3D_ERR_LAUNCH;
+    if (nk > 0 && hipMemcpyAsync(keep_host, keep, (size_t)nk * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    return (int)nk;
+}
+extern "C" int cg3d_nms_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thresh, void *ws, cg3d_stream_t stream) {
+    return nms_host_keep(boxes, n, keep_host, thresh, 1, ws, cg3d_hs(stream));
+}
+extern "C" int cg3d_nms_normal_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thresh, void *ws, cg3d_stream_t stream) {
+    return nms_host_keep(boxes, n, keep_host, thresh, 0, ws, cg3d_hs(stream));
+}
 extern "C" int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off, int32_t nseg,
                                 int64_t max_seg, float thresh, int32_t rotated, uint64_t *mask_ws, int64_t *keep,
                                 int32_t *num_keep, cg3d_stream_t stream) {

@@ -94,7 +94,9 @@ __global__ void k_clip_coef(const double *__restrict__ sum, float max_norm, floa
     const float norm = (float)sqrt(*sum);
     *norm_out = norm;
     const float c = max_norm / (norm + 1e-6f);
-    *coef_out = c < 1.f ? c : 1.f;
+    // torch.clamp(max_norm / (norm + 1e-6), max=1) propagates NaN: a non-finite gradient norm poisons EVERY parameter, as
+    // the reference's clip_grad_norm_ does (tools/train_utils/train_utils.py:40-47), instead of corrupting only some tensors
+    *coef_out = (c < 1.f || c != c) ? c : 1.f;
 }
 extern "C" int cg3d_grad_norm_clip(const int64_t *table, const int32_t *pid, int64_t nrows, const int64_t *grads, float max_norm,
                                    double *scratch, float *norm, float *coef, cg3d_stream_t stream) {

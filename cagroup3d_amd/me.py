@@ -376,14 +376,34 @@ def _morton_order(coords_i32):
     return order[:n].long()
 
 
+_CACHE_LOCK = __import__("threading").RLock()
+
+
+def _cached(cache, key, build, limit=None, cross_stream=False):
+    """Get-or-build on one of the module-level host caches (offset tables, chunk tables, identity pair lists ...).  The
+    coordinate-prefetch worker (detectors/cagroup3d.py::_PrefetchWorker) runs the same code as the main thread, so lookup,
+    the size-triggered `clear()` and the insert happen under ONE lock.  cross_stream: the cache is read by BOTH threads
+    (the kernel-offset tables) -- an entry built on a device is published only after the building thread's stream has
+    finished its upload, or the other thread would read the table on ITS stream with nothing ordering it after the copy
+    (those entries are permanent: the wait is paid once per key, never in steady state)."""
+    with _CACHE_LOCK:
+        hit = cache.get(key)
+        if hit is None:
+            hit = build()
+            if cross_stream and torch.cuda.is_available() and _lib.get().is_device:
+                torch.cuda.current_stream().synchronize()
+            if limit is not None and len(cache) > limit:
+                cache.clear()
+            cache[key] = hit
+        return hit
+
+
 _offset_cache = {}
 
 
 def _offsets(kernel_size, spacing, device):
     ck = (int(kernel_size), int(spacing), str(device))
-    if ck not in _offset_cache:
-        _offset_cache[ck] = _make_offsets(kernel_size, spacing, device)
-    return _offset_cache[ck]
+    return _cached(_offset_cache, ck, lambda: _make_offsets(kernel_size, spacing, device), cross_stream=True)
 
 
 def _make_offsets(kernel_size, spacing, device):
@@ -927,11 +947,8 @@ def _prep_bf16_group(weights, transposed, frag=False):
     elif lib.is_device:
         _WeightPlan.groups[(key, transposed, frag)] = [[w.detach() for w in weights], None, None]
         _WeightPlan.dirty = True
-    tab = _wptr_cache.get(key)
-    if tab is None:
-        if len(_wptr_cache) > 64:
-            _wptr_cache.clear()
-        tab = _wptr_cache[key] = h2d(list(key), torch.int64, weights[0].device) if lib.is_device else torch.tensor(key, dtype=torch.int64)
+    tab = _cached(_wptr_cache, key, lambda: h2d(list(key), torch.int64, weights[0].device) if lib.is_device
+                  else torch.tensor(key, dtype=torch.int64), 64)
     out = torch.empty((G * K, cout, cin) if transposed else (G * K, cin, cout), dtype=torch.int16, device=weights[0].device)
     lib.call("cg3d_spconv_prep_weights_frag" if frag else "cg3d_spconv_prep_weights_bf16_multi", ptr(None), ptr(tab),
              ptr(out if transposed else None), ptr(None if transposed else out), c_int32(G), c_int64(K), c_int32(cin),
@@ -1274,8 +1291,8 @@ _ident_cache = {}
 def _identity_pairs(n, seglen, device):
     """arange pair list + (0, start, count) segment table for an n-row dense weight gradient (cached)."""
     ck = (n, seglen, str(device))
-    hit = _ident_cache.get(ck)
-    if hit is None:
+
+    def build():
         ar = None
         for (n2, _, d2), v in _ident_cache.items():
             if n2 == n and d2 == str(device):
@@ -1284,11 +1301,8 @@ def _identity_pairs(n, seglen, device):
             ar = torch.arange(n, dtype=torch.int32, device=device)
         starts = np.arange(0, n, seglen, dtype=np.int64)
         tab = np.stack([np.zeros_like(starts), starts, np.minimum(seglen, n - starts)], 1).astype(np.int32)
-        hit = (ar, h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
-        if len(_ident_cache) > 256:
-            _ident_cache.clear()
-        _ident_cache[ck] = hit
-    return hit
+        return (ar, h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
+    return _cached(_ident_cache, ck, build, 256)
 
 
 class LinearFunction(torch.autograd.Function):
@@ -1464,7 +1478,11 @@ def rows_by_batch(b, n_batch=None):
     if not b.is_cuda:
         order = torch.sort(b, stable=True)[1]
         return list(torch.split(order, torch.bincount(b, minlength=n_batch or 0).tolist()))
+    # descents, plus (known batch size) ids outside [0, n_batch): `count_ids` would drop those silently and torch.split
+    # would then fail with an opaque size error -- they take the sort + bincount path below, which extends the list
     desc = (b[1:] < b[:-1]).sum().view(1)
+    if n_batch is not None:
+        desc = desc + (b[-1] >= n_batch) + (b[0] < 0)
     if n_batch is None:
         host = torch.cat([desc, b[-1:]]).tolist()          # batch-major: the last row holds the largest index
         if host[0] == 0:
@@ -1474,6 +1492,8 @@ def rows_by_batch(b, n_batch=None):
         host = torch.cat([desc, count_ids(b, n_batch)]).tolist()
         if host[0] == 0:
             return list(torch.split(torch.arange(b.numel(), device=b.device), host[1:]))
+    if int(b.min()) < 0:
+        raise ValueError("rows_by_batch: negative batch index")
     order = torch.sort(b, stable=True)[1]
     return list(torch.split(order, torch.bincount(b, minlength=n_batch or 0).tolist()))
 
@@ -1528,20 +1548,17 @@ def _roi_pairs(R, G, seglen, device):
     """Pair list of the per-RoI contraction's weight gradient: offset g pairs row r * G + g of the gathered grid rows
     with output row r.  int32 in [G * R], out [G * R] (offset-major), segment table (g, start, count <= seglen); cached."""
     ck = (R, G, seglen, str(device))
-    hit = _roi_pair_cache.get(ck)
-    if hit is None:
+
+    def build():
         r, g = np.arange(R, dtype=np.int64), np.arange(G, dtype=np.int64)
         pin = (r[None, :] * G + g[:, None]).reshape(-1).astype(np.int32)
         pout = np.tile(r, G).astype(np.int32)
         starts = np.arange(0, R, seglen, dtype=np.int64)
         tab = np.stack([np.repeat(g, len(starts)), (g[:, None] * R + starts[None, :]).reshape(-1),
                         np.tile(np.minimum(seglen, R - starts), G)], 1).astype(np.int32)
-        hit = (h2d(torch.from_numpy(pin), torch.int32, device), h2d(torch.from_numpy(pout), torch.int32, device),
-               h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
-        if len(_roi_pair_cache) > 16:
-            _roi_pair_cache.clear()
-        _roi_pair_cache[ck] = hit
-    return hit
+        return (h2d(torch.from_numpy(pin), torch.int32, device), h2d(torch.from_numpy(pout), torch.int32, device),
+                h2d(torch.from_numpy(tab), torch.int32, device), int(tab.shape[0]))
+    return _cached(_roi_pair_cache, ck, build, 16)
 
 
 class RoiContractFunction(torch.autograd.Function):
@@ -1718,8 +1735,8 @@ def _bn_chunks(bounds, device, C=64):
     rpb = 256 // max(1, min(C // 4, 256))
     step_rows = max(8, min(128, 8 * rpb))
     ck = (bounds, device, step_rows)
-    hit = _chunk_cache.get(ck)
-    if hit is None:
+
+    def build():
         b = np.asarray(bounds, dtype=np.int64)
         ng = b[1:] - b[:-1]
 
@@ -1737,11 +1754,8 @@ def _bn_chunks(bounds, device, C=64):
         app, napp, _ = table(np.full_like(ng, step_rows))
         ns = np.maximum(ng, 1).astype(np.float64)
         unb = h2d(torch.from_numpy((ns / np.maximum(ns - 1, 1)).astype(np.float32)), torch.float32, device).view(-1, 1)   # biased -> unbiased variance
-        hit = (red, nred, gco, h2d(torch.from_numpy(ns.astype(np.float32)), torch.float32, device), app, napp, unb)
-        if len(_chunk_cache) > 512:
-            _chunk_cache.clear()
-        _chunk_cache[ck] = hit
-    return hit
+        return (red, nred, gco, h2d(torch.from_numpy(ns.astype(np.float32)), torch.float32, device), app, napp, unb)
+    return _cached(_chunk_cache, ck, build, 512)
 
 
 class FusedBNActFunction(torch.autograd.Function):
@@ -1916,10 +1930,8 @@ ADD_RELU = __import__("os").environ.get("CG3D_ADD_RELU", "1") != "0"
 def _unit_bn(C, device):
     """(zeros, ones) float32 [1, C]: the identity BatchNorm (mean 0, variance 1, gamma 1, beta 0, eps 0)."""
     ck = (C, str(device))
-    hit = _unit_cache.get(ck)
-    if hit is None:
-        hit = _unit_cache[ck] = (torch.zeros((1, C), dtype=torch.float32, device=device), torch.ones((1, C), dtype=torch.float32, device=device))
-    return hit
+    return _cached(_unit_cache, ck, lambda: (torch.zeros((1, C), dtype=torch.float32, device=device),
+                                             torch.ones((1, C), dtype=torch.float32, device=device)))
 
 
 class AddReluFunction(torch.autograd.Function):

@@ -132,3 +132,31 @@ def nms_batched_sorted(boxes_sorted, seg_off_cpu, thresh, rotated):
     lib.call("cg3d_nms_batched", ptr(boxes_sorted), ptr(seg_d), ptr(moff_d), c_int32(nseg), c_int64(max_seg),
              c_float(thresh), c_int32(1 if rotated else 0), ptr(mask), ptr(keep), ptr(num), lib.stream())
     return keep, num[:nseg]
+
+
+class iou3d_nms_cuda:  # noqa: N801  (the reference's extension module name, iou3d_nms_api.cpp:11-17)
+    """The reference extension's two NMS entry points in their literal shape -- `nms_gpu(boxes, keep, thresh) -> num_kept`
+    with `boxes` sorted by descending score on the device and `keep` an int64 HOST tensor (iou3d_nms.h:9-12,
+    iou3d_nms.cpp:90-186) -- over cg3d_nms_gpu / cg3d_nms_normal_gpu.  Blocks the host like the reference; the detector
+    itself uses the device-resident forms above."""
+
+    @staticmethod
+    def _run(name, boxes, keep, thresh):
+        lib = _lib.get()
+        boxes = boxes.contiguous().float()
+        lib.check(boxes)
+        assert keep.dtype == torch.int64 and not keep.is_cuda and keep.is_contiguous() and keep.numel() >= boxes.shape[0]
+        n = boxes.shape[0]
+        ws = torch.empty(max(int(lib.raw("cg3d_nms_gpu_ws_bytes")(n)), 16), dtype=torch.uint8, device=boxes.device)
+        rc = lib.raw(name)(ptr(boxes), c_int64(n), keep.data_ptr(), c_float(thresh), ptr(ws), lib.stream())
+        if rc < 0:
+            raise _lib.CG3DError("%s failed: %d" % (name, rc))
+        return int(rc)
+
+    @staticmethod
+    def nms_gpu(boxes, keep, thresh):
+        return iou3d_nms_cuda._run("cg3d_nms_gpu", boxes, keep, thresh)
+
+    @staticmethod
+    def nms_normal_gpu(boxes, keep, thresh):
+        return iou3d_nms_cuda._run("cg3d_nms_normal_gpu", boxes, keep, thresh)

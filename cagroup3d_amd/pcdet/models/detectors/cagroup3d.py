@@ -163,9 +163,10 @@ class CAGroup3D(Detector3DTemplate):
         returns.  What the dry run may touch (and nothing else): the backbone's modules READ-ONLY (no parameter, buffer or
         attribute is written: `COORDS_ONLY` is a per-thread flag and BatchNorm / convolutions return placeholders under it),
         `dense_head.data_targets` / `_forced_selection` (pure functions of the batch), its own side stream, and the
-        host-side caches of `me.py` (`_offset_cache`, `_chunk_cache`, `_ident_cache`, the pinned staging rings -- keyed per
-        stream), whose get-or-insert updates are single dict operations under the GIL; their size-triggered `clear()`s only
-        drop entries that are rebuilt on the next miss.  A worker exception surfaces at `.result()`, i.e. one step late.  Submit the NEXT batch before starting the current step: the dry run is Python glue, short launches and
+        host-side caches of `me.py` (`_offset_cache`, `_chunk_cache`, `_ident_cache` ...: every get-or-build and every
+        size-triggered `clear()` runs under `me._CACHE_LOCK`, and the one cache both threads read -- the kernel-offset tables --
+        publishes an entry only after its upload has completed on the building thread's stream) and the pinned staging rings
+        (keyed per stream).  A worker exception surfaces at `.result()`, i.e. one step late.  Submit the NEXT batch before starting the current step: the dry run is Python glue, short launches and
         ~30 host reads of device counters (each a wait for the side stream); on its own thread those waits and every
         GIL-free stretch (launches, ATen calls, the autograd engine's C++ side) overlap with the issue path of the
         current step, which is what bounds the step once the kernels are fast (host path)."""

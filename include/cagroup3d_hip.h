@@ -13,6 +13,7 @@
  *       boxes_iou_bev_gpu     -> cg3d_boxes_iou_bev       (iou3d_nms.cpp:68-88,  kernel .cu:251-265)
  *       nms_gpu               -> cg3d_nms (rotated=1)     (iou3d_nms.cpp:90-136, kernel .cu:267-311)
  *       nms_normal_gpu        -> cg3d_nms (rotated=0)     (iou3d_nms.cpp:139-186,kernel .cu:328-372)
+ *       (literal forms with a HOST keep list and the count as return value: cg3d_nms_gpu / cg3d_nms_normal_gpu)
  *   reference pybind module `KNN_OP`          (pcdet/ops/knn/src/knn.cpp:28-45)
  *       knn_wrapper           -> cg3d_knn                 (knn_cuda.cu:58-115)
  *   reference pybind module `sort_vertices`   (pcdet/ops/rotated_iou/cuda_op/sort_vert.cpp:6-33)
@@ -400,6 +401,17 @@ int cg3d_nms(const float *boxes, int64_t n, float thresh, int32_t rotated,
 int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off,
                      int32_t nseg, int64_t max_seg, float thresh, int32_t rotated,
                      uint64_t *mask_ws, int64_t *keep, int32_t *num_keep, cg3d_stream_t stream);
+/* The reference's two literal entry points (pcdet/ops/iou3d_nms/src/iou3d_nms.h:9-12, iou3d_nms.cpp:90-186):
+ *   int nms_gpu(at::Tensor boxes [n,7] sorted by descending score, at::Tensor keep [n] int64 ON THE HOST, float thresh)
+ *   int nms_normal_gpu(same)                                   both return the number of kept boxes.
+ * Same argument order (boxes, keep, thresh), `keep` is HOST memory, the return value is the count (>= 0) or a negative
+ * CG3D_ERR_*; the call blocks the host until `keep` is filled, like the reference (which copies the mask to the host and
+ * scans there).  The reference cudaMallocs its mask per call (iou3d_nms.cpp:103,151); here the caller lends
+ * `ws`: cg3d_nms_gpu_ws_bytes(n) bytes of DEVICE scratch (mask tiles + device keep list + count).  Thin wrappers over
+ * cg3d_nms (rotated = 1 / 0); the product itself calls cg3d_nms / cg3d_nms_batched and leaves `keep` on the device. */
+int64_t cg3d_nms_gpu_ws_bytes(int64_t n);
+int cg3d_nms_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thresh, void *ws, cg3d_stream_t stream);
+int cg3d_nms_normal_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thresh, void *ws, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * kNN (brute force; reference knn_cuda.cu:58-94): for every query new_xyz[b,m,:] the k nearest

@@ -266,6 +266,26 @@ int cg3d_nms(const float *boxes, int64_t n, float thr, int32_t rotated, uint64_t
     og_nms_one(boxes, n, thr, rotated, mask_ws, keep, num_keep);
     return CG3D_OK;
 }
+/* the reference's literal forms (iou3d_nms.h:9-12): keep list handed back, count returned */
+int64_t cg3d_nms_gpu_ws_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    return n * ((n + 63) / 64) * 8 + n * 8 + 16;
+}
+static int og_nms_host_keep(const float *boxes, int64_t n, int64_t *keep_host, float thr, int rotated, void *ws) {
+    if (n < 0 || (n > 0 && (!boxes || !keep_host)) || !ws) return CG3D_ERR_ARG;
+    if (n == 0) return 0;
+    int32_t nk = 0;
+    og_nms_one(boxes, n, thr, rotated, (uint64_t *)ws, keep_host, &nk);
+    return (int)nk;
+}
+int cg3d_nms_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thr, void *ws, cg3d_stream_t s) {
+    (void)s;
+    return og_nms_host_keep(boxes, n, keep_host, thr, 1, ws);
+}
+int cg3d_nms_normal_gpu(const float *boxes, int64_t n, int64_t *keep_host, float thr, void *ws, cg3d_stream_t s) {
+    (void)s;
+    return og_nms_host_keep(boxes, n, keep_host, thr, 0, ws);
+}
 int cg3d_nms_batched(const float *boxes, const int64_t *seg_off, const int64_t *mask_off, int32_t nseg,
                      int64_t max_seg, float thr, int32_t rotated, uint64_t *mask_ws, int64_t *keep,
                      int32_t *num_keep, cg3d_stream_t s) {

@@ -94,7 +94,7 @@ int cg3d_grad_norm_clip(const int64_t *table, const int32_t *pid, int64_t nrows,
     *scratch = s;
     *norm = (float)sqrt(s);
     const float c = max_norm / (*norm + 1e-6f);
-    *coef = c < 1.f ? c : 1.f;
+    *coef = (c < 1.f || c != c) ? c : 1.f;     /* torch.clamp(max=1) propagates NaN */
     return CG3D_OK;
 }
 

@@ -24,3 +24,30 @@ def test_bench_two_ranks_one_device():
     assert b["n_gpus"] == 2 and b["steps"] == 2 and b["scaling"] == "weak" and b["value"] > 0
     assert b["config"]["parallelism"] == "dp2" and "cpu_baseline" not in b      # the CPU leg runs at N=1 only
     assert abs(b["value"] - 2 * 4 * 2 / (b["ms_per_step"] * 2e-3)) < 1e-6 * b["value"]   # whole-job scenes / time
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1) must be a real
+    two-rank run: bench.py re-executes itself under torch.distributed.run and the line says n_gpus == 2."""
+    env = dict(os.environ, CG3D_SINGLE_DEVICE="1", CG3D_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "S5k",
+           "--no-fp32"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["parallelism"] == "dp2"
+    assert len(b["per_rank_ms_per_step"]) == 2 and max(b["per_rank_ms_per_step"]) == pytest.approx(b["ms_per_step"])
+    assert b["comm"]["world"] == 2 and b["comm"]["collectives_per_step"] == 3 and sum(b["comm"]["bucket_bytes"].values()) > 4e8
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """Under a launcher whose WORLD_SIZE disagrees with --gpus the run stops before it touches a device (CPU-runnable):
+    a SCALE run must never print a 1-GPU number under `--gpus 8`."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

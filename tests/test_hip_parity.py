@@ -424,6 +424,26 @@ def test_nms_keep_bit_exact(oracle, hip, n, rotated):
         assert 0 < out.numel() <= n
 
 
+@pytest.mark.parametrize("n,rotated", [(0, True), (1, False), (300, True), (777, False)])
+def test_literal_nms_entry_points_match_the_device_form(oracle, hip, n, rotated):
+    """cg3d_nms_gpu / cg3d_nms_normal_gpu (the reference's `nms_gpu(boxes, keep, thresh) -> num` with a HOST keep tensor,
+    iou3d_nms.h:9-12): same kept indices as cg3d_nms, on the oracle and on the device."""
+    boxes = rand_boxes(n, seed=n + 11, yaw=rotated, extent=3.0)
+    scores = torch.rand(n, generator=torch.Generator().manual_seed(n))
+    b_sorted = boxes[scores.sort(0, descending=True)[1]].contiguous()
+    ext = iou3d_nms_utils.iou3d_nms_cuda
+
+    def fn(b):
+        keep = torch.full((max(n, 1),), -1, dtype=torch.int64)
+        num = (ext.nms_gpu if rotated else ext.nms_normal_gpu)(b, keep, 0.5)
+        dk, dn, _ = iou3d_nms_utils._nms_sorted(b, 0.5, rotated)
+        return keep[:num], dk[: int(dn.item())]
+    ref, out = both(oracle, hip, fn, b_sorted)
+    eq(ref[0], out[0])
+    eq(out[0], out[1].cpu())
+    eq(ref[0], ref[1])
+
+
 def test_nms_mask_words_bit_exact(oracle, hip):
     n = 500
     boxes = rand_boxes(n, seed=3, yaw=True, extent=2.0)

@@ -194,3 +194,27 @@ def test_deferred_log_reads_the_device_once_and_behaves_like_a_dict():
     assert dict(tb)["rcnn"] == 0.5 and {**tb}["loss_b"] == 2.0 and tb.get("missing", -1) == -1 and "loss_a" in tb
     assert json.loads(json.dumps(tb))["one_stage_loss"] == 3.0 and isinstance(tb, dict) and len(tb) == 7
     assert one["loss_a"] == 1.0                                       # the absorbed log can still be read on its own
+
+
+def test_deferred_log_write_and_remove_methods_see_the_pending_values():
+    """pop / setdefault / popitem / == / | / update on a log whose numbers are still pending; a key the user wrote before the
+    first read survives it; two logs that absorbed the same block share ONE host read."""
+    from cagroup3d_amd.pcdet.utils.common_utils import DeferredLog
+    mk = lambda: DeferredLog(("loss_bbox", "loss_cls"), torch.tensor([1.5, 2.5]))   # noqa: E731
+    assert mk().pop("loss_bbox") == 1.5 and mk().pop("nope", None) is None
+    assert mk().setdefault("loss_cls", 9.0) == 2.5 and mk().setdefault("new", 9.0) == 9.0
+    assert mk().popitem() == ("loss_cls", 2.5)
+    assert mk() == {"loss_bbox": 1.5, "loss_cls": 2.5} and mk() == mk() and mk() != {"loss_bbox": 1.5}
+    assert (mk() | {"x": 1}) == {"loss_bbox": 1.5, "loss_cls": 2.5, "x": 1} and ({"x": 1} | mk())["loss_cls"] == 2.5
+    d = mk()
+    d["loss_bbox"] = -1.0                       # written BEFORE the first read: must not be overwritten by the device value
+    d.update(loss_cls=-2.0, other=3)
+    assert d == {"loss_bbox": -1.0, "loss_cls": -2.0, "other": 3}
+    d = mk()
+    del d["loss_bbox"]
+    assert list(d) == ["loss_cls"]
+    src = mk()
+    a, b = DeferredLog().absorb(src), DeferredLog().absorb(src)
+    assert a["loss_cls"] == 2.5 and src._pend[0].host == [1.5, 2.5]      # materialised once ...
+    src._pend[0].values = None                                           # ... so the second log never touches the tensor
+    assert b["loss_bbox"] == 1.5

@@ -202,6 +202,41 @@ def test_hip_grad_norm_clip_is_clip_grad_norm(hip, max_norm, scale):
     assert abs(float(out[0]) - total) <= 2e-6 * total and abs(float(out[1]) - coef) <= 2e-6
 
 
+def _nonfinite_norm_case(lib, dev, bad):
+    """A NaN / Inf gradient: torch's clip coefficient clamp(max_norm / (norm + 1e-6), max=1) is NaN for a NaN norm and 0 for
+    an infinite one -- the fused form must hand the optimiser the same coefficient (no half-poisoned parameter set)."""
+    from ctypes import c_float, c_int64
+    g = torch.randn(4096)
+    g[17] = bad
+    g = g.to(dev)
+    rows_t = torch.tensor([(0, 0, 0, 0, 4096)], dtype=torch.int64).to(dev)
+    pid_t = torch.zeros(1, dtype=torch.int32).to(dev)
+    gp = torch.tensor([g.data_ptr()], dtype=torch.int64).to(dev)
+    sc = torch.empty(1, dtype=torch.float64, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    with _lib.use_library(lib):
+        lib.call("cg3d_grad_norm_clip", rows_t.data_ptr(), pid_t.data_ptr(), c_int64(1), gp.data_ptr(), c_float(10.0),
+                 sc.data_ptr(), out[0:1].data_ptr(), out[1:2].data_ptr(), lib.stream())
+    p = torch.nn.Parameter(torch.zeros(4096))
+    p.grad = g.cpu().clone()
+    total = torch.nn.utils.clip_grad_norm_([p], 10.0)
+    ref_coef = torch.clamp(10.0 / (total + 1e-6), max=1.0)
+    out = out.cpu()
+    assert torch.isnan(out[0]) == torch.isnan(total) and torch.isinf(out[0]) == torch.isinf(total)
+    assert torch.isnan(out[1]) == torch.isnan(ref_coef) and (torch.isnan(ref_coef) or float(out[1]) == float(ref_coef))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_oracle_grad_norm_clip_propagates_nonfinite(oracle, bad):
+    _nonfinite_norm_case(oracle, "cpu", bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_hip_grad_norm_clip_propagates_nonfinite(hip, bad):
+    _nonfinite_norm_case(hip, "cuda", bad)
+
+
 @pytest.mark.gpu
 def test_fused_clip_adamw_launch_matches_torch_on_device(hip):
     """ClippedAdamW on the device takes the library's one-launch step (after torch has created the state in step 1):
