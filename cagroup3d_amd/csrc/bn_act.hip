@@ -12,6 +12,8 @@
 // them themselves (in fp64, a few channels per thread).  The per-chunk partials + fp64 finalise kernel of rounds 1-2 cost
 // 130 launches of ~10 us per step for a few hundred KB of work.  (One slot was measured first: the ~1 200 workgroups of a
 // layer then queue on the same 2 C addresses at the L2 atomic unit -- 17 -> 70 us per launch.)
+// Determinism: the atomic chains make the slot sums (hence mean / var / running statistics / dgamma / dbeta) differ in the
+// last bits from run to run, like every atomic reduction of this library; the slots are added up in fp64.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include "cg3d_common.h"
 
@@ -160,17 +162,19 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
     for (int q = tq; q < cq; q += tpr) {
         float4 mu, vv;
         if (SUMS) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            // the 16 slot sums are added up in fp64 (each slot is an fp32 atomic chain over ~1/16 of the rows; the slot sums
+            // themselves are large and nearly equal, so their sum is where fp32 would lose the low bits E[x^2] - mean^2 needs)
+            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
                 const float4 u0 = reinterpret_cast<const float4 *>(sums + ((int64_t)(sl * 2) * G + g) * c)[q];
                 const float4 u1 = reinterpret_cast<const float4 *>(sums + ((int64_t)(sl * 2 + 1) * G + g) * c)[q];
-                a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w;
-                a1.x += u1.x; a1.y += u1.y; a1.z += u1.z; a1.w += u1.w;
+                a0[0] += u0.x; a0[1] += u0.y; a0[2] += u0.z; a0[3] += u0.w;
+                a1[0] += u1.x; a1[1] += u1.y; a1[2] += u1.z; a1[3] += u1.w;
             }
             const double n = group_n[g] > 0.f ? (double)group_n[g] : 1.0;
-            const double m0 = a0.x / n, m1 = a0.y / n, m2 = a0.z / n, m3 = a0.w / n;
-            const double v0 = a1.x / n - m0 * m0, v1 = a1.y / n - m1 * m1, v2 = a1.z / n - m2 * m2, v3 = a1.w / n - m3 * m3;
+            const double m0 = a0[0] / n, m1 = a0[1] / n, m2 = a0[2] / n, m3 = a0[3] / n;
+            const double v0 = a1[0] / n - m0 * m0, v1 = a1[1] / n - m1 * m1, v2 = a1[2] / n - m2 * m2, v3 = a1[3] / n - m3 * m3;
             mu = make_float4((float)m0, (float)m1, (float)m2, (float)m3);
             vv = make_float4((float)(v0 > 0 ? v0 : 0), (float)(v1 > 0 ? v1 : 0), (float)(v2 > 0 ? v2 : 0), (float)(v3 > 0 ? v3 : 0));
             if (first_of_group && tr == 0) {
@@ -274,14 +278,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         float4 sb, sg;
         if (SUMS) {
-            sb = make_float4(0.f, 0.f, 0.f, 0.f); sg = sb;
+            double b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};            // slot sums added in fp64, as in the forward
 #pragma unroll
             for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
                 const float4 u0 = reinterpret_cast<const float4 *>(dsums + ((int64_t)(sl * 2) * G + g) * c)[q];
                 const float4 u1 = reinterpret_cast<const float4 *>(dsums + ((int64_t)(sl * 2 + 1) * G + g) * c)[q];
-                sb.x += u0.x; sb.y += u0.y; sb.z += u0.z; sb.w += u0.w;
-                sg.x += u1.x; sg.y += u1.y; sg.z += u1.z; sg.w += u1.w;
+                b0[0] += u0.x; b0[1] += u0.y; b0[2] += u0.z; b0[3] += u0.w;
+                b1[0] += u1.x; b1[1] += u1.y; b1[2] += u1.z; b1[3] += u1.w;
             }
+            sb = make_float4((float)b0[0], (float)b0[1], (float)b0[2], (float)b0[3]);
+            sg = make_float4((float)b1[0], (float)b1[1], (float)b1[2], (float)b1[3]);
             if (first_of_group && tr == 0) {
                 reinterpret_cast<float4 *>(dbeta + (int64_t)g * c)[q] = sb;
                 reinterpret_cast<float4 *>(dgamma + (int64_t)g * c)[q] = sg;

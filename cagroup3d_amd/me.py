@@ -1795,7 +1795,8 @@ class FusedBNActFunction(torch.autograd.Function):
                 # (the cached group_n holds max(rows, 1): a group that is empty HERE must add 0 rows to the global count)
                 rows = h2d(torch.from_numpy(np.diff(np.asarray(bounds, dtype=np.int64)).astype(np.float32)), torch.float32, x.device)
                 sums, group_n = _all_ranks_sums(sums, rows, G * C, sync[0])
-                _SYNC_ROWS[0] = group_n                  # (the caller's running-variance update needs the global row counts)
+                if nachunk == 0:
+                    nachunk = 1        # no rows HERE: one empty chunk still writes mean / var and the running statistics of the global batch
             # mean / variance are derived from the table inside the apply launch (and written out for the backward pass)
             lib.call("cg3d_bn_apply_sums", ptr(x), ptr(res), ptr(achunks), c_int64(nachunk), c_int32(G), c_int32(C), ptr(sums),
                      ptr(group_n), c_float(eps), ptr(gamma), ptr(beta), c_int32(act), ptr(y), ptr(y16), ptr(mean), ptr(var),
@@ -1813,16 +1814,23 @@ class FusedBNActFunction(torch.autograd.Function):
             _ROWS16[y.data_ptr()] = (y, y16)
         ctx.save_for_backward(x, y, mean, var, gamma, chunks, gco, group_n, achunks)
         ctx.meta = (nchunk, G, C, act, bool(use_batch), residual is not None, float(eps), nachunk)
-        ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)      # or autograd fills a zero gradient for `mean` and `var` on every backward
-        return y, mean, var
+        # (group_n: the row counts the statistics were taken over -- every rank's rows under --sync_bn; the caller's
+        # running-variance update needs them)
+        n_rows = group_n.detach()
+        ctx.mark_non_differentiable(mean, var, n_rows)
+        return y, mean, var, n_rows
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy, _dm, _dv, _dn=None):
         x, y, mean, var, gamma, chunks, gco, group_n, achunks = ctx.saved_tensors
         nchunk, G, C, act, use_batch, has_res, eps, nachunk = ctx.meta
         if dy is None:
-            return (None,) * 12
+            if ctx.sync is None:
+                return (None,) * 12
+            # --sync_bn: the peers are about to all-reduce this layer's backward table -- a rank-local "no gradient reached
+            # this output" must not skip the collective (the ranks would pair different all-reduces, or hang)
+            dy = torch.zeros_like(x)
         lib = _lib.get()
         dy = dy.contiguous()
         dsums = ctx.dsums if getattr(ctx, "dsums", None) is not None else torch.zeros(BN_SLOTS * 2 * G * C, dtype=torch.float32, device=x.device)
@@ -1849,9 +1857,6 @@ class FusedBNActFunction(torch.autograd.Function):
         if local is not None:
             dbeta, dgamma = local[0], local[1]
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
-
-
-_SYNC_ROWS = [None]
 
 
 def _all_ranks_sums(table, group_n, gc, group):
@@ -1906,13 +1911,13 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     if track and G == 1 and b0.momentum is not None:
         running = (b0.running_mean, b0.running_var, b0.num_batches_tracked, float(b0.momentum))
     sync = _sync_group_of(b0) if use_batch else None
-    y, mean, var = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in,
-                                            b0.eps, running, sync)
+    y, mean, var, n_rows = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in,
+                                                    b0.eps, running, sync)
     if track and running is None:
         with torch.no_grad():
             m = b0.momentum
             if sync is not None:
-                n_all = _SYNC_ROWS[0].view(-1, 1)
+                n_all = n_rows.view(-1, 1)
                 unb = var * (n_all / (n_all - 1).clamp(min=1))
             else:
                 unb = var * _bn_chunks(tuple(bounds), feats.device, C)[6]

@@ -171,7 +171,7 @@ class CAGroup3DRoIHead(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, nn.modules.batchnorm._BatchNorm) and x.shape[1] % 4 == 0 and x.shape[0] > 0:
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and x.shape[1] % 4 == 0 and (x.shape[0] > 0 or isinstance(m, nn.SyncBatchNorm)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = ME.fused_bn_act(x, [m], act=ME.ACT_RELU if relu else ME.ACT_NONE)
                 i += 2 if relu else 1

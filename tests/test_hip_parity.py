@@ -347,7 +347,7 @@ def test_fused_bn_act_matches_oracle(oracle, hip, act, c, bounds):
 
     def fn(x, res, dy, gamma, beta):
         x, res, gamma, beta = [t.clone().requires_grad_(True) for t in (x, res, gamma, beta)]
-        y, mean, var = me.FusedBNActFunction.apply(x, gamma, beta, res, bounds, act, True, None, None, 1e-5)
+        y, mean, var, _ = me.FusedBNActFunction.apply(x, gamma, beta, res, bounds, act, True, None, None, 1e-5)
         (y * dy).sum().backward()
         return y.detach(), mean, var, x.grad, res.grad, gamma.grad, beta.grad
     ref, out = both(oracle, hip, fn, x, res, dy, gamma, beta)

@@ -67,6 +67,28 @@ def _worker(rank, world, port, out, liboracle):
                 b.eval()
             y = me.fused_bn_act(parts[rank][0], my_bns, lb, me.ACT_NONE)
             assert torch.isfinite(y).all()
+        # A rank with NO rows at all (an RoI head that received no proposals): the
+        # collectives of forward AND backward must still pair up (a hang here is the failure), the statistics are the
+        # other rank's, and the running statistics stay identical on both ranks.
+        torch.manual_seed(11)
+        bn = nn.SyncBatchNorm(C)
+        ref = nn.BatchNorm1d(C)
+        ref.load_state_dict(bn.state_dict())
+        x_full = torch.randn(23, C) * 3 + 1
+        x = (x_full if rank == 0 else x_full[:0]).clone().requires_grad_(True)
+        y = me.fused_bn_act(x, [bn], (0, x.shape[0]), me.ACT_RELU)
+        follow = nn.SyncBatchNorm(C)                       # a second layer on top (rank 1: zero rows through both)
+        z = me.fused_bn_act(y, [follow], (0, y.shape[0]), me.ACT_NONE)
+        loss = z.square().sum() if rank == 0 else z.sum() * 0.0
+        loss.backward()
+        xr = x_full.clone().requires_grad_(True)
+        yr = torch.relu(ref(xr))
+        if rank == 0:
+            torch.testing.assert_close(y.detach(), yr.detach(), rtol=1e-4, atol=1e-5)
+            assert x.grad is not None and torch.isfinite(x.grad).all()
+        torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
     if rank == 0:
         open(out, "w").write("ok")
     dist.barrier()
