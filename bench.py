@@ -428,7 +428,8 @@ def main():
                                         "(k_spconv_pairs_wgrad_rows16 on the bf16 row copies); activations, weights, gradients, "
                                         "BatchNorm, 1x1x1 convolutions, heads, losses and the optimizer stay fp32"
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
-                          "last_loss": tb.get("loss_all")},
+                          "last_loss": tb.get("loss_all"),
+                          "backbone_issue": dict(__import__("cagroup3d_amd.engine", fromlist=["STATS"]).STATS)},
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32

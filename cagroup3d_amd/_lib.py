@@ -93,6 +93,11 @@ _SIGNATURES = {
     "cg3d_knn": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P]),
     "cg3d_ball_query": (c_int32, [c_int32, c_int32, c_int32, c_float, c_int32, P, P, P, P]),
     "cg3d_sort_vertices": (c_int32, [c_int32, c_int32, c_int32, P, P, P, P, P]),
+    # include/cagroup3d_program.h
+    "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
+    "cg3d_event_create": (c_int32, [P]),
+    "cg3d_event_destroy": (c_int32, [c_int64]),
+    "cg3d_event_elapsed_ms": (c_int32, [c_int64, c_int64, P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -23,6 +23,7 @@ SOURCES = {
     "sort_vertices.hip": ["-ffp-contract=off"],
     "bn_act.hip": [],
     "loss.hip": [],
+    "program.hip": [],                       # cg3d_run_program: the launch-table executor (include/cagroup3d_program.h)
     "optim.hip": ["-ffp-contract=off"],      # same rounding as the oracle's plain C (and torch's kernel: no contraction across statements)
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CG3D_HIPCC_EXTRA", "").split()
@@ -45,7 +46,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    hdrs = [os.path.join(HERE, "cg3d_common.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_hip.h")]
+    hdrs = [os.path.join(HERE, "cg3d_common.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_hip.h"),
+            os.path.join(HERE, "..", "..", "include", "cagroup3d_program.h")]
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)

@@ -1,0 +1,46 @@
+// program.hip -- cg3d_run_program: a table of C-ABI calls issued back to back on one stream (include/cagroup3d_program.h).
+// The host language then pays for ONE foreign call per network pass instead of one per launch; see engine.py.
+#include "cg3d_common.h"
+
+static inline int prog_memset(void *dst, int value, int64_t nbytes, cg3d_stream_t s) {
+    if (nbytes < 0 || (nbytes > 0 && !dst)) return CG3D_ERR_ARG;
+    if (nbytes == 0) return CG3D_OK;
+    return hipMemsetAsync(dst, value, (size_t)nbytes, cg3d_hs(s)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+static inline int prog_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t height,
+                              cg3d_stream_t s) {
+    if (width < 0 || height < 0 || dpitch < width || spitch < width) return CG3D_ERR_ARG;
+    if (width == 0 || height == 0) return CG3D_OK;
+    if (!dst || !src) return CG3D_ERR_ARG;
+    return hipMemcpy2DAsync(dst, (size_t)dpitch, src, (size_t)spitch, (size_t)width, (size_t)height, hipMemcpyDeviceToDevice,
+                            cg3d_hs(s)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+static inline int prog_event_record(int64_t handle, cg3d_stream_t s) {
+    if (!handle) return CG3D_ERR_ARG;
+    return hipEventRecord((hipEvent_t)(intptr_t)handle, cg3d_hs(s)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+#define CG3D_PROG_MEMSET prog_memset
+#define CG3D_PROG_COPY2D prog_copy2d
+#define CG3D_PROG_EVENT_RECORD prog_event_record
+#define CG3D_PROGRAM_IMPL
+#include "../../include/cagroup3d_program.h"
+
+extern "C" int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, int64_t *fail_at) {
+    return cg3d_program_run(prog, nops, stream, fail_at);
+}
+extern "C" int cg3d_event_create(int64_t *handle) {
+    if (!handle) return CG3D_ERR_ARG;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return CG3D_ERR_LAUNCH;
+    *handle = (int64_t)(intptr_t)e;
+    return CG3D_OK;
+}
+extern "C" int cg3d_event_destroy(int64_t handle) {
+    if (!handle) return CG3D_ERR_ARG;
+    return hipEventDestroy((hipEvent_t)(intptr_t)handle) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
+extern "C" int cg3d_event_elapsed_ms(int64_t start, int64_t stop, float *ms) {
+    if (!start || !stop || !ms) return CG3D_ERR_ARG;
+    if (hipEventSynchronize((hipEvent_t)(intptr_t)stop) != hipSuccess) return CG3D_ERR_LAUNCH;
+    return hipEventElapsedTime(ms, (hipEvent_t)(intptr_t)start, (hipEvent_t)(intptr_t)stop) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}

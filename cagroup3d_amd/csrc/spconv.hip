@@ -1628,9 +1628,12 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
                                        const int32_t *pair_out, const int32_t *seg, int64_t nseg, float *dW,
                                        int32_t K, int32_t cin, int32_t cout, int32_t precision, cg3d_stream_t stream) {
     if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
+    // CG3D_WGRAD_ACCUMULATE: dW += ... (the caller initialised dW -- e.g. one zero-fill for every weight gradient of a pass)
+    const bool accumulate = (precision & CG3D_WGRAD_ACCUMULATE) != 0;
+    precision &= ~CG3D_WGRAD_ACCUMULATE;
     if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
-    if (hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (!accumulate && hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (nseg == 0) return CG3D_OK;
     if (precision >= 1) {   // bf16 operands: fp32 rows rounded on the fly (1) or rows stored as bf16 (2); fp32 accumulate
         if (cin % 4 != 0 || cout % 4 != 0 || (((uintptr_t)X | (uintptr_t)dY) & 15)) return CG3D_ERR_ARG;

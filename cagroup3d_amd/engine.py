@@ -1,0 +1,876 @@
+"""Launch programs for the BiResNet backbone: one foreign call per pass (include/cagroup3d_program.h).
+
+The per-layer host path of `me.py` -- an `autograd.Function`, three or four `torch.empty`, a ctypes call with twenty marshalled
+arguments and a `SparseTensor` per op -- cost the launching thread ~110 us per layer: 15 ms of the 30 ms a training step took to
+ISSUE, with the GPU waiting (profiles/r04_host_sections.txt).  Here the same sequence of C-ABI calls is written down once per
+step as a table of rows (opcode + arguments) by plain integer arithmetic: every activation, gradient, statistics table and
+scratch buffer of the pass is an offset into ONE arena, the coordinate structures (kernel maps, tile plans, pair lists, segment
+tables) are the ones `me.CoordinateManager` builds anyway, the weights' bf16 copies are slices of the step's weight arena.
+`cg3d_run_program` then issues the whole forward pass -- and, from the one autograd node that stands for the backbone, the whole
+backward pass -- from C.
+
+What a program contains is exactly what the per-layer path launches (same kernels, same arguments, same decisions: the
+functions `me._use_tile`, `SparseConvFunction._implicit`, `_wgrad_seg_len`... are called from here), so the per-layer path stays
+the specification: `tests/test_engine.py` runs both and compares every output and gradient.  Differences, all on purpose:
+  * zero-initialised buffers (statistics tables, atomic-scatter outputs) live in one region per pass, cleared by ONE memset;
+  * all parameter gradients of the backbone are slices of one zero-filled buffer per backward pass, accumulated into with
+    CG3D_WGRAD_ACCUMULATE, and handed to the parameters directly (no AccumulateGrad node per parameter);
+  * sums of gradient contributions are formed when the gradient is first read, one launch per extra contribution.
+
+Reference: pcdet/models/backbones_3d/biresnet.py:8-406 (the module tree `emit` walks is cagroup3d_amd's mirror of it).
+"""
+import os
+import struct
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import me as ME
+
+ENABLED = os.environ.get("CG3D_ENGINE", "1") != "0"
+# how the backbone passes of this process were issued (bench.py prints it: a run that silently fell back to the per-layer
+# path must not be read as an engine measurement)
+STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_ready": 0}
+
+# opcodes of include/cagroup3d_program.h
+(OP_NOP, OP_MEMSET, OP_COPY2D, OP_TO_BF16, OP_TILE_FWD, OP_SPCONV_FWD, OP_SPCONV_FWD_TILED, OP_PAIRS_FWD, OP_PAIRS_WGRAD,
+ OP_LINEAR_FWD, OP_BN_SUMS, OP_BN_APPLY_SUMS, OP_BN_APPLY, OP_BN_BWD_SUMS, OP_BN_BWD_APPLY_SUMS, OP_BN_BWD_APPLY, OP_INTERP_MAP,
+ OP_INTERP_FWD, OP_INTERP_BWD, OP_GATHER_ROWS, OP_SCATTER_ADD_ROWS, OP_SCATTER_MEAN_FWD, OP_SCATTER_MEAN_BWD,
+ OP_EVENT_RECORD) = range(24)
+STRIDE = 24
+WGRAD_ACC = 0x100
+
+# An address inside a program row is either absolute (< 2^60: weights, coordinate structures, module buffers) or an offset into
+# one of the regions below, tagged in the top bits and resolved when the pass is run.
+TAG = 60
+R_ACT, R_ZF, R_ZB, R_PG, R_DOUT, R_IN = (r << TAG for r in range(1, 7))
+#   R_ACT  activations, gradients, scratch          R_ZF  zero-filled at the start of the forward pass
+#   R_ZB   zero-filled at the start of the backward pass
+#   R_PG   the parameter-gradient buffer of a backward pass (fresh zeros per pass)
+#   R_DOUT the gradient of the backbone output (known when backward runs)       R_IN the input features
+ALIGN = 256
+
+
+def _fbits(x):
+    return struct.unpack("<I", struct.pack("<f", float(x)))[0]
+
+
+class NotReady(Exception):
+    """Something the program needs does not exist yet (a weight not recorded in the step's weight arena): the caller runs the
+    per-layer path this step."""
+
+
+class T:
+    """A feature matrix inside a program: fp32 rows [n, c] at `p` (+ optional bf16 copy, + the BatchNorm statistics table its
+    producer filled) and, during backward emission, the list of its gradient contributions."""
+    __slots__ = ("p", "n", "c", "p16", "stats", "need", "gc", "gsum", "gsum16")
+
+    def __init__(self, p, n, c, need=True):
+        self.p, self.n, self.c, self.p16, self.stats, self.need = p, n, c, 0, 0, need
+        self.gc = None          # [(address, bf16 address or 0)] gradient contributions (backward emission)
+        self.gsum = None        # address of their sum once it has been formed
+        self.gsum16 = 0
+
+
+class _Events:
+    """A pair of C-ABI timing events with the `elapsed_time` face of torch.cuda.Event (me.KernelProfile.records)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        h = (ctypes_i64(), ctypes_i64())
+        lib.call("cg3d_event_create", ctypes_ref(h[0]))
+        lib.call("cg3d_event_create", ctypes_ref(h[1]))
+        self.h = (h[0].value, h[1].value)
+
+    def elapsed_time(self, _other=None):
+        ms = ctypes_f32()
+        self.lib.call("cg3d_event_elapsed_ms", self.h[0], self.h[1], ctypes_ref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self.lib.call("cg3d_event_destroy", self.h[0])
+            self.lib.call("cg3d_event_destroy", self.h[1])
+        except Exception:
+            pass
+
+
+def ctypes_i64():
+    import ctypes
+    return ctypes.c_int64(0)
+
+
+def ctypes_f32():
+    import ctypes
+    return ctypes.c_float(0.0)
+
+
+def ctypes_ref(x):
+    import ctypes
+    return ctypes.cast(ctypes.pointer(x), ctypes.c_void_p)
+
+
+class _EvStart:          # (ev0 of a KernelProfile record: elapsed_time(ev1) is answered by the pair)
+    def __init__(self, pair):
+        self.pair = pair
+
+    def elapsed_time(self, _ev1):
+        return self.pair.elapsed_time()
+
+
+class Program:
+    """The rows of one pass, still with region-relative addresses."""
+
+    def __init__(self):
+        self.rows = []
+        self.prof = []          # (row index, flops, bytes, meta, per-pair bytes): conv launches (KernelProfile)
+
+    def add(self, *row):
+        self.rows.append(row)
+
+    def table(self):
+        P = np.zeros((len(self.rows), STRIDE), dtype=np.int64)
+        for i, r in enumerate(self.rows):
+            P[i, :len(r)] = r
+        return P
+
+
+class Builder:
+    def __init__(self, lib, device, gen):
+        self.lib, self.dev, self.gen = lib, device, gen
+        self.f, self.b = Program(), Program()
+        self.tape = []
+        self.size = {R_ACT: 0, R_ZF: 0, R_ZB: 0, R_PG: 0}
+        self.keep = []                  # tensors the rows point into (tables built at emission time)
+        self.params = []                # (parameter, offset in R_PG)
+        self._pidx = {}
+        self.late = []                  # (program, row, column, fn() -> tensor): operands that exist only at run time
+        self.marks = {}                 # name -> backward row index (callbacks between two parts of the backward pass)
+        self.mark_at = {}               # tape position -> name
+        self.bf16 = ME.PRECISION == 1 and ME.BF16_ROWS
+
+    # ---------------------------------------------------------------- memory
+    def alloc(self, nbytes, region=R_ACT):
+        off = self.size[region]
+        self.size[region] = off + ((int(nbytes) + ALIGN - 1) & ~(ALIGN - 1))
+        return region + off
+
+    def new(self, n, c, need=True):
+        return T(self.alloc(max(n, 1) * c * 4), n, c, need)
+
+    def pgrad(self, param):
+        """Address (in R_PG) of the gradient of `param`."""
+        k = id(param)
+        off = self._pidx.get(k)
+        if off is None:
+            off = self._pidx[k] = self.alloc(param.numel() * 4, R_PG)
+            self.params.append((param, off - R_PG))
+        return off
+
+    def rows16(self, t):
+        """bf16 copy of the rows of `t` (written by its producer, or by one conversion pass)."""
+        if not t.p16:
+            t.p16 = self.alloc(max(t.n, 1) * t.c * 2)
+            self.f.add(OP_TO_BF16, t.p, t.p16, t.n * t.c)
+        return t.p16
+
+    def host_table(self, data, dtype):
+        t = ME.h2d(data, dtype, self.dev)
+        self.keep.append(t)
+        return t.data_ptr()
+
+    # ---------------------------------------------------------------- gradients (backward emission)
+    def gadd(self, t, p, p16=0):
+        if t.need:
+            if t.gc is None:
+                t.gc = []
+            t.gc.append((p, p16))
+            t.gsum = None
+
+    def grad(self, t, want16=False):
+        """(address, bf16 address or 0) of the complete gradient of `t`, or None when no contribution arrived."""
+        if not t.gc:
+            return None
+        if t.gsum is None:
+            if len(t.gc) == 1:
+                t.gsum, t.gsum16 = t.gc[0]
+            else:
+                acc = t.gc[0][0]
+                for p, _ in t.gc[1:]:
+                    out = self.alloc(max(t.n, 1) * t.c * 4)
+                    self._add_rows(self.b, acc, p, out, t.n, t.c, ME.ACT_NONE, 0)
+                    acc = out
+                t.gsum, t.gsum16 = acc, 0
+        if want16 and not t.gsum16:
+            t.gsum16 = self.alloc(max(t.n, 1) * t.c * 2)
+            self.b.add(OP_TO_BF16, t.gsum, t.gsum16, t.n * t.c)
+        return t.gsum, t.gsum16
+
+    def _unit(self, c):
+        z, o = ME._unit_bn(c, self.dev)
+        return z.data_ptr(), o.data_ptr()
+
+    def _add_rows(self, prog, a, b, y, n, c, act, y16):
+        """y = act(a + b) (b may be 0): cg3d_bn_apply with the identity normalisation, as me.AddReluFunction does."""
+        z, o = self._unit(c)
+        ch = ME._bn_chunks((0, n), self.dev, c)
+        prog.add(OP_BN_APPLY, a, b, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, act, y, y16)
+
+    # ---------------------------------------------------------------- weights of the step's arena
+    def _planned(self, w3, frag, need_plain):
+        P = ME._WeightPlan
+        e = P.singles.get((w3.data_ptr(), frag))
+        if e is None or e[0].shape != w3.shape or (need_plain and not e[1]) or e[3] is None or P.dirty or P.gen != self.gen:
+            ME._planned_single(w3, need_plain, frag)          # records it: converted from the next forward on
+            raise NotReady("weight not in the step's arena yet")
+        return e[3].data_ptr(), (e[4].data_ptr() if e[4] is not None else 0)
+
+    # ---------------------------------------------------------------- convolution (me.SparseConvFunction)
+    def conv(self, x, weight, kmap, K, cin, cout):
+        lib = self.lib
+        w3 = weight.view(K, cin, cout)
+        pin, pout, _, P = kmap.pairs(None)
+        use16 = self.bf16 and ME._use_bf16(cin)
+        tile_f = ME._use_tile(kmap, K, cin, cout, kmap.n_out, None)
+        tile_b = x.need and ME._use_tile(kmap, K, cout, cin, kmap.n_in, None)
+        implicit_f = ME.SparseConvFunction._implicit(kmap, P, cin, cout, kmap.n_out, None)
+        # operands: forward = the transposed copy (fragment order for the tile kernel), data gradient = the plain copy
+        wt = wp = 0
+        if tile_f:
+            wt, wpf = self._planned(w3, True, tile_b)
+            if tile_b:
+                wp = wpf
+        elif ME._use_bf16(cin):
+            wt, _ = self._planned(w3, False, False)
+        if tile_b and not tile_f:
+            _, wp = self._planned(w3, True, True)
+        if x.need and not tile_b and ME._use_bf16(cout):
+            _, wp = self._planned(w3, False, True)                # (the per-layer path converts this one on the spot when missing)
+        xg = self.rows16(x) if use16 else x.p
+        rows16 = bool(use16)
+        n_in, n_out = kmap.n_in, kmap.n_out
+        prog = self.f
+        if tile_f:
+            plan = kmap.tile_plan(False)
+            y = self.new(n_out, cout)
+            if ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 512 and plan.ntile > 0:
+                y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
+            self._tile_row(prog, xg, wt, plan, y.p, n_in, cin, cout, False, y.stats, P)
+        elif implicit_f:
+            y = self.new(n_out, cout)
+            self._prof(prog, "implicit_bf16", K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 4.0 * K * n_out)
+            prog.add(OP_SPCONV_FWD, xg, wt, kmap.nbr.data_ptr(), 0, y.p, n_in, n_out, K, cin, cout, 2 if rows16 else 1)
+        else:
+            seg, nseg = kmap.segments(ME._seg_len_fwd(), None)
+            y = T(self.alloc(max(n_out, 1) * cout * 4, R_ZF), n_out, cout)          # atomic scatter into zeros
+            prec = 1 if ME._use_bf16(cin) else 0
+            wptr = wt if prec else w3.data_ptr()
+            self._prof(prog, "pairs_bf16" if prec else "pairs", K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 8.0 * P,
+                       wb=2.0 if prec else 4.0, nseg=nseg)
+            prog.add(OP_PAIRS_FWD, xg, wptr, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out, cin, cout,
+                     2 if rows16 else prec, 1)
+        self.tape.append(lambda: self._conv_bwd(x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b))
+        return y
+
+    def _prof(self, prog, kind, K, cin, cout, P, n_in, n_out, xb, map_bytes, wb=2.0, nseg=0, groups=1):
+        wbytes = wb * groups * K * cin * cout
+        prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, xb * n_in * cin + 4.0 * n_out * cout + wbytes + map_bytes,
+                          (kind, K, cin, cout, P, n_out, nseg), xb * P * cin + 4.0 * n_out * cout + wbytes + map_bytes))
+
+    def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P):
+        def p(t):
+            return t.data_ptr() if t is not None else 0
+        self._prof(prog, "tile_bf16", plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out)
+        prog.add(OP_TILE_FWD, x16, wf, p(plan.slots), p(plan.live), p(plan.pass_tab), p(plan.npass), p(plan.ulist), plan.maxpass,
+                 plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin, cout, 1,
+                 1 if wrev else 0, stats)
+
+    def _conv_bwd(self, x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b):
+        g = self.grad(y, want16=self.bf16 and ME._use_bf16(cout))
+        if g is None:
+            return
+        dy, dy16 = g
+        prog = self.b
+        pin, pout = kmap.pairs(None)[:2]
+        use16 = self.bf16 and ME._use_bf16(cout)
+        dyg = dy16 if use16 else dy
+        if x.need:
+            if tile_b:
+                plan = kmap.tile_plan(True)
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
+                self._tile_row(prog, dyg, wp, plan, dx, kmap.n_out, cout, cin, kmap.symmetric, 0, P)
+            elif ME.SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, None):
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
+                if not wp:
+                    raise NotReady("plain bf16 copy missing")
+                self._prof(prog, "implicit_bf16", K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 4.0 * K * kmap.n_in)
+                prog.add(OP_SPCONV_FWD, dyg, wp, kmap.nbrT.data_ptr(), 0, dx, kmap.n_out, kmap.n_in, K, cout, cin, 2 if use16 else 1)
+            else:
+                seg, nseg = kmap.segments(ME._seg_len_fwd(), None)
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4, R_ZB)
+                if ME._use_bf16(cout):
+                    if not wp:
+                        raise NotReady("plain bf16 copy missing")
+                    self._prof(prog, "pairs_bf16", K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 8.0 * P, nseg=nseg)
+                    prog.add(OP_PAIRS_FWD, dyg, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin,
+                             2 if use16 else 1, 1)
+                else:
+                    # fp32 operands: W^T as its own tensor, formed when the pass runs (the weights may change until then)
+                    self._prof(prog, "pairs", K, cout, cin, P, kmap.n_out, kmap.n_in, 4.0, 8.0 * P, wb=4.0, nseg=nseg)
+                    self.late.append((prog, len(prog.rows), 2, lambda w=w3: w.detach().transpose(1, 2).contiguous()))
+                    prog.add(OP_PAIRS_FWD, dy, 0, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin, 0, 1)
+            self.gadd(x, dx)
+        # weight gradient
+        wprec = 1 if (ME._use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+        xw, dyw = x.p, dy
+        if wprec and x.p16 and cout % 8 == 0 and self.bf16:
+            xw, dyw, wprec = x.p16, (dy16 if dy16 else self.grad(y, want16=True)[1]), 2
+        seg, nseg = (kmap.wgrad_segments if wprec else kmap.segments)(ME._wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), None)
+        eb = 2.0 if wprec == 2 else 4.0
+        if ME.KernelProfile.wgrad:
+            prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, eb * (kmap.n_in * cin + kmap.n_out * cout) + 4.0 * K * cin * cout + 8.0 * P,
+                              ("wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"), K, cin, cout, P, kmap.n_out, nseg),
+                              eb * P * (cin + cout) + 4.0 * K * cin * cout))
+        prog.add(OP_PAIRS_WGRAD, xw, dyw, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), K, cin, cout,
+                 wprec | WGRAD_ACC)
+
+    # ---------------------------------------------------------------- 1x1x1 convolution (me.LinearFunction)
+    def linear(self, x, weight, cin, cout):
+        n = x.n
+        own = ME.LinearFunction._own(n, cin, cout) and self.lib.is_device
+        w2 = weight.view(cin, cout)
+        if own:
+            wt, wp = self._planned(w2.view(1, cin, cout), True, x.need)
+            x16 = self.rows16(x)
+            y = self.new(n, cout)
+            units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin // 64
+            ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
+            part = 0
+            if ksplit > 1:
+                part = self.alloc(ksplit * max(n, 1) * cout * 4)
+            elif ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 1024:
+                y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
+            self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin, cout, max(ksplit, 1), y.stats, part)
+        else:
+            # generic form (fp32 parity mode / the oracle): the pair kernel on the identity map, me.LinearFunction._rows_gemm
+            ar, seg, nseg = ME._identity_pairs(n, 128 if self.lib.is_device else (1 << 30), self.dev)
+            y = T(self.alloc(max(n, 1) * cout * 4, R_ZF), n, cout)
+            self.f.add(OP_PAIRS_FWD, x.p, w2.data_ptr(), ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 0, 1)
+            wp = 0
+        self.tape.append(lambda: self._linear_bwd(x, y, weight, w2, cin, cout, own, wp))
+        return y
+
+    def _linear_bwd(self, x, y, weight, w2, cin, cout, own, wp):
+        g = self.grad(y, want16=own)
+        if g is None:
+            return
+        dy, dy16 = g
+        n, prog = x.n, self.b
+        if x.need:
+            if own:
+                dx = self.alloc(max(n, 1) * cin * 4)
+                units, nchunk = -(-n // 128) * (cin // (128 if cin % 128 == 0 else 64)), cout // 64
+                ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
+                part = self.alloc(ksplit * max(n, 1) * cin * 4) if ksplit > 1 else 0
+                prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx, n, cout, cin, max(ksplit, 1), 0, part)
+            else:
+                ar, seg, nseg = ME._identity_pairs(n, 128 if self.lib.is_device else (1 << 30), self.dev)
+                dx = self.alloc(max(n, 1) * cin * 4, R_ZB)
+                self.late.append((prog, len(prog.rows), 2, lambda w=w2: w.detach().t().contiguous()))
+                prog.add(OP_PAIRS_FWD, dy, 0, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, dx, n, cout, cin, 0, 1)
+            self.gadd(x, dx)
+        wprec = 1 if (ME._use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+        xc, dyc = x.p, dy
+        if wprec and own and x.p16 and dy16 and cout % 8 == 0:
+            xc, dyc, wprec = x.p16, dy16, 2
+        ar, seg, nseg = ME._identity_pairs(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1), self.dev)
+        prog.add(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
+                 wprec | WGRAD_ACC)
+
+    # ---------------------------------------------------------------- BatchNorm (+ residual) (+ activation) (me.FusedBNActFunction)
+    def bn_act(self, x, bn, act, res=None):
+        n, c = x.n, x.c
+        if not (bn.training and bn.track_running_stats and bn.momentum is not None and c % 4 == 0) or ME._sync_group_of(bn) is not None:
+            raise NotReady("BatchNorm form without a program counterpart (evaluation statistics, --sync_bn)")
+        red, nred, _, group_n, app, napp, _ = ME._bn_chunks((0, n), self.dev, c)
+        prog = self.f
+        sums = x.stats
+        if not sums:
+            sums = self.alloc(ME.BN_SLOTS * 2 * c * 4, R_ZF)
+            prog.add(OP_BN_SUMS, x.p, red.data_ptr(), nred, 1, c, sums)
+        mv = self.alloc(2 * c * 4, R_ZF)
+        mean, var = mv, mv + c * 4
+        y = self.new(n, c)
+        if self.bf16 and ME._use_bf16(c):
+            y.p16 = self.alloc(max(n, 1) * c * 2)
+        gamma, beta = bn.weight, bn.bias
+        prog.add(OP_BN_APPLY_SUMS, x.p, res.p if res is not None else 0, app.data_ptr(), napp, 1, c, sums, group_n.data_ptr(),
+                 _fbits(bn.eps), gamma.data_ptr(), beta.data_ptr(), act, y.p, y.p16, mean, var, bn.running_mean.data_ptr(),
+                 bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), _fbits(bn.momentum))
+        self.tape.append(lambda: self._bn_bwd(x, y, res, bn, act, mean, var, (red, nred, group_n, app, napp)))
+        return y
+
+    def _bn_bwd(self, x, y, res, bn, act, mean, var, ch):
+        g = self.grad(y)
+        if g is None:
+            return
+        dy = g[0]
+        red, nred, group_n, app, napp = ch
+        n, c, prog = x.n, x.c, self.b
+        dsums = self.alloc(ME.BN_SLOTS * 2 * c * 4, R_ZB)
+        eps = _fbits(bn.eps)
+        prog.add(OP_BN_BWD_SUMS, dy, x.p, y.p, red.data_ptr(), nred, 1, c, mean, var, eps, act, dsums)
+        dx = self.alloc(max(n, 1) * c * 4) if x.need else 0
+        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.bf16 and ME._use_bf16(c)) else 0
+        dres = self.alloc(max(n, 1) * c * 4) if (res is not None and res.need) else 0
+        if not dx:
+            dx = self.alloc(max(n, 1) * c * 4)          # (the kernel always writes dX)
+        prog.add(OP_BN_BWD_APPLY_SUMS, dy, x.p, y.p, app.data_ptr(), napp, 1, c, mean, var, eps, bn.weight.data_ptr(), dsums,
+                 group_n.data_ptr(), act, 1, dx, dx16, dres, self.pgrad(bn.bias), self.pgrad(bn.weight))
+        self.gadd(x, dx, dx16)
+        if dres:
+            self.gadd(res, dres)
+
+    # ---------------------------------------------------------------- relu(a [+ b]) / a + b
+    def add_act(self, a, b, act):
+        y = self.new(a.n, a.c, need=a.need or (b is not None and b.need))
+        if act == ME.ACT_RELU and self.bf16 and ME._use_bf16(a.c):
+            y.p16 = self.alloc(max(a.n, 1) * a.c * 2)
+        self._add_rows(self.f, a.p, b.p if b is not None else 0, y.p, a.n, a.c, act, y.p16)
+        self.tape.append(lambda: self._add_act_bwd(a, b, y, act))
+        return y
+
+    def _add_act_bwd(self, a, b, y, act):
+        g = self.grad(y)
+        if g is None:
+            return
+        dy = g[0]
+        if act == ME.ACT_NONE:
+            self.gadd(a, dy, g[1])                      # the same rows are the gradient of both addends
+            if b is not None:
+                self.gadd(b, dy, g[1])
+            return
+        # relu: dz = dy where y > 0 -- cg3d_bn_bwd_apply with the identity normalisation (use_batch_stats = 0: dx = dz)
+        n, c = a.n, a.c
+        z, o = self._unit(c)
+        ch = ME._bn_chunks((0, n), self.dev, c)
+        dz = self.alloc(max(n, 1) * c * 4)
+        self.b.add(OP_BN_BWD_APPLY, dy, y.p, y.p, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, z, o, act, 0, dz, 0, 0)
+        self.gadd(a, dz)
+        if b is not None:
+            self.gadd(b, dz)
+
+    # ---------------------------------------------------------------- interpolation (SparseTensor.features_at_coordinates)
+    def interp(self, x, idx, w, nq):
+        y = self.new(nq, x.c, need=x.need)
+        self.f.add(OP_INTERP_FWD, x.p, idx.data_ptr(), w.data_ptr(), y.p, nq, x.c)
+        self.tape.append(lambda: self._interp_bwd(x, y, idx, w, nq))
+        return y
+
+    def _interp_bwd(self, x, y, idx, w, nq):
+        g = self.grad(y)
+        if g is None or not x.need:
+            return
+        df = self.alloc(max(x.n, 1) * x.c * 4, R_ZB)
+        self.b.add(OP_INTERP_BWD, g[0], idx.data_ptr(), w.data_ptr(), df, nq, x.c)
+        self.gadd(x, df)
+
+    # ---------------------------------------------------------------- average pooling (me.ScatterMeanFunction)
+    def scatter_mean(self, x, smap, n_out):
+        J, n_in = smap.shape
+        y = self.new(n_out, x.c, need=x.need)
+        cnt = self.alloc(max(n_out, 1) * 4)
+        # (the call zero-fills `out` and `cnt` itself)
+        self.f.add(OP_SCATTER_MEAN_FWD, x.p, smap.data_ptr(), J, y.p, cnt, n_in, n_out, x.c)
+        self.tape.append(lambda: self._scatter_mean_bwd(x, y, smap, cnt, n_out))
+        return y
+
+    def _scatter_mean_bwd(self, x, y, smap, cnt, n_out):
+        g = self.grad(y)
+        if g is None or not x.need:
+            return
+        J, n_in = smap.shape
+        df = self.alloc(max(n_in, 1) * x.c * 4)
+        self.b.add(OP_SCATTER_MEAN_BWD, g[0], cnt, smap.data_ptr(), J, df, n_in, n_out, x.c)
+        self.gadd(x, df)
+
+    # ---------------------------------------------------------------- channel concatenation
+    def cat(self, ts):
+        n, c = ts[0].n, sum(t.c for t in ts)
+        y = self.new(n, c, need=any(t.need for t in ts))
+        o = 0
+        for t in ts:
+            self.f.add(OP_COPY2D, y.p + o * 4, c * 4, t.p, t.c * 4, t.c * 4, n)
+            o += t.c
+        self.tape.append(lambda: self._cat_bwd(ts, y))
+        return y
+
+    def _cat_bwd(self, ts, y):
+        g = self.grad(y)
+        if g is None:
+            return
+        o, c = 0, y.c
+        for t in ts:
+            if t.need:
+                d = self.alloc(max(t.n, 1) * t.c * 4)
+                self.b.add(OP_COPY2D, d, t.c * 4, g[0] + o * 4, c * 4, t.c * 4, t.n)
+                self.gadd(t, d)
+            o += t.c
+
+    # ---------------------------------------------------------------- backward emission
+    def mark(self, name):
+        """A named point of the forward pass: when the backward pass has consumed everything recorded AFTER it (i.e. the
+        gradients of every layer after this point are complete), `marks[name]` = the backward row reached."""
+        self.mark_at[len(self.tape)] = name
+
+    def emit_backward(self, out):
+        out.gc = [(R_DOUT, 0)]
+        for i in range(len(self.tape) - 1, -1, -1):
+            self.tape[i]()
+            name = self.mark_at.get(i)
+            if name is not None:
+                self.marks[name] = len(self.b.rows)
+        self.tape = None
+
+
+# ------------------------------------------------------------------------------------------------ module walkers
+class _X:
+    """A sparse tensor inside a program: features + the coordinate map they live on."""
+    __slots__ = ("t", "key")
+
+    def __init__(self, t, key):
+        self.t, self.key = t, key
+
+
+class Emitter:
+    """Walks the BiResNet module tree (cagroup3d_amd/pcdet/models/backbones_3d/biresnet.py) like its forward methods do."""
+
+    def __init__(self, builder, mgr):
+        self.b, self.mgr = builder, mgr
+        self._interp = {}
+        self._coordsf = {}
+
+    # -- layers
+    def conv(self, m, x):
+        mgr = self.mgr
+        assert m.bias is None, "the backbone's convolutions carry no bias"
+        if isinstance(m, ME.MinkowskiConvolutionTranspose):
+            in_ts = mgr.get(x.key).tensor_stride
+            out_ts = in_ts // m.stride
+            cands = [k for k in mgr._maps if k.tensor_stride == out_ts and mgr._strided.get((k, m.stride)) == x.key]
+            assert cands, "transposed convolution needs the finer map it was strided from"
+            out_key = cands[0]
+            km = mgr.kernel_map(x.key, out_key, m.kernel_size, m.dilation, True)
+            return _X(self.b.conv(x.t, m.kernel, km, m.kernel_volume, m.in_channels, m.out_channels), out_key)
+        out_key = mgr.stride(x.key, m.stride) if m.stride > 1 else x.key
+        if m.kernel_volume == 1 and m.stride == 1:
+            return _X(self.b.linear(x.t, m.kernel, m.in_channels, m.out_channels), out_key)
+        km = mgr.kernel_map(x.key, out_key, m.kernel_size, m.dilation, False)
+        return _X(self.b.conv(x.t, m.kernel, km, m.kernel_volume, m.in_channels, m.out_channels), out_key)
+
+    def bn(self, m, x, act=ME.ACT_NONE, residual=None):
+        return _X(self.b.bn_act(x.t, m.bn, act, residual.t if residual is not None else None), x.key)
+
+    def relu(self, x):
+        return _X(self.b.add_act(x.t, None, ME.ACT_RELU), x.key)
+
+    def add_relu(self, a, b):
+        assert a.key == b.key
+        return _X(self.b.add_act(a.t, b.t, ME.ACT_RELU), a.key)
+
+    def add(self, a, b):
+        assert a.key == b.key
+        return _X(self.b.add_act(a.t, b.t, ME.ACT_NONE), a.key)
+
+    def pool(self, m, x):
+        pmap, out_key = m.pool_map(self.mgr, x.key)
+        return _X(self.b.scatter_mean(x.t, pmap, self.mgr.get(out_key).n), out_key)
+
+    def at_coordinates(self, x, dst_key):
+        """x interpolated at the voxel positions of the map `dst_key` (features_at_coordinates(dst.C.float()))."""
+        ck = (x.key, dst_key)
+        hit = self._interp.get(ck)
+        if hit is None:
+            dst = self.mgr.get(dst_key)
+            q = self._coordsf.get(dst_key)
+            if q is None:
+                q = self._coordsf[dst_key] = dst.coords.float().contiguous()
+            hit = self._interp[ck] = ME.interp_tables(self.mgr.get(x.key), q)
+            self.b.keep.append(hit)
+        idx, w = hit
+        return _X(self.b.interp(x.t, idx, w, idx.shape[0]), dst_key)
+
+    def seq(self, mods, x):
+        """me.Sequential.forward: BatchNorm followed by ReLU is one fused launch pair."""
+        mods = list(mods)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, ME.MinkowskiBatchNorm) and isinstance(nxt, ME.MinkowskiReLU):
+                x = self.bn(m, x, ME.ACT_RELU)
+                i += 2
+                continue
+            x = self.module(m, x)
+            i += 1
+        return x
+
+    def module(self, m, x):
+        from .pcdet.models.backbones_3d import biresnet as B
+        if isinstance(m, (ME.MinkowskiConvolution, ME.MinkowskiConvolutionTranspose)):
+            return self.conv(m, x)
+        if isinstance(m, ME.MinkowskiBatchNorm):
+            return self.bn(m, x)
+        if isinstance(m, ME.MinkowskiReLU):
+            return self.relu(x)
+        if isinstance(m, ME.MinkowskiAvgPooling):
+            return self.pool(m, x)
+        if isinstance(m, torch.nn.Sequential):
+            return self.seq(m, x)
+        if isinstance(m, B.BasicBlock):
+            out = self.conv(m.conv2, self.bn(m.norm1, self.conv(m.conv1, x), ME.ACT_RELU))
+            res = x if m.downsample is None else self.module(m.downsample, x)
+            return self.bn(m.norm2, out, ME.ACT_NONE if m.no_relu else ME.ACT_RELU, res)
+        if isinstance(m, B.Bottleneck):
+            out = self.bn(m.norm1, self.conv(m.conv1, x), ME.ACT_RELU)
+            out = self.bn(m.norm2, self.conv(m.conv2, out), ME.ACT_RELU)
+            res = x if m.downsample is None else self.module(m.downsample, x)
+            return self.bn(m.norm3, self.conv(m.conv3, out), ME.ACT_NONE if m.no_relu else ME.ACT_RELU, res)
+        if isinstance(m, B.DAPPM):
+            feats = [self.module(m.scale0, x)]
+            for scale, process in ((m.scale1, m.process1), (m.scale2, m.process2), (m.scale3, m.process3), (m.scale4, m.process4)):
+                up = self.at_coordinates(self.module(scale, x), x.key)
+                feats.append(self.module(process, self.add(up, feats[-1])))
+            cat = _X(self.b.cat([f.t for f in feats]), x.key)
+            return self.add(self.module(m.compression, cat), self.module(m.shortcut, x))
+        raise NotReady("no program form for %s" % type(m).__name__)
+
+    def biresnet(self, net, x, mid_mark=False):
+        """BiResNet.forward (cagroup3d_amd/pcdet/models/backbones_3d/biresnet.py; reference biresnet.py:358-406)."""
+        x = self.module(net.conv1, x)
+        l1 = self.module(net.layer1, x)
+        l2 = self.module(net.layer2, self.relu(l1))
+        if mid_mark:
+            self.b.mark("mid")           # every deeper layer's gradient is complete when the backward pass is back here
+        r2 = self.relu(l2)
+        l3 = self.module(net.layer3, r2)
+        hi = self.module(net.layer3_, r2)
+        r3, rh = self.relu(l3), self.relu(hi)
+        lo_r = self.add_relu(l3, self.module(net.down3, rh))
+        hi_r = self.add_relu(hi, self.at_coordinates(self.module(net.compression3, r3), hi.key))
+        l4 = self.module(net.layer4, lo_r)
+        hi = self.module(net.layer4_, hi_r)
+        r4, rh = self.relu(l4), self.relu(hi)
+        lo_r = self.add_relu(l4, self.module(net.down4, rh))
+        hi_r = self.add_relu(hi, self.at_coordinates(self.module(net.compression4, r4), hi.key))
+        hi = self.module(net.layer5_, hi_r)
+        hi = self.add(hi, self.at_coordinates(self.module(net.spp, self.module(net.layer5, lo_r)), hi.key))
+        return self.module(net.out, hi)
+
+
+# ------------------------------------------------------------------------------------------------ a compiled pass
+class Compiled:
+    """Forward + backward tables of one batch, the tensors they point into, and the region sizes."""
+
+    def __init__(self, b, out, out_key, n_in, c_in, mgr=None):
+        self.mgr = mgr                   # the coordinate manager owns the maps / plans / pair lists the rows point into
+        self.fwd, self.bwd = b.f.table(), b.b.table()
+        self.fprof, self.bprof = b.f.prof, b.b.prof
+        self.size = dict(b.size)
+        self.keep, self.params, self.late, self.marks = b.keep, b.params, b.late, b.marks
+        self.late_f = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.f]
+        self.late_b = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.b]
+        self.out = (out.p, out.n, out.c, out.p16)
+        self.out_key = out_key
+        self.n_in, self.c_in = n_in, c_in
+        self.gen = b.gen
+        self.lib = b.lib
+        self.dev = b.dev
+        self.stream_device = None
+
+    def usable(self):
+        P = ME._WeightPlan
+        return (not P.dirty) and P.gen == self.gen and _lib.get() is self.lib
+
+
+def compile_backbone(net, sp, mid_mark=False):
+    """Program pair for `net` (BiResNet, training mode) on the sparse tensor `sp` (only its coordinate side and shape are
+    read).  Builds -- through the coordinate manager, with its host reads -- every map, plan and table the pass needs.
+    Raises NotReady when something is missing (first steps: weights not yet in the step's arena)."""
+    lib = _lib.get()
+    b = Builder(lib, sp.F.device if sp.F is not None else sp.C.device, ME._WeightPlan.gen)
+    n, c = sp.F.shape
+    x = _X(T(R_IN, n, c, need=False), sp.coordinate_map_key)
+    out = Emitter(b, sp.coordinate_manager).biresnet(net, x, mid_mark)
+    b.emit_backward(out.t)
+    return Compiled(b, out.t, out.key, n, c, sp.coordinate_manager)
+
+
+def _resolve(table, bases):
+    P = table.copy()
+    tag = P >> TAG
+    for r, base in bases.items():
+        m = tag == (r >> TAG)
+        if m.any():
+            P[m] += base - r
+    return P
+
+
+def _with_events(P, prof, lib):
+    """Rows of `P` with an event pair around every profiled row; returns (table, records for me.KernelProfile)."""
+    if not prof:
+        return P, []
+    out, recs, last = [], [], 0
+    for (row, flops, nbytes, meta, pbytes) in prof:
+        ev = _Events(lib)
+        out.append(P[last:row])
+        e0 = np.zeros((1, STRIDE), dtype=np.int64)
+        e0[0, 0], e0[0, 1] = OP_EVENT_RECORD, ev.h[0]
+        e1 = e0.copy()
+        e1[0, 1] = ev.h[1]
+        out += [e0, P[row:row + 1], e1]
+        last = row + 1
+        recs.append((_EvStart(ev), None, flops, nbytes, meta, pbytes))
+    out.append(P[last:])
+    return np.concatenate(out), recs
+
+
+def _run(lib, P, nrows=None):
+    P = np.ascontiguousarray(P)
+    n = P.shape[0] if nrows is None else nrows
+    if n == 0:
+        return
+    import ctypes
+    fail = ctypes.c_int64(-1)
+    rc = lib.raw("cg3d_run_program")(P.ctypes.data, n, lib.stream(), ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    if rc != 0:
+        raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, int(P[fail.value, 0]) if 0 <= fail.value < n else -1, rc))
+
+
+class BackboneFunction(torch.autograd.Function):
+    """The whole backbone as ONE autograd node: forward = the forward table, backward = the backward table; the parameters'
+    gradients are written to one fresh zero-filled buffer and handed to the parameters here (`p.grad = view`, added to an
+    existing gradient), so no AccumulateGrad node runs per parameter.
+
+    hooks: None or {mark name: (callable, ids of the parameters whose gradients must be visible to it)} -- the callable runs
+    between the two parts of the backward table cut at that mark (the data-parallel exchange sends its mid bucket there)."""
+
+    @staticmethod
+    def forward(ctx, feats, anchor, comp, hooks, io):
+        lib = comp.lib
+        feats = feats.contiguous()
+        assert feats.shape == (comp.n_in, comp.c_in) and feats.dtype == torch.float32
+        sz = comp.size
+        zf, zb, act = sz[R_ZF], sz[R_ZB], sz[R_ACT]
+        arena = torch.empty(zf + zb + act + ALIGN, dtype=torch.uint8, device=feats.device)
+        base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
+        bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: feats.data_ptr()}
+        P = _resolve(comp.fwd, bases)
+        keep = []
+        for r, c, fn in comp.late_f:
+            t = fn()
+            keep.append(t)
+            P[r, c] = t.data_ptr()
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, base, 0, zf)
+        prof = bool(ME.KernelProfile.enabled and lib.is_device)
+        if prof:
+            P, recs = _with_events(P, comp.fprof, lib)
+            ME.KernelProfile.records.extend(recs)
+        _run(lib, np.concatenate([head, P]))
+        ctx.comp, ctx.arena, ctx.bases, ctx.feats, ctx.keep, ctx.hooks, ctx.prof = comp, arena, bases, feats, keep, hooks, prof
+        p, n, c, p16 = comp.out
+        shift = bases[R_ACT] - arena.data_ptr()
+        off = p - R_ACT + shift
+        y = arena[off:off + n * c * 4].view(torch.float32).view(n, c)
+        if p16 and io is not None:
+            o16 = p16 - R_ACT + shift
+            io["y16"] = arena[o16:o16 + n * c * 2].view(torch.int16).view(n, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        comp, lib, hooks = ctx.comp, ctx.comp.lib, ctx.hooks or {}
+        dy = dy.contiguous()
+        bases = dict(ctx.bases)
+        pg = torch.zeros(max(comp.size[R_PG] // 4, 1), dtype=torch.float32, device=dy.device)
+        bases[R_PG], bases[R_DOUT] = pg.data_ptr(), dy.data_ptr()
+        P = _resolve(comp.bwd, bases)
+        keep = []
+        for r, c, fn in comp.late_b:
+            t = fn()
+            keep.append(t)
+            P[r, c] = t.data_ptr()
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+        cuts = sorted((row, name) for name, row in comp.marks.items() if name in hooks)
+        parts, last = [], 0
+        for row, name in cuts:
+            parts.append((P[last:row], comp_prof_slice(comp.bprof, last, row), name))
+            last = row
+        parts.append((P[last:], comp_prof_slice(comp.bprof, last, P.shape[0]), None))
+        given = set()
+
+        def give(ids):
+            # hand the gradients written so far to their parameters (ids None: all that are left)
+            with torch.no_grad():
+                for prm, off in comp.params:
+                    k = id(prm)
+                    if k in given or (ids is not None and k not in ids):
+                        continue
+                    g = pg[off // 4: off // 4 + prm.numel()].view_as(prm)
+                    prm.grad = g if prm.grad is None else prm.grad + g
+                    given.add(k)
+        first = True
+        for rows, prof, name in parts:
+            if ctx.prof:
+                rows, recs = _with_events(rows, prof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, rows]) if first else rows)
+            first = False
+            if name is not None:
+                fn, ids = hooks[name]
+                give(ids)
+                fn()
+        give(None)
+        ctx.arena = ctx.keep = ctx.feats = None
+        return None, None, None, None, None
+
+
+def comp_prof_slice(prof, lo, hi):
+    return [(r - lo, f, b, m, pb) for (r, f, b, m, pb) in prof if lo <= r < hi]
+
+
+def run_backbone(net, sp, comp=None, hooks=None):
+    """Forward pass of `net` on `sp` through its program; returns the output SparseTensor.  `comp`: the pair compiled ahead
+    (CAGroup3D.prefetch_coordinates), else compiled here.  Raises NotReady when the program cannot be built yet."""
+    try:
+        if comp is None or not comp.usable() or (hooks and any(k not in comp.marks for k in hooks)):
+            comp = compile_backbone(net, sp, mid_mark=bool(hooks and "mid" in hooks))
+            STATS["compiled_inline"] += 1
+        else:
+            STATS["compiled_ahead"] += 1
+    except NotReady:
+        STATS["not_ready"] += 1
+        raise
+    STATS["program_passes"] += 1
+    anchor = net.conv1[0].kernel
+    io = {}
+    y = BackboneFunction.apply(sp.F, anchor, comp, hooks, io)
+    if io.get("y16") is not None:
+        ME._ROWS16[y.data_ptr()] = (y, io["y16"])       # the head's first convolutions gather from the bf16 copy
+    return ME.SparseTensor(features=y, coordinate_map_key=comp.out_key, coordinate_manager=sp.coordinate_manager)
+
+
+def applicable(net, compiling=False):
+    """A training step in the bench precision on the device library.  CG3D_ENGINE_ANY=1 (tests) also admits the fp32 parity
+    mode -- on the device library and on the CPU oracle -- where every product runs through the generic pair kernels.
+    compiling: asked by the dry run that compiles the program ahead (it runs under no_grad)."""
+    if not ENABLED or not net.training or ME.coords_only() or not (compiling or torch.is_grad_enabled()):
+        return False
+    lib = _lib.get()
+    if lib.is_device and ME.PRECISION == 1 and ME.BF16_ROWS:
+        return True
+    return os.environ.get("CG3D_ENGINE_ANY") == "1" and ME.PRECISION == 0

@@ -114,9 +114,12 @@ class TwoBucketGradSync:
         if tensor.requires_grad:
             tensor.register_hook(self._on_backbone_output_grad)
 
-    def attach_mid(self, tensor):
+    def begin_mid(self):
         self._mid_sent = False
         self._mid_work = None
+
+    def attach_mid(self, tensor):
+        self.begin_mid()
         if self.mid and tensor.requires_grad:
             tensor.register_hook(self._on_stem_output_grad)
 

@@ -379,18 +379,18 @@ def _morton_order(coords_i32):
 _CACHE_LOCK = __import__("threading").RLock()
 
 
-def _cached(cache, key, build, limit=None, cross_stream=False):
+def _cached(cache, key, build, limit=None):
     """Get-or-build on one of the module-level host caches (offset tables, chunk tables, identity pair lists ...).  The
     coordinate-prefetch worker (detectors/cagroup3d.py::_PrefetchWorker) runs the same code as the main thread, so lookup,
-    the size-triggered `clear()` and the insert happen under ONE lock.  cross_stream: the cache is read by BOTH threads
-    (the kernel-offset tables) -- an entry built on a device is published only after the building thread's stream has
-    finished its upload, or the other thread would read the table on ITS stream with nothing ordering it after the copy
-    (those entries are permanent: the wait is paid once per key, never in steady state)."""
+    the size-triggered `clear()` and the insert happen under ONE lock.  An entry built on the WORKER thread (its uploads
+    go through the side stream) is published only after that stream has finished them: the main thread would otherwise read
+    the table on ITS stream with nothing ordering it after the copy.  (The wait blocks only the worker, once per key.)"""
     with _CACHE_LOCK:
         hit = cache.get(key)
         if hit is None:
             hit = build()
-            if cross_stream and torch.cuda.is_available() and _lib.get().is_device:
+            if __import__("threading").current_thread() is not __import__("threading").main_thread() \
+                    and torch.cuda.is_available() and _lib.get().is_device:
                 torch.cuda.current_stream().synchronize()
             if limit is not None and len(cache) > limit:
                 cache.clear()
@@ -403,7 +403,7 @@ _offset_cache = {}
 
 def _offsets(kernel_size, spacing, device):
     ck = (int(kernel_size), int(spacing), str(device))
-    return _cached(_offset_cache, ck, lambda: _make_offsets(kernel_size, spacing, device), cross_stream=True)
+    return _cached(_offset_cache, ck, lambda: _make_offsets(kernel_size, spacing, device))
 
 
 def _make_offsets(kernel_size, spacing, device):
@@ -798,11 +798,14 @@ class _WeightPlan:
     keep = None         # the arenas
     live = False        # inside a detector forward that called prepare_weights(): arena answers are valid
     pending = True      # the weights may have changed since the last conversion
+    gen = 0             # bumped whenever the arenas are rebuilt (addresses handed out before are stale: engine.Compiled.usable)
 
     @classmethod
     def reset(cls):
-        cls.singles, cls.groups, cls.table, cls.nrows, cls.dirty, cls.keep = {}, {}, None, 0, False, None
-        cls.live, cls.pending = False, True
+        with _CACHE_LOCK:
+            cls.singles, cls.groups, cls.table, cls.nrows, cls.dirty, cls.keep = {}, {}, None, 0, False, None
+            cls.live, cls.pending = False, True
+            cls.gen += 1
 
     @classmethod
     def _rebuild(cls, device):
@@ -852,6 +855,7 @@ class _WeightPlan:
         tab = _np.concatenate(rows) if rows else _np.zeros((0, 6), dtype=_np.int64)
         cls.table, cls.nrows = h2d(torch.from_numpy(tab), torch.int64, device), int(tab.shape[0])
         cls.keep, cls.dirty = (arena_t, arena_p), False
+        cls.gen += 1
 
 
 def prepare_weights(training=True):
@@ -871,8 +875,9 @@ def prepare_weights(training=True):
         P.reset()
         return
     if P.dirty:
-        dev = next(iter(P.singles.values()))[0].device if P.singles else next(iter(P.groups.values()))[0][0].device
-        P._rebuild(dev)
+        with _CACHE_LOCK:           # (the prefetch worker records weights too: engine.Builder._planned)
+            dev = next(iter(P.singles.values()))[0].device if P.singles else next(iter(P.groups.values()))[0][0].device
+            P._rebuild(dev)
         P.pending = True
     need = training or P.pending or any(e[2] != e[0]._version for e in P.singles.values()) or \
         any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
@@ -899,8 +904,9 @@ def _planned_single(w3, need_plain, frag=False):
             return e
         return None
     if _lib.get().is_device and w3.dim() == 3:
-        P.singles[(w3.data_ptr(), frag)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
-        P.dirty = True
+        with _CACHE_LOCK:
+            P.singles[(w3.data_ptr(), frag)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
+            P.dirty = True
     return None
 
 
@@ -1688,6 +1694,19 @@ class InterpolateFunction(torch.autograd.Function):
         return df, None, None
 
 
+def interp_tables(src_map, q):
+    """Corner rows int32 [nq, 8] (-1 = absent) and weights float32 [nq, 8] of the trilinear interpolation of the coordinate
+    map `src_map` at the continuous coordinates q float32 [nq, 4] (cg3d_interp_map): coordinates only."""
+    lib = _lib.get()
+    nq = q.shape[0]
+    idx = torch.empty((max(nq, 1), 8), dtype=torch.int32, device=q.device)
+    w = torch.empty((max(nq, 1), 8), dtype=torch.float32, device=q.device)
+    lib.check(q)
+    lib.call("cg3d_interp_map", ptr(q), c_int64(nq), c_int32(src_map.tensor_stride), ptr(src_map.keys), ptr(src_map.vals),
+             c_int64(src_map.cap), ptr(idx), ptr(w), lib.stream())
+    return idx[:nq], w[:nq]
+
+
 class ScatterMeanFunction(torch.autograd.Function):
     """out[m] = mean of F[i] over {(j, i): map[j, i] == m}; map int32 [J, n_in]."""
 
@@ -2073,16 +2092,8 @@ class SparseTensor:
         """Trilinear interpolation of this tensor at continuous coordinates [nq,4] (b,x,y,z)."""
         if coords_only():
             return _fake(query.shape[0], self.F.shape[1], self.F)
-        lib = _lib.get()
-        q = query.to(torch.float32).contiguous()
-        m = self._map
-        nq = q.shape[0]
-        idx = torch.empty((max(nq, 1), 8), dtype=torch.int32, device=q.device)
-        w = torch.empty((max(nq, 1), 8), dtype=torch.float32, device=q.device)
-        lib.check(q)
-        lib.call("cg3d_interp_map", ptr(q), c_int64(nq), c_int32(m.tensor_stride), ptr(m.keys), ptr(m.vals),
-                 c_int64(m.cap), ptr(idx), ptr(w), lib.stream())
-        return InterpolateFunction.apply(self.F, idx[:nq], w[:nq])
+        idx, w = interp_tables(self._map, query.to(torch.float32).contiguous())
+        return InterpolateFunction.apply(self.F, idx, w)
 
     def _same_map(self, o):
         assert self.coordinate_map_key == o.coordinate_map_key and self.coordinate_manager is o.coordinate_manager, \
@@ -2199,13 +2210,13 @@ class MinkowskiAvgPooling(nn.Module):
         assert dimension == 3 and dilation == 1
         self.kernel_size, self.stride = int(kernel_size), int(stride)
 
-    def forward(self, x):
+    def pool_map(self, mgr, in_key):
+        """(pmap int32 [27, n_in], output map key): cg3d_pool_map, cached on the coordinate manager."""
         lib = _lib.get()
-        mgr = x.coordinate_manager
-        src = x._map
-        out_key = mgr.stride(x.coordinate_map_key, self.stride) if self.stride > 1 else x.coordinate_map_key
+        src = mgr.get(in_key)
+        out_key = mgr.stride(in_key, self.stride) if self.stride > 1 else in_key
         dst = mgr.get(out_key)
-        ck = ("pool", x.coordinate_map_key, out_key, self.kernel_size)
+        ck = ("pool", in_key, out_key, self.kernel_size)
         pmap = mgr._kmaps.get(ck)
         if pmap is None:
             assert self.kernel_size // 2 * src.tensor_stride <= dst.tensor_stride, "pool kernel wider than 2*stride+1"
@@ -2215,6 +2226,12 @@ class MinkowskiAvgPooling(nn.Module):
                      c_int64(dst.cap), ptr(pmap), lib.stream())
             pmap = pmap[:, :src.n].contiguous() if src.n > 0 else pmap[:, :0]
             mgr._kmaps[ck] = pmap
+        return pmap, out_key
+
+    def forward(self, x):
+        mgr = x.coordinate_manager
+        pmap, out_key = self.pool_map(mgr, x.coordinate_map_key)
+        dst = mgr.get(out_key)
         out = _fake(dst.n, x.F.shape[1], x.F) if coords_only() else ScatterMeanFunction.apply(x.F, pmap, dst.n)
         return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
 

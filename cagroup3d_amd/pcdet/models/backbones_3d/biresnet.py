@@ -169,6 +169,18 @@ class BiResNet(nn.Module):
         return ME.Sequential(*mods)
 
     def forward(self, input_dict):
+        from .... import engine
+        if engine.applicable(self):
+            # the whole pass as one launch program (engine.py): one foreign call forward, one backward
+            gs = getattr(self, "grad_sync", None)
+            hooks = None
+            if gs is not None and gs.mid:
+                gs.begin_mid()
+                hooks = {"mid": (lambda: gs._on_stem_output_grad(None), {id(p) for p in gs.mid})}
+            try:
+                return {"sp_tensor": engine.run_backbone(self, input_dict["sp_tensor"], input_dict.get("engine_program"), hooks)}
+            except engine.NotReady:
+                pass                                                  # (first steps: weights not in the step's arena yet)
         x = self.conv1(input_dict["sp_tensor"])                       # ts 1
         l1 = self.layer1(x)                                           # ts 2
         l2 = self.layer2(self.relu(l1))                               # ts 4

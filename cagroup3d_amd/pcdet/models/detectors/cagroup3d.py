@@ -102,7 +102,8 @@ class CAGroup3D(Detector3DTemplate):
         """points (N,7) = (b,x,y,z,r,g,b) -> sparse tensor on the 0.02 m grid; one (the first) point's
         colour per voxel (cagroup3d.py:18-25).  `prepared`: the coordinate side from `prefetch_coordinates`."""
         if prepared is not None:
-            mgr, key, uniq, n_in, event, keep, targets = prepared
+            mgr, key, uniq, n_in, event, keep, targets = prepared[:7]
+            object.__setattr__(self, "_engine_program", prepared[7] if len(prepared) > 7 else None)
             assert n_in == points.shape[0], "prefetched coordinates belong to another batch"
             torch.cuda.current_stream().wait_event(event)
             ME.release_to_stream(mgr, [keep, targets], torch.cuda.current_stream())
@@ -135,9 +136,27 @@ class CAGroup3D(Detector3DTemplate):
             coordinates = points[:, :4].clone()
             coordinates[:, 1:] /= self.voxel_size
             ME.set_coords_only(True)
+            program = None
             try:
                 sp = ME.SparseTensor(coordinates=coordinates, features=points[:, 4:])
-                out = self.backbone_3d({"sp_tensor": sp, "batch_size": batch_dict["batch_size"]})["sp_tensor"]
+                out = None
+                from .... import engine
+                ME.set_coords_only(False)
+                if engine.applicable(self.backbone_3d, compiling=True):
+                    # the backbone's launch program for this batch (engine.py): compiling it builds every map, plan and table
+                    # the pass needs -- it IS the dry run -- and the step then runs the backbone with one call each way
+                    try:
+                        gs = getattr(self.backbone_3d, "grad_sync", None)
+                        feat = ME._fake(sp.F.shape[0], sp.F.shape[1], sp.F)
+                        program = engine.compile_backbone(self.backbone_3d, sp._like(feat), mid_mark=bool(gs is not None and gs.mid))
+                        m = sp.coordinate_manager.get(program.out_key)
+                        out = ME.SparseTensor(features=ME._fake(m.n, self.backbone_3d.num_point_features, sp.F),
+                                              coordinate_map_key=program.out_key, coordinate_manager=sp.coordinate_manager)
+                    except engine.NotReady:
+                        program = None
+                ME.set_coords_only(True)
+                if out is None:
+                    out = self.backbone_3d({"sp_tensor": sp, "batch_size": batch_dict["batch_size"]})["sp_tensor"]
                 _ = out.decomposition_permutations            # the head's first host read
             finally:
                 ME.set_coords_only(False)
@@ -156,7 +175,7 @@ class CAGroup3D(Detector3DTemplate):
             event = torch.cuda.Event()
             event.record(side)
         return (sp.coordinate_manager, sp.coordinate_map_key, sp.unique_index, points.shape[0], event,
-                [sp.unique_index, sp.inverse_mapping], targets)
+                [sp.unique_index, sp.inverse_mapping, program.keep if program is not None else None], targets, program)
 
     def prefetch_coordinates_async(self, batch_dict):
         """`prefetch_coordinates` on a worker thread: returns a handle whose `.result()` is what `prefetch_coordinates`
@@ -197,7 +216,9 @@ class CAGroup3D(Detector3DTemplate):
         object.__setattr__(self.module_list[1], "semantic_threshold",
                            max(self.semantic_value - int(cur_epoch) * self.semantic_iter_value, self.semantic_min_threshold))
         batch_dict["points"][:, -3:] = batch_dict["points"][:, -3:] / 255.
+        object.__setattr__(self, "_engine_program", None)
         batch_dict["sp_tensor"] = self.voxelization(batch_dict["points"], batch_dict.pop("prepared", None))
+        batch_dict["engine_program"] = self._engine_program          # the backbone's launch program compiled by the dry run
         for i, module in enumerate(self.module_list):
             batch_dict.update(module(batch_dict))
             if i == 0 and self.training and getattr(self, "grad_sync", None) is not None:

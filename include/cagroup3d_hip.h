@@ -190,6 +190,9 @@ int cg3d_spconv_pairs_fwd(const float *X, const float *W, const int32_t *pair_in
                           const int32_t *seg, int64_t nseg, const float *bias, float *Y, int64_t n_out,
                           int32_t cin, int32_t cout, int32_t precision, int32_t accumulate,
                           cg3d_stream_t stream);
+/* precision | CG3D_WGRAD_ACCUMULATE: dW is NOT zero-filled, the products are added to what the caller put there (a pass that
+ * zero-fills all of its weight gradients with one memset, or a gradient accumulated over several calls). */
+#define CG3D_WGRAD_ACCUMULATE 0x100
 int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair_in, const int32_t *pair_out,
                             const int32_t *seg, int64_t nseg, float *dW, int32_t K, int32_t cin, int32_t cout,
                             int32_t precision, cg3d_stream_t stream);

@@ -244,7 +244,9 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pin,
                             int32_t precision, cg3d_stream_t s) {
     (void)s;
     if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
-    memset(dW, 0, (size_t)K * cin * cout * sizeof(float));
+    const int accumulate = (precision & CG3D_WGRAD_ACCUMULATE) != 0;
+    precision &= ~CG3D_WGRAD_ACCUMULATE;
+    if (!accumulate) memset(dW, 0, (size_t)K * cin * cout * sizeof(float));
     const int32_t AB = 16;
     int32_t nab = (cin + AB - 1) / AB;
 #pragma omp parallel for schedule(dynamic, 1)

@@ -1,0 +1,45 @@
+/* oracle_program.c -- cg3d_run_program on the CPU oracle (TEST INFRASTRUCTURE: the checker, never the product): the shared
+ * dispatcher of include/cagroup3d_program.h over the oracle's own entry points, so that the host-side engine
+ * (cagroup3d_amd/engine.py) can be run and checked on a GPU-less box.  Memset / strided copy are libc; events are dummies. */
+#include <string.h>
+#include "../include/cagroup3d_hip.h"
+
+static int op_memset(void *dst, int value, int64_t nbytes, cg3d_stream_t s) {
+    (void)s;
+    if (nbytes < 0 || (nbytes > 0 && !dst)) return CG3D_ERR_ARG;
+    if (nbytes > 0) memset(dst, value, (size_t)nbytes);
+    return CG3D_OK;
+}
+static int op_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t height, cg3d_stream_t s) {
+    (void)s;
+    if (width < 0 || height < 0 || dpitch < width || spitch < width) return CG3D_ERR_ARG;
+    if (width == 0 || height == 0) return CG3D_OK;
+    if (!dst || !src) return CG3D_ERR_ARG;
+    for (int64_t r = 0; r < height; r++) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, (size_t)width);
+    return CG3D_OK;
+}
+static int op_event_record(int64_t handle, cg3d_stream_t s) {
+    (void)s;
+    return handle ? CG3D_OK : CG3D_ERR_ARG;
+}
+#define CG3D_PROG_MEMSET op_memset
+#define CG3D_PROG_COPY2D op_copy2d
+#define CG3D_PROG_EVENT_RECORD op_event_record
+#define CG3D_PROGRAM_IMPL
+#include "../include/cagroup3d_program.h"
+
+int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, int64_t *fail_at) {
+    return cg3d_program_run(prog, nops, stream, fail_at);
+}
+int cg3d_event_create(int64_t *handle) {
+    static int64_t next = 1;
+    if (!handle) return CG3D_ERR_ARG;
+    *handle = next++;
+    return CG3D_OK;
+}
+int cg3d_event_destroy(int64_t handle) { return handle ? CG3D_OK : CG3D_ERR_ARG; }
+int cg3d_event_elapsed_ms(int64_t start, int64_t stop, float *ms) {
+    if (!start || !stop || !ms) return CG3D_ERR_ARG;
+    *ms = 0.f;
+    return CG3D_OK;
+}
