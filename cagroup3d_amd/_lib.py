@@ -93,6 +93,13 @@ _SIGNATURES = {
     "cg3d_knn": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P]),
     "cg3d_ball_query": (c_int32, [c_int32, c_int32, c_int32, c_float, c_int32, P, P, P, P]),
     "cg3d_sort_vertices": (c_int32, [c_int32, c_int32, c_int32, P, P, P, P, P]),
+    # include/cagroup3d_stages.h
+    "cg3d_roi_match": (c_int32, [P, P, P, c_int32, c_int32, c_float, P, c_int32, c_int32, P, P, P, P]),
+    "cg3d_roi_targets": (c_int32, [P, P, P, P, c_int32, c_int32, c_float, P, c_int32, c_int32, P, P, P, c_int32, c_int32, c_float,
+                                   c_float, c_float, c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "cg3d_roi_grid_coords": (c_int32, [P, c_int64, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32, P, P]),
+    "cg3d_roi_reg_loss_fwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, c_float, P, P]),
+    "cg3d_roi_reg_loss_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, c_float, P, P, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
     "cg3d_event_create": (c_int32, [P]),

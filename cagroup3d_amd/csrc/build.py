@@ -19,6 +19,7 @@ SOURCES = {
     "linear.hip": ["-munsafe-fp-atomics"],
     "gather_scatter.hip": ["-munsafe-fp-atomics"],
     "iou3d_nms.hip": ["-ffp-contract=off"],
+    "stages.hip": ["-ffp-contract=off"],     # stage-level fused ops of the heads (RoI matching / targets / grid, class rows, proposals)
     "knn.hip": ["-ffp-contract=off"],
     "sort_vertices.hip": ["-ffp-contract=off"],
     "bn_act.hip": [],
@@ -46,7 +47,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    hdrs = [os.path.join(HERE, "cg3d_common.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_hip.h"),
+    hdrs = [os.path.join(HERE, "cg3d_common.h"), os.path.join(HERE, "dg_geom.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_hip.h"),
             os.path.join(HERE, "..", "..", "include", "cagroup3d_program.h")]
     objs = []
     for src, extra in SOURCES.items():

@@ -1,0 +1,296 @@
+// stages.hip -- stage-level fused operators of the two heads (include/cagroup3d_stages.h).
+//
+// Each entry point replaces a chain of tens of tensor launches of the reference (RoI <-> ground-truth matching, target
+// construction, grid coordinates, the regression loss; class-row construction and proposal decoding of the dense head) by
+// one pass with the same arithmetic in the same operation order.  Built with -ffp-contract=off: what is integer or a
+// comparison of fp32 values comes out bit-identical to the CPU oracle (oracle/oracle_stages.c).
+#include "dg_geom.h"
+#include "../../include/cagroup3d_stages.h"
+
+// ------------------------------------------------------------------------------------------------ helpers
+// torch.remainder(a, b) for floats: fmod, moved into the sign of the divisor
+__host__ __device__ static inline float st_remainder(float a, float b) {
+    float m = fmodf(a, b);
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+    return m;
+}
+#define ST_2PI 6.283185307179586f
+#define ST_PI 3.141592653589793f
+
+// padded RoI `i` of scene `b` (reoder_rois_for_refining + the enlargement of forward_train): roi[7], label, score
+__device__ static inline void st_load_roi(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                          const int64_t *__restrict__ labels, const int32_t *__restrict__ roi_off, int b, int i,
+                                          float enlarge, float roi[7], int64_t *label, float *score) {
+    const int o = roi_off[b], n = roi_off[b + 1] - o;
+    if (i < n) {
+        const float *p = boxes + (int64_t)(o + i) * 7;
+        roi[0] = p[0]; roi[1] = p[1]; roi[2] = p[2];
+        roi[3] = p[3] * enlarge; roi[4] = p[4] * enlarge; roi[5] = p[5] * enlarge;
+        roi[6] = p[6] * -1.f;
+        *label = labels[o + i];
+        if (score) *score = scores[o + i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) roi[k] = 0.f;
+        roi[6] = -0.f;
+        *label = 0;
+        if (score) *score = 0.f;
+    }
+}
+
+// boxes_iou3d_gpu (iou3d_nms_utils.py:59-79), its operation order
+__device__ static inline float st_iou3d(const float *a, const float *b) {
+    const float a_hmax = a[2] + a[5] / 2, a_hmin = a[2] - a[5] / 2;
+    const float b_hmax = b[2] + b[5] / 2, b_hmin = b[2] - b[5] / 2;
+    const float ob = d_box_overlap(a, b);
+    float oh = fminf(a_hmax, b_hmax) - fmaxf(a_hmin, b_hmin);
+    oh = oh < 0.f ? 0.f : oh;
+    const float o3 = ob * oh;
+    const float va = a[3] * a[4] * a[5], vb = b[3] * b[4] * b[5];
+    float u = va + vb - o3;
+    u = u < 1e-6f ? 1e-6f : u;
+    return o3 / u;
+}
+
+// ------------------------------------------------------------------------------------------------ RoI <-> GT matching
+// 16 lanes per RoI walk the scene's boxes; (value, index) max with the lowest index on ties.
+__global__ __launch_bounds__(256) void k_roi_match(const float *__restrict__ boxes, const int64_t *__restrict__ labels,
+                                                   const int32_t *__restrict__ roi_off, int nb, int rin, float enlarge,
+                                                   const float *__restrict__ gt_boxes, int gmax, int gdim,
+                                                   const int32_t *__restrict__ n_gt, float *__restrict__ max_ov,
+                                                   int32_t *__restrict__ assign) {
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+    const bool live = r < nb * rin;
+    const int b = live ? r / rin : 0, i = live ? r % rin : 0;
+    float roi[7];
+    int64_t label;
+    st_load_roi(boxes, nullptr, labels, roi_off, b, i, enlarge, roi, &label, nullptr);
+    const int ng = live ? n_gt[b] : 0;
+    float best = -1.f;
+    int arg = 0x7fffffff;
+    for (int g = lane; g < ng; g += 16) {
+        const float *q = gt_boxes + ((int64_t)b * gmax + g) * gdim;
+        if ((int64_t)q[7] != label) continue;
+        float gb[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6] * -1.f};
+        const float v = st_iou3d(roi, gb);
+        if (v > best) { best = v; arg = g; }          // g ascends per lane: the first maximum stays
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d, 16);
+        const int oa = __shfl_xor(arg, d, 16);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (live && lane == 0) {
+        const bool has = best >= 0.f;
+        max_ov[r] = has ? best : 0.f;
+        assign[r] = has ? arg : 0;
+    }
+}
+extern "C" int cg3d_roi_match(const float *boxes, const int64_t *labels, const int32_t *roi_off, int32_t nb, int32_t rin,
+                              float enlarge, const float *gt_boxes, int32_t gmax, int32_t gdim, const int32_t *n_gt,
+                              float *max_ov, int32_t *assign, cg3d_stream_t stream) {
+    if (nb < 0 || rin < 0 || gmax < 0 || gdim < 8) return CG3D_ERR_ARG;
+    const int64_t n = (int64_t)nb * rin;
+    if (n == 0) return CG3D_OK;
+    if (!roi_off || !n_gt || !max_ov || !assign) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_roi_match, dim3((unsigned)cg3d_divup(n, 16)), dim3(256), 0, cg3d_hs(stream), boxes, labels, roi_off, nb,
+                       rin, enlarge, gt_boxes, gmax, gdim, n_gt, max_ov, assign);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sampled RoIs -> targets
+__global__ __launch_bounds__(128) void k_roi_targets(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                     const int64_t *__restrict__ labels, const int32_t *__restrict__ roi_off,
+                                                     int nb, int rin, float enlarge, const float *__restrict__ gt_boxes, int gmax,
+                                                     int gdim, const float *__restrict__ max_ov,
+                                                     const int32_t *__restrict__ assign, const int32_t *__restrict__ keep,
+                                                     int rsel, int code_size, float reg_fg, float cls_fg, float cls_bg,
+                                                     float cls_span, float *__restrict__ o_rois, float *__restrict__ o_gt_src,
+                                                     float *__restrict__ o_gt, float *__restrict__ o_gt_label,
+                                                     float *__restrict__ o_iou, float *__restrict__ o_score,
+                                                     int64_t *__restrict__ o_label, int64_t *__restrict__ o_reg_valid,
+                                                     float *__restrict__ o_cls_label, float *__restrict__ o_reg_target) {
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= nb * rsel) return;
+    const int b = j / rsel, src = keep[j];
+    float roi[7], score;
+    int64_t label;
+    st_load_roi(boxes, scores, labels, roi_off, b, src, enlarge, roi, &label, &score);
+    const int64_t pr = (int64_t)b * rin + src;
+    const float iou = max_ov[pr];
+    const float *q = gt_boxes + ((int64_t)b * gmax + assign[pr]) * gdim;
+    float g[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6] * -1.f};
+#pragma unroll
+    for (int k = 0; k < 7; k++) { o_rois[(int64_t)j * 7 + k] = roi[k]; o_gt_src[(int64_t)j * 7 + k] = g[k]; }
+    o_gt_label[j] = (float)(int64_t)q[7];
+    o_iou[j] = iou;
+    o_score[j] = score;
+    o_label[j] = label;
+    o_reg_valid[j] = iou > reg_fg ? 1 : 0;
+    const bool fg = iou > cls_fg, bg = iou < cls_bg;
+    o_cls_label[j] = (!fg && !bg) ? (iou - cls_bg) / cls_span : (fg ? 1.f : 0.f);
+    // canonical frame of the RoI (assign_targets, cagroup_roi_head.py:300-324)
+    const float ry = st_remainder(roi[6], ST_2PI);
+    float c[7];
+    c[0] = g[0] - roi[0]; c[1] = g[1] - roi[1]; c[2] = g[2] - roi[2];
+    c[3] = g[3]; c[4] = g[4]; c[5] = g[5];
+    c[6] = st_remainder(g[6], ST_2PI) - ry;
+    if (code_size > 6) {
+        const float ang = -ry, cs = cosf(ang), sn = sinf(ang);
+        const float x = c[0] * cs + c[1] * (-sn) + c[2] * 0.f, y = c[0] * sn + c[1] * cs + c[2] * 0.f;
+        c[0] = x; c[1] = y;
+        float h = st_remainder(c[6], ST_2PI);
+        if (h > ST_PI * 0.5f && h < ST_PI * 1.5f) h = st_remainder(h + ST_PI, ST_2PI);
+        if (h > ST_PI) h = h - ST_2PI;
+        c[6] = fminf(fmaxf(h, -ST_PI / 2), ST_PI / 2);
+    }
+    // regression targets: encode_torch against the RoI with centre (and heading) zeroed; sizes clamped in place like there
+    const float a3 = fmaxf(roi[3], 1e-5f), a4 = fmaxf(roi[4], 1e-5f), a5 = fmaxf(roi[5], 1e-5f);
+    c[3] = fmaxf(c[3], 1e-5f); c[4] = fmaxf(c[4], 1e-5f); c[5] = fmaxf(c[5], 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 7; k++) o_gt[(int64_t)j * 7 + k] = c[k];
+    const float diag = sqrtf(a3 * a3 + a4 * a4);
+    float *t = o_reg_target + (int64_t)j * code_size;
+    t[0] = c[0] / diag; t[1] = c[1] / diag; t[2] = c[2] / a5;
+    t[3] = logf(c[3] / a3); t[4] = logf(c[4] / a4); t[5] = logf(c[5] / a5);
+    if (code_size == 7) t[6] = c[6];
+    if (code_size == 8) { t[6] = cosf(c[6]); t[7] = sinf(c[6]); }      /* encode_angle_by_sincos (cagroup_utils.py:128-130) */
+}
+extern "C" int cg3d_roi_targets(const float *boxes, const float *scores, const int64_t *labels, const int32_t *roi_off,
+                                int32_t nb, int32_t rin, float enlarge, const float *gt_boxes, int32_t gmax, int32_t gdim,
+                                const float *max_ov, const int32_t *assign, const int32_t *keep, int32_t rsel, int32_t code_size,
+                                float reg_fg, float cls_fg, float cls_bg, float cls_span, float *o_rois, float *o_gt_src,
+                                float *o_gt, float *o_gt_label, float *o_iou, float *o_score, int64_t *o_label,
+                                int64_t *o_reg_valid, float *o_cls_label, float *o_reg_target, cg3d_stream_t stream) {
+    if (nb < 0 || rin < 0 || rsel < 0 || gdim < 8 || (code_size < 6 || code_size > 8)) return CG3D_ERR_ARG;
+    const int64_t m = (int64_t)nb * rsel;
+    if (m == 0) return CG3D_OK;
+    if (!roi_off || !gt_boxes || !max_ov || !assign || !keep || !o_rois || !o_gt_src || !o_gt || !o_gt_label || !o_iou ||
+        !o_score || !o_label || !o_reg_valid || !o_cls_label || !o_reg_target)
+        return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_roi_targets, dim3((unsigned)cg3d_divup(m, 128)), dim3(128), 0, cg3d_hs(stream), boxes, scores, labels,
+                       roi_off, nb, rin, enlarge, gt_boxes, gmax, gdim, max_ov, assign, keep, rsel, code_size, reg_fg, cls_fg,
+                       cls_bg, cls_span, o_rois, o_gt_src, o_gt, o_gt_label, o_iou, o_score, o_label, o_reg_valid, o_cls_label,
+                       o_reg_target);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RoI grid coordinates
+__global__ __launch_bounds__(256) void k_roi_grid_coords(const float *__restrict__ rois, int64_t total, int rps, int grid,
+                                                         int with_yaw, float vs, float lo, float hi, int ck,
+                                                         int32_t *__restrict__ coords) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g3 = grid * grid * grid;
+    const int64_t r = t / g3;
+    const int g = (int)(t - r * g3);
+    const int ix = g / (grid * grid), iy = (g / grid) % grid, iz = g % grid;
+    const float *p = rois + r * 7;
+    const float fg = (float)grid;
+    float lx = ((float)ix + 0.5f) / fg * p[3] - p[3] / 2;
+    float ly = ((float)iy + 0.5f) / fg * p[4] - p[4] / 2;
+    const float lz = ((float)iz + 0.5f) / fg * p[5] - p[5] / 2;
+    if (with_yaw) {
+        const float cs = cosf(p[6]), sn = sinf(p[6]);
+        const float x = lx * cs + ly * (-sn) + lz * 0.f, y = lx * sn + ly * cs + lz * 0.f;
+        lx = x; ly = y;
+    }
+    const float q[3] = {lx + p[0], ly + p[1], lz + p[2]};
+    int4 o;
+    o.x = (int)(r / rps);
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float f = floorf(q[k] / vs);
+        f = f < lo ? lo : f;           // torch.clamp(min, max): max(min(x, hi), lo) with NaN propagating; finite inputs here
+        f = f > hi ? hi : f;
+        v[k] = (int)f * ck;
+    }
+    o.y = v[0]; o.z = v[1]; o.w = v[2];
+    reinterpret_cast<int4 *>(coords)[t] = o;
+}
+extern "C" int cg3d_roi_grid_coords(const float *rois, int64_t n, int32_t rois_per_scene, int32_t grid, int32_t with_yaw,
+                                    float voxel_size, float clamp_lo, float clamp_hi, int32_t coord_key, int32_t *coords,
+                                    cg3d_stream_t stream) {
+    if (n < 0 || rois_per_scene <= 0 || grid <= 0 || !(voxel_size > 0.f)) return CG3D_ERR_ARG;
+    const int64_t total = n * grid * grid * grid;
+    if (total == 0) return CG3D_OK;
+    if (!rois || !coords) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_roi_grid_coords, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream), rois, total,
+                       rois_per_scene, grid, with_yaw, voxel_size, clamp_lo, clamp_hi, coord_key, coords);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RoI regression loss
+__device__ static inline float st_sl1_diff(const float *__restrict__ reg, const float *__restrict__ target,
+                                           const float *__restrict__ code_w, int64_t e, int cs) {
+    const float t = target[e], x = reg[e];
+    float d = (t != t) ? 0.f : x - t;
+    if (code_w) d = d * code_w[e % cs];
+    return d;
+}
+__global__ __launch_bounds__(256) void k_roi_reg_loss_fwd(const float *__restrict__ reg, const float *__restrict__ target,
+                                                          const int64_t *__restrict__ valid, const float *__restrict__ code_w,
+                                                          int64_t m, int cs, float beta, float weight, float *__restrict__ out) {
+    __shared__ float ssum[256], scnt[256];
+    float s = 0.f, c = 0.f;
+    for (int64_t e = threadIdx.x; e < m * cs; e += 256) {
+        const int64_t row = e / cs;
+        if (valid[row] <= 0) continue;
+        if (e % cs == 0) c += 1.f;
+        const float n = fabsf(st_sl1_diff(reg, target, code_w, e, cs));
+        s += (beta < 1e-5f) ? n : (n < beta ? 0.5f * n * n / beta : n - 0.5f * beta);
+    }
+    ssum[threadIdx.x] = s; scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { ssum[threadIdx.x] += ssum[threadIdx.x + d]; scnt[threadIdx.x] += scnt[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cnt = scnt[0];
+        out[0] = ssum[0] / (cnt < 1.f ? 1.f : cnt) * weight;
+        out[1] = cnt;
+    }
+}
+__global__ __launch_bounds__(256) void k_roi_reg_loss_bwd(const float *__restrict__ reg, const float *__restrict__ target,
+                                                          const int64_t *__restrict__ valid, const float *__restrict__ code_w,
+                                                          int64_t m, int cs, float beta, float weight,
+                                                          const float *__restrict__ fwd_out, const float *__restrict__ g,
+                                                          float *__restrict__ dreg) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * cs) return;
+    float r = 0.f;
+    if (valid[e / cs] > 0 && target[e] == target[e]) {
+        const float cnt = fwd_out[1];
+        const float d = st_sl1_diff(reg, target, code_w, e, cs), n = fabsf(d);
+        float dl = (beta < 1e-5f || n >= beta) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d / beta;
+        if (code_w) dl = dl * code_w[e % cs];
+        r = g[0] * weight / (cnt < 1.f ? 1.f : cnt) * dl;
+    }
+    dreg[e] = r;
+}
+extern "C" int cg3d_roi_reg_loss_fwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                                     int32_t cs, float beta, float weight, float *out, cg3d_stream_t stream) {
+    if (m < 0 || cs <= 0 || !out) return CG3D_ERR_ARG;
+    if (m > 0 && (!reg || !target || !valid)) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_roi_reg_loss_fwd, dim3(1), dim3(256), 0, cg3d_hs(stream), reg, target, valid, code_w, m, cs, beta,
+                       weight, out);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                                     int32_t cs, float beta, float weight, const float *fwd_out, const float *g, float *dreg,
+                                     cg3d_stream_t stream) {
+    if (m < 0 || cs <= 0) return CG3D_ERR_ARG;
+    if (m == 0) return CG3D_OK;
+    if (!reg || !target || !valid || !fwd_out || !g || !dreg) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_roi_reg_loss_bwd, dim3((unsigned)cg3d_divup(m * cs, 256)), dim3(256), 0, cg3d_hs(stream), reg, target,
+                       valid, code_w, m, cs, beta, weight, fwd_out, g, dreg);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

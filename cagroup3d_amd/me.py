@@ -2154,10 +2154,13 @@ class MinkowskiConvolution(_ConvBase):
     """Sparse convolution; `forward(x, coordinates)` evaluates it at caller-given output coordinates
     (reference: cagroup_roi_head.py:69)."""
 
-    def forward(self, x, coordinates=None):
+    def forward(self, x, coordinates=None, return_inverse=False):
+        """return_inverse: `coordinates` may hold duplicates (they are merged, rows in first-occurrence order); the result is
+        (tensor, inverse int32 [len(coordinates)]) with inverse[i] = output row of coordinate i."""
         mgr = x.coordinate_manager
+        inv = None
         if coordinates is not None:
-            out_key, _, _ = mgr.insert(coordinates.to(torch.int32).contiguous(), 1)
+            out_key, _, inv = mgr.insert(coordinates.to(torch.int32).contiguous(), 1)
         elif self.stride > 1:
             out_key = mgr.stride(x.coordinate_map_key, self.stride)
         else:
@@ -2172,7 +2175,8 @@ class MinkowskiConvolution(_ConvBase):
                 out = _fake(km.n_out, self.out_channels, x.F)
             else:
                 out = SparseConvFunction.apply(x.F, self._w3(), bias, km)
-        return SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
+        res = SparseTensor(features=out, coordinate_map_key=out_key, coordinate_manager=mgr)
+        return (res, inv) if return_inverse else res
 
 
 class MinkowskiConvolutionTranspose(_ConvBase):

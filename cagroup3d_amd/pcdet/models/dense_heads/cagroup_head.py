@@ -144,9 +144,11 @@ class CAGroup3DHead(nn.Module):
         out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
                     "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
         if self.predict_boxes:
+            object.__setattr__(self, "_flat_props", None)
             if self._merged is not None and not self.use_sem_score and \
                     not (self.training and self.nms_cfg.get("SCORE_THR_AGNOSTIC", None) is not None):
                 out_dict["pred_bbox_list"] = self.get_bboxes_batched(self._merged, batch_size)
+                out_dict["pred_bbox_flat"] = self._flat_props
             else:
                 out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
                                                              [None] * batch_size, rescale=False)
@@ -701,6 +703,8 @@ class CAGroup3DHead(nn.Module):
         out_boxes, out_scores = e_boxes[sel], e_score[sel]
         out_labels = ME.h2d(torch.from_numpy(gof % C), torch.long, dev)
         per_scene = num.reshape(B, C).sum(1).tolist()
+        # the same proposals FLAT (scene-major): the RoI head's fused training path reads them in place instead of padding them
+        object.__setattr__(self, "_flat_props", (out_boxes, out_scores, out_labels, per_scene))
         return list(zip(torch.split(out_boxes, per_scene), torch.split(out_scores, per_scene),
                         torch.split(out_labels, per_scene)))
 
@@ -812,15 +816,25 @@ class CAGroup3DHead(nn.Module):
 def split_gt_boxes(gt_boxes, label_dtype=torch.long):
     """Zero-padded [B, Gmax, 8] -> per-scene (boxes [G,7], labels [G]) lists
     (cagroup_head.py:298-318, cagroup3d.py:118-135)."""
-    boxes, labels = [], []
+    boxes, labels = GtList(), []
     valid = ~(gt_boxes == 0.).all(dim=-1)
     v = valid.cpu().numpy()                        # ONE host read (a boolean-mask selection per scene is a sync per scene)
+    prefix = True
     for b in range(gt_boxes.shape[0]):
         idx = np.nonzero(v[b])[0]
         if len(idx) == 0 or idx[-1] == len(idx) - 1:           # the padding rows come last (collate_batch): a prefix slice
             g = gt_boxes[b, :len(idx)]
         else:
             g = gt_boxes[b][ME.h2d(idx, torch.long, gt_boxes.device)]
+            prefix = False
         boxes.append(g[:, :7].contiguous())
         labels.append(g[:, 7].to(label_dtype))
+    if prefix:
+        boxes.prefix_counts = [int(x) for x in v.sum(1)]
     return boxes, labels
+
+
+class GtList(list):
+    """Per-scene ground-truth boxes; `prefix_counts` = real boxes per scene when every scene's boxes are the leading rows of
+    the zero-padded batch tensor (then that tensor itself can be handed to the stage kernels), else None."""
+    prefix_counts = None

@@ -20,6 +20,9 @@ from ..model_utils.cagroup_utils import CAGroupResidualCoder as ResidualCoder
 from .target_assigner.cagroup_proposal_target_layer import ProposalTargetLayer
 
 
+FUSED_ROI = __import__("os").environ.get("CG3D_FUSED_ROI", "1") != "0"
+
+
 class SimplePoolingLayer(nn.Module):
     def __init__(self, channels=(128, 128, 128), grid_kernel_size=5, grid_num=7, voxel_size=0.04, coord_key=2,
                  point_cloud_range=(-5.12 * 3, -5.12 * 3, -5.12 * 3, 5.12 * 3, 5.12 * 3, 5.12 * 3),
@@ -53,6 +56,22 @@ class SimplePoolingLayer(nn.Module):
                           (unq // gs[2]) % gs[1] - half, unq % gs[2] - half), dim=1)
         uc[:, 1:4] *= self.coord_key
         feat = self.grid_bn(self.grid_conv(sp_tensor, uc.int()), act=ME.ACT_ELU).F      # BN + ELU fused
+        return self._pool(feat, inv)
+
+    def forward_rois(self, sp_tensor, rois, rois_per_scene, with_yaw):
+        """The same layer from the RoIs themselves, float32 [n,7]: the grid points are generated, quantised and clamped by one
+        launch (ops/roi_stage.roi_grid_coords) and de-duplicated by the coordinate map the convolution is evaluated on
+        (cg3d_coord_map_build: hash insert, no sort) -- in place of ~25 tensor launches and a sort-based torch.unique.  Rows of
+        the de-duplicated map come in first-occurrence order instead of sorted order; nothing downstream depends on it."""
+        from ....ops.roi_stage import roi_grid_coords
+        gs = self.grid_size
+        assert gs[0] == gs[1] == gs[2]
+        coords = roi_grid_coords(rois, rois_per_scene, self.grid_num, with_yaw, self.voxel_size, -gs[0] / 2 + 1, gs[0] / 2 - 1,
+                                 self.coord_key)
+        out, inv = self.grid_conv(sp_tensor, coords, return_inverse=True)
+        return self._pool(self.grid_bn(out, act=ME.ACT_ELU).F, inv)
+
+    def _pool(self, feat, inv):
         if not self.pooling:
             return ME.gather_rows(feat, inv)       # scatter-add backward (atomics), not torch's sort-based index_put
         # one row per RoI, (grid, channel) order, times the kernel as a [G C, C2] matrix (ME.roi_contract)
@@ -133,6 +152,10 @@ class CAGroup3DRoIHead(nn.Module):
     def roi_grid_pool(self, input_dict):
         rois, bs = input_dict["rois"], input_dict["batch_size"]
         feats = [input_dict["middle_feature_list"][i] for i in self.middle_feature_source]
+        if FUSED_ROI and rois.dtype == torch.float32 and rois.shape[-1] == 7 and rois.numel() > 0:
+            flat = rois.reshape(-1, 7)
+            return torch.cat([layer.forward_rois(t, flat, rois.shape[1], self.code_size > 6)
+                              for layer, t in zip(self.roi_grid_pool_layers, feats)], dim=-1)
         xyz, _ = self.get_global_grid_points_of_roi(rois, grid_size=self.grid_size)
         xyz = xyz.view(bs, -1, 3)
         bidx = torch.arange(bs, device=xyz.device, dtype=xyz.dtype).view(bs, 1, 1).expand(-1, xyz.shape[1], 1)
@@ -183,7 +206,47 @@ class CAGroup3DRoIHead(nn.Module):
                 i += 1
         return x
 
+    def _forward_train_fused(self, input_dict, flat):
+        """forward_train on the FLAT proposals of the dense head (cagroup_head.get_bboxes_batched): matching, the padded index
+        space of reoder_rois_for_refining, the sampled gathers, the canonical-frame targets and the regression targets are
+        three launches around the one host read the sampling needs (ops/roi_stage.py); the reference's path (below) is ~120."""
+        from .... import _lib
+        from ....ops import roi_stage as RS
+        boxes, scores, labels, per_scene = flat
+        ptl = self.proposal_target_layer
+        bs = len(per_scene)
+        gt = input_dict["gt_boxes"].contiguous()
+        dev = gt.device
+        rin = max(1, max(per_scene))
+        tab = ME.h2d(np.concatenate([np.cumsum([0] + list(per_scene)), np.asarray(input_dict["gt_bboxes_3d"].prefix_counts)]),
+                     torch.int32, dev)
+        roi_off, n_gt = tab[:bs + 1], tab[bs + 1:]
+        enlarge = float(self.enlarge_ratio) if self.enlarge_ratio else 1.0
+        with torch.no_grad():
+            max_ov, assign = RS.roi_match(boxes, labels, roi_off, bs, rin, enlarge, gt, n_gt)
+            ov = max_ov.view(bs, rin).cpu().numpy()                         # the only host read of the stage
+            keep = np.concatenate([RS.subsample_rois_host(ov[i], ptl.roi_per_image, ptl.fg_ratio, ptl.reg_fg_thresh,
+                                                          ptl.cls_fg_thresh, ptl.cls_bg_thresh_l0, ptl.hard_bg_ratio)
+                                   for i in range(bs)])
+            t = RS.roi_targets(boxes, scores, labels, roi_off, bs, rin, enlarge, gt, max_ov, assign,
+                               ME.h2d(keep, torch.int32, dev), ptl.roi_per_image,
+                               self.code_size + (1 if self.encode_angle_by_sincos else 0), ptl.reg_fg_thresh,
+                               ptl.cls_fg_thresh, ptl.cls_bg_thresh)
+        input_dict.update(batch_size=bs)
+        input_dict.update(t)
+        input_dict["rcnn_reg"] = self._refine(input_dict)
+        return input_dict
+
+    def _fused_train_ok(self, input_dict):
+        flat, gtl = input_dict.get("pred_bbox_flat"), input_dict.get("gt_bboxes_3d")
+        return (FUSED_ROI and flat is not None and getattr(gtl, "prefix_counts", None) is not None and "gt_boxes" in input_dict
+                and all(n > 0 for n in gtl.prefix_counts) and (self.code_size == 6 and not self.encode_angle_by_sincos or self.code_size == 7)
+                and flat[0].shape[0] > 0 and flat[0].shape[1] == 7 and input_dict["gt_boxes"].shape[-1] >= 8
+                and input_dict["gt_boxes"].dtype == torch.float32)
+
     def forward_train(self, input_dict):
+        if self._fused_train_ok(input_dict):
+            return self._forward_train_fused(input_dict, input_dict["pred_bbox_flat"])
         res = self.reoder_rois_for_refining(input_dict["pred_bbox_list"])
         rois, roi_scores, roi_labels, bs = res[0], res[1], res[2], res[-1]
         if self.enlarge_ratio:
@@ -303,6 +366,18 @@ class CAGroup3DRoIHead(nn.Module):
     def get_box_reg_layer_loss(self, d):
         """Smooth-L1 on encoded residuals of foreground RoIs (+ rotated IoU loss) (:551-615)."""
         cs = self.code_size
+        assert self.reg_loss_type == "smooth-l1"
+        fused_reg = None
+        if FUSED_ROI and d.get("reg_targets") is not None:
+            # targets encoded by cg3d_roi_targets; mask, code weights, smooth-L1, sum and normalisation in one launch each way
+            from ....ops.roi_stage import roi_reg_loss
+            cw = self.reg_loss_func.code_weights
+            if cw is not None and cw.device != d["rcnn_reg"].device:
+                cw = cw.to(d["rcnn_reg"].device)
+            fused_reg = roi_reg_loss(d["rcnn_reg"].view(-1, d["rcnn_reg"].shape[-1]), d["reg_targets"], d["reg_valid_mask"].view(-1),
+                                     cw, self.reg_loss_func.beta, float(self.loss_weight.RCNN_REG_WEIGHT))
+            if not self.use_iou_loss:
+                return fused_reg, {}
         fg = d["reg_valid_mask"].view(-1) > 0
         gt_ct = d["gt_of_rois"][..., 0:cs]
         gt_src = d["gt_of_rois_src"][..., 0:cs].view(-1, cs)
@@ -311,14 +386,17 @@ class CAGroup3DRoIHead(nn.Module):
         n = gt_ct.view(-1, cs).shape[0]
         fg_sum = fg.long().sum()
         assert self.reg_loss_type == "smooth-l1"
-        anchors = roi_boxes.clone().detach().view(-1, cs)
-        anchors[:, 0:3] = 0
-        if cs > 6:
-            anchors[:, 6] = 0
-        targets = self.box_coder.encode_torch(gt_ct.view(n, cs), anchors)
-        l = self.reg_loss_func(rcnn_reg.view(n, -1).unsqueeze(dim=0), targets.unsqueeze(dim=0))
-        loss_reg = (l.view(n, -1) * fg.unsqueeze(dim=-1).float()).sum() / fg_sum.clamp(min=1)
-        loss_reg = loss_reg * self.loss_weight.RCNN_REG_WEIGHT
+        if fused_reg is not None:
+            loss_reg = fused_reg
+        else:
+            anchors = roi_boxes.clone().detach().view(-1, cs)
+            anchors[:, 0:3] = 0
+            if cs > 6:
+                anchors[:, 6] = 0
+            targets = self.box_coder.encode_torch(gt_ct.view(n, cs), anchors)
+            l = self.reg_loss_func(rcnn_reg.view(n, -1).unsqueeze(dim=0), targets.unsqueeze(dim=0))
+            loss_reg = (l.view(n, -1) * fg.unsqueeze(dim=-1).float()).sum() / fg_sum.clamp(min=1)
+            loss_reg = loss_reg * self.loss_weight.RCNN_REG_WEIGHT
         if not self.use_iou_loss:
             return loss_reg, {}
         loss_iou = torch.tensor(0., device=fg.device)

@@ -1,0 +1,80 @@
+/*
+ * cagroup3d_stages.h -- stage-level fused operators of the two heads (C-ABI, part of libcagroup3d_hip.so).
+ *
+ * The reference writes these stages as chains of tensor expressions (tens of launches each over a few hundred to a few
+ * hundred thousand rows, with the host reads that size them); each entry point below is ONE pass over the same data with
+ * the same arithmetic in the same operation order, so that integer outputs are bit-identical and fp32 outputs differ at most
+ * by the last-bit differences of exp / log / sin / cos between two math libraries.  Conventions as in cagroup3d_hip.h: raw
+ * device pointers, caller-owned outputs, status codes, no allocation, no synchronisation.  Citations are into /root/reference.
+ */
+#ifndef CAGROUP3D_STAGES_H
+#define CAGROUP3D_STAGES_H
+
+#include "cagroup3d_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Second stage, training: RoI <-> ground-truth matching, target construction, grid coordinates, regression loss.
+ *
+ * Proposals arrive FLAT: boxes float32 [M,7] (x,y,z,dx,dy,dz,heading in the dense head's convention), scores float32 [M],
+ * labels int64 [M], scene-major with roi_off int32 [nb+1].  The reference first pads them to [nb, rin, .] with zero rows
+ * (CAGroup3DRoIHead.reoder_rois_for_refining, pcdet/models/roi_heads/cagroup_roi_head.py:328-362: heading negated :358) and
+ * enlarges the sizes (forward_train :270-272); padded row i of scene b is proposal roi_off[b] + i when that is below
+ * roi_off[b+1] and an all-zero RoI with label 0 and score 0 otherwise.  Both entry points below address that padded index
+ * space without materialising it.  Ground truth: gt_boxes float32 [nb, gmax, gdim >= 8] zero-padded, class id in column 7
+ * (the batch_dict tensor itself), n_gt int32 [nb] real boxes per scene (a prefix); the heading is negated on the fly
+ * (mmdet3d -> pcdet, cagroup_proposal_target_layer.py:97).
+ *
+ * cg3d_roi_match (ProposalTargetLayer.get_max_iou_with_same_class, cagroup_proposal_target_layer.py:204-238, with
+ *   boxes_iou3d_gpu, pcdet/ops/iou3d_nms/iou3d_nms_utils.py:59-79): for every padded RoI the largest 3D IoU -- rotated BEV
+ *   overlap x height overlap / max(vol_a + vol_b - overlap, 1e-6) -- over the ground-truth boxes of ITS scene and ITS class,
+ *   and that box's index inside the scene (ties: the lowest index); a RoI whose class has no box in the scene gets overlap 0
+ *   and index 0.   max_ov float32 [nb*rin], assign int32 [nb*rin].
+ *
+ * cg3d_roi_targets (sample_rois_for_rcnn gathers :44-63, ProposalTargetLayer.forward :22-33, CAGroup3DRoIHead.assign_targets
+ *   cagroup_roi_head.py:291-326, and the regression targets of get_box_reg_layer_loss :551-577 = CAGroupResidualCoder.
+ *   encode_torch, pcdet/models/model_utils/cagroup_utils.py:101-136, against the RoI with its centre (and heading) zeroed):
+ *   keep int32 [nb*rsel] = the sampled padded index of every output row (the draw itself stays on the host: it follows the
+ *   reference's two host RNG streams).  code_size = columns of the regression target: 6 (no heading), 7 (heading
+ *   difference) or 8 (cos, sin of the heading: encode_angle_by_sincos).  Outputs, one row per sampled RoI:
+ *     o_rois [.,7], o_gt_src [.,7] (the matched box, pcdet heading), o_gt [.,7] (the same box in the RoI's canonical frame),
+ *     o_gt_label float32, o_iou float32, o_score float32, o_label int64, o_reg_valid int64 (iou > reg_fg),
+ *     o_cls_label float32 (1 above cls_fg, 0 below cls_bg, (iou - cls_bg) / cls_span between), o_reg_target [., code_size].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cg3d_roi_match(const float *boxes, const int64_t *labels, const int32_t *roi_off, int32_t nb, int32_t rin, float enlarge,
+                   const float *gt_boxes, int32_t gmax, int32_t gdim, const int32_t *n_gt, float *max_ov, int32_t *assign,
+                   cg3d_stream_t stream);
+int cg3d_roi_targets(const float *boxes, const float *scores, const int64_t *labels, const int32_t *roi_off, int32_t nb,
+                     int32_t rin, float enlarge, const float *gt_boxes, int32_t gmax, int32_t gdim, const float *max_ov,
+                     const int32_t *assign, const int32_t *keep, int32_t rsel, int32_t code_size, float reg_fg, float cls_fg,
+                     float cls_bg, float cls_span, float *o_rois, float *o_gt_src, float *o_gt, float *o_gt_label,
+                     float *o_iou, float *o_score, int64_t *o_label, int64_t *o_reg_valid, float *o_cls_label,
+                     float *o_reg_target, cg3d_stream_t stream);
+
+/* cg3d_roi_grid_coords (CAGroup3DRoIHead.get_dense_grid_points / get_global_grid_points_of_roi / roi_grid_pool,
+ *   cagroup_roi_head.py:199-261, and the quantisation of SimplePoolingLayer.forward :46-68): the grid^3 cell centres of every
+ *   RoI -- ((i + 0.5) / grid * size - size / 2, rotated by the heading when with_yaw, + centre), index order (ix, iy, iz) --
+ *   quantised to floor(p / voxel_size), clamped to [clamp_lo, clamp_hi] (as floats, then truncated) and multiplied by coord_key.
+ *   rois float32 [n,7]; coords int32 [n * grid^3, 4] = (scene = row / rois_per_scene, x, y, z), RoI-major.  Duplicates are
+ *   kept: cg3d_coord_map_build merges them (the reference: linearise + torch.unique :54-67). */
+int cg3d_roi_grid_coords(const float *rois, int64_t n, int32_t rois_per_scene, int32_t grid, int32_t with_yaw, float voxel_size,
+                         float clamp_lo, float clamp_hi, int32_t coord_key, int32_t *coords, cg3d_stream_t stream);
+
+/* cg3d_roi_reg_loss_{fwd,bwd} (get_box_reg_layer_loss, cagroup_roi_head.py:551-590 with WeightedSmoothL1Loss,
+ *   pcdet/utils/loss_utils.py:76-137): loss = weight / max(#valid, 1) * sum over valid rows and codes of
+ *   smooth_l1((reg - target) * code_w; beta); a NaN target takes the prediction (zero difference).
+ *   reg / target float32 [m, cs], valid int64 [m], code_w float32 [cs] (may be NULL) -> out float32 [2] = (loss, #valid).
+ *   bwd: g float32 [1] the upstream gradient (device), dreg float32 [m, cs]. */
+int cg3d_roi_reg_loss_fwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                          int32_t cs, float beta, float weight, float *out, cg3d_stream_t stream);
+int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                          int32_t cs, float beta, float weight, const float *fwd_out, const float *g, float *dreg,
+                          cg3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAGROUP3D_STAGES_H */

@@ -1,0 +1,226 @@
+/* oracle_stages.c -- CPU restatement of the stage-level operators of include/cagroup3d_stages.h.
+ *
+ * TEST INFRASTRUCTURE: the checker of tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never the product.
+ * Plain loops in the reference's own operation order (citations into /root/reference); pinned against the torch mirrors of
+ * the same reference code (tests/test_stages.py), which the reference's fixtures pin (tests/test_golden.py).
+ * Built with -ffp-contract=off like oracle_geom.c, whose rotated overlap it calls.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "../include/cagroup3d_stages.h"
+
+float og_box_overlap(const float *a, const float *b); /* oracle_geom.c (iou3d_nms_kernel.cu:99-225) */
+
+static const float OS_2PI = 6.283185307179586f, OS_PI = 3.141592653589793f;
+
+/* torch.remainder on floats (ATen BinaryOps: fmod moved into the sign of the divisor) */
+static float os_remainder(float a, float b) {
+    float m = fmodf(a, b);
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+    return m;
+}
+
+/* padded RoI i of scene b: reoder_rois_for_refining (cagroup_roi_head.py:328-362; heading sign :358) and the enlargement of
+ * forward_train (:270-272) */
+static void os_load_roi(const float *boxes, const float *scores, const int64_t *labels, const int32_t *roi_off, int b, int i,
+                        float enlarge, float roi[7], int64_t *label, float *score) {
+    const int o = roi_off[b], n = roi_off[b + 1] - o;
+    if (i < n) {
+        const float *p = boxes + (int64_t)(o + i) * 7;
+        roi[0] = p[0]; roi[1] = p[1]; roi[2] = p[2];
+        roi[3] = p[3] * enlarge; roi[4] = p[4] * enlarge; roi[5] = p[5] * enlarge;
+        roi[6] = p[6] * -1.f;
+        *label = labels[o + i];
+        if (score) *score = scores[o + i];
+    } else {
+        for (int k = 0; k < 6; k++) roi[k] = 0.f;
+        roi[6] = -0.f;
+        *label = 0;
+        if (score) *score = 0.f;
+    }
+}
+
+/* boxes_iou3d_gpu, iou3d_nms_utils.py:59-79 */
+static float os_iou3d(const float *a, const float *b) {
+    const float a_hmax = a[2] + a[5] / 2, a_hmin = a[2] - a[5] / 2;
+    const float b_hmax = b[2] + b[5] / 2, b_hmin = b[2] - b[5] / 2;
+    const float ob = og_box_overlap(a, b);
+    float oh = fminf(a_hmax, b_hmax) - fmaxf(a_hmin, b_hmin);
+    oh = oh < 0.f ? 0.f : oh;
+    const float o3 = ob * oh;
+    const float va = a[3] * a[4] * a[5], vb = b[3] * b[4] * b[5];
+    float u = va + vb - o3;
+    u = u < 1e-6f ? 1e-6f : u;
+    return o3 / u;
+}
+
+/* get_max_iou_with_same_class, cagroup_proposal_target_layer.py:204-238 */
+int cg3d_roi_match(const float *boxes, const int64_t *labels, const int32_t *roi_off, int32_t nb, int32_t rin, float enlarge,
+                   const float *gt_boxes, int32_t gmax, int32_t gdim, const int32_t *n_gt, float *max_ov, int32_t *assign,
+                   cg3d_stream_t stream) {
+    (void)stream;
+    if (nb < 0 || rin < 0 || gmax < 0 || gdim < 8) return CG3D_ERR_ARG;
+    if ((int64_t)nb * rin == 0) return CG3D_OK;
+    if (!roi_off || !n_gt || !max_ov || !assign) return CG3D_ERR_ARG;
+    for (int b = 0; b < nb; b++)
+        for (int i = 0; i < rin; i++) {
+            float roi[7];
+            int64_t label;
+            os_load_roi(boxes, NULL, labels, roi_off, b, i, enlarge, roi, &label, NULL);
+            float best = -1.f;
+            int arg = 0;
+            for (int g = 0; g < n_gt[b]; g++) {
+                const float *q = gt_boxes + ((int64_t)b * gmax + g) * gdim;
+                if ((int64_t)q[7] != label) continue;
+                float gb[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6] * -1.f};
+                const float v = os_iou3d(roi, gb);
+                if (v > best) { best = v; arg = g; }
+            }
+            max_ov[(int64_t)b * rin + i] = best >= 0.f ? best : 0.f;
+            assign[(int64_t)b * rin + i] = best >= 0.f ? arg : 0;
+        }
+    return CG3D_OK;
+}
+
+/* gathers of sample_rois_for_rcnn (:44-63), ProposalTargetLayer.forward (:22-33), assign_targets (cagroup_roi_head.py:291-326),
+ * encode_torch (cagroup_utils.py:101-136) as called by get_box_reg_layer_loss (cagroup_roi_head.py:551-577) */
+int cg3d_roi_targets(const float *boxes, const float *scores, const int64_t *labels, const int32_t *roi_off, int32_t nb,
+                     int32_t rin, float enlarge, const float *gt_boxes, int32_t gmax, int32_t gdim, const float *max_ov,
+                     const int32_t *assign, const int32_t *keep, int32_t rsel, int32_t code_size, float reg_fg, float cls_fg,
+                     float cls_bg, float cls_span, float *o_rois, float *o_gt_src, float *o_gt, float *o_gt_label,
+                     float *o_iou, float *o_score, int64_t *o_label, int64_t *o_reg_valid, float *o_cls_label,
+                     float *o_reg_target, cg3d_stream_t stream) {
+    (void)stream;
+    if (nb < 0 || rin < 0 || rsel < 0 || gdim < 8 || (code_size < 6 || code_size > 8)) return CG3D_ERR_ARG;
+    const int64_t m = (int64_t)nb * rsel;
+    if (m == 0) return CG3D_OK;
+    if (!roi_off || !gt_boxes || !max_ov || !assign || !keep || !o_rois || !o_gt_src || !o_gt || !o_gt_label || !o_iou ||
+        !o_score || !o_label || !o_reg_valid || !o_cls_label || !o_reg_target)
+        return CG3D_ERR_ARG;
+    for (int64_t j = 0; j < m; j++) {
+        const int b = (int)(j / rsel), src = keep[j];
+        float roi[7], score;
+        int64_t label;
+        os_load_roi(boxes, scores, labels, roi_off, b, src, enlarge, roi, &label, &score);
+        const int64_t pr = (int64_t)b * rin + src;
+        const float iou = max_ov[pr];
+        const float *q = gt_boxes + ((int64_t)b * gmax + assign[pr]) * gdim;
+        float g[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6] * -1.f};
+        for (int k = 0; k < 7; k++) { o_rois[j * 7 + k] = roi[k]; o_gt_src[j * 7 + k] = g[k]; }
+        o_gt_label[j] = (float)(int64_t)q[7];
+        o_iou[j] = iou;
+        o_score[j] = score;
+        o_label[j] = label;
+        o_reg_valid[j] = iou > reg_fg ? 1 : 0;
+        const int fg = iou > cls_fg, bg = iou < cls_bg;
+        o_cls_label[j] = (!fg && !bg) ? (iou - cls_bg) / cls_span : (fg ? 1.f : 0.f);
+        const float ry = os_remainder(roi[6], OS_2PI);
+        float c[7];
+        c[0] = g[0] - roi[0]; c[1] = g[1] - roi[1]; c[2] = g[2] - roi[2];
+        c[3] = g[3]; c[4] = g[4]; c[5] = g[5];
+        c[6] = os_remainder(g[6], OS_2PI) - ry;
+        if (code_size > 6) {
+            const float ang = -ry, cs = cosf(ang), sn = sinf(ang);
+            const float x = c[0] * cs + c[1] * (-sn) + c[2] * 0.f, y = c[0] * sn + c[1] * cs + c[2] * 0.f;
+            c[0] = x; c[1] = y;
+            float h = os_remainder(c[6], OS_2PI);
+            if (h > OS_PI * 0.5f && h < OS_PI * 1.5f) h = os_remainder(h + OS_PI, OS_2PI);
+            if (h > OS_PI) h = h - OS_2PI;
+            c[6] = fminf(fmaxf(h, -OS_PI / 2), OS_PI / 2);
+        }
+        const float a3 = fmaxf(roi[3], 1e-5f), a4 = fmaxf(roi[4], 1e-5f), a5 = fmaxf(roi[5], 1e-5f);
+        c[3] = fmaxf(c[3], 1e-5f); c[4] = fmaxf(c[4], 1e-5f); c[5] = fmaxf(c[5], 1e-5f);
+        for (int k = 0; k < 7; k++) o_gt[j * 7 + k] = c[k];
+        const float diag = sqrtf(a3 * a3 + a4 * a4);
+        float *t = o_reg_target + j * code_size;
+        t[0] = c[0] / diag; t[1] = c[1] / diag; t[2] = c[2] / a5;
+        t[3] = logf(c[3] / a3); t[4] = logf(c[4] / a4); t[5] = logf(c[5] / a5);
+        if (code_size == 7) t[6] = c[6];
+        if (code_size == 8) { t[6] = cosf(c[6]); t[7] = sinf(c[6]); } /* encode_angle_by_sincos (cagroup_utils.py:128-130) */
+    }
+    return CG3D_OK;
+}
+
+/* get_dense_grid_points / get_global_grid_points_of_roi (cagroup_roi_head.py:199-224), SimplePoolingLayer.forward :46-68 */
+int cg3d_roi_grid_coords(const float *rois, int64_t n, int32_t rois_per_scene, int32_t grid, int32_t with_yaw, float voxel_size,
+                         float clamp_lo, float clamp_hi, int32_t coord_key, int32_t *coords, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || rois_per_scene <= 0 || grid <= 0 || !(voxel_size > 0.f)) return CG3D_ERR_ARG;
+    const int64_t g3 = (int64_t)grid * grid * grid;
+    if (n * g3 == 0) return CG3D_OK;
+    if (!rois || !coords) return CG3D_ERR_ARG;
+    const float fg = (float)grid;
+    for (int64_t r = 0; r < n; r++) {
+        const float *p = rois + r * 7;
+        const float cs = with_yaw ? cosf(p[6]) : 1.f, sn = with_yaw ? sinf(p[6]) : 0.f;
+        for (int ix = 0; ix < grid; ix++)
+            for (int iy = 0; iy < grid; iy++)
+                for (int iz = 0; iz < grid; iz++) {
+                    float lx = ((float)ix + 0.5f) / fg * p[3] - p[3] / 2;
+                    float ly = ((float)iy + 0.5f) / fg * p[4] - p[4] / 2;
+                    const float lz = ((float)iz + 0.5f) / fg * p[5] - p[5] / 2;
+                    if (with_yaw) {
+                        const float x = lx * cs + ly * (-sn) + lz * 0.f, y = lx * sn + ly * cs + lz * 0.f;
+                        lx = x; ly = y;
+                    }
+                    const float q[3] = {lx + p[0], ly + p[1], lz + p[2]};
+                    int32_t *o = coords + (r * g3 + ((int64_t)ix * grid + iy) * grid + iz) * 4;
+                    o[0] = (int32_t)(r / rois_per_scene);
+                    for (int k = 0; k < 3; k++) {
+                        float f = floorf(q[k] / voxel_size);
+                        f = f < clamp_lo ? clamp_lo : f;
+                        f = f > clamp_hi ? clamp_hi : f;
+                        o[1 + k] = (int32_t)f * coord_key;
+                    }
+                }
+    }
+    return CG3D_OK;
+}
+
+/* get_box_reg_layer_loss (cagroup_roi_head.py:551-590) + WeightedSmoothL1Loss (loss_utils.py:76-137); sums in double */
+static float os_diff(const float *reg, const float *target, const float *code_w, int64_t e, int cs) {
+    const float t = target[e], x = reg[e];
+    float d = (t != t) ? 0.f : x - t;
+    if (code_w) d = d * code_w[e % cs];
+    return d;
+}
+int cg3d_roi_reg_loss_fwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                          int32_t cs, float beta, float weight, float *out, cg3d_stream_t stream) {
+    (void)stream;
+    if (m < 0 || cs <= 0 || !out) return CG3D_ERR_ARG;
+    if (m > 0 && (!reg || !target || !valid)) return CG3D_ERR_ARG;
+    double s = 0.0;
+    float cnt = 0.f;
+    for (int64_t r = 0; r < m; r++) {
+        if (valid[r] <= 0) continue;
+        cnt += 1.f;
+        for (int k = 0; k < cs; k++) {
+            const float n = fabsf(os_diff(reg, target, code_w, r * cs + k, cs));
+            s += (beta < 1e-5f) ? n : (n < beta ? 0.5f * n * n / beta : n - 0.5f * beta);
+        }
+    }
+    out[0] = (float)s / (cnt < 1.f ? 1.f : cnt) * weight;
+    out[1] = cnt;
+    return CG3D_OK;
+}
+int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, const int64_t *valid, const float *code_w, int64_t m,
+                          int32_t cs, float beta, float weight, const float *fwd_out, const float *g, float *dreg,
+                          cg3d_stream_t stream) {
+    (void)stream;
+    if (m < 0 || cs <= 0) return CG3D_ERR_ARG;
+    if (m == 0) return CG3D_OK;
+    if (!reg || !target || !valid || !fwd_out || !g || !dreg) return CG3D_ERR_ARG;
+    const float cnt = fwd_out[1];
+    for (int64_t e = 0; e < m * cs; e++) {
+        float r = 0.f;
+        if (valid[e / cs] > 0 && target[e] == target[e]) {
+            const float d = os_diff(reg, target, code_w, e, cs), n = fabsf(d);
+            float dl = (beta < 1e-5f || n >= beta) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d / beta;
+            if (code_w) dl = dl * code_w[e % cs];
+            r = g[0] * weight / (cnt < 1.f ? 1.f : cnt) * dl;
+        }
+        dreg[e] = r;
+    }
+    return CG3D_OK;
+}

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, "include", "cagroup3d_hip.h")).read() + open(os.path.join(ROOT, "include", "cagroup3d_program.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("cagroup3d_hip.h", "cagroup3d_stages.h", "cagroup3d_program.h"))
     src = src.split("#ifdef CG3D_PROGRAM_IMPL")[0] + src.split("#endif /* CG3D_PROGRAM_IMPL */")[-1]      # (the inline dispatcher is not a declaration)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cg3d_[a-z0-9_]+)\s*\(", src)))

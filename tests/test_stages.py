@@ -1,0 +1,302 @@
+"""Stage-level fused ops of the RoI head (include/cagroup3d_stages.h, ops/roi_stage.py).
+
+CPU: the oracle's restatement against the torch mirror of the reference code it replaces -- ProposalTargetLayer (pinned by
+the reference's fixture in test_golden.py), CAGroup3DRoIHead.assign_targets / get_dense_grid_points / get_box_reg_layer_loss,
+CAGroupResidualCoder.encode_torch (fixture-pinned too).  -m gpu: the HIP kernels against the oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from cagroup3d_amd import _lib
+from cagroup3d_amd import me as ME
+from cagroup3d_amd.ops import roi_stage as RS
+from cagroup3d_amd.pcdet.models.model_utils.cagroup_utils import CAGroupResidualCoder
+from cagroup3d_amd.pcdet.models.roi_heads.cagroup_roi_head import CAGroup3DRoIHead
+from cagroup3d_amd.pcdet.models.roi_heads.target_assigner.cagroup_proposal_target_layer import ProposalTargetLayer
+from cagroup3d_amd.pcdet.utils import common_utils
+from cagroup3d_amd.pcdet.utils.loss_utils import WeightedSmoothL1Loss
+from util import rand_boxes
+
+
+def _scene_case(seed, yaw, B=3, n_cls=6):
+    """Flat proposals of B scenes (uneven counts, one scene with few) + zero-padded ground truth [B, Gmax, 8]."""
+    g = torch.Generator().manual_seed(seed)
+    n_gt = [5, 9, 3][:B]
+    gmax = max(n_gt) + 2
+    gt = torch.zeros(B, gmax, 8)
+    per_scene, boxes, labels, scores = [], [], [], []
+    for b in range(B):
+        gb = rand_boxes(n_gt[b], seed=seed * 10 + b, yaw=yaw, extent=3.0)
+        gl = torch.randint(0, n_cls, (n_gt[b],), generator=g)
+        gt[b, :n_gt[b], :7], gt[b, :n_gt[b], 7] = gb, gl.float()
+        n = [150, 40, 260][b]
+        src = torch.randint(0, n_gt[b], (n,), generator=g)
+        jit = torch.randn(n, 7, generator=g) * torch.tensor([0.25, 0.25, 0.25, 0.2, 0.2, 0.2, 0.3 if yaw else 0.0])
+        jit[::7] *= 6.0                                        # far-off proposals: background
+        pb = gb[src] + jit
+        if yaw:
+            pb[:, 6] *= -1                                    # the dense head's heading convention (negated by the RoI head)
+        pb[:, 3:6] = pb[:, 3:6].abs() + 0.05
+        pl = gl[src].clone()
+        pl[::5] = torch.randint(0, n_cls, (len(pl[::5]),), generator=g)     # wrong-class proposals
+        per_scene.append(n)
+        boxes.append(pb); labels.append(pl); scores.append(torch.rand(n, generator=g))
+    return (torch.cat(boxes).float().contiguous(), torch.cat(scores).float(), torch.cat(labels).long(), per_scene, gt, n_gt)
+
+
+def _reference_chain(boxes, scores, labels, per_scene, gt, n_gt, code_size, enlarge, seed):
+    """reoder_rois_for_refining + enlargement + ProposalTargetLayer + assign_targets + the regression targets: the torch
+    mirror of the reference's path."""
+    head = CAGroup3DRoIHead.__new__(CAGroup3DRoIHead)
+    torch.nn.Module.__init__(head)
+    head.code_size, head.enlarge_ratio = code_size, enlarge
+    head.proposal_target_layer = ProposalTargetLayer(roi_per_image=128, fg_ratio=0.9, reg_fg_thresh=0.3)
+    pl = list(zip(torch.split(boxes, per_scene), torch.split(scores, per_scene), torch.split(labels, per_scene)))
+    rois, roi_scores, roi_labels, bs = head.reoder_rois_for_refining(pl)
+    if enlarge:
+        rois[..., 3:6] *= enlarge
+    d = {"rois": rois, "roi_scores": roi_scores, "roi_labels": roi_labels, "batch_size": bs,
+         "gt_bboxes_3d": [gt[b, :n_gt[b], :7].contiguous() for b in range(bs)],
+         "gt_labels_3d": [gt[b, :n_gt[b], 7].long() for b in range(bs)]}
+    np.random.seed(seed); torch.manual_seed(seed)
+    t = head.assign_targets(d)
+    cs = code_size
+    anchors = t["rois"][..., 0:cs].clone().view(-1, cs)
+    anchors[:, 0:3] = 0
+    if cs > 6:
+        anchors[:, 6] = 0
+    t["reg_targets"] = CAGroupResidualCoder(code_size=cs).encode_torch(t["gt_of_rois"][..., 0:cs].clone().view(-1, cs), anchors)
+    return t
+
+
+def _fused_chain(dev, boxes, scores, labels, per_scene, gt, n_gt, code_size, enlarge, seed):
+    bs = len(per_scene)
+    rin = max(1, max(per_scene))
+    tab = torch.tensor(np.concatenate([np.cumsum([0] + per_scene), n_gt]), dtype=torch.int32, device=dev)
+    roi_off, ngt = tab[:bs + 1], tab[bs + 1:]
+    boxes, scores, labels, gt = boxes.to(dev), scores.to(dev), labels.to(dev), gt.to(dev)
+    e = float(enlarge) if enlarge else 1.0
+    max_ov, assign = RS.roi_match(boxes, labels, roi_off, bs, rin, e, gt, ngt)
+    np.random.seed(seed); torch.manual_seed(seed)
+    ov = max_ov.view(bs, rin).cpu().numpy()
+    keep = np.concatenate([RS.subsample_rois_host(ov[i], 128, 0.9, 0.3, 0.55, 0.1, 0.8) for i in range(bs)])
+    t = RS.roi_targets(boxes, scores, labels, roi_off, bs, rin, e, gt, max_ov, assign,
+                       torch.from_numpy(keep).to(dev), 128, code_size, 0.3, 0.55, 0.15)
+    t["max_ov"], t["assign"], t["keep"] = max_ov, assign, keep
+    return t
+
+
+KEYS = ("rois", "gt_of_rois", "gt_of_rois_src", "gt_label_of_rois", "gt_iou_of_rois", "roi_scores", "roi_labels", "reg_valid_mask",
+        "rcnn_cls_labels")
+
+
+@pytest.mark.parametrize("seed,yaw,enlarge", [(0, False, 1.0), (1, True, 1.0), (2, True, 1.15), (3, False, 0)])
+def test_oracle_roi_sampling_and_targets_equal_the_torch_chain(oracle, seed, yaw, enlarge):
+    case = _scene_case(seed, yaw)
+    cs = 7 if yaw else 6
+    with _lib.use_library(oracle):
+        ref = _reference_chain(*case, cs, enlarge, seed)
+        out = _fused_chain("cpu", *case, cs, enlarge, seed)
+    assert int(ref["reg_valid_mask"].sum()) > 20                               # the case has foreground
+    for k in KEYS:
+        a, b = out[k], ref[k]
+        assert a.shape == b.shape, k
+        if a.dtype == torch.int64:
+            assert torch.equal(a, b), k
+        else:
+            torch.testing.assert_close(a, b.float(), rtol=1e-5, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+    v = ref["reg_valid_mask"].view(-1) > 0                                     # (targets of background rows are never read)
+    torch.testing.assert_close(out["reg_targets"][v], ref["reg_targets"][v], rtol=1e-5, atol=2e-6)
+
+
+def test_oracle_roi_match_padding_rows_and_missing_classes(oracle):
+    """Padded (all-zero) RoIs carry label 0: overlap 0 with the scene's first class-0 box, or box 0 when it has none."""
+    boxes, scores, labels, per_scene, gt, n_gt = _scene_case(5, False)
+    gt[1, :, 7] = torch.where(gt[1, :, 7] == 0, torch.ones(()), gt[1, :, 7])   # scene 1: no class-0 box
+    gt[0, 2, 7] = 0.0                                                           # scene 0: its first class-0 box is box <= 2
+    bs, rin = len(per_scene), max(per_scene)
+    tab = torch.tensor(np.concatenate([np.cumsum([0] + per_scene), n_gt]), dtype=torch.int32)
+    with _lib.use_library(oracle):
+        ov, asg = RS.roi_match(boxes, labels, tab[:bs + 1], bs, rin, 1.0, gt, tab[bs + 1:])
+    ov, asg = ov.view(bs, rin), asg.view(bs, rin)
+    assert float(ov[1, per_scene[1]:].abs().sum()) == 0.0 and int(asg[1, per_scene[1]:].abs().sum()) == 0
+    first0 = int(torch.nonzero(gt[0, :n_gt[0], 7] == 0)[0])
+    assert torch.all(asg[0, per_scene[0]:] == first0) and float(ov[0, per_scene[0]:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("yaw", [False, True])
+def test_oracle_roi_grid_coords_equal_the_torch_chain(oracle, yaw):
+    head = CAGroup3DRoIHead.__new__(CAGroup3DRoIHead)
+    torch.nn.Module.__init__(head)
+    head.code_size = 7 if yaw else 6
+    B, R, G, vs, ck, gs = 2, 40, 7, 0.04, 2, 768
+    rois = rand_boxes(B * R, seed=11, yaw=yaw, extent=3.0)
+    rois[5] = 0.0                                              # a padded RoI: all 343 points in one voxel
+    rois[7, :3] = 100.0                                        # far outside: clamped
+    xyz, _ = head.get_global_grid_points_of_roi(rois.view(B, R, 7), grid_size=G)
+    vox = torch.floor(xyz.reshape(-1, 3) / vs)
+    vox = torch.clamp(vox, min=-gs / 2 + 1, max=gs / 2 - 1).long() * ck
+    bidx = torch.arange(B).repeat_interleave(R * G ** 3)
+    want = torch.cat([bidx.view(-1, 1), vox], 1).int()
+    with _lib.use_library(oracle):
+        got = RS.roi_grid_coords(rois, R, G, yaw, vs, -gs / 2 + 1, gs / 2 - 1, ck)
+    if not yaw:
+        assert torch.equal(got, want)
+    else:           # the rotation is a library matmul in the torch chain: a point within an ulp of a voxel face may move one cell
+        diff = (got != want).any(1)
+        assert float(diff.float().mean()) < 1e-3 and int((got - want).abs().max()) <= ck
+    assert int(got[:, 1:].abs().max()) == (gs // 2 - 1) * ck
+
+
+@pytest.mark.parametrize("cs,frac", [(6, 0.4), (7, 0.0), (7, 1.0)])
+def test_oracle_roi_reg_loss_equals_the_torch_chain(oracle, cs, frac):
+    g = torch.Generator().manual_seed(cs)
+    m = 512
+    reg, tgt = torch.randn(m, cs, generator=g) * 0.3, torch.randn(m, cs, generator=g) * 0.3
+    tgt[::9] = reg[::9]
+    tgt[3, 2] = float("nan")
+    valid = (torch.rand(m, generator=g) < frac).long()
+    valid[3] = 1 if frac > 0 else 0
+    cw = torch.rand(cs, generator=g) + 0.5
+    lf = WeightedSmoothL1Loss(code_weights=cw.tolist())
+    r0 = reg.clone().requires_grad_(True)
+    l = lf(r0.view(m, -1).unsqueeze(0), tgt.unsqueeze(0))
+    want = (l.view(m, -1) * (valid > 0).unsqueeze(-1).float()).sum() / (valid > 0).long().sum().clamp(min=1) * 1.7
+    (want * 0.6).backward()
+    r1 = reg.clone().requires_grad_(True)
+    with _lib.use_library(oracle):
+        got = RS.roi_reg_loss(r1, tgt, valid, lf.code_weights, lf.beta, 1.7)
+        (got * 0.6).backward()
+    torch.testing.assert_close(got.detach(), want.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(r1.grad, r0.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_host_subsampling_follows_the_reference_rng_streams():
+    """subsample_rois_host == ProposalTargetLayer.subsample_rois (fixture-pinned in test_golden.py) for the same seeds, in all
+    four branches of the draw."""
+    ptl = ProposalTargetLayer(roi_per_image=128, fg_ratio=0.9, reg_fg_thresh=0.3)
+    g = torch.Generator().manual_seed(0)
+    cases = [torch.rand(300, generator=g), torch.rand(300, generator=g) * 0.25, torch.rand(90, generator=g) * 0.5 + 0.4,
+             torch.cat([torch.rand(40, generator=g) * 0.05, torch.rand(10, generator=g) * 0.5 + 0.5]),
+             torch.rand(200, generator=g) * 0.15 + 0.12]
+    for i, ov in enumerate(cases):
+        np.random.seed(i); torch.manual_seed(i)
+        want = ptl.subsample_rois(ov).numpy()
+        np.random.seed(i); torch.manual_seed(i)
+        got = RS.subsample_rois_host(ov.numpy(), 128, 0.9, 0.3, 0.55, 0.1, 0.8)
+        assert np.array_equal(got, want), i
+
+
+# ---------------------------------------------------------------------------------------------------------------- gpu
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,yaw,enlarge", [(0, False, 1.0), (1, True, 1.15)])
+def test_hip_roi_match_and_targets_match_oracle(hip, oracle, seed, yaw, enlarge):
+    case = _scene_case(seed, yaw)
+    cs = 7 if yaw else 6
+    with _lib.use_library(oracle):
+        ref = _fused_chain("cpu", *case, cs, enlarge, seed)
+    out = _fused_chain("cuda", *case, cs, enlarge, seed)
+    assert torch.equal(out["max_ov"].cpu(), ref["max_ov"]) and torch.equal(out["assign"].cpu(), ref["assign"])      # bit-exact
+    assert np.array_equal(out["keep"], ref["keep"])
+    for k in KEYS + ("reg_targets",):
+        a, b = out[k].cpu(), ref[k]
+        if a.dtype == torch.int64:
+            assert torch.equal(a, b), k
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("yaw", [False, True])
+def test_hip_roi_grid_coords_match_oracle(hip, oracle, yaw):
+    rois = rand_boxes(4 * 128, seed=3, yaw=yaw, extent=3.0)
+    rois[::17] = 0.0
+    with _lib.use_library(oracle):
+        want = RS.roi_grid_coords(rois, 128, 7, yaw, 0.04, -383.0, 383.0, 2)
+    got = RS.roi_grid_coords(rois.cuda(), 128, 7, yaw, 0.04, -383.0, 383.0, 2).cpu()
+    if not yaw:
+        assert torch.equal(got, want)
+    else:           # sin / cos of two math libraries
+        assert float((got != want).any(1).float().mean()) < 1e-3 and int((got - want).abs().max()) <= 2
+
+
+@pytest.mark.gpu
+def test_hip_roi_reg_loss_matches_oracle(hip, oracle):
+    g = torch.Generator().manual_seed(1)
+    m, cs = 512, 6
+    reg, tgt = torch.randn(m, cs, generator=g) * 0.3, torch.randn(m, cs, generator=g) * 0.3
+    valid = (torch.rand(m, generator=g) < 0.3).long()
+    cw = torch.rand(cs, generator=g) + 0.5
+    res = []
+    for dev, lib in (("cpu", oracle), ("cuda", None)):
+        r = reg.clone().to(dev).requires_grad_(True)
+        ctx = _lib.use_library(lib) if lib is not None else _lib.use_library(_lib.get())
+        with ctx:
+            l = RS.roi_reg_loss(r, tgt.to(dev), valid.to(dev), cw.to(dev), 1.0 / 9, 1.0)
+            l.backward()
+        res.append((l.detach().cpu(), r.grad.cpu()))
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_hip_pooling_layer_from_rois_equals_the_grid_point_form(hip):
+    """SimplePoolingLayer.forward_rois (fused grid generation + hash de-duplication) == forward on explicit grid points
+    (linearise + torch.unique): the order of the de-duplicated rows differs, the pooled rows must not."""
+    from cagroup3d_amd.pcdet.models.roi_heads.cagroup_roi_head import SimplePoolingLayer
+    from util import surface_coords
+    torch.manual_seed(0)
+    dev = "cuda"
+    coords = surface_coords(6000, batch=2, extent=40, seed=2).to(dev)
+    coords[:, 1:] *= 2
+    sp = ME.SparseTensor(coordinates=coords, features=torch.randn(coords.shape[0], 64, device=dev), tensor_stride=2)
+    layer = SimplePoolingLayer(channels=(64, 128, 128), grid_kernel_size=5, grid_num=7, voxel_size=0.04, coord_key=2, pooling=True).to(dev)
+    layer.train()
+    head = CAGroup3DRoIHead.__new__(CAGroup3DRoIHead)
+    torch.nn.Module.__init__(head)
+    head.code_size = 6
+    rois = rand_boxes(2 * 16, seed=4, yaw=False, extent=1.2, device=dev)
+    rois[3] = 0.0
+    xyz, _ = head.get_global_grid_points_of_roi(rois.view(2, 16, 7), grid_size=7)
+    bidx = torch.arange(2, device=dev, dtype=xyz.dtype).view(2, 1, 1).expand(-1, 16 * 343, 1)
+    gp = torch.cat([bidx, xyz.view(2, -1, 3)], dim=-1).reshape(-1, 4)
+    a = layer(sp, grid_points=gp)
+    b = layer.forward_rois(sp, rois, 16, False)
+    torch.testing.assert_close(b, a, rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------- detector
+@pytest.mark.parametrize("dataset,cfgname", [("scannet", "S5k"), ("sunrgbd", "S5k-yaw")])
+def test_detector_step_with_and_without_the_fused_roi_stage(oracle, dataset, cfgname, monkeypatch):
+    """One training step of the whole detector on the oracle, RoI stage fused vs the tensor-expression path: same sampled
+    RoIs (same host RNG streams), same second-stage loss, same gradients."""
+    from cagroup3d_amd import build_model
+    from cagroup3d_amd.pcdet.models.roi_heads import cagroup_roi_head as RH
+    res = []
+    with _lib.use_library(oracle):
+        model, cfg = build_model.build_cagroup3d(dataset)
+        model.train()
+        model.dense_head.force_gt_selection = True
+        model.dense_head.force_class_logit_boost = 6.0
+        model.roi_head.proposal_target_layer.reg_fg_thresh = 0.02       # an untrained net's proposals overlap their boxes little
+        for fused in (False, True):
+            monkeypatch.setattr(RH, "FUSED_ROI", fused)
+            calls = []
+            orig = RS.roi_targets
+            monkeypatch.setattr(RS, "roi_targets", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+            model.zero_grad()
+            torch.manual_seed(1); np.random.seed(1)
+            batch = build_model.synthetic_batch(cfgname, 2, device="cpu")
+            ret, tb, disp = model(batch)
+            ret["loss"].backward()
+            assert bool(calls) == fused                      # the fused path really ran (or really did not)
+            res.append((dict(tb), batch["rois"].clone(), batch["reg_valid_mask"].clone(),
+                        torch.cat([p.grad.flatten() for p in model.roi_head.parameters()])))
+            monkeypatch.setattr(RS, "roi_targets", orig)
+    (tb0, rois0, v0, g0), (tb1, rois1, v1, g1) = res
+    assert int(v0.sum()) > 0
+    torch.testing.assert_close(rois1, rois0, rtol=1e-6, atol=1e-6)
+    assert torch.equal(v1, v0)
+    for k in tb0:
+        assert abs(tb0[k] - tb1[k]) <= 1e-4 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
+    torch.testing.assert_close(g1, g0, rtol=2e-3, atol=1e-5)
