@@ -100,6 +100,12 @@ _SIGNATURES = {
     "cg3d_roi_grid_coords": (c_int32, [P, c_int64, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32, P, P]),
     "cg3d_roi_reg_loss_fwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, c_float, P, P]),
     "cg3d_roi_reg_loss_bwd": (c_int32, [P, P, P, P, c_int64, c_int32, c_float, c_float, P, P, P, P]),
+    "cg3d_class_nblk": (c_int32, [c_int64]),
+    "cg3d_class_count": (c_int32, [P, c_int64, c_int32, P, P, P, P]),
+    "cg3d_class_rows": (c_int32, [P, c_int64, c_int32, c_int32, P, P, P, P, P, c_int32, c_float, c_int32, P, c_int32, P, P, P, P]),
+    "cg3d_gather_rows2": (c_int32, [P, P, c_int64, P, P, c_int64, c_int32, P]),
+    "cg3d_scatter_add_rows2": (c_int32, [P, P, P, P, c_int64, c_int64, c_int32, P]),
+    "cg3d_count_ids": (c_int32, [P, c_int64, c_int32, c_int32, c_int32, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
     "cg3d_event_create": (c_int32, [P]),

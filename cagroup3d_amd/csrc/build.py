@@ -19,7 +19,7 @@ SOURCES = {
     "linear.hip": ["-munsafe-fp-atomics"],
     "gather_scatter.hip": ["-munsafe-fp-atomics"],
     "iou3d_nms.hip": ["-ffp-contract=off"],
-    "stages.hip": ["-ffp-contract=off"],     # stage-level fused ops of the heads (RoI matching / targets / grid, class rows, proposals)
+    "stages.hip": ["-ffp-contract=off", "-munsafe-fp-atomics"],     # stage-level fused ops of the heads (RoI matching / targets / grid, class rows, proposals)
     "knn.hip": ["-ffp-contract=off"],
     "sort_vertices.hip": ["-ffp-contract=off"],
     "bn_act.hip": [],

@@ -294,3 +294,249 @@ extern "C" int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, cons
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ================================================================================================ dense head: class rows
+#define CR_BLK 1024          // voxels per block of the ordered compaction
+
+extern "C" int32_t cg3d_class_nblk(int64_t n) { return (int32_t)cg3d_divup(n > 0 ? n : 1, CR_BLK); }
+
+// selected voxels of (class blockIdx.y, block blockIdx.x); blocks of class 0 also reduce the coordinate columns
+__global__ __launch_bounds__(CR_BLK) void k_class_count(const uint8_t *__restrict__ hit, int64_t n, int nc,
+                                                        const int32_t *__restrict__ coords, int nblk,
+                                                        int32_t *__restrict__ block_cnt, int32_t *__restrict__ block_mm) {
+    __shared__ int s_cnt[CR_BLK / 64];
+    __shared__ int s_mm[CR_BLK / 64][6];
+    const int c = blockIdx.y, blk = blockIdx.x;
+    const int64_t r = (int64_t)blk * CR_BLK + threadIdx.x;
+    const bool h = r < n && hit[r * nc + c] != 0;
+    const unsigned long long bal = __ballot(h);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    if (c == 0) {
+        int v[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        if (r < n) {
+            const int4 q = reinterpret_cast<const int4 *>(coords)[r];
+            v[0] = v[3] = q.y; v[1] = v[4] = q.z; v[2] = v[5] = q.w;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[k] = min(v[k], __shfl_xor(v[k], d));
+                v[3 + k] = max(v[3 + k], __shfl_xor(v[3 + k], d));
+            }
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 6; k++) s_mm[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < CR_BLK / 64; w++) t += s_cnt[w];
+        block_cnt[c * nblk + blk] = t;
+    }
+    if (c == 0 && threadIdx.x < 6) {
+        int m = s_mm[0][threadIdx.x];
+        for (int w = 1; w < CR_BLK / 64; w++) m = threadIdx.x < 3 ? min(m, s_mm[w][threadIdx.x]) : max(m, s_mm[w][threadIdx.x]);
+        block_mm[blk * 6 + threadIdx.x] = m;
+    }
+}
+// one workgroup per class: exclusive prefix of its block counts (in place) and its total; workgroup nc reduces the bounds
+__global__ __launch_bounds__(256) void k_class_scan(int32_t *__restrict__ block_cnt, const int32_t *__restrict__ block_mm, int nc,
+                                                    int nblk, int32_t *__restrict__ totals) {
+    __shared__ int s[256];
+    const int c = blockIdx.x;
+    if (c == nc) {
+        if (threadIdx.x < 6) {
+            const bool lo = threadIdx.x < 3;
+            int m = lo ? 0x7fffffff : (int)0x80000000;
+            for (int b = 0; b < nblk; b++) m = lo ? min(m, block_mm[b * 6 + threadIdx.x]) : max(m, block_mm[b * 6 + threadIdx.x]);
+            totals[nc + threadIdx.x] = m;
+        }
+        return;
+    }
+    int32_t *row = block_cnt + (int64_t)c * nblk;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? row[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int t = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) row[i] = carry + s[threadIdx.x] - v;
+        carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[c] = carry;
+}
+extern "C" int cg3d_class_count(const uint8_t *hit, int64_t n, int32_t nc, const int32_t *coords, int32_t *block_off,
+                                int32_t *totals, cg3d_stream_t stream) {
+    if (n < 0 || nc <= 0 || nc > 65535 || !block_off || !totals) return CG3D_ERR_ARG;
+    if (n > 0 && (!hit || !coords)) return CG3D_ERR_ARG;
+    const int nblk = cg3d_class_nblk(n);
+    // the per-block bounds wait behind the counts in the same buffer: block_off must hold nc * nblk + 6 * nblk int32
+    int32_t *block_mm = block_off + (int64_t)nc * nblk;
+    hipLaunchKernelGGL(k_class_count, dim3(nblk, nc), dim3(CR_BLK), 0, cg3d_hs(stream), hit, n, nc, coords, nblk, block_off, block_mm);
+    hipLaunchKernelGGL(k_class_scan, dim3(nc + 1), dim3(256), 0, cg3d_hs(stream), block_off, block_mm, nc, nblk, totals);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+__global__ __launch_bounds__(CR_BLK) void k_class_rows(const uint8_t *__restrict__ hit, int64_t n, int nc, int nbatch, int nblk,
+                                                       const int32_t *__restrict__ block_off, const int32_t *__restrict__ totals,
+                                                       const int32_t *__restrict__ coords, const int32_t *__restrict__ pad_row,
+                                                       const float *__restrict__ offsets, int nvote, float voxel_size, int ts,
+                                                       const float *__restrict__ vs_tab, int expand, int32_t *__restrict__ src,
+                                                       int32_t *__restrict__ fine, int32_t *__restrict__ coarse) {
+    __shared__ int s_cnt[CR_BLK / 64];
+    const int c = blockIdx.y, blk = blockIdx.x;
+    const bool pads = blk == nblk;                      // the last block of a class places its pad voxels
+    int64_t r = (int64_t)blk * CR_BLK + threadIdx.x;
+    bool h;
+    if (pads) {
+        h = (int)threadIdx.x < nbatch;
+        r = h ? pad_row[threadIdx.x] : 0;
+    } else {
+        h = r < n && hit[r * nc + c] != 0;
+    }
+    const unsigned long long bal = __ballot(h);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (!h) return;
+    int before = __popcll(bal & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) before += s_cnt[w];
+    // class geometry of the list: start_c rows of earlier classes, n_c rows of this one (selected + pads)
+    int start = 0;
+    for (int k = 0; k < c; k++) start += totals[k] + nbatch;
+    const int n_c = totals[c] + nbatch;
+    const int j = pads ? totals[c] + before : block_off[c * nblk + blk] + before;
+    const int64_t base = (int64_t)start * (nvote + 1);
+    const int4 q = reinterpret_cast<const int4 *>(coords)[r];
+    const int bp = c * nbatch + q.x;
+    const float vs[3] = {vs_tab[c * 3 + 0], vs_tab[c * 3 + 1], vs_tab[c * 3 + 2]};
+    const float ori[3] = {(float)q.y * voxel_size, (float)q.z * voxel_size, (float)q.w * voxel_size};
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        lo[k] = (float)(totals[nc + k] - ts) * voxel_size;
+        hi[k] = (float)(totals[nc + 3 + k] + ts) * voxel_size;
+    }
+    for (int v = 0; v <= nvote; v++) {
+        float p[3];
+        int64_t dst;
+        int s;
+        if (v < nvote) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float t = ori[k] + offsets[r * (nvote * 3) + v * 3 + k];
+                t = t < hi[k] ? t : hi[k];            // torch.max(torch.min(voted, max_bound), min_bound)
+                p[k] = t > lo[k] ? t : lo[k];
+            }
+            dst = base + (int64_t)j * nvote + v;
+            s = (int)(r * nvote + v);
+        } else {
+            p[0] = ori[0]; p[1] = ori[1]; p[2] = ori[2];
+            dst = base + (int64_t)n_c * nvote + j;
+            s = (int)(n * nvote + r);
+        }
+        src[dst] = s;
+        int4 f, g;
+        f.x = g.x = bp;
+        const float fe = (float)expand;
+        f.y = (int)floorf(p[0] / vs[0]); f.z = (int)floorf(p[1] / vs[1]); f.w = (int)floorf(p[2] / vs[2]);
+        g.y = (int)(floorf(p[0] / (vs[0] * fe)) * fe); g.z = (int)(floorf(p[1] / (vs[1] * fe)) * fe);
+        g.w = (int)(floorf(p[2] / (vs[2] * fe)) * fe);
+        reinterpret_cast<int4 *>(fine)[dst] = f;
+        reinterpret_cast<int4 *>(coarse)[dst] = g;
+    }
+}
+extern "C" int cg3d_class_rows(const uint8_t *hit, int64_t n, int32_t nc, int32_t nbatch, const int32_t *block_off,
+                               const int32_t *totals, const int32_t *coords, const int32_t *pad_row, const float *offsets,
+                               int32_t nvote, float voxel_size, int32_t ts, const float *vs_tab, int32_t expand, int32_t *src,
+                               int32_t *fine, int32_t *coarse, cg3d_stream_t stream) {
+    if (n <= 0 || nc <= 0 || nc > 65535 || nbatch <= 0 || nbatch > CR_BLK || nvote < 1 || expand < 1) return CG3D_ERR_ARG;
+    if (!hit || !block_off || !totals || !coords || !pad_row || !offsets || !vs_tab || !src || !fine || !coarse) return CG3D_ERR_ARG;
+    if (n * (int64_t)(nvote + 1) >= 0x7fffffffLL) return CG3D_ERR_ARG;
+    const int nblk = cg3d_class_nblk(n);
+    hipLaunchKernelGGL(k_class_rows, dim3(nblk + 1, nc), dim3(CR_BLK), 0, cg3d_hs(stream), hit, n, nc, nbatch, nblk, block_off,
+                       totals, coords, pad_row, offsets, nvote, voxel_size, ts, vs_tab, expand, src, fine, coarse);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ two-piece gather
+__global__ void k_gather_rows2(const float *__restrict__ Fa, const float *__restrict__ Fb, int64_t na,
+                               const int32_t *__restrict__ idx, float *__restrict__ out, int64_t n, int cq) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = t / cq;
+    const int g = (int)(t % cq);
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    const float4 *s = r < na ? reinterpret_cast<const float4 *>(Fa) + r * cq : reinterpret_cast<const float4 *>(Fb) + (r - na) * cq;
+    reinterpret_cast<float4 *>(out)[i * cq + g] = s[g];
+}
+extern "C" int cg3d_gather_rows2(const float *Fa, const float *Fb, int64_t na, const int32_t *idx, float *out, int64_t n,
+                                 int32_t c, cg3d_stream_t stream) {
+    if (n < 0 || c < 4 || c % 4 != 0 || na < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!Fa || !Fb || !idx || !out || (((uintptr_t)Fa | (uintptr_t)Fb | (uintptr_t)out) & 15)) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_gather_rows2, dim3((unsigned)cg3d_divup(n * (c / 4), 256)), dim3(256), 0, cg3d_hs(stream), Fa, Fb, na, idx,
+                       out, n, c / 4);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+// one channel per lane, like k_scatter_add_rows (gather_scatter.hip): a wave's atomics land on consecutive floats
+__global__ void k_scatter_add_rows2(const float *__restrict__ dout, const int32_t *__restrict__ idx, float *__restrict__ dFa,
+                                    float *__restrict__ dFb, int64_t na, int64_t n, int c) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = t / c;
+    const int a = (int)(t - i * c);
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    float *d = r < na ? dFa + r * c : dFb + (r - na) * c;
+    unsafeAtomicAdd(d + a, dout[i * c + a]);
+}
+extern "C" int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, float *dFb, int64_t na, int64_t n,
+                                      int32_t c, cg3d_stream_t stream) {
+    if (n < 0 || c < 1 || na < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!dout || !idx || !dFa || !dFb) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_scatter_add_rows2, dim3((unsigned)cg3d_divup(n * c, 256)), dim3(256), 0, cg3d_hs(stream), dout, idx, dFa,
+                       dFb, na, n, c);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ id histogram
+template <typename T>
+__global__ __launch_bounds__(256) void k_count_ids(const T *__restrict__ ids, int64_t n, int stride, int m,
+                                                   unsigned long long *__restrict__ counts) {
+    extern __shared__ int s_h[];
+    for (int i = threadIdx.x; i < m; i += 256) s_h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t v = (int64_t)ids[i * stride];
+        if (v >= 0 && v < m) atomicAdd(&s_h[v], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256)
+        if (s_h[i]) atomicAdd(&counts[i], (unsigned long long)s_h[i]);
+}
+extern "C" int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts,
+                              cg3d_stream_t stream) {
+    if (n < 0 || m <= 0 || m > 8192 || stride < 1 || !counts) return CG3D_ERR_ARG;
+    if (hipMemsetAsync(counts, 0, (size_t)m * 8, cg3d_hs(stream)) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (n == 0) return CG3D_OK;
+    if (!ids) return CG3D_ERR_ARG;
+    const unsigned g = (unsigned)(cg3d_divup(n, 256 * 8) < 1024 ? cg3d_divup(n, 256 * 8) : 1024);
+    if (is64) hipLaunchKernelGGL(k_count_ids<int64_t>, dim3(g), dim3(256), (size_t)m * 4, cg3d_hs(stream), (const int64_t *)ids, n, stride, m, (unsigned long long *)counts);
+    else hipLaunchKernelGGL(k_count_ids<int32_t>, dim3(g), dim3(256), (size_t)m * 4, cg3d_hs(stream), (const int32_t *)ids, n, stride, m, (unsigned long long *)counts);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

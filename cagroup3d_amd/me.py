@@ -126,12 +126,13 @@ class CoordinateMapKey:
 
 
 class _CoordMap:
-    __slots__ = ("coords", "keys", "vals", "cap", "n", "tensor_stride", "_perms")
+    __slots__ = ("coords", "keys", "vals", "cap", "n", "tensor_stride", "_perms", "_perms_sorted")
 
     def __init__(self, coords, keys, vals, cap, n, tensor_stride):
         self.coords, self.keys, self.vals, self.cap, self.n = coords, keys, vals, cap, n
         self.tensor_stride = tensor_stride
         self._perms = None
+        self._perms_sorted = False
 
 
 class KernelMap:
@@ -1473,11 +1474,12 @@ def sorted_batch_counts(b, n_batch):
     return host[1:] if host[0] == 0 else None
 
 
-def rows_by_batch(b, n_batch=None):
+def rows_by_batch(b, n_batch=None, info=None):
     """Per-batch row index lists (ascending) of a batch-index column: torch.split(stable argsort, counts) with ONE host
     read.  Rows of every map of this build are batch-major ((batch, Morton) order, strided maps in first-occurrence order
     of their parents), so the sort is normally the identity: the number of descents rides along with the counts and the
-    ~10 merge-sort launches are only paid when it is not zero."""
+    ~10 merge-sort launches are only paid when it is not zero.  info (a dict): info["sorted"] = the column was batch-major,
+    i.e. the lists are consecutive row ranges."""
     b = b.reshape(-1).long()
     if b.numel() == 0:
         return []
@@ -1493,10 +1495,14 @@ def rows_by_batch(b, n_batch=None):
         host = torch.cat([desc, b[-1:]]).tolist()          # batch-major: the last row holds the largest index
         if host[0] == 0:
             counts = count_ids(b, host[1] + 1).tolist()    # (second read only on this path without a known batch size)
+            if info is not None:
+                info["sorted"] = True
             return list(torch.split(torch.arange(b.numel(), device=b.device), counts))
     else:
         host = torch.cat([desc, count_ids(b, n_batch)]).tolist()
         if host[0] == 0:
+            if info is not None:
+                info["sorted"] = True
             return list(torch.split(torch.arange(b.numel(), device=b.device), host[1:]))
     if int(b.min()) < 0:
         raise ValueError("rows_by_batch: negative batch index")
@@ -1505,12 +1511,19 @@ def rows_by_batch(b, n_batch=None):
 
 
 def count_ids(ids, m):
-    """torch.bincount(ids, minlength=m) for ids known to lie in [0, m): one comparison against the m bins and a row sum --
-    bincount first scans its input for min and max (two single-workgroup-chain reductions, 14 + 23 us on 150 k ids)."""
+    """torch.bincount(ids, minlength=m) for ids known to lie in [0, m) (others are ignored): one histogram launch
+    (cg3d_count_ids) on an int32 / int64 id vector or strided id column -- bincount first scans its input for min and max (two
+    single-workgroup-chain reductions, 14 + 23 us on 150 k ids)."""
     n = ids.numel()
-    if n == 0 or m * n > (1 << 27) or not ids.is_cuda:
-        return torch.bincount(ids.reshape(-1), minlength=m)[:m] if n else torch.zeros(m, dtype=torch.int64, device=ids.device)
-    return (torch.arange(m, device=ids.device, dtype=ids.dtype).view(-1, 1) == ids.view(1, -1)).sum(1)
+    if n == 0:
+        return torch.zeros(m, dtype=torch.int64, device=ids.device)
+    lib = _lib.get()
+    if m > 8192 or ids.dim() != 1 or ids.dtype not in (torch.int32, torch.int64) or ids.is_cuda != lib.is_device:
+        return torch.bincount(ids.reshape(-1).long(), minlength=m)[:m]
+    counts = torch.empty(m, dtype=torch.int64, device=ids.device)
+    lib.call("cg3d_count_ids", ptr(ids), c_int64(n), c_int32(ids.stride(0)), c_int32(1 if ids.dtype == torch.int64 else 0), c_int32(m),
+             ptr(counts), lib.stream())
+    return counts
 
 
 class GatherRowsFunction(torch.autograd.Function):
@@ -2076,8 +2089,23 @@ class SparseTensor:
             if m.n == 0:
                 m._perms = []
             else:
-                m._perms = rows_by_batch(m.coords[:, 0])
+                info = {}
+                m._perms = rows_by_batch(m.coords[:, 0], info=info)
+                m._perms_sorted = bool(info.get("sorted"))
         return m._perms
+
+    def batch_row_starts(self, n_batch):
+        """Host list: first row of every scene when the rows of the map are batch-major and all n_batch scenes are present
+        (then scene b is the row range [starts[b], starts[b + 1])), else None.  No device read beyond the one
+        `decomposition_permutations` makes."""
+        perms = self.decomposition_permutations
+        if not getattr(self._map, "_perms_sorted", False) or len(perms) != n_batch or any(len(p) == 0 for p in perms):
+            return None
+        starts, r = [], 0
+        for p in perms:
+            starts.append(r)
+            r += len(p)
+        return starts
 
     @property
     def decomposed_coordinates(self):

@@ -1,0 +1,69 @@
+"""Dense-head stage ops through the C-ABI of include/cagroup3d_stages.h:
+
+* `class_rows`    selection per class + pad voxels + the [votes ; originals] point set + its two quantisations
+                  (reference dense_heads/cagroup_head.py:209-258) -- three launches and ONE host read in place of ~60 tensor
+                  launches (nonzero, argsort, the index arithmetic of the class-major layout, two floors ...);
+* `gather_rows2`  rows of a table held in two pieces (the reference concatenates [vote features ; backbone features] first).
+"""
+from ctypes import c_float, c_int32, c_int64
+
+import torch
+
+from .. import _lib
+from .._lib import ptr
+
+
+def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, expand, n_batch):
+    """hit bool / uint8 [N, C]; coords int32 [N,4]; pad_row int32 [B]; offsets float32 [N, n_vote*3]; vs_tab float32 [C,3].
+    -> (src int32 [T], fine int32 [T,4], coarse int32 [T,4], sel list[C]) with T = (sum(sel) + C*B) * (n_vote + 1)."""
+    lib = _lib.get()
+    N, C = hit.shape
+    hit8 = hit.contiguous().view(torch.uint8) if hit.dtype == torch.bool else hit.contiguous()
+    coords, pad_row, offsets, vs_tab = coords.contiguous(), pad_row.contiguous(), offsets.contiguous(), vs_tab.contiguous()
+    assert coords.dtype == torch.int32 and pad_row.dtype == torch.int32 and offsets.dtype == torch.float32
+    lib.check(hit8, coords, pad_row, offsets, vs_tab)
+    dev = coords.device
+    nblk = int(lib.raw("cg3d_class_nblk")(N))
+    work = torch.empty((C + 6) * nblk + C + 6, dtype=torch.int32, device=dev)
+    block_off, totals = work[:(C + 6) * nblk], work[(C + 6) * nblk:]
+    lib.call("cg3d_class_count", ptr(hit8), c_int64(N), c_int32(C), ptr(coords), ptr(block_off), ptr(totals), lib.stream())
+    sel = totals[:C].tolist()                                     # the stage's host read (the reference: torch.nonzero)
+    T = (sum(sel) + C * n_batch) * (n_vote + 1)
+    out = torch.empty((T, 9), dtype=torch.int32, device=dev)      # one allocation: src | fine | coarse
+    flat = out.view(-1)
+    src, fine, coarse = flat[:T], flat[T:5 * T].view(T, 4), flat[5 * T:].view(T, 4)
+    lib.call("cg3d_class_rows", ptr(hit8), c_int64(N), c_int32(C), c_int32(n_batch), ptr(block_off), ptr(totals), ptr(coords),
+             ptr(pad_row), ptr(offsets), c_int32(n_vote), c_float(voxel_size), c_int32(ts), ptr(vs_tab), c_int32(expand),
+             ptr(src), ptr(fine), ptr(coarse), lib.stream())
+    return src, fine, coarse, sel
+
+
+class _GatherRows2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fa, fb, idx):
+        lib = _lib.get()
+        fa, fb = fa.contiguous(), fb.contiguous()
+        lib.check(fa, fb, idx)
+        n, c = idx.shape[0], fa.shape[1]
+        assert fb.shape[1] == c and idx.dtype == torch.int32
+        out = torch.empty((n, c), dtype=torch.float32, device=fa.device)
+        lib.call("cg3d_gather_rows2", ptr(fa), ptr(fb), c_int64(fa.shape[0]), ptr(idx), ptr(out), c_int64(n), c_int32(c), lib.stream())
+        ctx.save_for_backward(idx)
+        ctx.shapes = (fa.shape[0], fb.shape[0], c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        na, nb, c = ctx.shapes
+        lib = _lib.get()
+        dout = dout.contiguous()
+        d = torch.zeros((na + nb, c), dtype=torch.float32, device=dout.device)       # one fill for both pieces
+        lib.call("cg3d_scatter_add_rows2", ptr(dout), ptr(idx), ptr(d), ptr(d[na:]), c_int64(na), c_int64(idx.shape[0]), c_int32(c),
+                 lib.stream())
+        return d[:na], d[na:], None
+
+
+def gather_rows2(fa, fb, idx):
+    """out[i] = cat([fa, fb])[idx[i]] without the concatenation; gradients are scattered back into the two pieces."""
+    return _GatherRows2.apply(fa, fb, idx)

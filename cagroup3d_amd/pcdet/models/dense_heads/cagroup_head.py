@@ -31,6 +31,7 @@ SUNRGBD_CLASS_SIZES = [[0.6343, 0.4861, 0.2782], [0.2373, 0.3839, 0.2155], [0.27
 
 
 FUSED_LOSSES = __import__("os").environ.get("CG3D_FUSED_LOSSES", "1") != "0"
+FUSED_HEAD = __import__("os").environ.get("CG3D_FUSED_HEAD", "1") != "0"
 
 
 def _conv_bn_elu(cin, cout, k):
@@ -112,34 +113,39 @@ class CAGroup3DHead(nn.Module):
         batch_size = input_dict["batch_size"]
         out = input_dict["sp_tensor"]
         semantic_scores = self.semantic_conv(out)
-        pad_id = torch.stack([p[0] for p in semantic_scores.decomposition_permutations]).long()  # first row of every scene
         ts = out.coordinate_map_key.get_key()[0][0]
-        xyz_vox = out.C[:, 1:]
-        # (column reductions of the strided [N, 3] view run one workgroup chain per column: 100 + 52 us on 156 k rows;
-        # the same numbers as row reductions of a contiguous [3, N] copy: 3 x 5 us)
-        xyz_t = xyz_vox.t().contiguous()
-        max_bound = (xyz_t.amax(1) + ts) * self.voxel_size
-        min_bound = (xyz_t.amin(1) - ts) * self.voxel_size
-
         voxel_offsets = self.offset_block(out)
         offset_features = self.feature_offset(out).F
         n_vote = 3 if self.with_yaw else 1
-        ori_xyz = xyz_vox.float() * self.voxel_size
-        voted = ori_xyz.view(-1, 1, 3) + voxel_offsets.F.detach().view(-1, n_vote, 3)
-        voted = torch.max(torch.min(voted, max_bound.view(1, 1, 3)), min_bound.view(1, 1, 3))
-        batch_col = out.C[:, :1].float()
         offset_features = offset_features.view(offset_features.shape[0], n_vote, -1)
         sem_prob = semantic_scores.F.detach().sigmoid()
         forced = None
         if self.force_gt_selection:
             forced = self._forced_pre
             object.__setattr__(self, "_forced_pre", None)     # (plain attribute: skip nn.Module.__setattr__'s registration checks)
-            if forced is None or forced.shape[0] != ori_xyz.shape[0]:
-                forced = self._forced_selection(input_dict, out, ori_xyz)
+            if forced is None or forced.shape[0] != out.F.shape[0]:
+                forced = self._forced_selection(input_dict, out, out.C[:, 1:].float() * self.voxel_size)
 
         object.__setattr__(self, "_merged", None)
-        branch = self._class_branches_batched if self.batched else self._class_branches_loop
-        outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
+        fused = self.batched and FUSED_HEAD and out.F.shape[0] > 0
+        if fused:
+            # selection, pad voxels, voted positions (with the scene-bound clamp) and both quantisations: ops/head_stage.class_rows
+            outs = self._class_branches_batched(out, sem_prob, forced, None, None, None, None, offset_features, n_vote, batch_size,
+                                                votes=voxel_offsets.F.detach(), ts=ts)
+        else:
+            pad_id = torch.stack([p[0] for p in semantic_scores.decomposition_permutations]).long()  # first row of every scene
+            xyz_vox = out.C[:, 1:]
+            # (column reductions of the strided [N, 3] view run one workgroup chain per column: 100 + 52 us on 156 k rows;
+            # the same numbers as row reductions of a contiguous [3, N] copy: 3 x 5 us)
+            xyz_t = xyz_vox.t().contiguous()
+            max_bound = (xyz_t.amax(1) + ts) * self.voxel_size
+            min_bound = (xyz_t.amin(1) - ts) * self.voxel_size
+            ori_xyz = xyz_vox.float() * self.voxel_size
+            voted = ori_xyz.view(-1, 1, 3) + voxel_offsets.F.detach().view(-1, n_vote, 3)
+            voted = torch.max(torch.min(voted, max_bound.view(1, 1, 3)), min_bound.view(1, 1, 3))
+            batch_col = out.C[:, :1].float()
+            branch = self._class_branches_batched if self.batched else self._class_branches_loop
+            outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
         centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
         out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
                     "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
@@ -217,49 +223,75 @@ class CAGroup3DHead(nn.Module):
         """Per-class BatchNorm + ELU over contiguous row groups: one fused launch pair for all classes."""
         return ME.fused_bn_act(feats, [b.bn for b in bns], bounds, ME.ACT_ELU)
 
+    @torch.no_grad()
+    def _class_rows_torch(self, hit, pad_id, batch_col, voted, ori_xyz, n_vote, B):
+        """The class-major row construction as tensor expressions (the form the fused stage op replaces and is tested
+        against): -> (src int64 [T] rows of the [votes ; originals] table, fine / coarse float [T,4] quantised coordinates)."""
+        N, C = hit.shape
+        dev = hit.device
+        vs_tab = self._vs_table(dev)
+        sel_cls, sel_row = torch.nonzero(hit.t(), as_tuple=True)                 # class-major, rows ascending
+        ar_c = torch.arange(C, device=dev)
+        all_cls = torch.cat([sel_cls, ar_c.repeat_interleave(B)])
+        all_pos = torch.cat([sel_row, N + torch.arange(B, device=dev).repeat(C)])  # pads go last in a class
+        all_row = torch.cat([sel_row, pad_id.repeat(C)])
+        order = torch.argsort(all_cls * (N + B) + all_pos)
+        e_cls, e_row = all_cls[order], all_row[order]
+        E = e_cls.shape[0]
+        n_c = ME.count_ids(e_cls, C)
+        start_c = torch.cumsum(n_c, 0) - n_c
+        j = torch.arange(E, device=dev) - start_c[e_cls]
+        base = start_c[e_cls] * (n_vote + 1)
+        dest_vote = (base + j * n_vote).unsqueeze(1) + torch.arange(n_vote, device=dev).unsqueeze(0)
+        dest_ori = base + n_c[e_cls] * n_vote + j
+        total = E * (n_vote + 1)
+        src = torch.empty(total, dtype=torch.long, device=dev)          # row of the [votes ; originals] table
+        src[dest_vote.reshape(-1)] = (e_row.unsqueeze(1) * n_vote + torch.arange(n_vote, device=dev).unsqueeze(0)).reshape(-1)
+        src[dest_ori] = N * n_vote + e_row
+        row_cls = torch.empty(total, dtype=torch.long, device=dev)
+        row_cls[dest_vote.reshape(-1)] = e_cls.unsqueeze(1).expand(-1, n_vote).reshape(-1)
+        row_cls[dest_ori] = e_cls
+        src_vox = torch.where(src < N * n_vote, src // n_vote, src - N * n_vote)      # backbone row of each fused row
+        xyz_tab = torch.cat([voted.reshape(-1, 3), ori_xyz], dim=0)
+        fuse_xyz = xyz_tab[src]
+        bprime = row_cls.float() * B + batch_col[src_vox, 0]
+        vs = vs_tab[row_cls]
+        fine = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / vs)], dim=1)
+        coarse = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / (vs * self.expand)) * self.expand], dim=1)
+
+        return src, fine, coarse
+
     def _class_branches_batched(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
-                                batch_size):
+                                batch_size, votes=None, ts=None):
         """All class branches at once: rows of class c live at batch index c*B + b of ONE coordinate map,
         class-major, so every hash build / kernel map / convolution / NMS is a single (grouped) launch.
-        Row order inside a class equals the loop version's, so results match it up to fp32 summation order."""
+        Row order inside a class equals the loop version's, so results match it up to fp32 summation order.
+        votes / ts given: the row construction runs as the fused stage op (ops/head_stage.class_rows) on the predicted votes
+        themselves; otherwise as the tensor expressions below on the precomputed voted positions."""
         C, B, dev = self.n_classes, batch_size, out.F.device
         N, ch = out.F.shape
         elu = torch.nn.functional.elu
-        with torch.no_grad():
-            hit = sem_prob > self.semantic_threshold
-            if forced is not None:
-                hit = forced                         # the forced mode REPLACES the net's selection (sizes independent of the weights)
-            sel_cls, sel_row = torch.nonzero(hit.t(), as_tuple=True)                 # class-major, rows ascending
-            ar_c = torch.arange(C, device=dev)
-            all_cls = torch.cat([sel_cls, ar_c.repeat_interleave(B)])
-            all_pos = torch.cat([sel_row, N + torch.arange(B, device=dev).repeat(C)])  # pads go last in a class
-            all_row = torch.cat([sel_row, pad_id.repeat(C)])
-            order = torch.argsort(all_cls * (N + B) + all_pos)
-            e_cls, e_row = all_cls[order], all_row[order]
-            E = e_cls.shape[0]
-            n_c = ME.count_ids(e_cls, C)
-            start_c = torch.cumsum(n_c, 0) - n_c
-            j = torch.arange(E, device=dev) - start_c[e_cls]
-            base = start_c[e_cls] * (n_vote + 1)
-            dest_vote = (base + j * n_vote).unsqueeze(1) + torch.arange(n_vote, device=dev).unsqueeze(0)
-            dest_ori = base + n_c[e_cls] * n_vote + j
-            total = E * (n_vote + 1)
-            src = torch.empty(total, dtype=torch.long, device=dev)          # row of the [votes ; originals] table
-            src[dest_vote.reshape(-1)] = (e_row.unsqueeze(1) * n_vote + torch.arange(n_vote, device=dev).unsqueeze(0)).reshape(-1)
-            src[dest_ori] = N * n_vote + e_row
-            row_cls = torch.empty(total, dtype=torch.long, device=dev)
-            row_cls[dest_vote.reshape(-1)] = e_cls.unsqueeze(1).expand(-1, n_vote).reshape(-1)
-            row_cls[dest_ori] = e_cls
-            src_vox = torch.where(src < N * n_vote, src // n_vote, src - N * n_vote)      # backbone row of each fused row
-            xyz_tab = torch.cat([voted.reshape(-1, 3), ori_xyz], dim=0)
-            fuse_xyz = xyz_tab[src]
-            bprime = row_cls.float() * B + batch_col[src_vox, 0]
-            vs_tab = self._vs_table(fuse_xyz.device)
-            vs = vs_tab[row_cls]
-            fine = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / vs)], dim=1)
-            coarse = torch.cat([bprime.unsqueeze(1), torch.floor(fuse_xyz / (vs * self.expand)) * self.expand], dim=1)
-        feat_tab = torch.cat([offset_features.reshape(N * n_vote, -1), out.F], dim=0)
-        fuse_feat = ME.gather_rows(feat_tab, src)
+        vs_tab = self._vs_table(dev)
+        if votes is not None:
+            from ....ops import head_stage as HS
+            with torch.no_grad():
+                hit = forced if forced is not None else sem_prob > self.semantic_threshold
+                starts = out.batch_row_starts(B)
+                if starts is None:
+                    pad_row = torch.stack([p[0] for p in out.decomposition_permutations]).to(torch.int32)
+                else:
+                    pad_row = ME.h2d(starts, torch.int32, dev)
+                src, fine, coarse, _ = HS.class_rows(hit, out.C, pad_row, votes, n_vote, self.voxel_size, int(ts),
+                                                     vs_tab, self.expand, B)
+            fuse_feat = HS.gather_rows2(offset_features.reshape(N * n_vote, -1), out.F, src)
+        else:
+            with torch.no_grad():
+                hit = sem_prob > self.semantic_threshold
+                if forced is not None:
+                    hit = forced                         # the forced mode REPLACES the net's selection (sizes independent of the weights)
+                src, fine, coarse = self._class_rows_torch(hit, pad_id, batch_col, voted, ori_xyz, n_vote, B)
+            feat_tab = torch.cat([offset_features.reshape(N * n_vote, -1), out.F], dim=0)
+            fuse_feat = ME.gather_rows(feat_tab, src)
 
         avg = ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
         cls_map = ME.SparseTensor(coordinates=fine, features=fuse_feat, quantization_mode=avg)

@@ -74,6 +74,48 @@ int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, const int64_t *
                           int32_t cs, float beta, float weight, const float *fwd_out, const float *g, float *dreg,
                           cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dense head: rows of the class branches (CAGroup3DHead.forward, pcdet/models/dense_heads/cagroup_head.py:209-258).
+ *
+ * For every class c the reference selects the backbone voxels with sigmoid(semantic score) > threshold plus one pad voxel
+ * per scene (:227-233), and builds the point set [voted positions ; original positions] of the selection (:234-252), which it
+ * quantises at the class voxel size and at `expand` times it (:254-271).  All classes live in ONE coordinate space here
+ * (batch index c * nbatch + scene): the selection of class c is rows [start_c, start_c + n_c) of a class-major list (selected
+ * voxels ascending, pads last), and its fused rows are [start_c * (nvote + 1), ...): first the n_c * nvote vote rows
+ * (voxel-major), then the n_c original rows.
+ *
+ *   hit uint8 [n, nc] row-major (voxel selected for class), coords int32 [n,4] (scene, x, y, z) of the backbone voxels.
+ * cg3d_class_count: block_off int32 [(nc + 6) * cg3d_class_nblk(n)]: its first nc * nblk entries = for every (class, block of
+ *   1024 voxels) the number of selected voxels of that class in earlier blocks (the rest is scratch); totals int32 [nc + 6] = selected voxels per class, then the minimum and
+ *   the maximum of the three coordinate columns (the scene bounds of :209-212).  The caller reads totals[0..nc) to size the
+ *   outputs of cg3d_class_rows (the reference: torch.nonzero).
+ * cg3d_class_rows: with E = sum(totals) + nc * nbatch and pad_row int32 [nbatch] (the first voxel of every scene),
+ *   offsets float32 [n, nvote * 3] (the predicted votes), voxel_size / ts of the backbone map, vs_tab float32 [nc,3]:
+ *   src int32 [E * (nvote + 1)] = row of every fused row in the table [votes (n * nvote rows) ; originals (n rows)],
+ *   fine / coarse int32 [E * (nvote + 1), 4] = (c * nbatch + scene, floor(p / vs_c)), (.., floor(p / (vs_c * expand)) * expand)
+ *   with p = the original position coords * voxel_size, or that plus the vote clamped to the scene bounds
+ *   [(min - ts) * voxel_size, (max + ts) * voxel_size].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int32_t cg3d_class_nblk(int64_t n);
+int cg3d_class_count(const uint8_t *hit, int64_t n, int32_t nc, const int32_t *coords, int32_t *block_off, int32_t *totals,
+                     cg3d_stream_t stream);
+int cg3d_class_rows(const uint8_t *hit, int64_t n, int32_t nc, int32_t nbatch, const int32_t *block_off, const int32_t *totals,
+                    const int32_t *coords, const int32_t *pad_row, const float *offsets, int32_t nvote, float voxel_size,
+                    int32_t ts, const float *vs_tab, int32_t expand, int32_t *src, int32_t *fine, int32_t *coarse,
+                    cg3d_stream_t stream);
+
+/* Row gather from a table held in two pieces, and its adjoint (cagroup_head.py:238-252: the features of the fused rows are
+ * rows of [vote features ; backbone features]; the reference concatenates the two first).
+ *   out[i,:] = idx[i] < na ? Fa[idx[i],:] : Fb[idx[i] - na,:];   dFa / dFb accumulate (+=, the caller zero-fills them). */
+int cg3d_gather_rows2(const float *Fa, const float *Fb, int64_t na, const int32_t *idx, float *out, int64_t n, int32_t c,
+                      cg3d_stream_t stream);
+int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, float *dFb, int64_t na, int64_t n, int32_t c,
+                           cg3d_stream_t stream);
+
+/* counts[v] = number of i with ids[i * stride] == v, 0 <= v < m (values outside are ignored); ids int32 (is64 == 0) or int64;
+ * counts int64 [m], zero-filled by the call.  (torch.bincount on an id column without its min / max scans.) */
+int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

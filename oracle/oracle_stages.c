@@ -224,3 +224,132 @@ int cg3d_roi_reg_loss_bwd(const float *reg, const float *target, const int64_t *
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ dense head: class rows
+ * cagroup_head.py:209-258 (selection :227-233, [votes ; originals] :234-252, the two quantisations :254-271) */
+#define OS_CR_BLK 1024
+int32_t cg3d_class_nblk(int64_t n) { return (int32_t)(((n > 0 ? n : 1) + OS_CR_BLK - 1) / OS_CR_BLK); }
+
+int cg3d_class_count(const uint8_t *hit, int64_t n, int32_t nc, const int32_t *coords, int32_t *block_off, int32_t *totals,
+                     cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || nc <= 0 || nc > 65535 || !block_off || !totals) return CG3D_ERR_ARG;
+    if (n > 0 && (!hit || !coords)) return CG3D_ERR_ARG;
+    const int nblk = cg3d_class_nblk(n);
+    for (int c = 0; c < nc; c++) {
+        int run = 0;
+        for (int blk = 0; blk < nblk; blk++) {
+            block_off[(int64_t)c * nblk + blk] = run;
+            const int64_t r1 = (int64_t)(blk + 1) * OS_CR_BLK < n ? (int64_t)(blk + 1) * OS_CR_BLK : n;
+            for (int64_t r = (int64_t)blk * OS_CR_BLK; r < r1; r++) run += hit[r * nc + c] != 0;
+        }
+        totals[c] = run;
+    }
+    for (int k = 0; k < 3; k++) {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int64_t r = 0; r < n; r++) {
+            const int v = coords[r * 4 + 1 + k];
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        totals[nc + k] = lo;
+        totals[nc + 3 + k] = hi;
+    }
+    return CG3D_OK;
+}
+
+int cg3d_class_rows(const uint8_t *hit, int64_t n, int32_t nc, int32_t nbatch, const int32_t *block_off, const int32_t *totals,
+                    const int32_t *coords, const int32_t *pad_row, const float *offsets, int32_t nvote, float voxel_size,
+                    int32_t ts, const float *vs_tab, int32_t expand, int32_t *src, int32_t *fine, int32_t *coarse,
+                    cg3d_stream_t stream) {
+    (void)stream; (void)block_off;
+    if (n <= 0 || nc <= 0 || nc > 65535 || nbatch <= 0 || nbatch > OS_CR_BLK || nvote < 1 || expand < 1) return CG3D_ERR_ARG;
+    if (!hit || !totals || !coords || !pad_row || !offsets || !vs_tab || !src || !fine || !coarse) return CG3D_ERR_ARG;
+    if (n * (int64_t)(nvote + 1) >= 0x7fffffffLL) return CG3D_ERR_ARG;
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {                       /* scene bounds, :209-212 */
+        lo[k] = (float)(totals[nc + k] - ts) * voxel_size;
+        hi[k] = (float)(totals[nc + 3 + k] + ts) * voxel_size;
+    }
+    const float fe = (float)expand;
+    int64_t start = 0;
+    for (int c = 0; c < nc; c++) {
+        const int n_c = totals[c] + nbatch;
+        const int64_t base = start * (nvote + 1);
+        int j = 0;
+        for (int64_t it = 0; it < n + nbatch; it++) {
+            int64_t r;
+            if (it < n) {
+                if (!hit[it * nc + c]) continue;
+                r = it;
+            } else {
+                r = pad_row[it - n];                    /* one pad voxel per scene, after the selection (:231-233) */
+            }
+            const int32_t *q = coords + r * 4;
+            const float *vs = vs_tab + c * 3;
+            for (int v = 0; v <= nvote; v++) {
+                float p[3];
+                int64_t dst;
+                for (int k = 0; k < 3; k++) {
+                    const float ori = (float)q[1 + k] * voxel_size;
+                    if (v < nvote) {
+                        float t = ori + offsets[r * (nvote * 3) + v * 3 + k];
+                        t = t < hi[k] ? t : hi[k];
+                        p[k] = t > lo[k] ? t : lo[k];
+                    } else {
+                        p[k] = ori;
+                    }
+                }
+                if (v < nvote) { dst = base + (int64_t)j * nvote + v; src[dst] = (int32_t)(r * nvote + v); }
+                else { dst = base + (int64_t)n_c * nvote + j; src[dst] = (int32_t)(n * nvote + r); }
+                fine[dst * 4] = coarse[dst * 4] = c * nbatch + q[0];
+                for (int k = 0; k < 3; k++) {
+                    fine[dst * 4 + 1 + k] = (int32_t)floorf(p[k] / vs[k]);
+                    coarse[dst * 4 + 1 + k] = (int32_t)(floorf(p[k] / (vs[k] * fe)) * fe);
+                }
+            }
+            j++;
+        }
+        start += n_c;
+    }
+    return CG3D_OK;
+}
+
+int cg3d_gather_rows2(const float *Fa, const float *Fb, int64_t na, const int32_t *idx, float *out, int64_t n, int32_t c,
+                      cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || c < 4 || c % 4 != 0 || na < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!Fa || !Fb || !idx || !out) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t r = idx[i];
+        memcpy(out + i * c, r < na ? Fa + r * c : Fb + (r - na) * c, (size_t)c * sizeof(float));
+    }
+    return CG3D_OK;
+}
+int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, float *dFb, int64_t na, int64_t n, int32_t c,
+                           cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || c < 1 || na < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!dout || !idx || !dFa || !dFb) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t r = idx[i];
+        float *d = r < na ? dFa + r * c : dFb + (r - na) * c;
+        for (int a = 0; a < c; a++) d[a] += dout[i * c + a];
+    }
+    return CG3D_OK;
+}
+
+int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || m <= 0 || m > 8192 || stride < 1 || !counts) return CG3D_ERR_ARG;
+    memset(counts, 0, (size_t)m * 8);
+    if (n == 0) return CG3D_OK;
+    if (!ids) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t v = is64 ? ((const int64_t *)ids)[i * stride] : (int64_t)((const int32_t *)ids)[i * stride];
+        if (v >= 0 && v < m) counts[v]++;
+    }
+    return CG3D_OK;
+}

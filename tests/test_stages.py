@@ -300,3 +300,116 @@ def test_detector_step_with_and_without_the_fused_roi_stage(oracle, dataset, cfg
     for k in tb0:
         assert abs(tb0[k] - tb1[k]) <= 1e-4 * max(1.0, abs(tb0[k])), (k, tb0[k], tb1[k])
     torch.testing.assert_close(g1, g0, rtol=2e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------- dense head
+def _head_case(seed, n_vote, N=5000, C=18, B=3, frac=0.04):
+    from util import surface_coords
+    g = torch.Generator().manual_seed(seed)
+    c = surface_coords(N, batch=B, extent=40, seed=seed)
+    c = torch.unique(c, dim=0)                                   # batch-major rows, like every map of the engine
+    c[:, 1:] *= 2                                                # tensor stride 2
+    N = c.shape[0]
+    hit = torch.rand(N, C, generator=g) < frac
+    hit[:, 5] = False                                            # a class that selects nothing: only its pads
+    hit[:, 7] = torch.rand(N, generator=g) < 0.6                 # a class that selects most
+    votes = torch.randn(N, n_vote * 3, generator=g) * 0.4
+    votes[::11] *= 30.0                                          # far votes: clamped to the scene bounds
+    pad = torch.tensor([int(torch.nonzero(c[:, 0] == b)[0]) for b in range(B)], dtype=torch.int32)
+    return c.int().contiguous(), hit, votes, pad, B, C
+
+
+def _torch_class_rows(head, c, hit, votes, pad, B, n_vote, ts=2):
+    vs = head.voxel_size
+    xyz_vox = c[:, 1:]
+    xyz_t = xyz_vox.t().contiguous()
+    max_bound, min_bound = (xyz_t.amax(1) + ts) * vs, (xyz_t.amin(1) - ts) * vs
+    ori = xyz_vox.float() * vs
+    voted = ori.view(-1, 1, 3) + votes.view(-1, n_vote, 3)
+    voted = torch.max(torch.min(voted, max_bound.view(1, 1, 3)), min_bound.view(1, 1, 3))
+    return head._class_rows_torch(hit, pad.long(), c[:, :1].float(), voted, ori, n_vote, B)
+
+
+def _mini_head(C):
+    from cagroup3d_amd.pcdet.models.dense_heads.cagroup_head import CAGroup3DHead, SCANNET_CLASS_SIZES, SUNRGBD_CLASS_SIZES
+    head = CAGroup3DHead.__new__(CAGroup3DHead)
+    torch.nn.Module.__init__(head)
+    head.voxel_size, head.expand, head.n_classes = 0.02, 3, C
+    sizes = SCANNET_CLASS_SIZES if C == 18 else SUNRGBD_CLASS_SIZES
+    head.voxel_size_list = np.clip(np.array(sizes) / 2., 0.04, 1.0).tolist()
+    head._vs_cache = None
+    return head
+
+
+@pytest.mark.parametrize("seed,n_vote,C", [(0, 1, 18), (1, 3, 10)])
+def test_oracle_class_rows_equal_the_torch_chain(oracle, seed, n_vote, C):
+    from cagroup3d_amd.ops import head_stage as HS
+    c, hit, votes, pad, B, _ = _head_case(seed, n_vote, C=C)
+    head = _mini_head(C)
+    with _lib.use_library(oracle):
+        want_src, want_fine, want_coarse = _torch_class_rows(head, c, hit, votes, pad, B, n_vote)
+        src, fine, coarse, sel = HS.class_rows(hit, c, pad, votes, n_vote, head.voxel_size, 2, head._vs_table(c.device), head.expand, B)
+    assert sel == hit.sum(0).tolist() and sel[5] == 0
+    assert torch.equal(src.long(), want_src)                      # bit-exact: integer outputs
+    assert torch.equal(fine, want_fine.to(torch.int32)) and torch.equal(coarse, want_coarse.to(torch.int32))
+
+
+def test_oracle_gather_rows2_and_count_ids(oracle):
+    from cagroup3d_amd.ops import head_stage as HS
+    g = torch.Generator().manual_seed(0)
+    fa, fb = torch.randn(300, 64, generator=g), torch.randn(120, 64, generator=g)
+    idx = torch.randint(0, 420, (2000,), generator=g).int()
+    a0, b0 = fa.clone().requires_grad_(True), fb.clone().requires_grad_(True)
+    want = torch.cat([a0, b0])[idx.long()]
+    w = torch.randn(2000, 64, generator=g)
+    (want * w).sum().backward()
+    a1, b1 = fa.clone().requires_grad_(True), fb.clone().requires_grad_(True)
+    with _lib.use_library(oracle):
+        got = HS.gather_rows2(a1, b1, idx)
+        (got * w).sum().backward()
+        ids = torch.randint(-2, 80, (5000,), generator=g)
+        col = torch.stack([ids.int(), torch.zeros(5000, dtype=torch.int32)], 1)[:, 0]          # a strided int32 column
+        assert torch.equal(ME.count_ids(ids, 72), torch.bincount(ids[(ids >= 0) & (ids < 72)], minlength=72))
+        assert torch.equal(ME.count_ids(col, 72), torch.bincount(ids[(ids >= 0) & (ids < 72)], minlength=72))
+    assert torch.equal(got, want.detach())
+    torch.testing.assert_close(a1.grad, a0.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(b1.grad, b0.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_vote,C,N", [(0, 1, 18, 5000), (1, 3, 10, 5000), (2, 1, 18, 150000)])
+def test_hip_class_rows_match_oracle(hip, oracle, seed, n_vote, C, N):
+    from cagroup3d_amd.ops import head_stage as HS
+    c, hit, votes, pad, B, _ = _head_case(seed, n_vote, N=N, C=C)
+    head = _mini_head(C)
+    with _lib.use_library(oracle):
+        want = HS.class_rows(hit, c, pad, votes, n_vote, head.voxel_size, 2, head._vs_table(c.device), head.expand, B)
+    head._vs_cache = None
+    got = HS.class_rows(hit.cuda(), c.cuda(), pad.cuda(), votes.cuda(), n_vote, head.voxel_size, 2, head._vs_table(torch.device("cuda")),
+                        head.expand, B)
+    assert got[3] == want[3]
+    for a, b in zip(got[:3], want[:3]):
+        assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.gpu
+def test_hip_gather_rows2_and_count_ids_match_oracle(hip, oracle):
+    from cagroup3d_amd.ops import head_stage as HS
+    g = torch.Generator().manual_seed(0)
+    fa, fb = torch.randn(3000, 64, generator=g), torch.randn(1200, 64, generator=g)
+    idx = torch.randint(0, 4200, (20000,), generator=g).int()
+    w = torch.randn(20000, 64, generator=g)
+    res = []
+    for dev, lib in (("cpu", oracle), ("cuda", _lib.get())):
+        a, b = fa.clone().to(dev).requires_grad_(True), fb.clone().to(dev).requires_grad_(True)
+        with _lib.use_library(lib):
+            out = HS.gather_rows2(a, b, idx.to(dev))
+            (out * w.to(dev)).sum().backward()
+            ids = torch.randint(-2, 80, (200000,), generator=g).to(dev)
+            cnt = ME.count_ids(ids, 72)
+        res.append((out.detach().cpu(), a.grad.cpu(), b.grad.cpu(), cnt.cpu(), ids.cpu()))
+    assert torch.equal(res[1][0], res[0][0])
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-5, atol=1e-5)
+    for r in res:
+        assert torch.equal(r[3], torch.bincount(r[4][(r[4] >= 0) & (r[4] < 72)], minlength=72))
