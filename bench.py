@@ -62,7 +62,10 @@ def parse():
                     help="MFMA operand type of the sparse-conv forward/data-gradient (BASELINE.json configs[1]: bf16 backbone); "
                          "accumulation, storage and the weight gradient are fp32 in both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="S50k:1", help="config:scenes timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", default="S50k:4", help="config:scenes per step timed on the CPU oracle (the GPU's own batch)")
+    ap.add_argument("--head-precision", choices=["bf16", "fp32"], default="bf16",
+                    help="operand type of the two heads' convolutions (class branches, RoI pooling, 1x1x1 layers) in the bf16 run: "
+                         "fp32 = BASELINE.json configs[1] read literally (\"bf16 backbone\"); the other one is timed as a sub-record")
     ap.add_argument("--cpu-sample-1t", default="S5k:1", help="config:scenes of the single-thread CPU leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
@@ -194,12 +197,13 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def cpu_baseline_subprocess(args, threads=None, sample=None, budget=45):
+def cpu_baseline_subprocess(args, threads=None, sample=None, budget=80):
     """The cpu_baseline leg in a child process (this process runs torch's host ops on one thread), on `threads` or
     min(host cores, 16) threads: measured on the 256-thread GPU host the oracle's step takes 2.9 / 2.1 / 2.8 / 5.3 / 14.1 s
     at 8 / 16 / 32 / 64 / 128 threads (profiles/r03_cpu_thread_scaling.txt, tools/cpu_thread_scaling.py) -- 16 is its best."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads or min(os.cpu_count() or 1, 16)), CG3D_CPU_BUDGET_S=str(budget))
+    env.pop("CG3D_ENGINE_ANY", None)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", sample or args.cpu_sample,
@@ -266,6 +270,7 @@ def main():
         dist.init_process_group(backend=os.environ.get("CG3D_DIST_BACKEND", "nccl"))   # "nccl" = RCCL on ROCm
     forced = not args.natural
     me.PRECISION = 1 if args.precision == "bf16" else 0
+    me.HEAD_PRECISION = 0 if (args.precision == "bf16" and args.head_precision == "fp32") else None
 
     model, cfg = make_model(args.dataset, forced, dev, build_model.VOXEL_SIZE_OF_CONFIG.get(args.config))
     model.train()
@@ -411,6 +416,20 @@ def main():
                     "roofline_unit": r32["unit"], "frac": r32["frac"], "frac_8d_per_layer": r32["frac_8d_per_layer"],
                     "avg_launch_ms": r32["avg_launch_ms"], "conv_bound_over_step_time": r32["conv_bound_over_step_time"]}
         me.PRECISION = 1
+    other_heads = None
+    if me.PRECISION == 1 and not args.no_fp32 and os.environ.get("CG3D_BENCH_FP32", "1") != "0":
+        # the same bf16 backbone with the heads in the OTHER precision (fp32 heads = configs[1] read literally, bf16 heads = the
+        # wider scope), same process, model and batch
+        keep = me.HEAD_PRECISION
+        me.HEAD_PRECISION = 0 if keep is None else None
+        n2 = max(3, min(args.steps, 6))
+        for _ in range(3):
+            train_step(net, opt, batch, clip)
+        dt2, _, _ = timed_run(n2)
+        if rank == 0:
+            other_heads = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2, "warmup": 3,
+                           "heads": "fp32" if keep is None else "bf16"}
+        me.HEAD_PRECISION = keep
     finish_prefetch(net)            # the worker thread is done and joined before anything else happens (cpu_baseline, exit)
 
     if rank == 0:
@@ -423,16 +442,22 @@ def main():
                    else "natural selection of the untrained net"),
                           "scenes_per_gpu": args.batch, "points_per_scene": int("".join(ch for ch in args.config.split("-")[0] if ch.isdigit())) * 1000,
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
-                          "precision": ("bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
-                                        "backbone, class branches and RoI pooling; forward, data gradient AND weight gradient "
-                                        "(k_spconv_pairs_wgrad_rows16 on the bf16 row copies); activations, weights, gradients, "
-                                        "BatchNorm, 1x1x1 convolutions, heads, losses and the optimizer stay fp32"
+                          "precision": (("bf16 MFMA operands (fp32 accumulate) in the convolutions (>= 16 input channels) of the BACKBONE "
+                                         "only -- forward, data gradient and weight gradient; both heads (class branches, RoI pooling, "
+                                         "1x1x1 layers) run fp32 operands: BASELINE.json configs[1] read literally"
+                                         if me.HEAD_PRECISION == 0 else
+                                         "bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
+                                         "backbone, class branches, RoI pooling and the 1x1x1 layers; forward, data gradient AND weight "
+                                         "gradient (k_spconv_pairs_wgrad_rows16 on the bf16 row copies)") +
+                                        "; activations, weights, gradients, BatchNorm, losses and the optimizer stay fp32"
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
                           "last_loss": tb.get("loss_all"),
                           "backbone_issue": dict(__import__("cagroup3d_amd.engine", fromlist=["STATS"]).STATS)},
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32
+        if other_heads is not None:
+            out["bf16_backbone_only" if other_heads["heads"] == "fp32" else "bf16_all_convolutions"] = other_heads
         if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):
             out["comm"] = model.grad_sync.report()
         if use_dist:

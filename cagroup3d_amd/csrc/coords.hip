@@ -37,27 +37,40 @@ __device__ static inline bool quantised_key(const int32_t *__restrict__ coords, 
     return cg3d_pack(v.x, v.y, v.z, v.w, key);
 }
 
-__global__ void k_insert(const int32_t *__restrict__ coords, int64_t n, int32_t qs, unsigned long long *keys,
-                         int32_t *vals, uint64_t capm1, int32_t *slot_of, int32_t *status) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// A run of consecutive rows with the same key (the 343 grid points of a degenerate RoI all name one voxel; neighbouring grid
+// points of a small RoI share theirs: cagroup_roi_head.py:199-224) is inserted by its FIRST lane only -- the lowest row of the
+// run, which is what atomicMin would leave anyway -- and the slot is handed to the rest of the run by a shuffle: 22 k
+// same-address atomics per step serialised at the L2 atomic unit (0.47 ms in the RoI stage's map build).
+__global__ __launch_bounds__(256) void k_insert(const int32_t *__restrict__ coords, int64_t n, int32_t qs, unsigned long long *keys,
+                                                int32_t *vals, uint64_t capm1, int32_t *slot_of, int32_t *status) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int4 c;
-    uint64_t key;
-    if (!quantised_key(coords, i, qs, &c, &key)) {
-        *status = CG3D_ERR_RANGE;
-        slot_of[i] = -1;
-        return;
+    uint64_t key = ~0ull;                               // (CG3D_EMPTY_KEY is no valid key: bit 63 of a packed key is 0)
+    bool valid = false;
+    if (i < n) {
+        valid = quantised_key(coords, i, qs, &c, &key);
+        if (!valid) { *status = CG3D_ERR_RANGE; key = ~0ull; }
     }
-    uint64_t slot = cg3d_hash(key) & capm1;
-    for (;;) {
-        unsigned long long prev = atomicCAS(&keys[slot], CG3D_EMPTY_KEY, (unsigned long long)key);
-        if (prev == CG3D_EMPTY_KEY || prev == key) {
-            atomicMin(&vals[slot], (int32_t)i);  // representative = first occurrence
-            slot_of[i] = (int32_t)slot;
-            return;
+    const uint64_t prev = __shfl_up((unsigned long long)key, 1);
+    const bool head = lane == 0 || key != prev || !valid;
+    int32_t slot_i = -1;
+    if (valid && head) {
+        uint64_t slot = cg3d_hash(key) & capm1;
+        for (;;) {
+            unsigned long long was = atomicCAS(&keys[slot], CG3D_EMPTY_KEY, (unsigned long long)key);
+            if (was == CG3D_EMPTY_KEY || was == key) {
+                atomicMin(&vals[slot], (int32_t)i);  // representative = first occurrence
+                slot_i = (int32_t)slot;
+                break;
+            }
+            slot = (slot + 1) & capm1;
         }
-        slot = (slot + 1) & capm1;
     }
+    const unsigned long long heads = __ballot(head);
+    const int src = 63 - __clzll(heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)));
+    slot_i = __shfl(slot_i, src);
+    if (i < n) slot_of[i] = slot_i;
 }
 
 // Two-kernel exclusive scan of 0/1 flags (2048 elements per block), the flags computed on the fly:

@@ -540,3 +540,143 @@ extern "C" int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ================================================================================================ dense head: proposals
+__global__ void k_prop_keys(const int64_t *__restrict__ seg, const float *__restrict__ smax, int64_t n,
+                            int64_t *__restrict__ keys) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = ~__float_as_uint(smax[i]);
+    keys[i] = (int64_t)(((uint64_t)seg[i] << 32) | (uint64_t)b);
+}
+extern "C" int cg3d_prop_keys(const int64_t *seg, const float *smax, int64_t n, int64_t *keys, cg3d_stream_t stream) {
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!seg || !smax || !keys) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_prop_keys, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, cg3d_hs(stream), seg, smax, n, keys);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+// segment of candidate t: the last s with cand_off[s] <= t
+__device__ static inline int st_seg_of(const int32_t *__restrict__ cand_off, int nseg, int t) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cand_off[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// A workgroup takes PE_PER entries per thread: one slot-range atomic and one histogram flush per workgroup (a slot atomic per
+// wave and a counter atomic per entry were 20 k + 72 k atomics on 73 addresses: 129 us).
+#define PE_PER 8
+__global__ __launch_bounds__(256) void k_prop_entries(const int64_t *__restrict__ order, const int32_t *__restrict__ seg_start,
+                                                      const int32_t *__restrict__ cand_off, int nseg, int nbatch,
+                                                      const float *__restrict__ scores, int nc, float thr,
+                                                      unsigned long long *__restrict__ ekeys, int32_t *__restrict__ counts) {
+    __shared__ int s_hist[512];
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int ncand = cand_off[nseg], np = nbatch * nc;
+    for (int i = threadIdx.x; i < np; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    unsigned long long key[PE_PER];
+    int mine = 0;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PE_PER;
+    int s = -1, t_of_s = -1;
+#pragma unroll
+    for (int q = 0; q < PE_PER; q++) {
+        const int64_t e = e0 + q;
+        key[q] = 0;
+        if (e < (int64_t)ncand * nc) {
+            const int t = (int)(e / nc), i = (int)(e - (int64_t)t * nc);
+            if (t != t_of_s) { s = st_seg_of(cand_off, nseg, t); t_of_s = t; }
+            const int64_t row = order[seg_start[s] + t - cand_off[s]];
+            const float sc = scores[row * nc + i];
+            if (sc > thr) {
+                const int p = (s % nbatch) * nc + i;
+                key[q] = ((unsigned long long)p << 54) | ((unsigned long long)(~__float_as_uint(sc)) << 22) | (unsigned long long)e | (1ull << 63);
+                atomicAdd(&s_hist[p], 1);
+                mine++;
+            }
+        }
+    }
+    // exclusive prefix of `mine` over the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    if (threadIdx.x == 0) {
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(&counts[np], tot) : 0;
+    }
+    __syncthreads();
+    int64_t dst = (int64_t)s_base + before;
+#pragma unroll
+    for (int q = 0; q < PE_PER; q++)
+        if (key[q]) ekeys[dst++] = key[q] & ~(1ull << 63);
+    for (int i = threadIdx.x; i < np; i += 256)
+        if (s_hist[i]) atomicAdd(&counts[i], s_hist[i]);
+}
+extern "C" int cg3d_prop_entries(const int64_t *order, const int32_t *seg_start, const int32_t *cand_off, int32_t nseg,
+                                 int32_t ncand, int32_t nbatch, const float *scores, int32_t nc, float thr, int64_t *ekeys,
+                                 int32_t *counts, cg3d_stream_t stream) {
+    if (nseg < 0 || ncand < 0 || nbatch <= 0 || nc <= 0 || (int64_t)nbatch * nc >= 512 || (int64_t)ncand * nc >= (1ll << 22) || !counts)
+        return CG3D_ERR_ARG;
+    if (hipMemsetAsync(counts, 0, ((size_t)nbatch * nc + 1) * 4, cg3d_hs(stream)) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (ncand == 0 || nseg == 0) return CG3D_OK;
+    if (!order || !seg_start || !cand_off || !scores || !ekeys) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_prop_entries, dim3((unsigned)cg3d_divup((int64_t)ncand * nc, 256 * PE_PER)), dim3(256), 0, cg3d_hs(stream),
+                       order, seg_start, cand_off, nseg, nbatch, scores, nc, thr, (unsigned long long *)ekeys, counts);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+__global__ __launch_bounds__(256) void k_prop_gather(const unsigned long long *__restrict__ ekeys, int64_t total,
+                                                     const int64_t *__restrict__ order, const int32_t *__restrict__ seg_start,
+                                                     const int32_t *__restrict__ cand_off, int nseg, int nc,
+                                                     const float *__restrict__ points, const float *__restrict__ bbox_pred, int ndim,
+                                                     const float *__restrict__ scores, float *__restrict__ e_boxes,
+                                                     float *__restrict__ nms_boxes, float *__restrict__ e_score) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int e = (int)(ekeys[k] & ((1ull << 22) - 1));
+    const int t = e / nc, i = e - t * nc;
+    const int s = st_seg_of(cand_off, nseg, t);
+    const int64_t row = order[seg_start[s] + t - cand_off[s]];
+    const float *p = points + row * 3, *b = bbox_pred + row * ndim;
+    float o[7];
+    o[0] = p[0] + (b[1] - b[0]) / 2; o[1] = p[1] + (b[3] - b[2]) / 2; o[2] = p[2] + (b[5] - b[4]) / 2;
+    if (ndim == 6) {
+        o[3] = b[0] + b[1]; o[4] = b[2] + b[3]; o[5] = b[4] + b[5]; o[6] = 0.f;
+    } else {                                            // 'fcaf3d': (sin(2a) ln q, cos(2a) ln q)  (cagroup_head.py:689-703)
+        const float scale = b[0] + b[1] + b[2] + b[3];
+        const float q = expf(sqrtf(b[6] * b[6] + b[7] * b[7]));
+        o[3] = scale / (1 + q); o[4] = scale / (1 + q) * q; o[5] = b[5] + b[4];
+        o[6] = 0.5f * atan2f(b[6], b[7]);
+    }
+#pragma unroll
+    for (int c = 0; c < 7; c++) { e_boxes[k * 7 + c] = o[c]; nms_boxes[k * 7 + c] = (c == 6 && ndim == 8) ? o[c] * -1.f : o[c]; }
+    e_score[k] = scores[row * nc + i];
+}
+extern "C" int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, const int32_t *seg_start,
+                                const int32_t *cand_off, int32_t nseg, int32_t nc, const float *points, const float *bbox_pred,
+                                int32_t ndim, const float *scores, float *e_boxes, float *nms_boxes, float *e_score,
+                                cg3d_stream_t stream) {
+    if (total < 0 || nseg < 0 || nc <= 0 || (ndim != 6 && ndim != 8)) return CG3D_ERR_ARG;
+    if (total == 0) return CG3D_OK;
+    if (!ekeys || !order || !seg_start || !cand_off || !points || !bbox_pred || !scores || !e_boxes || !nms_boxes || !e_score)
+        return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_prop_gather, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream),
+                       (const unsigned long long *)ekeys, total, order, seg_start, cand_off, nseg, nc, points, bbox_pred, ndim, scores,
+                       e_boxes, nms_boxes, e_score);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

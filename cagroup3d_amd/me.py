@@ -522,10 +522,48 @@ FWD_SEG = 128  # pairs per workgroup of cg3d_spconv_pairs_fwd
 #   1 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[1] "bf16 backbone".
 # Features, weights, gradients and the weight-gradient kernel stay fp32 in both modes.
 PRECISION = 0
+# Precision of a PART of the step: `precision_scope(p)` overrides PRECISION for the calling thread (the detector runs the two
+# heads under `HEAD_PRECISION` when that is set: BASELINE.json configs[1] words its precision as "bf16 backbone").  A Function
+# records the precision its forward ran under and its backward runs under the same one, whichever thread the autograd
+# engine calls it on; the coordinate-prefetch worker never sees another thread's override.
+HEAD_PRECISION = None
+_tls_prec = __import__("threading").local()
+
+
+def _prec():
+    v = getattr(_tls_prec, "v", None)
+    return PRECISION if v is None else v
+
+
+class precision_scope:
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        self.old = getattr(_tls_prec, "v", None)
+        if self.p is not None:
+            _tls_prec.v = self.p
+        return self
+
+    def __exit__(self, *exc):
+        _tls_prec.v = self.old
+        return False
+
+
+def _ctx_precision(fn):
+    """Decorator of a Function.backward: runs it under the precision its forward recorded in ctx.prec."""
+    def wrapped(ctx, *a):
+        old = getattr(_tls_prec, "v", None)
+        _tls_prec.v = getattr(ctx, "prec", None)
+        try:
+            return fn(ctx, *a)
+        finally:
+            _tls_prec.v = old
+    return wrapped
 
 
 def _use_bf16(cin):
-    return PRECISION == 1 and cin % 8 == 0 and cin >= 16
+    return _prec() == 1 and cin % 8 == 0 and cin >= 16
 
 
 # bf16 mode: maps whose neighbourhood occupancy P / (K * n_out) is at least this run the output-stationary
@@ -1074,7 +1112,7 @@ def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
     covers (64-channel chunks in, 64 or multiples of 128 out), enough rows to give every CU a tile.  Since the rows reach
     LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
     transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
-    return (TILE_KERNEL and _lib.get().is_device and PRECISION == 1 and BF16_ROWS and row_bounds is None
+    return (TILE_KERNEL and _lib.get().is_device and _prec() == 1 and BF16_ROWS and row_bounds is None
             and 1 < K <= 32 and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
 
 
@@ -1112,6 +1150,7 @@ class SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, kmap, row_bounds=None):
+        ctx.prec = _prec()
         x = x.contiguous()
         w3 = weight.contiguous()
         ctx.kmap, ctx.has_bias, ctx.row_bounds = kmap, bias is not None, row_bounds
@@ -1146,6 +1185,7 @@ class SparseConvFunction(torch.autograd.Function):
         return _conv_pairs(xg, w3, pin, pout, seg, nseg, b, kmap.n_out, P, w_bf16_t=wt)
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         x, w3, xb, wp = ctx.saved_tensors
         kmap, rb = ctx.kmap, ctx.row_bounds
@@ -1215,7 +1255,7 @@ class GroupedConvFunction(torch.autograd.Function):
         row groups), bf16 row copies, channel counts the kernel's register tile covers.  The rows of a pass are staged once
         for all of its slot-table blocks, so the 5^3 / 9^3 class convolutions (K = 125 / 729) gather each distinct
         neighbour row once per pass instead of once per offset."""
-        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and PRECISION == 1 and BF16_ROWS
+        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and _prec() == 1 and BF16_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and (cin == 64 or cin % 128 == 0) and (cout == 64 or cout % 128 == 0))
 
     @staticmethod
@@ -1226,6 +1266,7 @@ class GroupedConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kmap, row_bounds, closed, *weights):
+        ctx.prec = _prec()
         x = x.contiguous()
         G, (K, cin, cout) = len(weights), weights[0].shape
         ctx.kmap, ctx.row_bounds, ctx.shape, ctx.closed = kmap, row_bounds, (G, K, cin, cout), closed
@@ -1245,6 +1286,7 @@ class GroupedConvFunction(torch.autograd.Function):
         return _conv_pairs(xg, (G * K, cin, cout), pin, pout, seg, nseg, None, kmap.n_out, P, w_bf16_t=wt)
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         x, xb = ctx.saved_tensors[:2]
         weights = ctx.saved_tensors[2:]
@@ -1336,7 +1378,7 @@ class LinearFunction(torch.autograd.Function):
     def _own(n, cin, cout):
         """The hand-written streaming kernel (cg3d_linear_fwd, csrc/linear.hip): bench precision, bf16 row copies, channel
         counts in multiples of 64 on both sides (the data gradient is the same kernel with the roles swapped)."""
-        return (LINEAR_KERNEL and PRECISION == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
+        return (LINEAR_KERNEL and _prec() == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and cin >= 64 and cout >= 64)
 
     @staticmethod
@@ -1362,6 +1404,7 @@ class LinearFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
+        ctx.prec = _prec()
         ctx.has_bias = bias is not None
         n, (cin, cout) = x.shape[0], w.shape
         ctx.own = LinearFunction._own(n, cin, cout)
@@ -1377,6 +1420,7 @@ class LinearFunction(torch.autograd.Function):
         return torch.addmm(bias, x, w) if bias is not None else x @ w
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         x, w, x16, wp = ctx.saved_tensors
         dx = dw = db = None
@@ -1425,6 +1469,7 @@ class LinearTFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
+        ctx.prec = _prec()
         n, (cout, cin) = x.shape[0], w.shape
         x = x.contiguous()
         x16 = _to_bf16(x, keep=True)
@@ -1434,6 +1479,7 @@ class LinearTFunction(torch.autograd.Function):
         return LinearFunction._own_gemm(x16, wp, bias.contiguous() if bias is not None else None, n, cin, cout, want_stats=True)
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         x16, w, wt = ctx.saved_tensors
         n, (cout, cin) = dy.shape[0], w.shape
@@ -1593,10 +1639,11 @@ class RoiContractFunction(torch.autograd.Function):
     @staticmethod
     def available(feats, w):
         G, C, C2 = w.shape
-        return ROI_CONTRACT and PRECISION == 1 and BF16_ROWS and C % 64 == 0 and C2 % 64 == 0 and feats.shape[1] == C
+        return ROI_CONTRACT and _prec() == 1 and BF16_ROWS and C % 64 == 0 and C2 % 64 == 0 and feats.shape[1] == C
 
     @staticmethod
     def forward(ctx, feats, idx, w):
+        ctx.prec = _prec()
         lib = _lib.get()
         G, C, C2 = w.shape
         feats = feats.contiguous()
@@ -1619,6 +1666,7 @@ class RoiContractFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         g16, idx, w, wp = ctx.saved_tensors
         lib = _lib.get()
@@ -1796,6 +1844,7 @@ class FusedBNActFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, bounds, act, use_batch, mean_in, var_in, eps, running=None, sync=None):
+        ctx.prec = _prec()
         # running: None or (running_mean [G*C], running_var, num_batches_tracked, momentum), updated in the statistics launch
         # sync: None or (process group,): statistics over every rank's rows (--sync_bn; reference tools/train.py:118-119)
         lib = _lib.get()
@@ -1854,6 +1903,7 @@ class FusedBNActFunction(torch.autograd.Function):
         return y, mean, var, n_rows
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy, _dm, _dv, _dn=None):
         x, y, mean, var, gamma, chunks, gco, group_n, achunks = ctx.saved_tensors
         nchunk, G, C, act, use_batch, has_res, eps, nachunk = ctx.meta
@@ -1979,6 +2029,7 @@ class AddReluFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
+        ctx.prec = _prec()
         lib = _lib.get()
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
@@ -1998,6 +2049,7 @@ class AddReluFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_ctx_precision
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dy, y, 0.0)
@@ -2036,6 +2088,7 @@ class SparseTensor:
                 coordinates = torch.floor(coordinates)
             ci = coordinates.to(torch.int32).contiguous()
             key, uniq, inv = self.coordinate_manager.insert(ci, int(tensor_stride), sort=True)
+            self.rows_batch_major = bool(MORTON_ROWS and ci.shape[0] > 1)    # (batch, Morton) row order: the batch column ascends
             self.coordinate_map_key = key
             self.unique_index, self.inverse_mapping = uniq, inv
             n_out = uniq.shape[0]
@@ -2050,6 +2103,7 @@ class SparseTensor:
             self.coordinate_manager, self.coordinate_map_key = coordinate_manager, coordinate_map_key
             self.F = features
             self.unique_index = self.inverse_mapping = None
+            self.rows_batch_major = False
         assert self.F.shape[0] == self._map.n, (self.F.shape, self._map.n)
 
     # -- accessors

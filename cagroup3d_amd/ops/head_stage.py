@@ -29,9 +29,9 @@ def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, ex
     lib.call("cg3d_class_count", ptr(hit8), c_int64(N), c_int32(C), ptr(coords), ptr(block_off), ptr(totals), lib.stream())
     sel = totals[:C].tolist()                                     # the stage's host read (the reference: torch.nonzero)
     T = (sum(sel) + C * n_batch) * (n_vote + 1)
-    out = torch.empty((T, 9), dtype=torch.int32, device=dev)      # one allocation: src | fine | coarse
+    out = torch.empty((T, 9), dtype=torch.int32, device=dev)      # one allocation: fine | coarse | src (16-byte aligned rows first)
     flat = out.view(-1)
-    src, fine, coarse = flat[:T], flat[T:5 * T].view(T, 4), flat[5 * T:].view(T, 4)
+    fine, coarse, src = flat[:4 * T].view(T, 4), flat[4 * T:8 * T].view(T, 4), flat[8 * T:]
     lib.call("cg3d_class_rows", ptr(hit8), c_int64(N), c_int32(C), c_int32(n_batch), ptr(block_off), ptr(totals), ptr(coords),
              ptr(pad_row), ptr(offsets), c_int32(n_vote), c_float(voxel_size), c_int32(ts), ptr(vs_tab), c_int32(expand),
              ptr(src), ptr(fine), ptr(coarse), lib.stream())

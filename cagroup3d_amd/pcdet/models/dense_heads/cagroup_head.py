@@ -333,10 +333,15 @@ class CAGroup3DHead(nn.Module):
         scale_vec = torch.stack([sc.scale for sc in self.scales])
         bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
         points = fine_C[:, 1:].float() * vs_tab[rc]
-        perm = torch.sort(fb, stable=True)[1]                              # (class, scene)-major, rows ascending inside
-        merged = [t[perm] for t in (centerness, bbox_pred, cls_score, points)]
+        if ME.MORTON_ROWS and cls_map.rows_batch_major:
+            # rows of the class map are already (class, scene)-major (SparseTensor inserts in (batch, Morton) order): no sort,
+            # no four gathers -- and none of their sort-based index_put backward passes
+            merged, seg = [centerness, bbox_pred, cls_score, points], fb
+        else:
+            perm = torch.sort(fb, stable=True)[1]                          # (class, scene)-major, rows ascending inside
+            merged, seg = [t[perm] for t in (centerness, bbox_pred, cls_score, points)], fb[perm]
         object.__setattr__(self, "_merged", {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2],
-                                             "points": merged[3], "seg": fb[perm], "per_scene": per_scene})
+                                             "points": merged[3], "seg": seg, "per_scene": per_scene})
         pieces = [torch.split(t, per_scene) for t in merged]
         outs = []
         for c in range(C):
@@ -695,6 +700,10 @@ class CAGroup3DHead(nn.Module):
         reads in total (the loop version syncs twice per class per scene)."""
         C, B = self.n_classes, batch_size
         dev = m["points"].device
+        nd = m["bbox_pred"].shape[1]
+        if FUSED_HEAD and m["seg"].shape[0] > 0 and (nd == 6 or (nd == 8 and self.yaw_parametrization == "fcaf3d")) \
+                and B * C < 512 and len(m["per_scene"]) == B * C:
+            return self._get_bboxes_fused(m, B)
         scores = m["cls_score"].detach().sigmoid() * m["centerness"].detach().sigmoid()
         seg = m["seg"]                                                     # c*B + b, non-decreasing
         per = ME.h2d(m["per_scene"], torch.long, dev)
@@ -736,6 +745,70 @@ class CAGroup3DHead(nn.Module):
         out_labels = ME.h2d(torch.from_numpy(gof % C), torch.long, dev)
         per_scene = num.reshape(B, C).sum(1).tolist()
         # the same proposals FLAT (scene-major): the RoI head's fused training path reads them in place instead of padding them
+        object.__setattr__(self, "_flat_props", (out_boxes, out_scores, out_labels, per_scene))
+        return list(zip(torch.split(out_boxes, per_scene), torch.split(out_scores, per_scene),
+                        torch.split(out_labels, per_scene)))
+
+    @torch.no_grad()
+    def _get_bboxes_fused(self, m, B):
+        """`get_bboxes_batched` through the stage ops of include/cagroup3d_stages.h: ONE sort for the per-map top NMS_PRE
+        (key = segment | inverted score bits), the candidates' (row, class) entries above SCORE_THR emitted with a key that
+        already IS their final order (problem | inverted score bits | entry id), ONE sort of those keys, decoding only the
+        boxes that enter NMS.  Two host reads (entry counts, kept counts) instead of three; ~25 launches instead of ~70."""
+        from ctypes import c_float, c_int32, c_int64
+        from .... import _lib
+        from ...._lib import ptr
+        lib = _lib.get()
+        C, dev = self.n_classes, m["points"].device
+        scores = (m["cls_score"].detach().sigmoid() * m["centerness"].detach().sigmoid()).contiguous()
+        smax = scores.max(dim=1)[0]
+        seg = m["seg"].contiguous()
+        E = seg.shape[0]
+        per = np.asarray(m["per_scene"], dtype=np.int64)
+        pre = int(self.nms_cfg.NMS_PRE)
+        if pre > 0:
+            keys = torch.empty(E, dtype=torch.int64, device=dev)
+            lib.call("cg3d_prop_keys", ptr(seg), ptr(smax), c_int64(E), ptr(keys), lib.stream())
+            order = torch.sort(keys, stable=True)[1]
+            cnt = np.minimum(per, pre)
+        else:
+            order = torch.arange(E, device=dev)
+            cnt = per
+        nseg = per.shape[0]
+        seg_start = np.cumsum(per) - per
+        cand_off = np.concatenate([[0], np.cumsum(cnt)])
+        ncand = int(cand_off[-1])
+        if ncand * C >= (1 << 22):
+            raise NotImplementedError("more than 2^22 (candidate, class) pairs")
+        tab = ME.h2d(np.concatenate([seg_start, cand_off]), torch.int32, dev)
+        seg_start_d, cand_off_d = tab[:nseg], tab[nseg:]
+        points, bbox_pred = m["points"].detach().contiguous(), m["bbox_pred"].detach().contiguous()
+        nd = bbox_pred.shape[1]
+        ekeys = torch.empty(max(ncand * C, 1), dtype=torch.int64, device=dev)
+        counts = torch.empty(B * C + 1, dtype=torch.int32, device=dev)
+        lib.call("cg3d_prop_entries", ptr(order), ptr(seg_start_d), ptr(cand_off_d), c_int32(nseg), c_int32(ncand), c_int32(B),
+                 ptr(scores), c_int32(C), c_float(float(self.nms_cfg.SCORE_THR)), ptr(ekeys), ptr(counts), lib.stream())
+        cnt_host = counts.cpu().numpy().astype(np.int64)                    # host read 1
+        total = int(cnt_host[-1])
+        seg_off = np.zeros(B * C + 1, dtype=np.int64)
+        seg_off[1:] = np.cumsum(cnt_host[:-1])
+        skeys = torch.sort(ekeys[:total])[0]
+        out3 = torch.empty((max(total, 1), 15), dtype=torch.float32, device=dev)
+        flat = out3.view(-1)
+        e_boxes, nms_boxes, e_score = flat[:7 * total].view(total, 7), flat[7 * total:14 * total].view(total, 7), flat[14 * total:15 * total]
+        lib.call("cg3d_prop_gather", ptr(skeys), c_int64(total), ptr(order), ptr(seg_start_d), ptr(cand_off_d), c_int32(nseg), c_int32(C),
+                 ptr(points), ptr(bbox_pred), c_int32(nd), ptr(scores), ptr(e_boxes), ptr(nms_boxes), ptr(e_score), lib.stream())
+        keep, num = nms_batched_sorted(nms_boxes, seg_off, float(self.nms_cfg.IOU_THR), nd == 8)
+        num = num.cpu().numpy().astype(np.int64)                                       # host read 2
+        off = seg_off
+        idx = np.concatenate([np.arange(off[g], off[g] + num[g]) for g in range(B * C)] + [np.zeros(0, np.int64)])
+        gof = np.repeat(np.arange(B * C), num)
+        ht = ME.h2d(np.concatenate([idx, off[gof], gof % C]), torch.long, dev)          # one table for the three index vectors
+        n_keep = idx.shape[0]
+        sel = keep[ht[:n_keep]] + ht[n_keep:2 * n_keep]
+        out_boxes, out_scores = e_boxes[sel], e_score[sel]
+        out_labels = ht[2 * n_keep:]
+        per_scene = num.reshape(B, C).sum(1).tolist()
         object.__setattr__(self, "_flat_props", (out_boxes, out_scores, out_labels, per_scene))
         return list(zip(torch.split(out_boxes, per_scene), torch.split(out_scores, per_scene),
                         torch.split(out_labels, per_scene)))

@@ -220,11 +220,14 @@ class CAGroup3D(Detector3DTemplate):
         batch_dict["sp_tensor"] = self.voxelization(batch_dict["points"], batch_dict.pop("prepared", None))
         batch_dict["engine_program"] = self._engine_program          # the backbone's launch program compiled by the dry run
         for i, module in enumerate(self.module_list):
-            batch_dict.update(module(batch_dict))
+            # the two heads (and their losses) under ME.HEAD_PRECISION when that is set ("bf16 backbone", fp32 heads)
+            with ME.precision_scope(ME.HEAD_PRECISION if i > 0 else None):
+                batch_dict.update(module(batch_dict))
             if i == 0 and self.training and getattr(self, "grad_sync", None) is not None:
                 self.grad_sync.attach(batch_dict["sp_tensor"].F)      # heads' gradients are complete when this one is
         if self.training:
-            loss, tb_dict, disp_dict = self.get_training_loss(batch_dict)
+            with ME.precision_scope(ME.HEAD_PRECISION):
+                loss, tb_dict, disp_dict = self.get_training_loss(batch_dict)
             disp_dict["cur_semantic_value"] = self.module_list[1].semantic_threshold
             return {"loss": loss}, tb_dict, disp_dict
         return self.post_processing(batch_dict)

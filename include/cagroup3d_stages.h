@@ -116,6 +116,31 @@ int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, fl
  * counts int64 [m], zero-filled by the call.  (torch.bincount on an id column without its min / max scans.) */
 int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dense head: proposals (CAGroup3DHead._get_bboxes_single / _nms, cagroup_head.py:579-624,747-797), all scenes and class
+ * maps at once.  Rows of the merged class maps are sorted by segment s = class map * nbatch + scene.
+ *
+ * cg3d_prop_keys: keys int64 [n] = seg << 32 | ~bits(smax) (smax >= 0: the row's best score): ascending key order is
+ *   (segment ascending, score descending), equal keys keep their row order under a stable sort -- the reference's
+ *   per-map `topk(NMS_PRE)` (:590-594) becomes "the first min(size, NMS_PRE) rows of every segment" of ONE sort.
+ * cg3d_prop_entries: `order` int64 [n] = row of every sorted position; seg_start int32 [nseg] = first sorted position of
+ *   every segment, cand_off int32 [nseg + 1] = first candidate of every segment (candidate t of segment s is sorted position
+ *   seg_start[s] + t - cand_off[s]; ncand = cand_off[nseg], known to the caller).  Every (candidate t, class i) with scores[row, i] > thr (:763-765) is an entry of the
+ *   NMS problem p = (s % nbatch) * nc + i:  ekeys[slot] = p << 54 | ~bits(score) << 22 | (t * nc + i), slots in no particular
+ *   order (an ascending sort of the keys is the order the reference reaches: problem, score descending, (t, i) ascending);
+ *   counts int32 [nbatch * nc + 1] = entries per problem, then their total (zero-filled by the call).
+ *   Limits: nbatch * nc < 512, ncand * nc < 2^22.
+ * cg3d_prop_gather: for the sorted entry keys the decoded boxes (_bbox_pred_to_bbox, :654-703: ndim 6 = no heading, heading
+ *   column 0; ndim 8 = the 'fcaf3d' parametrisation), the boxes handed to NMS (heading negated when ndim == 8, :770) and the
+ *   scores.  e_boxes / nms_boxes float32 [total,7], e_score float32 [total].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cg3d_prop_keys(const int64_t *seg, const float *smax, int64_t n, int64_t *keys, cg3d_stream_t stream);
+int cg3d_prop_entries(const int64_t *order, const int32_t *seg_start, const int32_t *cand_off, int32_t nseg, int32_t ncand,
+                      int32_t nbatch, const float *scores, int32_t nc, float thr, int64_t *ekeys, int32_t *counts, cg3d_stream_t stream);
+int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, const int32_t *seg_start,
+                     const int32_t *cand_off, int32_t nseg, int32_t nc, const float *points, const float *bbox_pred,
+                     int32_t ndim, const float *scores, float *e_boxes, float *nms_boxes, float *e_score, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

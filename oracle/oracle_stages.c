@@ -353,3 +353,74 @@ int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ dense head: proposals
+ * _get_bboxes_single (cagroup_head.py:579-624), _bbox_pred_to_bbox (:654-703), _nms entry selection (:747-770) */
+static uint32_t os_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+int cg3d_prop_keys(const int64_t *seg, const float *smax, int64_t n, int64_t *keys, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!seg || !smax || !keys) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) keys[i] = (int64_t)(((uint64_t)seg[i] << 32) | (uint64_t)(uint32_t)~os_bits(smax[i]));
+    return CG3D_OK;
+}
+static int os_seg_of(const int32_t *cand_off, int nseg, int t) {
+    int s = 0;
+    while (s + 1 < nseg && cand_off[s + 1] <= t) s++;
+    return s;
+}
+int cg3d_prop_entries(const int64_t *order, const int32_t *seg_start, const int32_t *cand_off, int32_t nseg, int32_t ncand,
+                      int32_t nbatch, const float *scores, int32_t nc, float thr, int64_t *ekeys, int32_t *counts,
+                      cg3d_stream_t stream) {
+    (void)stream;
+    if (nseg < 0 || ncand < 0 || nbatch <= 0 || nc <= 0 || (int64_t)nbatch * nc >= 512 || (int64_t)ncand * nc >= (1ll << 22) || !counts)
+        return CG3D_ERR_ARG;
+    memset(counts, 0, ((size_t)nbatch * nc + 1) * 4);
+    if (ncand == 0 || nseg == 0) return CG3D_OK;
+    if (!order || !seg_start || !cand_off || !scores || !ekeys) return CG3D_ERR_ARG;
+    int64_t slot = 0;
+    for (int t = 0; t < ncand; t++) {
+        const int s = os_seg_of(cand_off, nseg, t);
+        const int64_t row = order[seg_start[s] + t - cand_off[s]];
+        for (int i = 0; i < nc; i++) {
+            const float sc = scores[row * nc + i];
+            if (!(sc > thr)) continue;                                  /* scores[:, i] > SCORE_THR (:763) */
+            const int p = (s % nbatch) * nc + i;
+            ekeys[slot++] = (int64_t)(((uint64_t)p << 54) | ((uint64_t)(uint32_t)~os_bits(sc) << 22) | (uint64_t)((int64_t)t * nc + i));
+            counts[p]++;
+        }
+    }
+    counts[nbatch * nc] = (int32_t)slot;
+    return CG3D_OK;
+}
+int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, const int32_t *seg_start,
+                     const int32_t *cand_off, int32_t nseg, int32_t nc, const float *points, const float *bbox_pred,
+                     int32_t ndim, const float *scores, float *e_boxes, float *nms_boxes, float *e_score, cg3d_stream_t stream) {
+    (void)stream;
+    if (total < 0 || nseg < 0 || nc <= 0 || (ndim != 6 && ndim != 8)) return CG3D_ERR_ARG;
+    if (total == 0) return CG3D_OK;
+    if (!ekeys || !order || !seg_start || !cand_off || !points || !bbox_pred || !scores || !e_boxes || !nms_boxes || !e_score)
+        return CG3D_ERR_ARG;
+    for (int64_t k = 0; k < total; k++) {
+        const int e = (int)((uint64_t)ekeys[k] & ((1ull << 22) - 1));
+        const int t = e / nc, i = e - t * nc;
+        const int s = os_seg_of(cand_off, nseg, t);
+        const int64_t row = order[seg_start[s] + t - cand_off[s]];
+        const float *p = points + row * 3, *b = bbox_pred + row * ndim;
+        float o[7];
+        o[0] = p[0] + (b[1] - b[0]) / 2; o[1] = p[1] + (b[3] - b[2]) / 2; o[2] = p[2] + (b[5] - b[4]) / 2;
+        if (ndim == 6) {
+            o[3] = b[0] + b[1]; o[4] = b[2] + b[3]; o[5] = b[4] + b[5]; o[6] = 0.f;
+        } else {
+            const float scale = b[0] + b[1] + b[2] + b[3];
+            const float q = expf(sqrtf(b[6] * b[6] + b[7] * b[7]));
+            o[3] = scale / (1 + q); o[4] = scale / (1 + q) * q; o[5] = b[5] + b[4];
+            o[6] = 0.5f * atan2f(b[6], b[7]);
+        }
+        for (int c = 0; c < 7; c++) { e_boxes[k * 7 + c] = o[c]; nms_boxes[k * 7 + c] = (c == 6 && ndim == 8) ? o[c] * -1.f : o[c]; }
+        e_score[k] = scores[row * nc + i];
+    }
+    return CG3D_OK;
+}
