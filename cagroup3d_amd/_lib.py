@@ -109,6 +109,8 @@ _SIGNATURES = {
     "cg3d_prop_keys": (c_int32, [P, P, c_int64, P, P]),
     "cg3d_prop_entries": (c_int32, [P, P, P, c_int32, c_int32, c_int32, P, c_int32, c_float, P, P, P]),
     "cg3d_prop_gather": (c_int32, [P, c_int64, P, P, P, c_int32, c_int32, P, P, c_int32, P, P, P, P, P]),
+    "cg3d_rotated_iou3d_fwd": (c_int32, [P, P, c_int64, P, P]),
+    "cg3d_rotated_iou3d_bwd": (c_int32, [P, P, c_int64, P, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
     "cg3d_event_create": (c_int32, [P]),
@@ -122,6 +124,7 @@ class CG3DError(RuntimeError):
     pass
 
 
+_DEBUG_SYNC = open(os.environ["CG3D_DEBUG_SYNC"], "w") if os.environ.get("CG3D_DEBUG_SYNC") else None
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None) or (lambda: torch.cuda.current_device())
 
@@ -146,6 +149,12 @@ class Library:
         rc = getattr(self._dll, name)(*args)
         if rc != CG3D_OK:
             raise CG3DError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+        if _DEBUG_SYNC and self.is_device:
+            # dev aid (CG3D_DEBUG_SYNC=<file>): the entry point's name goes to the file BEFORE the device is waited for, so that
+            # after a GPU memory fault (which kills the process without a traceback) the last line names the faulting call
+            _DEBUG_SYNC.write("%s %s\n" % (name, " ".join(str(getattr(a, "value", a)) for a in args)))
+            _DEBUG_SYNC.flush()
+            torch.cuda.synchronize()
 
     def stream(self):
         """Raw handle of torch's current stream on the current device (hipStream_t)."""

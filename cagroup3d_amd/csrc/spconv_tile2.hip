@@ -48,13 +48,15 @@ __host__ __device__ static inline int t2_a_bytes(int ucap) { return (ucap + 1) *
 // Register tile of a wave: 128 rows x 64 channels = 4 x 2 MFMA blocks (128 accumulators) kept over all passes, offset
 // blocks and input-channel chunks of the unit; at the end the KG waves holding partial sums of one block exchange halves
 // through the row tile (free by then), leave their rows row-major in LDS and store them 16 bytes per lane.
+// bx: index of the workgroup among the workgroups of ITS unit kind; tile_base: first tile of that kind (a launch may mix
+// units of both kinds: k_spconv_tile2_mix)
 template <int NCO>
-__global__ __launch_bounds__(256, 2) void k_spconv_tile2(
+__device__ __forceinline__ void t2_unit(
     const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf, const uint16_t *__restrict__ slots,
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
     const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,
     const int32_t *__restrict__ order, const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
-    int32_t nunit, int32_t ny, int32_t gz, int32_t wrev, float *__restrict__ stats, int32_t stagger) {
+    int32_t nunit, int32_t ny, int32_t gz, int32_t wrev, float *__restrict__ stats, int32_t stagger, const unsigned bx, const int32_t tile_base) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
     constexpr int NC = NCO * 64;                        // output channels of the unit
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
     // walks ONE contiguous range of units: the halo rows two neighbouring tiles share meet in one L2
     int u;
     {
-        const int u_lo = nunit >> 3, u_rem = nunit & 7, x = blockIdx.x & 7;
-        u = x * u_lo + (x < u_rem ? x : u_rem) + (blockIdx.x >> 3);
-        if ((int)(blockIdx.x >> 3) >= u_lo + (x < u_rem ? 1 : 0)) return;      // (grid rounded up to a multiple of 8)
+        const int u_lo = nunit >> 3, u_rem = nunit & 7, x = bx & 7;
+        u = x * u_lo + (x < u_rem ? x : u_rem) + (bx >> 3);
+        if ((int)(bx >> 3) >= u_lo + (x < u_rem ? 1 : 0)) return;      // (grid rounded up to a multiple of 8)
     }
     // Two workgroups share a CU and start together: left alone they stage, multiply and store in lockstep -- the matrix
     // pipe idles while both gather, and is contended while both multiply (profiles/r03_tile_trace.txt).  The workgroups
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
     // 256 per round) start a few microseconds late, so that one's gather / exchange / store falls into the other's multiply.
     if (stagger > 0 && ((blockIdx.x >> 8) & 1))
         for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles ~ 2.2 us each
-    const int64_t tile = u / (ny * gz);
+    const int64_t tile = tile_base + u / (ny * gz);
     const int yb = (u / gz) % ny, zi = u % gz;
     int64_t row0 = tile * T2_TM, wslot0 = 0;
     int rows = (int)(n_out - row0 < T2_TM ? n_out - row0 : T2_TM);
@@ -448,6 +450,31 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(
 #endif
 }
 
+#define T2_PARAMS                                                                                                              \
+    const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf, const uint16_t *__restrict__ slots,                       \
+        const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,             \
+        const int32_t *__restrict__ ulist, int32_t maxpass, int32_t ucap, const int32_t *__restrict__ tiles,                   \
+        const int32_t *__restrict__ order, const float *__restrict__ bias, float *__restrict__ Y, int64_t n_out, int32_t K,    \
+        int32_t cin, int32_t cout
+#define T2_ARGS X, Wf, slots, live, pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout
+
+template <int NCO>
+__global__ __launch_bounds__(256, 2) void k_spconv_tile2(T2_PARAMS, int32_t nunit, int32_t ny, int32_t gz, int32_t wrev,
+                                                         float *__restrict__ stats, int32_t stagger) {
+    t2_unit<NCO>(T2_ARGS, nunit, ny, gz, wrev, stats, stagger, blockIdx.x, 0);
+}
+// The tail of a launch in half units.  Workgroups are dispatched in index order onto 512 slots (two per CU): a launch of
+// 642 full units (the 128 -> 128 layers at tensor stride 4) runs one full round and then 130 units on half-empty CUs -- 1.65
+// rounds of time for 1.25 rounds of work (profiles/r03_tile_units_scaling.txt).  Here the tiles of the last, partial round
+// are cut into units of 64 output channels instead of 128: twice as many, half as long, spread over all CUs; they come
+// last in index order, the full units before them keep their XCD-contiguous ranges.
+__global__ __launch_bounds__(256, 2) void k_spconv_tile2_mix(T2_PARAMS, int32_t grid2, int32_t nunit2, int32_t ny2, int32_t nunit1,
+                                                             int32_t ny1, int32_t tile_split, int32_t wrev,
+                                                             float *__restrict__ stats, int32_t stagger) {
+    if ((int)blockIdx.x < grid2) t2_unit<2>(T2_ARGS, nunit2, ny2, 1, wrev, stats, stagger, blockIdx.x, 0);
+    else t2_unit<1>(T2_ARGS, nunit1, ny1, 1, wrev, stats, 0, blockIdx.x - grid2, tile_split);
+}
+
 extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
     return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES + T2_IDX_BYTES + 2 * 128 * sizeof(float);
 }
@@ -494,7 +521,25 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
         hipLaunchKernelGGL((k_spconv_tile2<NW>), dim3(grid), dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist,    \
                            maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev ? 1 : 0, stats, stagger); \
     } while (0)
-    if (cout >= 128) T2_LAUNCH(2); else T2_LAUNCH(1);
+    // tail in half units (see k_spconv_tile2_mix): only when the last round is at most half full
+    static const int tail_env = getenv("CG3D_TILE_TAIL") ? atoi(getenv("CG3D_TILE_TAIL")) : 1;
+    const int64_t SLOTS = 512, rem = nunit % SLOTS;
+    const int64_t tail_tiles = (tail_env && cout >= 128 && ksplit == 1 && nunit > SLOTS && rem > 0 && 2 * rem <= SLOTS) ? rem / ny : 0;
+    if (tail_tiles > 0) {
+        static bool attr_mix = false;
+        if (!attr_mix) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_tile2_mix), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    80 * 1024) != hipSuccess)
+                return CG3D_ERR_LAUNCH;
+            attr_mix = true;
+        }
+        const int32_t tile_split = (int32_t)(ntile - tail_tiles), ny1 = cout / 64;
+        const int32_t nunit2 = tile_split * ny, nunit1 = (int32_t)tail_tiles * ny1;
+        const int32_t grid2 = (nunit2 + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_spconv_tile2_mix, dim3((unsigned)(grid2 + (nunit1 + 7) / 8 * 8)), dim3(256), lds, s, X, Wf, slots, live,
+                           pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, grid2, nunit2, ny, nunit1,
+                           ny1, tile_split, wrev ? 1 : 0, stats, stagger);
+    } else if (cout >= 128) T2_LAUNCH(2); else T2_LAUNCH(1);
 #undef T2_LAUNCH
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;

@@ -680,3 +680,229 @@ extern "C" int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ================================================================================================ rotated 3D IoU, fused
+// One thread per box pair; the reference's tensor expressions in their operation order (fp32, no contraction).
+#define RI_EPS 1e-8f
+struct RiPair {
+    float c1x[4], c1y[4], c2x[4], c2y[4];       // corners (box2corners_th)
+    float vx[24], vy[24];                        // candidate vertices: 4 + 4 corners, 16 edge intersections (i major)
+    float t2[16];                                // intersection parameter along the edge of box 1
+    unsigned mask;
+    int idx[9];
+    float S;                                     // signed shoelace sum
+};
+__device__ static inline bool ri_cmp_vert(float x1, float y1, float x2, float y2) {      // sort_vert_kernel.cu:15-40
+    const double E = 1e-8;
+    if ((double)fabsf(x1 - x2) < E && (double)fabsf(y2 - y1) < E) return false;
+    if (y1 > 0 && y2 < 0) return true;
+    if (y1 < 0 && y2 > 0) return false;
+    float n1 = (float)((double)(x1 * x1 + y1 * y1) + E);
+    float n2 = (float)((double)(x2 * x2 + y2 * y2) + E);
+    if (y1 > 0 && y2 > 0) return (double)(fabsf(x1) * x1 / n1 - fabsf(x2) * x2 / n2) > E;
+    if (y1 < 0 && y2 < 0) return (double)(fabsf(x1) * x1 / n1 - fabsf(x2) * x2 / n2) < E;
+    return false;
+}
+__device__ static inline void ri_corners(float x, float y, float w, float h, float a, float *cx, float *cy) {
+    const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f}, sy[4] = {0.5f, 0.5f, -0.5f, -0.5f};
+    const float sn = sinf(a), cs = cosf(a);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float x4 = sx[c] * w, y4 = sy[c] * h;
+        cx[c] = (x4 * cs + y4 * (-sn)) + x;
+        cy[c] = (x4 * sn + y4 * cs) + y;
+    }
+}
+__device__ static inline bool ri_in(float px, float py, const float *qx, const float *qy) {       // box1_in_box2, :57-82
+    const float abx = qx[1] - qx[0], aby = qy[1] - qy[0], adx = qx[3] - qx[0], ady = qy[3] - qy[0];
+    const float amx = px - qx[0], amy = py - qy[0];
+    const float p_ab = abx * amx + aby * amy, n_ab = abx * abx + aby * aby;
+    const float p_ad = adx * amx + ady * amy, n_ad = adx * adx + ady * ady;
+    const float ra = p_ab / n_ab, rd = p_ad / n_ad;
+    return ra > -1e-6f && ra < 1.000001f && rd > -1e-6f && rd < 1.000001f;
+}
+// 2D part: b = (x, y, w, h, alpha).  Returns the intersection area.
+__device__ static float ri_area(const float *b1, const float *b2, RiPair &P) {
+    ri_corners(b1[0], b1[1], b1[2], b1[3], b1[4], P.c1x, P.c1y);
+    ri_corners(b2[0], b2[1], b2[2], b2[3], b2[4], P.c2x, P.c2y);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        P.vx[k] = P.c1x[k]; P.vy[k] = P.c1y[k]; P.vx[4 + k] = P.c2x[k]; P.vy[4 + k] = P.c2y[k];
+        if (ri_in(P.c1x[k], P.c1y[k], P.c2x, P.c2y)) mask |= 1u << k;
+        if (ri_in(P.c2x[k], P.c2y[k], P.c1x, P.c1y)) mask |= 1u << (4 + k);
+    }
+    for (int i = 0; i < 4; i++) {
+        const float x1 = P.c1x[i], y1 = P.c1y[i], x2 = P.c1x[(i + 1) & 3], y2 = P.c1y[(i + 1) & 3];
+        for (int j = 0; j < 4; j++) {
+            const float x3 = P.c2x[j], y3 = P.c2y[j], x4 = P.c2x[(j + 1) & 3], y4 = P.c2y[(j + 1) & 3];
+            const float num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+            const float den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4);
+            const float den_u = (x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3);
+            float t = den_t / num, u = -den_u / num;
+            if (num == 0.f) { t = -1.f; u = -1.f; }
+            const bool m = (t > 0.f) && (t < 1.f) && (u > 0.f) && (u < 1.f);
+            const float t2 = den_t / (num + RI_EPS);
+            const int e = i * 4 + j;
+            P.t2[e] = t2;
+            const float mf = m ? 1.f : 0.f;
+            P.vx[8 + e] = (x1 + t2 * (x2 - x1)) * mf;
+            P.vy[8 + e] = (y1 + t2 * (y2 - y1)) * mf;
+            if (m) mask |= 1u << (8 + e);
+        }
+    }
+    P.mask = mask;
+    const int nv = __popc(mask);
+    // sort_indices (:127-147) + sort_vertices_forward on the vertices relative to their mean
+    float mx = 0.f, my = 0.f;
+    for (int k = 0; k < 24; k++)
+        if ((mask >> k) & 1u) { mx += P.vx[k]; my += P.vy[k]; }
+    mx = mx / (float)nv; my = my / (float)nv;
+    int pad = 0;
+    for (int j = 8; j < 24; ++j) if (!((mask >> j) & 1u)) { pad = j; break; }
+    int *out = P.idx;
+    if (nv < 3) {
+        for (int j = 0; j < 9; ++j) out[j] = pad;
+    } else {
+        for (int j = 0; j < 9; ++j) out[j] = 0;
+        for (int j = 0; j < nv && j < 9; ++j) {
+            float x_min = 1.f, y_min = (float)(-1e-8);
+            int i_take = 0;
+            float x2 = 0.f, y2 = 0.f;
+            if (j > 0) { x2 = P.vx[out[j - 1]] - mx; y2 = P.vy[out[j - 1]] - my; }
+            for (int k = 0; k < 24; ++k) {
+                if (!((mask >> k) & 1u)) continue;
+                const float x = P.vx[k] - mx, y = P.vy[k] - my;
+                bool take = ri_cmp_vert(x, y, x_min, y_min);
+                if (j > 0) take = take && ri_cmp_vert(x2, y2, x, y);
+                if (take) { x_min = x; y_min = y; i_take = k; }
+            }
+            out[j] = i_take;
+        }
+        if (nv < 9) out[nv] = out[0];
+        for (int j = nv + 1; j < 9; ++j) out[j] = pad;
+        if (nv == 8) {
+            int counter = 0;
+            for (int j = 0; j < 4; ++j)
+                for (int k = 4; k < 8; ++k) if (out[k] == out[j]) counter++;
+            if (counter == 4) { out[4] = out[0]; for (int j = 5; j < 9; ++j) out[j] = pad; }
+        }
+    }
+    float S = 0.f;                                      // calculate_area, :150-166
+    for (int m = 0; m < 8; m++) S += P.vx[out[m]] * P.vy[out[m + 1]] - P.vy[out[m]] * P.vx[out[m + 1]];
+    P.S = S;
+    return fabsf(S) / 2;
+}
+struct Ri3d { float area, zo, u3d, inter3d; bool zmax1_lt, zmin1_gt; };
+__device__ static float ri_iou3d(const float *p, const float *q, RiPair &P, Ri3d &R) {             // cal_iou_3d, :86-109
+    const float b1[5] = {p[0], p[1], p[3], p[4], p[6]}, b2[5] = {q[0], q[1], q[3], q[4], q[6]};
+    const float zmax1 = p[2] + p[5] * 0.5f, zmin1 = p[2] - p[5] * 0.5f, zmax2 = q[2] + q[5] * 0.5f, zmin2 = q[2] - q[5] * 0.5f;
+    float zo = fminf(zmax1, zmax2) - fmaxf(zmin1, zmin2);
+    zo = zo < 0.f ? 0.f : zo;
+    const float area = ri_area(b1, b2, P);
+    const float u = b1[2] * b1[3] + b2[2] * b2[3] - area;
+    const float iou2d = area / u;
+    const float inter3d = iou2d * u * zo;
+    const float v1 = p[3] * p[4] * p[5], v2 = q[3] * q[4] * q[5];
+    const float u3d = v1 + v2 - inter3d;
+    R.area = area; R.zo = zo; R.u3d = u3d; R.inter3d = inter3d; R.zmax1_lt = zmax1 < zmax2; R.zmin1_gt = zmin1 > zmin2;
+    return inter3d / u3d;
+}
+__global__ __launch_bounds__(64) void k_rotated_iou3d_fwd(const float *__restrict__ pred, const float *__restrict__ target, int64_t n,
+                                                          float *__restrict__ iou) {
+    const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+    if (i >= n) return;
+    float p[7], q[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { p[k] = pred[i * 7 + k]; q[k] = target[i * 7 + k]; }
+    RiPair P;
+    Ri3d R;
+    iou[i] = ri_iou3d(p, q, P, R);
+}
+__global__ __launch_bounds__(64) void k_rotated_iou3d_bwd(const float *__restrict__ pred, const float *__restrict__ target, int64_t n,
+                                                          const float *__restrict__ g, float *__restrict__ dpred) {
+    const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+    if (i >= n) return;
+    float p[7], q[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { p[k] = pred[i * 7 + k]; q[k] = target[i * 7 + k]; }
+    RiPair P;
+    Ri3d R;
+    ri_iou3d(p, q, P, R);
+    const float go = g[i];
+    // iou = I / U, U = v1 + v2 - I, I = area * zo (the reference forms it as (area / u) * u * zo: the u's cancel in the gradient)
+    const float I = R.inter3d, U = R.u3d;
+    const float gI = go * (U + I) / (U * U), gv1 = -go * I / (U * U);
+    const float gA = gI * R.zo, gzo = R.zo > 0.f ? gI * R.area : 0.f;
+    float d[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // height overlap: min(zmax1, zmax2) - max(zmin1, zmin2), z +- l / 2
+    d[2] += gzo * ((R.zmax1_lt ? 1.f : 0.f) - (R.zmin1_gt ? 1.f : 0.f));
+    d[5] += gzo * 0.5f * ((R.zmax1_lt ? 1.f : 0.f) + (R.zmin1_gt ? 1.f : 0.f));
+    // volume of the predicted box
+    d[3] += gv1 * p[4] * p[5]; d[4] += gv1 * p[3] * p[5]; d[5] += gv1 * p[3] * p[4];
+    // area = |S| / 2 -> the selected vertices
+    const float gS = gA * (P.S > 0.f ? 0.5f : (P.S < 0.f ? -0.5f : 0.f));
+    float gvx[24], gvy[24];
+    for (int k = 0; k < 24; k++) { gvx[k] = 0.f; gvy[k] = 0.f; }
+    for (int m = 0; m < 8; m++) {
+        const int a = P.idx[m], b = P.idx[m + 1];
+        gvx[a] += gS * P.vy[b]; gvy[a] -= gS * P.vx[b];
+        gvy[b] += gS * P.vx[a]; gvx[b] -= gS * P.vy[a];
+    }
+    // vertices -> corners of box 1 (corners directly; intersections through the edge parameter)
+    float gcx[4], gcy[4];
+    for (int k = 0; k < 4; k++) { gcx[k] = gvx[k]; gcy[k] = gvy[k]; }
+    for (int ii = 0; ii < 4; ii++) {
+        const int i2 = (ii + 1) & 3;
+        const float x1 = P.c1x[ii], y1 = P.c1y[ii], x2 = P.c1x[i2], y2 = P.c1y[i2];
+        for (int j = 0; j < 4; j++) {
+            const int e = ii * 4 + j;
+            if (!((P.mask >> (8 + e)) & 1u)) continue;
+            const float gx = gvx[8 + e], gy = gvy[8 + e];
+            if (gx == 0.f && gy == 0.f) continue;
+            const float x3 = P.c2x[j], y3 = P.c2y[j], x4 = P.c2x[(j + 1) & 3], y4 = P.c2y[(j + 1) & 3];
+            const float num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+            const float den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4);
+            const float D = num + RI_EPS, t2 = P.t2[e];
+            const float a34y = y3 - y4, a34x = x3 - x4;
+            const float gt = gx * (x2 - x1) + gy * (y2 - y1);
+            // d t2 / d q = (d den_t / d q * D - den_t * d num / d q) / D^2
+            const float iD2 = 1.f / (D * D);
+            const float dt_x1 = (a34y * D - den_t * a34y) * iD2, dt_y1 = (-a34x * D + den_t * a34x) * iD2;
+            const float dt_x2 = (den_t * a34y) * iD2, dt_y2 = (-den_t * a34x) * iD2;
+            gcx[ii] += gx * (1.f - t2) + gt * dt_x1; gcy[ii] += gy * (1.f - t2) + gt * dt_y1;
+            gcx[i2] += gx * t2 + gt * dt_x2;         gcy[i2] += gy * t2 + gt * dt_y2;
+        }
+    }
+    // corners -> (x, y, w, h, alpha)
+    {
+        const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f}, sy[4] = {0.5f, 0.5f, -0.5f, -0.5f};
+        const float sn = sinf(p[6]), cs = cosf(p[6]);
+        for (int c = 0; c < 4; c++) {
+            const float x4 = sx[c] * p[3], y4 = sy[c] * p[4];
+            d[0] += gcx[c]; d[1] += gcy[c];
+            d[3] += gcx[c] * sx[c] * cs + gcy[c] * sx[c] * sn;
+            d[4] += -gcx[c] * sy[c] * sn + gcy[c] * sy[c] * cs;
+            d[6] += gcx[c] * (-x4 * sn - y4 * cs) + gcy[c] * (x4 * cs - y4 * sn);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) dpred[i * 7 + k] = d[k];
+}
+extern "C" int cg3d_rotated_iou3d_fwd(const float *pred, const float *target, int64_t n, float *iou, cg3d_stream_t stream) {
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!pred || !target || !iou) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_rotated_iou3d_fwd, dim3((unsigned)cg3d_divup(n, 64)), dim3(64), 0, cg3d_hs(stream), pred, target, n, iou);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, int64_t n, const float *g, float *dpred,
+                                      cg3d_stream_t stream) {
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!pred || !target || !g || !dpred) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_rotated_iou3d_bwd, dim3((unsigned)cg3d_divup(n, 64)), dim3(64), 0, cg3d_hs(stream), pred, target, n, g, dpred);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

@@ -142,3 +142,42 @@ def cal_iou_3d(box3d1, box3d2, verbose=False):
         z_range = (torch.max(zmax1, zmax2) - torch.min(zmin1, zmin2)).clamp_min(0.)
         return inter3d / u3d, c1, c2, z_range, u3d
     return inter3d / u3d
+
+
+# ------------------------------------------------------------------------------------------------ fused form
+FUSED = __import__("os").environ.get("CG3D_FUSED_ROT_IOU", "1") != "0"
+
+
+class RotatedIoU3D(Function):
+    """cal_iou_3d of aligned pairs as one launch each way (cg3d_rotated_iou3d_{fwd,bwd}, include/cagroup3d_stages.h): the same
+    expressions in the same order, the gradient with respect to `pred` written out analytically along the reference's autograd
+    graph (the reference: ~80 tensor launches forward, as many again backward, around its one native kernel)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        from ctypes import c_int64
+        lib = _lib.get()
+        p, t = pred.contiguous().float(), target.contiguous().float()
+        assert p.dim() == 2 and p.shape[1] == 7 and t.shape == p.shape
+        lib.check(p, t)
+        iou = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+        lib.call("cg3d_rotated_iou3d_fwd", ptr(p), ptr(t), c_int64(p.shape[0]), ptr(iou), lib.stream())
+        ctx.save_for_backward(p, t)
+        return iou
+
+    @staticmethod
+    def backward(ctx, g):
+        from ctypes import c_int64
+        p, t = ctx.saved_tensors
+        lib = _lib.get()
+        g = g.contiguous().float()
+        d = torch.empty_like(p)
+        lib.call("cg3d_rotated_iou3d_bwd", ptr(p), ptr(t), c_int64(p.shape[0]), ptr(g), ptr(d), lib.stream())
+        return d, None
+
+
+def rotated_iou3d(pred, target):
+    """(n,7) x (n,7) -> (n,) rotated 3D IoU, differentiable in `pred`; a target that needs a gradient takes the tensor form."""
+    if FUSED and not target.requires_grad and pred.dim() == 2 and pred.shape[1] == 7:
+        return RotatedIoU3D.apply(pred, target)
+    return cal_iou_3d(pred[None, ...], target[None, ...])[0]

@@ -2,12 +2,12 @@
 import torch
 import torch.nn as nn
 
-from ...ops.rotated_iou import cal_iou_3d
+from ...ops.rotated_iou import cal_iou_3d, rotated_iou3d  # noqa: F401
 from .loss_utils import AxisAlignedBboxOverlaps3D, weight_reduce_loss
 
 
 def iou_3d_loss(pred, target, weight=None, reduction="mean", avg_factor=None):
-    loss = 1 - cal_iou_3d(pred[None, ...], target[None, ...])
+    loss = 1 - rotated_iou3d(pred, target).unsqueeze(0)        # (1, n), the shape the reference's batched form returns
     return weight_reduce_loss(loss, weight, reduction, avg_factor)
 
 

@@ -141,6 +141,20 @@ int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, 
                      const int32_t *cand_off, int32_t nseg, int32_t nc, const float *points, const float *bbox_pred,
                      int32_t ndim, const float *scores, float *e_boxes, float *nms_boxes, float *e_score, cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Differentiable rotated 3D IoU of aligned box pairs (the SUN RGB-D box losses: IoU3DLoss, pcdet/utils/iou3d_loss.py:14-30,
+ * over cal_iou_3d, pcdet/ops/rotated_iou/oriented_iou_loss.py:86-109; box2corners_th :6-35; oriented_box_intersection_2d,
+ * box_intersection_2d.py:13-184 with sort_vertices, cuda_op/sort_vert_kernel.cu:15-134).  The reference runs ~80 tensor
+ * launches around its one native kernel and lets autograd differentiate them; here one launch each way:
+ *   pred / target float32 [n,7] (x, y, z, dx, dy, dz, heading) -> iou float32 [n];
+ *   bwd: g float32 [n] (upstream gradient of iou) -> dpred float32 [n,7] = g * d iou / d pred (the 24 candidate vertices, the
+ *   polygon order and the shoelace sum are recomputed; the gradient follows the reference's graph: through the corner and
+ *   edge-intersection coordinates of the polygon's vertices, the height overlap and the volume of `pred`; masks and the
+ *   vertex order carry no gradient; targets receive none).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cg3d_rotated_iou3d_fwd(const float *pred, const float *target, int64_t n, float *iou, cg3d_stream_t stream);
+int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, int64_t n, const float *g, float *dpred, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

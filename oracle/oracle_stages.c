@@ -424,3 +424,54 @@ int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, 
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ rotated 3D IoU of box pairs
+ * forward: the reference's expressions in fp32; backward: central differences of the same function evaluated in double
+ * (an independent derivative: the product differentiates analytically). */
+#define REAL float
+#define RN(x) ri_##x##_f
+#define RSIN sinf
+#define RCOS cosf
+#include "oracle_rotiou.inc"
+#undef REAL
+#undef RN
+#undef RSIN
+#undef RCOS
+#define REAL double
+#define RN(x) ri_##x##_d
+#define RSIN sin
+#define RCOS cos
+#include "oracle_rotiou.inc"
+#undef REAL
+#undef RN
+#undef RSIN
+#undef RCOS
+
+int cg3d_rotated_iou3d_fwd(const float *pred, const float *target, int64_t n, float *iou, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!pred || !target || !iou) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) iou[i] = ri_iou3d_f(pred + i * 7, target + i * 7);
+    return CG3D_OK;
+}
+int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, int64_t n, const float *g, float *dpred, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!pred || !target || !g || !dpred) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        double p[7], q[7];
+        for (int k = 0; k < 7; k++) { p[k] = pred[i * 7 + k]; q[k] = target[i * 7 + k]; }
+        for (int k = 0; k < 7; k++) {
+            const double h = 1e-6 * (fabs(p[k]) > 1.0 ? fabs(p[k]) : 1.0), keep = p[k];
+            p[k] = keep + h;
+            const double fp = ri_iou3d_d(p, q);
+            p[k] = keep - h;
+            const double fm = ri_iou3d_d(p, q);
+            p[k] = keep;
+            dpred[i * 7 + k] = (float)((double)g[i] * (fp - fm) / (2.0 * h));
+        }
+    }
+    return CG3D_OK;
+}

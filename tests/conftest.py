@@ -33,7 +33,7 @@ def pytest_collection_modifyitems(config, items):
 
 def _build_oracle():
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in sorted(os.listdir(os.path.join(ROOT, "oracle"))) if f.endswith(".c")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in sorted(os.listdir(os.path.join(ROOT, "oracle"))) if f.endswith((".c", ".inc"))]
     srcs += [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)

@@ -20,14 +20,15 @@ RTOL, ATOL = 1e-4, 1e-5
 _BATCH = {}
 
 
-def bench_coords():
-    """Voxel coordinates of the benchmark batch (S50k x 4, 0.02 m), as CAGroup3D.voxelization makes them."""
-    if "c" not in _BATCH:
-        pts = build_model.synthetic_batch("S50k", 4, device="cpu")["points"]
+def bench_coords(cfg="S50k", scenes=4, voxel=0.02):
+    """Voxel coordinates of a benchmark batch (default: S50k x 4, 0.02 m), as CAGroup3D.voxelization makes them."""
+    k = (cfg, scenes, voxel)
+    if k not in _BATCH:
+        pts = build_model.synthetic_batch(cfg, scenes, device="cpu")["points"]
         c = pts[:, :4].clone()
-        c[:, 1:] = torch.floor(c[:, 1:] / 0.02)
-        _BATCH["c"] = c.int().contiguous()
-    return _BATCH["c"]
+        c[:, 1:] = torch.floor(c[:, 1:] / voxel)
+        _BATCH[k] = c.int().contiguous()
+    return _BATCH[k]
 
 
 def _layer_case(coords, in_stride, ks, conv_stride, transpose, cin, cout, seed, calls=None):
@@ -71,7 +72,29 @@ LAYERS = [
 
 @pytest.mark.parametrize("name,in_stride,ks,cstride,transpose,cin,cout", LAYERS, ids=[l[0] for l in LAYERS])
 def test_benchmark_layer_matches_oracle(oracle, hip, monkeypatch, name, in_stride, ks, cstride, transpose, cin, cout):
-    coords = bench_coords()
+    _check_layer(oracle, hip, monkeypatch, bench_coords(), name, in_stride, ks, cstride, transpose, cin, cout, True)
+
+
+# BASELINE.json configs[3] (SUN RGB-D-shaped: 8 single-view 100 k-point scenes, 3 votes: the 64 -> 192 `feature_offset`
+# convolution, cagroup_head.py:170-172) and configs[4] (4 x 200 k points at 0.01 m: 2 500+ tiles per launch, five rounds of
+# tile-kernel units and more): the layers that carry those runs, on THEIR maps.
+OTHER = [
+    ("S100k-yaw x 8: feature_offset 64->192 @2", "S100k-yaw", 8, 0.02, 2, 3, 1, False, 64, 192, False),
+    ("S100k-yaw x 8: layer3_ 128->128 @4", "S100k-yaw", 8, 0.02, 4, 3, 1, False, 128, 128, True),
+    ("S100k-yaw x 8: down3 128->256 @4->8", "S100k-yaw", 8, 0.02, 4, 3, 2, False, 128, 256, True),
+    ("S200k x 4 @0.01: layer1 64->64 @2", "S200k", 4, 0.01, 2, 3, 1, False, 64, 64, True),
+    ("S200k x 4 @0.01: layer3_ 128->128 @4", "S200k", 4, 0.01, 4, 3, 1, False, 128, 128, True),
+    ("S200k x 4 @0.01: out convT k2 256->256 @4->2", "S200k", 4, 0.01, 4, 2, 2, True, 256, 256, True),
+]
+
+
+@pytest.mark.parametrize("name,cfg,scenes,voxel,in_stride,ks,cstride,transpose,cin,cout,tile", OTHER, ids=[l[0] for l in OTHER])
+def test_layers_of_the_other_configs_match_oracle(oracle, hip, monkeypatch, name, cfg, scenes, voxel, in_stride, ks, cstride,
+                                                  transpose, cin, cout, tile):
+    _check_layer(oracle, hip, monkeypatch, bench_coords(cfg, scenes, voxel), name, in_stride, ks, cstride, transpose, cin, cout, tile)
+
+
+def _check_layer(oracle, hip, monkeypatch, coords, name, in_stride, ks, cstride, transpose, cin, cout, expect_tile):
     monkeypatch.setattr(me, "PRECISION", 1)
     tile_calls, wgrad_calls = [], []
     real_tile = me._conv_tile
@@ -91,9 +114,10 @@ def test_benchmark_layer_matches_oracle(oracle, hip, monkeypatch, name, in_strid
     assert ref[3] == out[3], "map sizes differ between oracle and device"
     n_in, n_out, P = out[3]
     # the device really took the benchmark's kernels: tile kernel forward + data gradient, bf16-row weight gradient
-    assert len(tile_calls) == 2, "forward and data gradient must run k_spconv_tile (got %d)" % len(tile_calls)
+    if expect_tile:
+        assert len(tile_calls) == 2, "forward and data gradient must run k_spconv_tile (got %d)" % len(tile_calls)
     assert wgrad_calls == [2], "the weight gradient must run the bf16-row kernel (precision 2)"
-    if in_stride <= 4 and not transpose:
+    if expect_tile and in_stride <= 4 and not transpose:
         units = max(t * max(c // 128, 1) for t, c in tile_calls)
         assert units > 2 * 256, "benchmark-size map: every persistent workgroup walks several units (%d units)" % units
     for nm, r, o in zip(("y", "dx", "dw"), ref[:3], out[:3]):

@@ -14,7 +14,8 @@ from cagroup3d_amd import build_model, me, train
 
 
 def run(precision, args):
-    me.PRECISION = 1 if precision == "bf16" else 0
+    me.PRECISION = 1 if precision.startswith("bf16") else 0
+    me.HEAD_PRECISION = 0 if precision == "bf16-backbone" else None      # "bf16 backbone" read literally: fp32 heads
     me._WeightPlan.reset()
     np.random.seed(0)
     torch.manual_seed(0)
@@ -29,9 +30,11 @@ def run(precision, args):
     losses, it, t0 = [], 0, time.time()
     quiet = lambda *a, **k: None
     for epoch in range(args.epochs):
+        print("[%s] epoch %d it %d %.0fs" % (precision, epoch, it, time.time() - t0), file=sys.stderr, flush=True)
         it = train.train_one_epoch(model, opt, sched, ds, min(epoch, args.thr_epochs), it, oc.GRAD_NORM_CLIP, log=quiet, losses=losses)
     torch.cuda.synchronize()
     secs = time.time() - t0
+    print("[%s] eval" % precision, file=sys.stderr, flush=True)
     res = train.eval_one_epoch(model, val, cfg.CLASS_NAMES, torch.device("cuda"), log=quiet)
     per = len(ds)
     curve = [float(np.mean(losses[e * per:(e + 1) * per])) for e in range(args.epochs)]
@@ -54,7 +57,7 @@ def main():
     out = {"what": "CAGroup3D trained from seed 0 on %d synthetic %s scenes (classes learnable from shape), %d epochs x %d iterations, "
                    "batch %d, AdamW 1e-3, decay x0.1 at 70%% / 90%%, clip 10; evaluated on %d held-out scenes with indoor_eval"
                    % (args.scenes, args.config, args.epochs, -(-args.scenes // args.batch), args.batch, args.val),
-           "runs": [run("fp32", args), run("bf16", args)]}
+           "runs": [run("fp32", args), run("bf16", args), run("bf16-backbone", args)]}
     if args.repeat_fp32:
         out["runs"].append(dict(run("fp32", args), precision="fp32 (second run, same seed)"))
     a, b = out["runs"][0], out["runs"][1]
