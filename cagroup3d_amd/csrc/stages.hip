@@ -906,3 +906,106 @@ extern "C" int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, in
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ================================================================================================ vote targets (ScanNet form)
+// order-preserving map float -> uint32 (atomicMin / atomicMax on the image order like the floats)
+__device__ static inline uint32_t st_fkey(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// (written with a shift: the `k & 0x80000000u ? k & 0x7fffffffu : ~k` form crashes instruction selection of this compiler)
+__device__ static inline float st_funkey(uint32_t k) { return __uint_as_float((k >> 31) ? (k ^ 0x80000000u) : ~k); }
+
+__global__ void k_inst_init(uint32_t *__restrict__ ws, int64_t cells, int np) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= cells * 8) return;
+    const int f = (int)(i & 7);
+    ws[i] = f < 3 ? 0xffffffffu : (f < 6 ? 0u : (f == 6 ? (uint32_t)np : 0u));       // min keys | max keys | first point | -
+}
+__global__ void k_inst_stats(const float *__restrict__ xyz, const int64_t *__restrict__ ins, int nb, int np, int ni,
+                             uint32_t *__restrict__ ws) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nb * np) return;
+    const int64_t id = ins[i];
+    if (id < 0 || id >= ni) return;
+    const int b = (int)(i / np), pt = (int)(i - (int64_t)b * np);
+    uint32_t *w = ws + ((int64_t)b * ni + id) * 8;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t key = st_fkey(xyz[i * 3 + k]);
+        atomicMin(&w[k], key);
+        atomicMax(&w[3 + k], key);
+    }
+    atomicMin(&w[6], (uint32_t)pt);
+}
+__global__ void k_inst_centers(const uint32_t *__restrict__ ws, const int64_t *__restrict__ sem, int nb, int np, int ni,
+                               const float *__restrict__ gt_ctr, int gmax, const int32_t *__restrict__ n_gt, int n_classes,
+                               float *__restrict__ centers) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nb * ni) return;
+    const int b = c / ni;
+    const uint32_t *w = ws + (int64_t)c * 8;
+    const int first = (int)w[6];
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (first < np) {
+        const int64_t sid = sem[(int64_t)b * np + first];
+        if (sid >= (int64_t)n_classes) {
+            ox = -10000.f; oy = -10000.f; oz = -10000.f;
+        } else {
+            const float cx = 0.5f * (st_funkey(w[0]) + st_funkey(w[3]));
+            const float cy = 0.5f * (st_funkey(w[1]) + st_funkey(w[4]));
+            const float cz = 0.5f * (st_funkey(w[2]) + st_funkey(w[5]));
+            float best = 3.0e38f;
+            int arg = 0;
+            const int ng = n_gt[b];
+            const float *q0 = gt_ctr + (int64_t)b * gmax * 3;
+            for (int g = 0; g < ng; g++) {
+                const float dx = cx - q0[g * 3], dy = cy - q0[g * 3 + 1], dz = cz - q0[g * 3 + 2];
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (d < best) { best = d; arg = g; }
+            }
+            ox = q0[arg * 3]; oy = q0[arg * 3 + 1]; oz = q0[arg * 3 + 2];
+        }
+    }
+    centers[(int64_t)c * 3] = ox; centers[(int64_t)c * 3 + 1] = oy; centers[(int64_t)c * 3 + 2] = oz;
+}
+extern "C" int cg3d_instance_centers(const float *xyz, const int64_t *ins, const int64_t *sem, int32_t nb, int32_t np, int32_t ni,
+                                     const float *gt_ctr, int32_t gmax, const int32_t *n_gt, int32_t n_classes, float *centers,
+                                     int32_t *ws, cg3d_stream_t stream) {
+    if (nb <= 0 || np <= 0 || ni <= 0 || gmax < 0) return CG3D_ERR_ARG;
+    if (!xyz || !ins || !sem || !gt_ctr || !n_gt || !centers || !ws) return CG3D_ERR_ARG;
+    const int64_t cells = (int64_t)nb * ni;
+    hipLaunchKernelGGL(k_inst_init, dim3((unsigned)cg3d_divup(cells * 8, 256)), dim3(256), 0, cg3d_hs(stream), (uint32_t *)ws, cells, np);
+    hipLaunchKernelGGL(k_inst_stats, dim3((unsigned)cg3d_divup((int64_t)nb * np, 256)), dim3(256), 0, cg3d_hs(stream), xyz, ins, nb, np,
+                       ni, (uint32_t *)ws);
+    hipLaunchKernelGGL(k_inst_centers, dim3((unsigned)cg3d_divup(cells, 64)), dim3(64), 0, cg3d_hs(stream), (const uint32_t *)ws, sem, nb,
+                       np, ni, gt_ctr, gmax, n_gt, n_classes, centers);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+__global__ void k_vote_targets(const float *__restrict__ vox_xyz, const int64_t *__restrict__ vox_scene,
+                               const int64_t *__restrict__ nearest, int64_t n, const int64_t *__restrict__ ins, int np,
+                               const float *__restrict__ centers, int ni, float *__restrict__ off_t, float *__restrict__ off_m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = vox_scene[i];
+    const int64_t major = ins[b * np + nearest[i]];
+    const float *c = centers + (b * ni + major) * 3;
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t = c[k] - vox_xyz[i * 3 + k];
+        const bool real = !(t < -100.f);
+        all = all && real;
+        off_t[i * 3 + k] = real ? t : 0.f;
+    }
+    off_m[i] = all ? 1.f : 0.f;
+}
+extern "C" int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene, const int64_t *nearest, int64_t n,
+                                 const int64_t *ins, int32_t np, const float *centers, int32_t ni, float *off_t, float *off_m,
+                                 cg3d_stream_t stream) {
+    if (n < 0 || np <= 0 || ni <= 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!vox_xyz || !vox_scene || !nearest || !ins || !centers || !off_t || !off_m) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_vote_targets, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, cg3d_hs(stream), vox_xyz, vox_scene, nearest, n,
+                       ins, np, centers, ni, off_t, off_m);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

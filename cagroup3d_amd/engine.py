@@ -208,14 +208,29 @@ class Builder:
             self.b.add(OP_TO_BF16, t.gsum, t.gsum16, t.n * t.c)
         return t.gsum, t.gsum16
 
+    # The chunk / identity-pair / unit tables come out of me.py's host caches, which are CLEARED when they grow past their
+    # limit (every new row count is a new key: a training run with varying batches gets there within tens of steps).  A
+    # program holds raw addresses, so it must hold the tensors too -- a cleared cache once handed a compiled program's chunk
+    # tables to the allocator while the program was still to run (a GPU memory fault three minutes into a training run).
     def _unit(self, c):
         z, o = ME._unit_bn(c, self.dev)
+        self.keep.append((z, o))
         return z.data_ptr(), o.data_ptr()
+
+    def _chunks(self, n, c):
+        t = ME._bn_chunks((0, n), self.dev, c)
+        self.keep.append(t)
+        return t
+
+    def _ident(self, n, seglen):
+        t = ME._identity_pairs(n, seglen, self.dev)
+        self.keep.append(t)
+        return t
 
     def _add_rows(self, prog, a, b, y, n, c, act, y16):
         """y = act(a + b) (b may be 0): cg3d_bn_apply with the identity normalisation, as me.AddReluFunction does."""
         z, o = self._unit(c)
-        ch = ME._bn_chunks((0, n), self.dev, c)
+        ch = self._chunks(n, c)
         prog.add(OP_BN_APPLY, a, b, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, act, y, y16)
 
     # ---------------------------------------------------------------- weights of the step's arena
@@ -355,7 +370,7 @@ class Builder:
             self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin, cout, max(ksplit, 1), y.stats, part)
         else:
             # generic form (fp32 parity mode / the oracle): the pair kernel on the identity map, me.LinearFunction._rows_gemm
-            ar, seg, nseg = ME._identity_pairs(n, 128 if self.lib.is_device else (1 << 30), self.dev)
+            ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
             y = T(self.alloc(max(n, 1) * cout * 4, R_ZF), n, cout)
             self.f.add(OP_PAIRS_FWD, x.p, w2.data_ptr(), ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 0, 1)
             wp = 0
@@ -376,7 +391,7 @@ class Builder:
                 part = self.alloc(ksplit * max(n, 1) * cin * 4) if ksplit > 1 else 0
                 prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx, n, cout, cin, max(ksplit, 1), 0, part)
             else:
-                ar, seg, nseg = ME._identity_pairs(n, 128 if self.lib.is_device else (1 << 30), self.dev)
+                ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
                 dx = self.alloc(max(n, 1) * cin * 4, R_ZB)
                 self.late.append((prog, len(prog.rows), 2, lambda w=w2: w.detach().t().contiguous()))
                 prog.add(OP_PAIRS_FWD, dy, 0, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, dx, n, cout, cin, 0, 1)
@@ -385,7 +400,7 @@ class Builder:
         xc, dyc = x.p, dy
         if wprec and own and x.p16 and dy16 and cout % 8 == 0:
             xc, dyc, wprec = x.p16, dy16, 2
-        ar, seg, nseg = ME._identity_pairs(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1), self.dev)
+        ar, seg, nseg = self._ident(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1))
         prog.add(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
                  wprec | WGRAD_ACC)
 
@@ -394,7 +409,7 @@ class Builder:
         n, c = x.n, x.c
         if not (bn.training and bn.track_running_stats and bn.momentum is not None and c % 4 == 0) or ME._sync_group_of(bn) is not None:
             raise NotReady("BatchNorm form without a program counterpart (evaluation statistics, --sync_bn)")
-        red, nred, _, group_n, app, napp, _ = ME._bn_chunks((0, n), self.dev, c)
+        red, nred, _, group_n, app, napp, _ = self._chunks(n, c)
         prog = self.f
         sums = x.stats
         if not sums:
@@ -455,7 +470,7 @@ class Builder:
         # relu: dz = dy where y > 0 -- cg3d_bn_bwd_apply with the identity normalisation (use_batch_stats = 0: dx = dz)
         n, c = a.n, a.c
         z, o = self._unit(c)
-        ch = ME._bn_chunks((0, n), self.dev, c)
+        ch = self._chunks(n, c)
         dz = self.alloc(max(n, 1) * c * 4)
         self.b.add(OP_BN_BWD_APPLY, dy, y.p, y.p, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, z, o, act, 0, dz, 0, 0)
         self.gadd(a, dz)

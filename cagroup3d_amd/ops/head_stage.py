@@ -67,3 +67,28 @@ class _GatherRows2(torch.autograd.Function):
 def gather_rows2(fa, fb, idx):
     """out[i] = cat([fa, fb])[idx[i]] without the concatenation; gradients are scattered back into the two pieces."""
     return _GatherRows2.apply(fa, fb, idx)
+
+
+def vote_targets(xyz, ins, sem, gt_ctr, n_gt, n_classes, n_ins, vox_xyz, vox_scene, nearest):
+    """ScanNet-form vote targets of all scenes (reference cagroup_head.py:454-498) in two calls: per-instance bounding boxes and
+    the ground-truth centre each instance votes for (cg3d_instance_centers), then the masked per-voxel offsets
+    (cg3d_vote_targets).  xyz float32 [B,P,3]; ins / sem int64 [B,P]; gt_ctr float32 [B,G,3], n_gt int32 [B]; vox_xyz [N,3],
+    vox_scene / nearest int64 [N] -> (off_t [N,3], off_m float32 [N])."""
+    lib = _lib.get()
+    xyz, ins, sem, gt_ctr = xyz.contiguous(), ins.contiguous(), sem.contiguous(), gt_ctr.contiguous()
+    vox_xyz, vox_scene, nearest = vox_xyz.contiguous(), vox_scene.contiguous(), nearest.contiguous()
+    assert ins.dtype == torch.int64 and sem.dtype == torch.int64 and vox_scene.dtype == torch.int64 and nearest.dtype == torch.int64
+    lib.check(xyz, ins, sem, gt_ctr, n_gt, vox_xyz, vox_scene, nearest)
+    B, P = ins.shape
+    dev = xyz.device
+    centers = torch.empty((B, n_ins, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty(8 * B * n_ins, dtype=torch.int32, device=dev)
+    lib.call("cg3d_instance_centers", ptr(xyz), ptr(ins), ptr(sem), c_int32(B), c_int32(P), c_int32(n_ins), ptr(gt_ctr),
+             c_int32(gt_ctr.shape[1]), ptr(n_gt), c_int32(n_classes), ptr(centers), ptr(ws), lib.stream())
+    N = vox_xyz.shape[0]
+    out = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    flat = out.view(-1)
+    off_t, off_m = flat[:3 * N].view(N, 3), flat[3 * N:]
+    lib.call("cg3d_vote_targets", ptr(vox_xyz), ptr(vox_scene), ptr(nearest), c_int64(N), ptr(ins), c_int32(P), ptr(centers),
+             c_int32(n_ins), ptr(off_t), ptr(off_m), lib.stream())
+    return off_t, off_m

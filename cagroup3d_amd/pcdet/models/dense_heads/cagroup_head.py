@@ -427,7 +427,10 @@ class CAGroup3DHead(nn.Module):
         if not self.with_yaw:
             n_ins = (torch.stack(list(ins_masks)).amax(1) if equal_pts else torch.stack([im.max() for im in ins_masks])).cpu().numpy() + 1      # one host read for all scenes
         if not self.with_yaw and equal_pts:
-            perms = ME.rows_by_batch(vox_scene, B)
+            info = {}
+            perms = _Perms(ME.rows_by_batch(vox_scene, B, info=info))
+            perms.sorted = bool(info.get("sorted"))
+            perms.starts = [0] + np.cumsum([p.shape[0] for p in perms]).tolist()
             counts = ME.h2d([p.shape[0] for p in perms], torch.long, dev)
             t, mk = self._vote_targets_masks_batched(vox_xyz, vox_scene, perms, gt_bboxes, scene_points, sem_masks, ins_masks, n_ins)
             off_t, off_m = t, mk.float()
@@ -600,6 +603,20 @@ class CAGroup3DHead(nn.Module):
         xyz = torch.stack([sp[:, :3] for sp in scene_points])                          # [B, P, 3]
         ins, sem = torch.stack(list(ins_masks)), torch.stack(list(sem_masks))          # [B, P]
         I = int(n_ins.max())
+        if FUSED_HEAD and ins.dtype == torch.int64 and sem.dtype == torch.int64 and all(len(g) > 0 for g in gt_bboxes):
+            # instance bounding boxes, the box each instance votes for and the masked offsets as stage ops (ops/head_stage.py):
+            # the tensor form below materialises [B, P, I, 3] masked copies of the points three times over
+            from ....ops import head_stage as HS
+            n_gt = [len(g) for g in gt_bboxes]
+            gt_ctr = torch.nn.utils.rnn.pad_sequence([g[:, :3].to(dev) for g in gt_bboxes], batch_first=True)
+            contiguous = all(int(p.shape[0]) > 0 for p in perms) and getattr(perms, "sorted", False)
+            if contiguous:          # batch-major rows: scene b is a row range
+                nearest = torch.cat([knn(1, xyz[b:b + 1], vox_xyz[perms.starts[b]:perms.starts[b + 1]][None].contiguous())[0, 0] for b in range(B)]).long()
+            else:
+                nearest = torch.empty(vox_xyz.shape[0], dtype=torch.long, device=dev)
+                for b in range(B):
+                    nearest[perms[b]] = knn(1, xyz[b:b + 1], vox_xyz[perms[b]][None].contiguous())[0, 0].long()
+            return HS.vote_targets(xyz, ins, sem, gt_ctr, ME.h2d(n_gt, torch.int32, dev), self.n_classes, I, vox_xyz, vox_scene, nearest)
         member = ins.unsqueeze(2) == torch.arange(I, device=dev).view(1, 1, -1)        # [B, P, I]
         big = torch.full((1, 1, 1, 1), float("inf"), device=dev)
         lo = torch.where(member.unsqueeze(3), xyz.unsqueeze(2), big).amin(1)           # [B, I, 3]
@@ -937,6 +954,11 @@ def split_gt_boxes(gt_boxes, label_dtype=torch.long):
     if prefix:
         boxes.prefix_counts = [int(x) for x in v.sum(1)]
     return boxes, labels
+
+
+class _Perms(list):
+    """Per-scene row lists + whether they are consecutive row ranges (`sorted`, `starts`)."""
+    sorted, starts = False, None
 
 
 class GtList(list):

@@ -155,6 +155,28 @@ int cg3d_prop_gather(const int64_t *ekeys, int64_t total, const int64_t *order, 
 int cg3d_rotated_iou3d_fwd(const float *pred, const float *target, int64_t n, float *iou, cg3d_stream_t stream);
 int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, int64_t n, const float *g, float *dpred, cg3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Vote targets of the dense head, ScanNet form (CAGroup3DHead.loss, cagroup_head.py:454-498): every backbone voxel takes the
+ * instance of its nearest raw point (kNN, k = 1) and votes for the centre of the ground-truth box nearest to that instance's
+ * bounding-box centre.  The reference loops over torch.unique(instance ids) per scene; scenes hold the same number of raw
+ * points here (np), instance ids lie in [0, ni).
+ *
+ * cg3d_instance_centers: xyz float32 [nb, np, 3], ins / sem int64 [nb, np] (instance and semantic id of every raw point),
+ *   gt_ctr float32 [nb, gmax, 3] with n_gt int32 [nb] valid rows, n_classes: for every (scene, instance) the bounding box of
+ *   its points, the semantic id of its first point, and from them  centers float32 [nb, ni, 3] = the centre of the
+ *   ground-truth box nearest (Euclidean, ties: the lower index) to the bounding-box centre when the instance is an object
+ *   (semantic id < n_classes; :470-478), (-10000, -10000, -10000) for an instance that is present but no object (:466), zeros
+ *   for an id no point carries.  ws: 8 * nb * ni int32 of scratch.
+ * cg3d_vote_targets: vox_xyz float32 [n,3], vox_scene int64 [n], nearest int64 [n] (index of the voxel's nearest raw point in
+ *   its scene) -> off_t float32 [n,3] = centre of the nearest point's instance - voxel position (0 where that is below -100,
+ *   :488-494), off_m float32 [n] = 1 where all three components are real votes.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int cg3d_instance_centers(const float *xyz, const int64_t *ins, const int64_t *sem, int32_t nb, int32_t np, int32_t ni,
+                          const float *gt_ctr, int32_t gmax, const int32_t *n_gt, int32_t n_classes, float *centers, int32_t *ws,
+                          cg3d_stream_t stream);
+int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene, const int64_t *nearest, int64_t n, const int64_t *ins,
+                      int32_t np, const float *centers, int32_t ni, float *off_t, float *off_m, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -475,3 +475,64 @@ int cg3d_rotated_iou3d_bwd(const float *pred, const float *target, int64_t n, co
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ vote targets, ScanNet form
+ * cagroup_head.py:454-498: per instance the bounding box of its points (:462-468), non-object instances voted far away
+ * (:466), objects -> the centre of the nearest ground-truth box (:470-478); per voxel the instance of its nearest raw point
+ * (:480-486) and the masked offset (:488-494). */
+int cg3d_instance_centers(const float *xyz, const int64_t *ins, const int64_t *sem, int32_t nb, int32_t np, int32_t ni,
+                          const float *gt_ctr, int32_t gmax, const int32_t *n_gt, int32_t n_classes, float *centers, int32_t *ws,
+                          cg3d_stream_t stream) {
+    (void)stream; (void)ws;
+    if (nb <= 0 || np <= 0 || ni <= 0 || gmax < 0) return CG3D_ERR_ARG;
+    if (!xyz || !ins || !sem || !gt_ctr || !n_gt || !centers) return CG3D_ERR_ARG;
+    for (int b = 0; b < nb; b++)
+        for (int id = 0; id < ni; id++) {
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int first = np;
+            for (int p = 0; p < np; p++) {
+                if (ins[(int64_t)b * np + p] != id) continue;
+                if (first == np) first = p;
+                for (int k = 0; k < 3; k++) {
+                    const float v = xyz[((int64_t)b * np + p) * 3 + k];
+                    lo[k] = v < lo[k] ? v : lo[k];
+                    hi[k] = v > hi[k] ? v : hi[k];
+                }
+            }
+            float *o = centers + ((int64_t)b * ni + id) * 3;
+            o[0] = o[1] = o[2] = 0.f;
+            if (first == np) continue;
+            if (!(sem[(int64_t)b * np + first] < n_classes)) { o[0] = o[1] = o[2] = -10000.f; continue; }
+            float best = INFINITY;
+            int arg = 0;
+            for (int g = 0; g < n_gt[b]; g++) {
+                const float *q = gt_ctr + ((int64_t)b * gmax + g) * 3;
+                const float dx = 0.5f * (lo[0] + hi[0]) - q[0], dy = 0.5f * (lo[1] + hi[1]) - q[1], dz = 0.5f * (lo[2] + hi[2]) - q[2];
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (d < best) { best = d; arg = g; }
+            }
+            const float *q = gt_ctr + ((int64_t)b * gmax + arg) * 3;
+            o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+        }
+    return CG3D_OK;
+}
+int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene, const int64_t *nearest, int64_t n, const int64_t *ins,
+                      int32_t np, const float *centers, int32_t ni, float *off_t, float *off_m, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || np <= 0 || ni <= 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!vox_xyz || !vox_scene || !nearest || !ins || !centers || !off_t || !off_m) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t b = vox_scene[i], major = ins[b * np + nearest[i]];
+        const float *c = centers + (b * ni + major) * 3;
+        int all = 1;
+        for (int k = 0; k < 3; k++) {
+            const float t = c[k] - vox_xyz[i * 3 + k];
+            const int real = !(t < -100.f);
+            all = all && real;
+            off_t[i * 3 + k] = real ? t : 0.f;
+        }
+        off_m[i] = all ? 1.f : 0.f;
+    }
+    return CG3D_OK;
+}

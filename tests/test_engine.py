@@ -143,3 +143,41 @@ def test_program_equals_per_layer_path_on_the_device(hip, cfgname, n):
     assert not bad, bad
     for k in ref[3]:
         assert _l2(ref[3][k].float(), got[3][k].float()) <= 3 * _l2(ref[3][k].float(), ref2[3][k].float()) + 1e-3, k
+
+
+def test_compiled_program_owns_the_cached_tables_it_points_into(oracle):
+    """me.py's host caches (chunk tables, identity pair lists, unit BatchNorm rows) are cleared when they grow -- in a training
+    run with varying batches within tens of steps.  A program holds raw addresses into those tables, so it must hold the
+    tensors themselves: every address in its rows that falls into a cached table must fall into a tensor of `comp.keep`."""
+    with _lib.use_library(oracle):
+        prec, me.PRECISION = me.PRECISION, 0
+        os.environ["CG3D_ENGINE_ANY"] = "1"
+        try:
+            model, _ = build_model.build_cagroup3d("scannet", seed=0)
+            model.train()
+            batch = build_model.synthetic_batch("S5k", 1, device="cpu")
+            sp = model.voxelization(batch["points"].clone())
+            me._chunk_cache.clear(); me._ident_cache.clear()
+            comp = engine.compile_backbone(model.backbone_3d, sp, mid_mark=False)
+            cached = []
+            me._walk_tensors = me._walk_tensors         # (same helper the stream hand-over uses)
+
+            def leaves(o, out):
+                if torch.is_tensor(o):
+                    out.append(o)
+                elif isinstance(o, (list, tuple)):
+                    for v in o:
+                        leaves(v, out)
+            leaves(list(me._chunk_cache.values()) + list(me._ident_cache.values()), cached)
+            kept = []
+            leaves(comp.keep, kept)
+        finally:
+            me.PRECISION = prec
+            os.environ.pop("CG3D_ENGINE_ANY", None)
+    assert len(cached) > 10
+    kept_ptrs = {t.data_ptr() for t in kept}
+    addrs = set(int(v) for v in np.concatenate([comp.fwd.reshape(-1), comp.bwd.reshape(-1)]))
+    used = [t for t in cached if t.numel() > 0 and t.data_ptr() in addrs]
+    assert len(used) > 10, "the program does not seem to use the cached tables at all"
+    missing = [t.shape for t in used if t.data_ptr() not in kept_ptrs]
+    assert not missing, "cached tables referenced by raw address only: %s" % missing[:5]

@@ -534,3 +534,53 @@ def test_hip_rotated_iou3d_matches_oracle_and_torch_autograd(hip, oracle):
     d = (pd.grad - p0.grad).abs().max(1)[0]
     ok = d <= 1e-3 * (1 + p0.grad.abs().max(1)[0])
     assert float(ok.float().mean()) > 0.995, float(ok.float().mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------- vote targets
+def _vote_case(dev, B=3, P=4000, N=3000, seed=0):
+    from cagroup3d_amd import build_model
+    batch = build_model.synthetic_batch("S5k", B, device="cpu")
+    pts = batch["points"]
+    sp = [pts[pts[:, 0] == b, 1:].to(dev) for b in range(B)]
+    P = min(len(s) for s in sp)
+    sp = [s[:P].contiguous() for s in sp]
+    ins = [torch.from_numpy(np.asarray(m))[:P].long().to(dev) for m in batch["instance_mask"]]
+    sem = [torch.from_numpy(np.asarray(m))[:P].long().to(dev) for m in batch["semantic_mask"]]
+    gt = batch["gt_boxes"]
+    gtb = [gt[b][~(gt[b] == 0).all(-1)][:, :7].to(dev) for b in range(B)]
+    g = torch.Generator().manual_seed(seed)
+    vox_scene = torch.sort(torch.randint(0, B, (N,), generator=g))[0].to(dev)
+    vox_xyz = torch.stack([sp[int(b)][int(i), :3] for b, i in zip(vox_scene.tolist(), torch.randint(0, P, (N,), generator=g).tolist())])
+    vox_xyz = (vox_xyz + torch.randn(N, 3, generator=g).to(dev) * 0.03).contiguous()
+    return sp, ins, sem, gtb, vox_xyz, vox_scene, B
+
+
+def _run_vote(head, case, fused, monkeypatch):
+    from cagroup3d_amd.pcdet.models.dense_heads import cagroup_head as CH
+    sp, ins, sem, gtb, vox_xyz, vox_scene, B = case
+    monkeypatch.setattr(CH, "FUSED_HEAD", fused)
+    info = {}
+    perms = CH._Perms(ME.rows_by_batch(vox_scene, B, info=info))
+    perms.sorted = bool(info.get("sorted"))
+    perms.starts = [0] + np.cumsum([p.shape[0] for p in perms]).tolist()
+    n_ins = np.asarray([int(i.max()) + 1 for i in ins])
+    return head._vote_targets_masks_batched(vox_xyz, vox_scene, perms, gtb, sp, sem, ins, n_ins)
+
+
+def test_oracle_vote_targets_equal_the_tensor_form(oracle, monkeypatch):
+    head = _mini_head(18)
+    with _lib.use_library(oracle):
+        case = _vote_case("cpu")
+        t0, m0 = _run_vote(head, case, False, monkeypatch)
+        t1, m1 = _run_vote(head, case, True, monkeypatch)
+    assert float(m0.float().mean()) > 0.05 and float(m0.float().mean()) < 0.95          # both kinds of voxels
+    assert torch.equal(m1 > 0, m0 > 0) and torch.equal(t1, t0)                            # selections and subtractions: exact
+
+
+@pytest.mark.gpu
+def test_hip_vote_targets_match_oracle(hip, oracle, monkeypatch):
+    head = _mini_head(18)
+    with _lib.use_library(oracle):
+        t0, m0 = _run_vote(head, _vote_case("cpu"), True, monkeypatch)
+    t1, m1 = _run_vote(head, _vote_case("cuda"), True, monkeypatch)
+    assert torch.equal(m1.cpu(), m0) and torch.equal(t1.cpu(), t0)
