@@ -148,15 +148,19 @@ class Library:
         return getattr(self._dll, name)
 
     def call(self, name, *args):
+        if _DEBUG_SYNC and self.is_device:
+            # dev aid (CG3D_DEBUG_SYNC=<file>): the entry point's name goes to the file BEFORE the call and the device is waited
+            # for after it, so that after a GPU memory fault (which kills the process without a traceback) the last line names
+            # the faulting call (a line without its " ok" never came back)
+            torch.cuda.synchronize()
+            _DEBUG_SYNC.write("%s %s" % (name, " ".join(str(getattr(a, "value", a)) for a in args)))
+            _DEBUG_SYNC.flush()
         rc = getattr(self._dll, name)(*args)
         if rc != CG3D_OK:
             raise CG3DError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
         if _DEBUG_SYNC and self.is_device:
-            # dev aid (CG3D_DEBUG_SYNC=<file>): the entry point's name goes to the file BEFORE the device is waited for, so that
-            # after a GPU memory fault (which kills the process without a traceback) the last line names the faulting call
-            _DEBUG_SYNC.write("%s %s\n" % (name, " ".join(str(getattr(a, "value", a)) for a in args)))
-            _DEBUG_SYNC.flush()
             torch.cuda.synchronize()
+            _DEBUG_SYNC.write(" ok\n")
 
     def stream(self):
         """Raw handle of torch's current stream on the current device (hipStream_t)."""

@@ -4,7 +4,7 @@ import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-RN = os.environ.get("ROUND", "r03")
+RN = os.environ.get("ROUND", "r04")
 
 
 def rd(name):

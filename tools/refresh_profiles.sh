@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): regenerates everything profiles/ holds for this round.  Outputs land in gpurun_out/refresh/;
 # copy them into profiles/ afterwards (tools/make_profiles_readme.py rebuilds the README from them).
 set -x
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/refresh; mkdir -p $O; RN=${ROUND:-r03}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/refresh; mkdir -p $O; RN=${ROUND:-r04}
 cd /tmp; export TMPDIR=/tmp
 python $R/tools/stream_bw.py > $O/${RN}_stream_bw.txt 2>&1
 python $R/bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/${RN}_bench_bf16.json

@@ -57,10 +57,10 @@ def main():
     out = {"what": "CAGroup3D trained from seed 0 on %d synthetic %s scenes (classes learnable from shape), %d epochs x %d iterations, "
                    "batch %d, AdamW 1e-3, decay x0.1 at 70%% / 90%%, clip 10; evaluated on %d held-out scenes with indoor_eval"
                    % (args.scenes, args.config, args.epochs, -(-args.scenes // args.batch), args.batch, args.val),
-           "runs": [run("fp32", args), run("bf16", args), run("bf16-backbone", args)]}
+           "runs": [run(p, args) for p in os.environ.get("CG3D_CONV_RUNS", "fp32,bf16,bf16-backbone").split(",")]}
     if args.repeat_fp32:
         out["runs"].append(dict(run("fp32", args), precision="fp32 (second run, same seed)"))
-    a, b = out["runs"][0], out["runs"][1]
+    a, b = out["runs"][0], out["runs"][min(1, len(out["runs"]) - 1)]
     out["bf16_minus_fp32"] = {"final_epoch_loss": b["epoch_mean_loss"][-1] - a["epoch_mean_loss"][-1],
                               "mAP_0.25": b["mAP_0.25"] - a["mAP_0.25"], "mAP_0.50": b["mAP_0.50"] - a["mAP_0.50"]}
     print(json.dumps(out, indent=1))
