@@ -106,6 +106,7 @@ _SIGNATURES = {
     "cg3d_gather_rows2": (c_int32, [P, P, c_int64, P, P, c_int64, c_int32, P]),
     "cg3d_scatter_add_rows2": (c_int32, [P, P, P, P, c_int64, c_int64, c_int32, P]),
     "cg3d_count_ids": (c_int32, [P, c_int64, c_int32, c_int32, c_int32, P, P]),
+    "cg3d_count_sorted_ids": (c_int32, [P, c_int64, c_int32, c_int32, c_int32, P, P]),
     "cg3d_prop_keys": (c_int32, [P, P, c_int64, P, P]),
     "cg3d_prop_entries": (c_int32, [P, P, P, c_int32, c_int32, c_int32, P, c_int32, c_float, P, P, P]),
     "cg3d_prop_gather": (c_int32, [P, c_int64, P, P, P, c_int32, c_int32, P, P, c_int32, P, P, P, P, P]),

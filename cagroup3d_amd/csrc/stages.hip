@@ -516,29 +516,41 @@ extern "C" int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, flo
 // ------------------------------------------------------------------------------------------------ id histogram
 template <typename T>
 __global__ __launch_bounds__(256) void k_count_ids(const T *__restrict__ ids, int64_t n, int stride, int m,
-                                                   unsigned long long *__restrict__ counts) {
+                                                   unsigned long long *__restrict__ counts, int check) {
     extern __shared__ int s_h[];
-    for (int i = threadIdx.x; i < m; i += 256) s_h[i] = 0;
+    for (int i = threadIdx.x; i < m + 1; i += 256) s_h[i] = 0;
     __syncthreads();
+    int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t v = (int64_t)ids[i * stride];
         if (v >= 0 && v < m) atomicAdd(&s_h[v], 1);
+        else bad++;
+        if (check && i > 0 && (int64_t)ids[(i - 1) * stride] > v) bad++;
     }
+    if (check && bad) atomicAdd(&s_h[m], bad);
     __syncthreads();
-    for (int i = threadIdx.x; i < m; i += 256)
+    for (int i = threadIdx.x; i < m + (check ? 1 : 0); i += 256)
         if (s_h[i]) atomicAdd(&counts[i], (unsigned long long)s_h[i]);
 }
-extern "C" int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts,
-                              cg3d_stream_t stream) {
+static int st_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, int check,
+                        cg3d_stream_t stream) {
     if (n < 0 || m <= 0 || m > 8192 || stride < 1 || !counts) return CG3D_ERR_ARG;
-    if (hipMemsetAsync(counts, 0, (size_t)m * 8, cg3d_hs(stream)) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(counts, 0, (size_t)(m + check) * 8, cg3d_hs(stream)) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (n == 0) return CG3D_OK;
     if (!ids) return CG3D_ERR_ARG;
     const unsigned g = (unsigned)(cg3d_divup(n, 256 * 8) < 1024 ? cg3d_divup(n, 256 * 8) : 1024);
-    if (is64) hipLaunchKernelGGL(k_count_ids<int64_t>, dim3(g), dim3(256), (size_t)m * 4, cg3d_hs(stream), (const int64_t *)ids, n, stride, m, (unsigned long long *)counts);
-    else hipLaunchKernelGGL(k_count_ids<int32_t>, dim3(g), dim3(256), (size_t)m * 4, cg3d_hs(stream), (const int32_t *)ids, n, stride, m, (unsigned long long *)counts);
+    if (is64) hipLaunchKernelGGL(k_count_ids<int64_t>, dim3(g), dim3(256), (size_t)(m + 1) * 4, cg3d_hs(stream), (const int64_t *)ids, n, stride, m, (unsigned long long *)counts, check);
+    else hipLaunchKernelGGL(k_count_ids<int32_t>, dim3(g), dim3(256), (size_t)(m + 1) * 4, cg3d_hs(stream), (const int32_t *)ids, n, stride, m, (unsigned long long *)counts, check);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
+}
+extern "C" int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts,
+                              cg3d_stream_t stream) {
+    return st_count_ids(ids, n, stride, is64, m, counts, 0, stream);
+}
+extern "C" int cg3d_count_sorted_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts,
+                                     cg3d_stream_t stream) {
+    return st_count_ids(ids, n, stride, is64, m, counts, 1, stream);
 }
 
 // ================================================================================================ dense head: proposals
@@ -919,21 +931,47 @@ __global__ void k_inst_init(uint32_t *__restrict__ ws, int64_t cells, int np) {
     const int f = (int)(i & 7);
     ws[i] = f < 3 ? 0xffffffffu : (f < 6 ? 0u : (f == 6 ? (uint32_t)np : 0u));       // min keys | max keys | first point | -
 }
-__global__ void k_inst_stats(const float *__restrict__ xyz, const int64_t *__restrict__ ins, int nb, int np, int ni,
-                             uint32_t *__restrict__ ws) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)nb * np) return;
-    const int64_t id = ins[i];
-    if (id < 0 || id >= ni) return;
-    const int b = (int)(i / np), pt = (int)(i - (int64_t)b * np);
-    uint32_t *w = ws + ((int64_t)b * ni + id) * 8;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint32_t key = st_fkey(xyz[i * 3 + k]);
-        atomicMin(&w[k], key);
-        atomicMax(&w[3 + k], key);
+// A workgroup takes IS_PTS points of ONE scene into a private LDS table (instance ids repeat all over a scene: 200 k points onto
+// ~80 cells x 7 words of global atomics serialised at the L2 for over a millisecond) and flushes the cells it touched.
+#define IS_PTS 8192
+#define IS_MAXI 512
+__global__ __launch_bounds__(256) void k_inst_stats(const float *__restrict__ xyz, const int64_t *__restrict__ ins, int nb, int np, int ni,
+                                                    uint32_t *__restrict__ ws) {
+    __shared__ uint32_t tab[IS_MAXI * 7];
+    const int chunks = (np + IS_PTS - 1) / IS_PTS;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const bool lds = ni <= IS_MAXI;
+    if (lds) {
+        for (int i = threadIdx.x; i < ni * 7; i += 256) {
+            const int f = i % 7;
+            tab[i] = f < 3 ? 0xffffffffu : (f < 6 ? 0u : (uint32_t)np);
+        }
+        __syncthreads();
     }
-    atomicMin(&w[6], (uint32_t)pt);
+    const int p1 = (ch + 1) * IS_PTS < np ? (ch + 1) * IS_PTS : np;
+    for (int pt = ch * IS_PTS + threadIdx.x; pt < p1; pt += 256) {
+        const int64_t i = (int64_t)b * np + pt;
+        const int64_t id = ins[i];
+        if (id < 0 || id >= ni) continue;
+        uint32_t *w = lds ? tab + id * 7 : ws + ((int64_t)b * ni + id) * 8;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t key = st_fkey(xyz[i * 3 + k]);
+            atomicMin(&w[k], key);
+            atomicMax(&w[3 + k], key);
+        }
+        atomicMin(&w[6], (uint32_t)pt);
+    }
+    if (!lds) return;
+    __syncthreads();
+    for (int c = threadIdx.x; c < ni; c += 256) {
+        const uint32_t *t = tab + c * 7;
+        if (t[6] >= (uint32_t)np) continue;                 // no point of this instance in the chunk
+        uint32_t *w = ws + ((int64_t)b * ni + c) * 8;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { atomicMin(&w[k], t[k]); atomicMax(&w[3 + k], t[3 + k]); }
+        atomicMin(&w[6], t[6]);
+    }
 }
 __global__ void k_inst_centers(const uint32_t *__restrict__ ws, const int64_t *__restrict__ sem, int nb, int np, int ni,
                                const float *__restrict__ gt_ctr, int gmax, const int32_t *__restrict__ n_gt, int n_classes,
@@ -973,8 +1011,8 @@ extern "C" int cg3d_instance_centers(const float *xyz, const int64_t *ins, const
     if (!xyz || !ins || !sem || !gt_ctr || !n_gt || !centers || !ws) return CG3D_ERR_ARG;
     const int64_t cells = (int64_t)nb * ni;
     hipLaunchKernelGGL(k_inst_init, dim3((unsigned)cg3d_divup(cells * 8, 256)), dim3(256), 0, cg3d_hs(stream), (uint32_t *)ws, cells, np);
-    hipLaunchKernelGGL(k_inst_stats, dim3((unsigned)cg3d_divup((int64_t)nb * np, 256)), dim3(256), 0, cg3d_hs(stream), xyz, ins, nb, np,
-                       ni, (uint32_t *)ws);
+    hipLaunchKernelGGL(k_inst_stats, dim3((unsigned)(nb * cg3d_divup(np, IS_PTS))), dim3(256), 0, cg3d_hs(stream), xyz, ins, nb, np, ni,
+                       (uint32_t *)ws);
     hipLaunchKernelGGL(k_inst_centers, dim3((unsigned)cg3d_divup(cells, 64)), dim3(64), 0, cg3d_hs(stream), (const uint32_t *)ws, sem, nb,
                        np, ni, gt_ctr, gmax, n_gt, n_classes, centers);
     CG3D_CHECK_LAUNCH();

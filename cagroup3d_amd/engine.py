@@ -144,6 +144,9 @@ class Builder:
         self.tape = []
         self.size = {R_ACT: 0, R_ZF: 0, R_ZB: 0, R_PG: 0}
         self.keep = []                  # tensors the rows point into (tables built at emission time)
+        # tables out of me.py's host caches: held for their lifetime only (the caches publish an entry after its upload has
+        # completed, and what frees one is this reference going away -- no stream hand-over needed: `keep` gets one)
+        self.keep_cached, self._held = [], set()
         self.params = []                # (parameter, offset in R_PG)
         self._pidx = {}
         self.late = []                  # (program, row, column, fn() -> tensor): operands that exist only at run time
@@ -212,20 +215,22 @@ class Builder:
     # limit (every new row count is a new key: a training run with varying batches gets there within tens of steps).  A
     # program holds raw addresses, so it must hold the tensors too -- a cleared cache once handed a compiled program's chunk
     # tables to the allocator while the program was still to run (a GPU memory fault three minutes into a training run).
+    def _hold(self, t):
+        """Keep a cached table (a tuple of tensors and ints) alive with the program -- once: the same table serves many rows."""
+        if id(t) not in self._held:
+            self._held.add(id(t))
+            self.keep_cached.append(t)
+        return t
+
     def _unit(self, c):
-        z, o = ME._unit_bn(c, self.dev)
-        self.keep.append((z, o))
+        z, o = self._hold(ME._unit_bn(c, self.dev))
         return z.data_ptr(), o.data_ptr()
 
     def _chunks(self, n, c):
-        t = ME._bn_chunks((0, n), self.dev, c)
-        self.keep.append(t)
-        return t
+        return self._hold(ME._bn_chunks((0, n), self.dev, c))
 
     def _ident(self, n, seglen):
-        t = ME._identity_pairs(n, seglen, self.dev)
-        self.keep.append(t)
-        return t
+        return self._hold(ME._identity_pairs(n, seglen, self.dev))
 
     def _add_rows(self, prog, a, b, y, n, c, act, y16):
         """y = act(a + b) (b may be 0): cg3d_bn_apply with the identity normalisation, as me.AddReluFunction does."""
@@ -695,6 +700,7 @@ class Compiled:
         self.fprof, self.bprof = b.f.prof, b.b.prof
         self.size = dict(b.size)
         self.keep, self.params, self.late, self.marks = b.keep, b.params, b.late, b.marks
+        self.keep_cached = b.keep_cached
         self.late_f = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.f]
         self.late_b = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.b]
         self.out = (out.p, out.n, out.c, out.p16)

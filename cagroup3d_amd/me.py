@@ -407,6 +407,12 @@ def _offsets(kernel_size, spacing, device):
     return _cached(_offset_cache, ck, lambda: _make_offsets(kernel_size, spacing, device))
 
 
+def _neg_offsets(kernel_size, spacing, device):
+    """The negated table (the other direction of a kernel map), cached like the table itself."""
+    ck = (int(kernel_size), int(spacing), str(device), "neg")
+    return _cached(_offset_cache, ck, lambda: (-_offsets(kernel_size, spacing, device)).contiguous())
+
+
 def _make_offsets(kernel_size, spacing, device):
     ks = int(kernel_size)
     rng = range(-(ks // 2), ks // 2 + 1) if ks % 2 == 1 else range(0, ks)
@@ -477,10 +483,10 @@ class CoordinateManager:
             src, dst = self._maps[in_key], self._maps[out_key]
             if not transpose:
                 offs = _offsets(kernel_size, src.tensor_stride * dilation, src.coords.device)
-                fwd_off, bwd_off = offs, (-offs).contiguous()      # o + off = i   /   i - off = o
+                fwd_off = offs                                     # o + off = i   (the other direction: i - off = o)
             else:
                 offs = _offsets(kernel_size, dst.tensor_stride * dilation, src.coords.device)
-                fwd_off, bwd_off = (-offs).contiguous(), offs      # o - off = i   /   i + off = o
+                fwd_off = _neg_offsets(kernel_size, dst.tensor_stride * dilation, src.coords.device)      # o - off = i
             nbr = self._lookup_map(dst.coords, src, fwd_off, in_key == out_key and int(kernel_size) % 2 == 1)
             # the lazy transposed map must not close over `self`: manager -> _kmaps -> KernelMap -> closure -> manager
             # is a reference cycle, and every step's coordinate structures (0.5 GB of device tensors at S50k x 4) then
@@ -797,6 +803,18 @@ def release_to_stream(mgr, extra, stream):
     _walk_tensors([mgr._maps, mgr._kmaps, extra], seen)
     for t in seen:
         t.record_stream(stream)
+
+
+def record_cached(tables, stream):
+    """Tables out of the host caches (built, possibly, on the prefetch stream) that a launch program will read on `stream`:
+    tell the allocator once per tensor -- they are long-lived and shared by many programs, so the mark rides on the tensor."""
+    seen = []
+    _walk_tensors(tables, seen)
+    sid = stream.cuda_stream
+    for t in seen:
+        if getattr(t, "_cg3d_rec", None) != sid:
+            t.record_stream(stream)
+            t._cg3d_rec = sid
 
 
 # bf16 row copies written by the BatchNorm apply kernels, keyed by the address of the fp32 tensor they mirror.  The entry
@@ -1509,14 +1527,31 @@ def linear_t(x, w, bias=None):
     return torch.nn.functional.linear(x, w, bias)
 
 
+def _sorted_counts(b, n_batch):
+    """Host list [violations, count_0 .. count_{n_batch-1}] of an int32 / int64 id vector (or strided id column) in ONE launch
+    and one host read (cg3d_count_sorted_ids), or None when the column is not of that kind / not on the bound library."""
+    lib = _lib.get()
+    if b.dim() != 1 or b.dtype not in (torch.int32, torch.int64) or b.is_cuda != lib.is_device or n_batch > 8192 or n_batch < 1:
+        return None
+    counts = torch.empty(n_batch + 1, dtype=torch.int64, device=b.device)
+    lib.call("cg3d_count_sorted_ids", ptr(b), c_int64(b.shape[0]), c_int32(b.stride(0)), c_int32(1 if b.dtype == torch.int64 else 0),
+             c_int32(n_batch), ptr(counts), lib.stream())
+    h = counts.tolist()
+    return [h[-1]] + h[:-1]
+
+
 def sorted_batch_counts(b, n_batch):
     """Rows per batch index (host list of n_batch ints) when the batch-index column `b` is non-decreasing with values in
     [0, n_batch), else None; one host read."""
-    b = b.reshape(-1)
+    b = b.reshape(-1) if b.dim() != 1 else b
     if b.numel() == 0:
         return [0] * n_batch
-    bad = ((b[1:] < b[:-1]).sum() + (b[-1] >= n_batch) + (b[0] < 0)).view(1).long()
-    host = torch.cat([bad, count_ids(b.long(), n_batch)]).tolist()
+    if b.dtype.is_floating_point:
+        b = b.long()
+    host = _sorted_counts(b, n_batch)
+    if host is None:
+        bad = ((b[1:] < b[:-1]).sum() + (b[-1] >= n_batch) + (b[0] < 0)).view(1).long()
+        host = torch.cat([bad, count_ids(b.long(), n_batch)]).tolist()
     return host[1:] if host[0] == 0 else None
 
 
@@ -1526,12 +1561,24 @@ def rows_by_batch(b, n_batch=None, info=None):
     of their parents), so the sort is normally the identity: the number of descents rides along with the counts and the
     ~10 merge-sort launches are only paid when it is not zero.  info (a dict): info["sorted"] = the column was batch-major,
     i.e. the lists are consecutive row ranges."""
-    b = b.reshape(-1).long()
+    b = b.reshape(-1) if b.dim() != 1 else b
     if b.numel() == 0:
         return []
     if not b.is_cuda:
+        b = b.long()
         order = torch.sort(b, stable=True)[1]
         return list(torch.split(order, torch.bincount(b, minlength=n_batch or 0).tolist()))
+    # (batch size not given: 1 024 bins, the trailing empty ones dropped; a larger index shows up as a violation)
+    host = _sorted_counts(b if b.dtype in (torch.int32, torch.int64) else b.long(), n_batch if n_batch is not None else 1024)
+    if host is not None and host[0] == 0:
+        counts = host[1:]
+        if n_batch is None:
+            while len(counts) > 1 and counts[-1] == 0:
+                counts.pop()
+        if info is not None:
+            info["sorted"] = True
+        return list(torch.split(torch.arange(b.numel(), device=b.device), counts))
+    b = b.long()
     # descents, plus (known batch size) ids outside [0, n_batch): `count_ids` would drop those silently and torch.split
     # would then fail with an opaque size error -- they take the sort + bincount path below, which extends the list
     desc = (b[1:] < b[:-1]).sum().view(1)

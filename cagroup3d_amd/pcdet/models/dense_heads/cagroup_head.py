@@ -941,18 +941,20 @@ def split_gt_boxes(gt_boxes, label_dtype=torch.long):
     boxes, labels = GtList(), []
     valid = ~(gt_boxes == 0.).all(dim=-1)
     v = valid.cpu().numpy()                        # ONE host read (a boolean-mask selection per scene is a sync per scene)
-    prefix = True
+    counts = v.sum(1)
+    prefix = all(int(n) == 0 or bool(v[b, :int(n)].all()) for b, n in enumerate(counts))
+    if prefix:
+        # the padding rows come last (collate_batch): every scene is a prefix slice of ONE contiguous copy / ONE cast
+        b7, l7 = gt_boxes[..., :7].contiguous(), gt_boxes[..., 7].to(label_dtype)
+        for b, n in enumerate(counts):
+            boxes.append(b7[b, :int(n)])
+            labels.append(l7[b, :int(n)])
+        boxes.prefix_counts = [int(x) for x in counts]
+        return boxes, labels
     for b in range(gt_boxes.shape[0]):
-        idx = np.nonzero(v[b])[0]
-        if len(idx) == 0 or idx[-1] == len(idx) - 1:           # the padding rows come last (collate_batch): a prefix slice
-            g = gt_boxes[b, :len(idx)]
-        else:
-            g = gt_boxes[b][ME.h2d(idx, torch.long, gt_boxes.device)]
-            prefix = False
+        g = gt_boxes[b][ME.h2d(np.nonzero(v[b])[0], torch.long, gt_boxes.device)]
         boxes.append(g[:, :7].contiguous())
         labels.append(g[:, 7].to(label_dtype))
-    if prefix:
-        boxes.prefix_counts = [int(x) for x in v.sum(1)]
     return boxes, labels
 
 

@@ -107,6 +107,8 @@ class CAGroup3D(Detector3DTemplate):
             assert n_in == points.shape[0], "prefetched coordinates belong to another batch"
             torch.cuda.current_stream().wait_event(event)
             ME.release_to_stream(mgr, [keep, targets], torch.cuda.current_stream())
+            if len(prepared) > 7 and prepared[7] is not None:
+                ME.record_cached(prepared[7].keep_cached, torch.cuda.current_stream())
             if targets is not None and self.training:
                 object.__setattr__(self.dense_head, "_data_targets", targets.get("loss"))
                 object.__setattr__(self.dense_head, "_forced_pre", targets.get("forced"))

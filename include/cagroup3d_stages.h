@@ -115,6 +115,10 @@ int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, fl
 /* counts[v] = number of i with ids[i * stride] == v, 0 <= v < m (values outside are ignored); ids int32 (is64 == 0) or int64;
  * counts int64 [m], zero-filled by the call.  (torch.bincount on an id column without its min / max scans.) */
 int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream);
+/* The same histogram plus, in counts[m] (counts int64 [m + 1]), the number of violations of "ids is non-decreasing with values in
+ * [0, m)": descents ids[i-1] > ids[i] and values outside the range.  Zero there means the rows of id v are the consecutive range
+ * [sum(counts[:v]), sum(counts[:v+1])) -- what the per-scene row lists of a batch-major map are read from in ONE launch. */
+int cg3d_count_sorted_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Dense head: proposals (CAGroup3DHead._get_bboxes_single / _nms, cagroup_head.py:579-624,747-797), all scenes and class

@@ -341,17 +341,28 @@ int cg3d_scatter_add_rows2(const float *dout, const int32_t *idx, float *dFa, fl
     return CG3D_OK;
 }
 
-int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream) {
-    (void)stream;
+static int os_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, int check) {
     if (n < 0 || m <= 0 || m > 8192 || stride < 1 || !counts) return CG3D_ERR_ARG;
-    memset(counts, 0, (size_t)m * 8);
+    memset(counts, 0, (size_t)(m + check) * 8);
     if (n == 0) return CG3D_OK;
     if (!ids) return CG3D_ERR_ARG;
+    int64_t prev = 0;
     for (int64_t i = 0; i < n; i++) {
         const int64_t v = is64 ? ((const int64_t *)ids)[i * stride] : (int64_t)((const int32_t *)ids)[i * stride];
         if (v >= 0 && v < m) counts[v]++;
+        else if (check) counts[m]++;
+        if (check && i > 0 && prev > v) counts[m]++;
+        prev = v;
     }
     return CG3D_OK;
+}
+int cg3d_count_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream) {
+    (void)stream;
+    return os_count_ids(ids, n, stride, is64, m, counts, 0);
+}
+int cg3d_count_sorted_ids(const void *ids, int64_t n, int32_t stride, int32_t is64, int32_t m, int64_t *counts, cg3d_stream_t stream) {
+    (void)stream;
+    return os_count_ids(ids, n, stride, is64, m, counts, 1);
 }
 
 /* ================================================================================================ dense head: proposals

