@@ -21,7 +21,7 @@ out = ["# profiles/ — round %s (MI355X, 1 GPU, ROCm 7.2)\n\n" % RN[1:].lstrip(
        "bash tools/pmc_sq.sh k_spconv_tile tools/mb_tile_one.py 4 128 128     # SQ counters, 128->128 layer (82 107 rows)\n"
        "bash tools/pmc_sq.sh wgrad_rows16 tools/mb_wgrad_one.py 4 128 128; bash tools/pmc_wgrad.sh 4 128 128   # weight gradient: SQ and L2 / memory-side counters\n"
        "python tools/mb_tile.py; python tools/mb_bn.py; python tools/host_profile.py; python tools/stream_bw.py\n```\n\n" % (RN, RN),
-       "Earlier rounds' files (`r01_*`, `r02_*`) are kept for comparison; `r02_synthetic_convergence*.json`: `tools/synthetic_convergence.py` (fp32 / bf16 / fp32 repeat from one seed; indoor_eval mAP / recall and the loss curves).\n\n",
+       "Earlier rounds' files (`r01_*` ... `r03_*`) are kept for comparison; `%s_synthetic_convergence.json` (and `r02_*`): `tools/synthetic_convergence.py` (fp32 / bf16 in every convolution / bf16 in the backbone only / fp32 again from one seed, 1 008 iterations; indoor_eval mAP / recall and the loss curves).\n\n" % RN,
        "Device copy rate on the box: " + rd("%s_stream_bw.txt" % RN).strip().splitlines()[-1] + ".\n\n"]
 import bench as _b
 for tag in ("bf16", "fp32"):
