@@ -416,17 +416,26 @@ extern "C" int cg3d_pool_map(const int32_t *in, int64_t n_in, int32_t out_stride
 // ------------------------------------------------------------------ pair-compacted kernel maps
 extern "C" int64_t cg3d_pairs_ws_bytes(int64_t total) { return (total + total / 1024 + 64) * (int64_t)sizeof(int32_t); }
 
-__global__ void k_pair_offsets(const int32_t *__restrict__ pos, int32_t K, int64_t n_out,
-                               const int32_t *__restrict__ row_bounds, int32_t G, const int32_t *total,
-                               int32_t *__restrict__ pair_off) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Round 4: the scanned positions are no longer stored (a 4-byte store and re-load per table entry, and a launch): the counting
+// pass leaves only the per-block sums in `ws`; the offsets of the (offset, group) lists are summed from them by one wave per
+// entry, and the fill pass redoes the in-block scan of its 2 048 entries while it writes the pairs.
+__global__ __launch_bounds__(64) void k_pair_offsets(const int32_t *__restrict__ nbr, const int32_t *__restrict__ bsum, int32_t K,
+                                                     int64_t n_out, const int32_t *__restrict__ row_bounds, int32_t G,
+                                                     int32_t *__restrict__ pair_off) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int64_t total = (int64_t)K * n_out;
+    int64_t at = total;
     if (t < K * G) {
         const int k = t / G, g = t % G;
-        const int64_t r = row_bounds ? row_bounds[g] : 0;
-        const int64_t at = (int64_t)k * n_out + r;
-        pair_off[t] = (at < (int64_t)K * n_out) ? pos[at] : *total;
+        at = (int64_t)k * n_out + (row_bounds ? row_bounds[g] : 0);
+        if (at > total) at = total;
     }
-    if (t == K * G) pair_off[t] = *total;
+    const int64_t blk = at / SCAN_ELEMS;
+    int32_t s = 0;
+    for (int64_t i = lane; i < blk; i += 64) s += bsum[i];
+    for (int64_t j = blk * SCAN_ELEMS + lane; j < at; j += 64) s += nbr[j] >= 0 ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) pair_off[t] = s;
 }
 extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, const int32_t *row_bounds, int32_t G,
                                 void *ws, int32_t *pair_off, cg3d_stream_t stream) {
@@ -438,35 +447,54 @@ extern "C" int cg3d_pairs_count(const int32_t *nbr, int32_t K, int64_t n_out, co
         if (hipMemsetAsync(pair_off, 0, ((int64_t)K * G + 1) * sizeof(int32_t), s) != hipSuccess) return CG3D_ERR_LAUNCH;
         return CG3D_OK;
     }
-    int32_t *pos = (int32_t *)ws;
+    int32_t *bsum = (int32_t *)ws;
     const int64_t nb = cg3d_divup(total, SCAN_ELEMS);
-    int32_t *bsum = pos + total;
-    int32_t *tot = bsum + nb + 1;
     const ScanSrc src = {nbr, nullptr};
     hipLaunchKernelGGL(k_scan_count<1>, dim3((unsigned)nb), dim3(256), 0, s, src, total, bsum);
-    hipLaunchKernelGGL(k_scan_write<1>, dim3((unsigned)nb), dim3(256), 0, s, src, total, bsum, pos, tot);
-    hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)cg3d_divup((int64_t)K * G + 1, 256)), dim3(256), 0, s, pos, K, n_out,
-                       row_bounds, G, tot, pair_off);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((unsigned)((int64_t)K * G + 1)), dim3(64), 0, s, nbr, bsum, K, n_out, row_bounds, G, pair_off);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
-__global__ void k_pair_fill(const int32_t *__restrict__ nbr, int64_t total, int64_t n_out,
-                            const int32_t *__restrict__ pos, int32_t *__restrict__ pin, int32_t *__restrict__ pout) {
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    int32_t i = nbr[t];
-    if (i < 0) return;
-    int32_t p = pos[t];
-    pin[p] = i;
-    pout[p] = (int32_t)(t % n_out);
+__global__ __launch_bounds__(256) void k_pair_fill(const int32_t *__restrict__ nbr, int64_t total, int64_t n_out,
+                                                   const int32_t *__restrict__ bsum, int32_t *__restrict__ pin,
+                                                   int32_t *__restrict__ pout) {
+    __shared__ int32_t red[4];
+    __shared__ int32_t wsum[4];
+    int32_t pre = 0;
+    for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += 256) pre += bsum[i];
+    const int32_t blk_base = block_sum_256(pre, red);
+    const int64_t base = blockIdx.x * (int64_t)SCAN_ELEMS + threadIdx.x * 8;
+    int32_t v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v[j] = (base + j < total) ? nbr[base + j] : -1;
+        s += v[j] >= 0 ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int32_t run = blk_base + inc - s;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (v[j] >= 0) {
+            pin[run] = v[j];
+            pout[run] = (int32_t)((base + j) % n_out);
+            run++;
+        }
 }
 extern "C" int cg3d_pairs_fill(const int32_t *nbr, int32_t K, int64_t n_out, const void *ws, int32_t *pair_in,
                                int32_t *pair_out, cg3d_stream_t stream) {
     if (K < 1 || n_out < 0) return CG3D_ERR_ARG;
     const int64_t total = (int64_t)K * n_out;
     if (total == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_pair_fill, dim3((unsigned)cg3d_divup(total, 256)), dim3(256), 0, cg3d_hs(stream), nbr, total,
-                       n_out, (const int32_t *)ws, pair_in, pair_out);
+    hipLaunchKernelGGL(k_pair_fill, dim3((unsigned)cg3d_divup(total, SCAN_ELEMS)), dim3(256), 0, cg3d_hs(stream), nbr, total, n_out,
+                       (const int32_t *)ws, pair_in, pair_out);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

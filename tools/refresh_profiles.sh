@@ -38,5 +38,5 @@ for a in "--dataset sunrgbd --config S100k-yaw --batch 8" "--config S200k" "--na
   echo "bench.py $a"
   python $R/bench.py $a --no-cpu-baseline --no-fp32 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   %.1f scenes/s  %.1f ms/step  roofline.frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac']))"
 done
-echo "tools/eval_bench.py"; python $R/tools/eval_bench.py 2>/dev/null | tail -1 ) > $O/${RN}_other_configs.txt 2>&1
+echo "tools/eval_bench.py"; python $R/tools/eval_bench.py 2>/dev/null | tail -1 ) 2>/dev/null > $O/${RN}_other_configs.txt
 cat $O/${RN}_other_configs.txt
