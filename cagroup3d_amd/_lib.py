@@ -114,6 +114,9 @@ _SIGNATURES = {
     "cg3d_rotated_iou3d_bwd": (c_int32, [P, P, c_int64, P, P, P]),
     "cg3d_instance_centers": (c_int32, [P, P, P, c_int32, c_int32, c_int32, P, c_int32, P, c_int32, P, P, P]),
     "cg3d_vote_targets": (c_int32, [P, P, P, c_int64, P, c_int32, P, c_int32, P, P, P]),
+    "cg3d_pos_loss_yaw_nblocks": (c_int32, [c_int64]),
+    "cg3d_pos_loss_yaw_fwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P]),
+    "cg3d_pos_loss_yaw_bwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
     "cg3d_event_create": (c_int32, [P]),

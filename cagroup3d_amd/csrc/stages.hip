@@ -831,22 +831,17 @@ __global__ __launch_bounds__(64) void k_rotated_iou3d_fwd(const float *__restric
     Ri3d R;
     iou[i] = ri_iou3d(p, q, P, R);
 }
-__global__ __launch_bounds__(64) void k_rotated_iou3d_bwd(const float *__restrict__ pred, const float *__restrict__ target, int64_t n,
-                                                          const float *__restrict__ g, float *__restrict__ dpred) {
-    const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
-    if (i >= n) return;
-    float p[7], q[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) { p[k] = pred[i * 7 + k]; q[k] = target[i * 7 + k]; }
+// d[7] = go * d iou3d(p, q) / d p  (the gradient along the reference's autograd graph; see cg3d_rotated_iou3d_bwd).  Returns iou.
+__device__ static float ri_backward(const float *p, const float *q, float go, float *d) {
     RiPair P;
     Ri3d R;
-    ri_iou3d(p, q, P, R);
-    const float go = g[i];
+    const float iou_ = ri_iou3d(p, q, P, R);
     // iou = I / U, U = v1 + v2 - I, I = area * zo (the reference forms it as (area / u) * u * zo: the u's cancel in the gradient)
     const float I = R.inter3d, U = R.u3d;
     const float gI = go * (U + I) / (U * U), gv1 = -go * I / (U * U);
     const float gA = gI * R.zo, gzo = R.zo > 0.f ? gI * R.area : 0.f;
-    float d[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 7; k++) d[k] = 0.f;
     // height overlap: min(zmax1, zmax2) - max(zmin1, zmin2), z +- l / 2
     d[2] += gzo * ((R.zmax1_lt ? 1.f : 0.f) - (R.zmin1_gt ? 1.f : 0.f));
     d[5] += gzo * 0.5f * ((R.zmax1_lt ? 1.f : 0.f) + (R.zmin1_gt ? 1.f : 0.f));
@@ -898,6 +893,16 @@ __global__ __launch_bounds__(64) void k_rotated_iou3d_bwd(const float *__restric
             d[6] += gcx[c] * (-x4 * sn - y4 * cs) + gcy[c] * (x4 * cs - y4 * sn);
         }
     }
+    return iou_;
+}
+__global__ __launch_bounds__(64) void k_rotated_iou3d_bwd(const float *__restrict__ pred, const float *__restrict__ target, int64_t n,
+                                                          const float *__restrict__ g, float *__restrict__ dpred) {
+    const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+    if (i >= n) return;
+    float p[7], q[7], d[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { p[k] = pred[i * 7 + k]; q[k] = target[i * 7 + k]; }
+    ri_backward(p, q, g[i], d);
 #pragma unroll
     for (int k = 0; k < 7; k++) dpred[i * 7 + k] = d[k];
 }
@@ -1044,6 +1049,107 @@ extern "C" int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene,
     if (!vox_xyz || !vox_scene || !nearest || !ins || !centers || !off_t || !off_m) return CG3D_ERR_ARG;
     hipLaunchKernelGGL(k_vote_targets, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, cg3d_hs(stream), vox_xyz, vox_scene, nearest, n,
                        ins, np, centers, ni, off_t, off_m);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
+
+// ================================================================================================ positives loss, yaw form
+// Centerness BCE + rotated IoU loss over the positive points of the class maps (SUN RGB-D: cagroup_head.py:532-546 with the
+// 'fcaf3d' box decode :689-703 and IoU3DLoss / cal_iou_3d): the yaw counterpart of cg3d_pos_loss (loss.hip).
+__device__ static inline void st_decode8(const float *p, const float *b, float *o) {
+    o[0] = p[0] + (b[1] - b[0]) / 2; o[1] = p[1] + (b[3] - b[2]) / 2; o[2] = p[2] + (b[5] - b[4]) / 2;
+    const float scale = b[0] + b[1] + b[2] + b[3];
+    const float q = expf(sqrtf(b[6] * b[6] + b[7] * b[7]));
+    o[3] = scale / (1 + q); o[4] = scale / (1 + q) * q; o[5] = b[5] + b[4];
+    o[6] = 0.5f * atan2f(b[6], b[7]);
+}
+__global__ __launch_bounds__(64) void k_pos_loss_yaw_fwd(const float *__restrict__ cent, const float *__restrict__ bbox,
+                                                         const float *__restrict__ points, const float *__restrict__ ctr_t,
+                                                         const float *__restrict__ bbox_t, int tstride,
+                                                         const int64_t *__restrict__ scene, const float *__restrict__ n_pos,
+                                                         const float *__restrict__ ctr_den, const int64_t *__restrict__ pos,
+                                                         int64_t npos, float wc, float wb, float eps, float *__restrict__ partial) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x; i < npos; i += (int64_t)gridDim.x * 64) {
+        const int64_t r = pos[i];
+        const float pc = cent[r], ct = ctr_t[r];
+        const float bce = fmaxf(pc, 0.f) - pc * ct + log1pf(expf(-fabsf(pc)));
+        float box[7], t[7];
+        st_decode8(points + r * 3, bbox + r * 8, box);
+#pragma unroll
+        for (int k = 0; k < 7; k++) t[k] = bbox_t[r * tstride + k];
+        RiPair P;
+        Ri3d R;
+        const float iou = ri_iou3d(box, t, P, R);
+        const int64_t sc = scene[r];
+        s0 += bce * (wc / (n_pos[sc] + eps));
+        s1 += (1.f - iou) * (wb * ct / ctr_den[sc]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = s0; partial[blockIdx.x * 2 + 1] = s1; }
+}
+__global__ __launch_bounds__(64) void k_pos_loss_yaw_bwd(const float *__restrict__ cent, const float *__restrict__ bbox,
+                                                         const float *__restrict__ points, const float *__restrict__ ctr_t,
+                                                         const float *__restrict__ bbox_t, int tstride,
+                                                         const int64_t *__restrict__ scene, const float *__restrict__ n_pos,
+                                                         const float *__restrict__ ctr_den, const int64_t *__restrict__ pos,
+                                                         int64_t npos, float wc, float wb, float eps,
+                                                         const float *__restrict__ gscale, float *__restrict__ dcent,
+                                                         float *__restrict__ dbbox) {
+    const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+    if (i >= npos) return;
+    const int64_t r = pos[i];
+    const float pc = cent[r], ct = ctr_t[r];
+    const int64_t sc = scene[r];
+    dcent[r] = gscale[0] * (1.f / (1.f + expf(-pc)) - ct) * (wc / (n_pos[sc] + eps));
+    const float *b = bbox + r * 8;
+    float box[7], t[7], g[7];
+    st_decode8(points + r * 3, b, box);
+#pragma unroll
+    for (int k = 0; k < 7; k++) t[k] = bbox_t[r * tstride + k];
+    // d (1 - iou): upstream -gscale[1] * weight on the IoU
+    ri_backward(box, t, -gscale[1] * (wb * ct / ctr_den[sc]), g);
+    // box -> the eight predictions ('fcaf3d' decode)
+    const float scale = b[0] + b[1] + b[2] + b[3];
+    const float r2 = b[6] * b[6] + b[7] * b[7], rr = sqrtf(r2), q = expf(rr), iq = 1.f / (1.f + q);
+    const float gs = g[3] * iq + g[4] * q * iq, gq = (g[4] - g[3]) * scale * iq * iq;
+    float d[8];
+    d[0] = -g[0] / 2 + gs; d[1] = g[0] / 2 + gs; d[2] = -g[1] / 2 + gs; d[3] = g[1] / 2 + gs;
+    d[4] = -g[2] / 2 + g[5]; d[5] = g[2] / 2 + g[5];
+    d[6] = 0.f; d[7] = 0.f;
+    if (rr > 0.f) {
+        d[6] = gq * q * b[6] / rr + g[6] * 0.5f * b[7] / r2;
+        d[7] = gq * q * b[7] / rr - g[6] * 0.5f * b[6] / r2;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) dbbox[r * 8 + k] = d[k];
+}
+extern "C" int cg3d_pos_loss_yaw_fwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                                     const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                                     const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                                     float *partial, cg3d_stream_t stream) {
+    if (npos < 0 || tstride < 7 || !partial) return CG3D_ERR_ARG;
+    const int64_t nb = cg3d_divup(npos, 64);
+    hipLaunchKernelGGL(k_pos_loss_yaw_fwd, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb))), dim3(64), 0, cg3d_hs(stream),
+                       centerness, bbox_pred, points, ctr_t, bbox_t, tstride, scene, n_pos, ctr_denorm, pos, npos, wc, wb, eps, partial);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int32_t cg3d_pos_loss_yaw_nblocks(int64_t npos) {
+    const int64_t nb = cg3d_divup(npos, 64);
+    return (int32_t)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+extern "C" int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                                     const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                                     const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                                     const float *gscale, float *dcenterness, float *dbbox_pred, cg3d_stream_t stream) {
+    if (npos < 0 || tstride < 7) return CG3D_ERR_ARG;
+    if (npos == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_pos_loss_yaw_bwd, dim3((unsigned)cg3d_divup(npos, 64)), dim3(64), 0, cg3d_hs(stream), centerness, bbox_pred,
+                       points, ctr_t, bbox_t, tstride, scene, n_pos, ctr_denorm, pos, npos, wc, wb, eps, gscale, dcenterness,
+                       dbbox_pred);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }

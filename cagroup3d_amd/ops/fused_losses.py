@@ -14,20 +14,24 @@ from .._lib import ptr
 
 
 class _PositivesLoss(torch.autograd.Function):
+    """bbox_pred [N,6]: the ScanNet form (axis-aligned IoU, cg3d_pos_loss); [N,8]: the yaw form ('fcaf3d' decode + rotated IoU,
+    cg3d_pos_loss_yaw of include/cagroup3d_stages.h)."""
+
     @staticmethod
     def forward(ctx, centerness, bbox_pred, points, ctr_t, bbox_t, scene, n_pos, ctr_denorm, pos, wc, wb, eps):
         lib = _lib.get()
         cent = centerness.contiguous().view(-1)
         bbox = bbox_pred.contiguous()
-        assert bbox.shape[1] == 6 and cent.shape[0] == bbox.shape[0]
+        assert bbox.shape[1] in (6, 8) and cent.shape[0] == bbox.shape[0]
+        ctx.sfx = sfx = "_yaw" if bbox.shape[1] == 8 else ""
         pts, ct, bt = points.contiguous(), ctr_t.to(torch.float32).contiguous(), bbox_t.to(torch.float32).contiguous()
         sc, ps = scene.to(torch.int64).contiguous(), pos.to(torch.int64).contiguous()
         npn, cdn = n_pos.to(torch.float32).contiguous(), ctr_denorm.to(torch.float32).contiguous()
         lib.check(cent, bbox, pts, ct, bt, sc, ps, npn, cdn)
         npos = int(ps.shape[0])
-        nb = int(lib.raw("cg3d_pos_loss_nblocks")(npos))
+        nb = int(lib.raw("cg3d_pos_loss%s_nblocks" % sfx)(npos))
         partial = torch.empty((nb, 2), dtype=torch.float32, device=cent.device)
-        lib.call("cg3d_pos_loss_fwd", ptr(cent), ptr(bbox), ptr(pts), ptr(ct), ptr(bt), c_int32(bt.shape[1]), ptr(sc), ptr(npn),
+        lib.call("cg3d_pos_loss%s_fwd" % sfx, ptr(cent), ptr(bbox), ptr(pts), ptr(ct), ptr(bt), c_int32(bt.shape[1]), ptr(sc), ptr(npn),
                  ptr(cdn), ptr(ps), c_int64(npos), c_float(wc), c_float(wb), c_float(eps), ptr(partial), lib.stream())
         ctx.save_for_backward(cent, bbox, pts, ct, bt, sc, npn, cdn, ps)
         ctx.meta = (float(wc), float(wb), float(eps), tuple(centerness.shape))
@@ -41,7 +45,7 @@ class _PositivesLoss(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         dcent = torch.zeros_like(cent)              # rows that are not positives get no gradient
         dbbox = torch.zeros_like(bbox)
-        lib.call("cg3d_pos_loss_bwd", ptr(cent), ptr(bbox), ptr(pts), ptr(ct), ptr(bt), c_int32(bt.shape[1]), ptr(sc), ptr(npn),
+        lib.call("cg3d_pos_loss%s_bwd" % ctx.sfx, ptr(cent), ptr(bbox), ptr(pts), ptr(ct), ptr(bt), c_int32(bt.shape[1]), ptr(sc), ptr(npn),
                  ptr(cdn), ptr(ps), c_int64(ps.shape[0]), c_float(wc), c_float(wb), c_float(eps), ptr(g), ptr(dcent), ptr(dbbox),
                  lib.stream())
         return (dcent.view(cshape), dbbox) + (None,) * 10

@@ -505,7 +505,9 @@ class CAGroup3DHead(nn.Module):
         beta = self.loss_offset.beta
         pos_inds = torch.nonzero(pos).squeeze(1)
         eps = torch.finfo(torch.float32).eps
-        if FUSED_LOSSES and not self.with_yaw and m["bbox_pred"].shape[1] == 6:
+        nd = m["bbox_pred"].shape[1]
+        if FUSED_LOSSES and ((not self.with_yaw and nd == 6) or (self.with_yaw and nd == 8 and self.yaw_parametrization == "fcaf3d"
+                                                                  and bbox_targets.shape[1] >= 7)):
             # vote loss, centerness loss and box loss as fused ops (one pass forward, one backward each: ops/fused_losses.py)
             from ....ops.fused_losses import positives_loss, smooth_l1_rows
             loss_vote = self.loss_offset.loss_weight * smooth_l1_rows(pred_v, tgt_v, w, beta) / B

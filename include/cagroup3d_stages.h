@@ -181,6 +181,21 @@ int cg3d_instance_centers(const float *xyz, const int64_t *ins, const int64_t *s
 int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene, const int64_t *nearest, int64_t n, const int64_t *ins,
                       int32_t np, const float *centers, int32_t ni, float *off_t, float *off_m, cg3d_stream_t stream);
 
+/* Positives loss of the class maps, yaw form (SUN RGB-D; the counterpart of cg3d_pos_loss in cagroup3d_hip.h): centerness BCE +
+ * rotated IoU loss over the positive points (cagroup_head.py:532-546) with the 'fcaf3d' box decode of the eight predictions
+ * (dx-, dx+, dy-, dy+, dz-, dz+, sin(2a) ln q, cos(2a) ln q) (:689-703) and cal_iou_3d.  Same arguments as cg3d_pos_loss_{fwd,bwd}
+ * with bbox_pred float32 [N,8] and bbox_t float32 [N,tstride >= 7] (x,y,z,dx,dy,dz,heading);
+ * partial float32 [cg3d_pos_loss_yaw_nblocks(npos)][2]; bwd writes dcenterness[r], dbbox_pred[r, 0:8] for r in pos. */
+int32_t cg3d_pos_loss_yaw_nblocks(int64_t npos);
+int cg3d_pos_loss_yaw_fwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                          const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                          const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                          float *partial, cg3d_stream_t stream);
+int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                          const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                          const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                          const float *gscale, float *dcenterness, float *dbbox_pred, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -547,3 +547,76 @@ int cg3d_vote_targets(const float *vox_xyz, const int64_t *vox_scene, const int6
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ positives loss, yaw form
+ * cagroup_head.py:532-546 with _bbox_pred_to_bbox 'fcaf3d' (:689-703): BCE in double like oracle_loss.c; the box term's
+ * gradient by central differences (double) of b -> 1 - iou3d(decode(p, b), t): independent of the product's analytic chain. */
+static void os_decode8_f(const float *p, const float *b, float *o) {
+    o[0] = p[0] + (b[1] - b[0]) / 2; o[1] = p[1] + (b[3] - b[2]) / 2; o[2] = p[2] + (b[5] - b[4]) / 2;
+    const float scale = b[0] + b[1] + b[2] + b[3];
+    const float q = expf(sqrtf(b[6] * b[6] + b[7] * b[7]));
+    o[3] = scale / (1 + q); o[4] = scale / (1 + q) * q; o[5] = b[5] + b[4];
+    o[6] = 0.5f * atan2f(b[6], b[7]);
+}
+static double os_box_term_d(const double *p, const double *b, const double *t) {
+    double o[7];
+    o[0] = p[0] + (b[1] - b[0]) / 2; o[1] = p[1] + (b[3] - b[2]) / 2; o[2] = p[2] + (b[5] - b[4]) / 2;
+    const double scale = b[0] + b[1] + b[2] + b[3], q = exp(sqrt(b[6] * b[6] + b[7] * b[7]));
+    o[3] = scale / (1 + q); o[4] = scale / (1 + q) * q; o[5] = b[5] + b[4];
+    o[6] = 0.5 * atan2(b[6], b[7]);
+    return 1.0 - ri_iou3d_d(o, t);
+}
+int32_t cg3d_pos_loss_yaw_nblocks(int64_t npos) {
+    const int64_t nb = (npos + 63) / 64;
+    return (int32_t)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+int cg3d_pos_loss_yaw_fwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                          const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                          const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                          float *partial, cg3d_stream_t stream) {
+    (void)stream;
+    if (npos < 0 || tstride < 7 || !partial) return CG3D_ERR_ARG;
+    const int nb = cg3d_pos_loss_yaw_nblocks(npos);
+    memset(partial, 0, (size_t)nb * 2 * sizeof(float));
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = 0; i < npos; i++) {
+        const int64_t r = pos[i], sc = scene[r];
+        const double x = centerness[r], ct = ctr_t[r];
+        const double bce = fmax(x, 0.0) - x * ct + log1p(exp(-fabs(x)));
+        float box[7];
+        os_decode8_f(points + r * 3, bbox_pred + r * 8, box);
+        const float iou = ri_iou3d_f(box, bbox_t + r * tstride);
+        s0 += bce * ((double)wc / ((double)n_pos[sc] + eps));
+        s1 += (1.0 - (double)iou) * ((double)wb * ct / (double)ctr_denorm[sc]);
+    }
+    partial[0] = (float)s0; partial[1] = (float)s1;
+    return CG3D_OK;
+}
+int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_pred, const float *points, const float *ctr_t,
+                          const float *bbox_t, int32_t tstride, const int64_t *scene, const float *n_pos,
+                          const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
+                          const float *gscale, float *dcenterness, float *dbbox_pred, cg3d_stream_t stream) {
+    (void)stream;
+    if (npos < 0 || tstride < 7) return CG3D_ERR_ARG;
+    if (npos == 0) return CG3D_OK;
+    for (int64_t i = 0; i < npos; i++) {
+        const int64_t r = pos[i], sc = scene[r];
+        const double x = centerness[r], ct = ctr_t[r];
+        dcenterness[r] = (float)((double)gscale[0] * (1.0 / (1.0 + exp(-x)) - ct) * ((double)wc / ((double)n_pos[sc] + eps)));
+        double p[3], b[8], t[7];
+        for (int k = 0; k < 3; k++) p[k] = points[r * 3 + k];
+        for (int k = 0; k < 8; k++) b[k] = bbox_pred[r * 8 + k];
+        for (int k = 0; k < 7; k++) t[k] = bbox_t[r * tstride + k];
+        const double g = (double)gscale[1] * ((double)wb * ct / (double)ctr_denorm[sc]);
+        for (int k = 0; k < 8; k++) {
+            const double h = 1e-6 * (fabs(b[k]) > 1.0 ? fabs(b[k]) : 1.0), keep = b[k];
+            b[k] = keep + h;
+            const double fp = os_box_term_d(p, b, t);
+            b[k] = keep - h;
+            const double fm = os_box_term_d(p, b, t);
+            b[k] = keep;
+            dbbox_pred[r * 8 + k] = (float)(g * (fp - fm) / (2.0 * h));
+        }
+    }
+    return CG3D_OK;
+}

@@ -585,3 +585,80 @@ def test_hip_vote_targets_match_oracle(hip, oracle, monkeypatch):
         t0, m0 = _run_vote(head, _vote_case("cpu"), True, monkeypatch)
     t1, m1 = _run_vote(head, _vote_case("cuda"), True, monkeypatch)
     assert torch.equal(m1.cpu(), m0) and torch.equal(t1.cpu(), t0)
+
+
+# ---------------------------------------------------------------------------------------------------------------- yaw positives loss
+def _yaw_pos_case(n=1500, B=3, seed=0, frac=0.4):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(n, 3, generator=g) - 0.5) * 6
+    bp = torch.rand(n, 8, generator=g) * 0.7 + 0.1
+    bp[:, 6:] = torch.randn(n, 2, generator=g) * 0.4
+    cent = torch.randn(n, 1, generator=g)
+    ctr_t = torch.rand(n, generator=g)
+    tgt = torch.cat([pts + (torch.rand(n, 3, generator=g) - 0.5) * 0.6, torch.rand(n, 3, generator=g) * 1.2 + 0.3,
+                     (torch.rand(n, 1, generator=g) - 0.5) * 3.0], 1)
+    scene = torch.randint(0, B, (n,), generator=g)
+    pos = torch.nonzero(torch.rand(n, generator=g) < frac).squeeze(1)
+    n_pos = torch.bincount(scene[pos], minlength=B).float().clamp(min=1.)
+    den = torch.zeros(B).index_add_(0, scene[pos], ctr_t[pos]).clamp(min=1e-6)
+    return pts, bp, cent, ctr_t, tgt, scene, pos, n_pos, den, B
+
+
+def _yaw_torch_chain(head, pts, bp, cent, ctr_t, tgt, scene, pos, n_pos, den, B, wc, wb, eps):
+    from cagroup3d_amd.ops import rotated_iou as RI
+    ps = scene[pos]
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(cent[pos], ctr_t[pos].unsqueeze(1), reduction="none")
+    lc = (bce.squeeze(1) * wc / (n_pos[ps] + eps)).sum()
+    boxes = head._bbox_pred_to_bbox(pts[pos], bp[pos])
+    iou = RI.cal_iou_3d(boxes[None], tgt[pos][None])[0]
+    lb = ((1 - iou) * ctr_t[pos] * wb / den[ps]).sum()
+    return lc, lb
+
+
+def _yaw_fused(dev, c, wc, wb, eps, gw):
+    from cagroup3d_amd.ops import fused_losses
+    pts, bp, cent, ctr_t, tgt, scene, pos, n_pos, den, B = [x.to(dev) if torch.is_tensor(x) else x for x in c]
+    b1, c1 = bp.clone().requires_grad_(True), cent.clone().requires_grad_(True)
+    out = fused_losses.positives_loss(c1, b1, pts, ctr_t, tgt, scene, n_pos, den, pos, wc, wb, eps)
+    (out[0] * gw[0] + out[1] * gw[1]).backward()
+    return out.detach().cpu(), c1.grad.cpu(), b1.grad.cpu()
+
+
+def test_oracle_yaw_positives_loss_equals_the_torch_chain(oracle):
+    head = _mini_head(10)
+    head.yaw_parametrization = "fcaf3d"
+    c = _yaw_pos_case()
+    wc, wb, eps, gw = 1.0 / 3, 1.0 / 3, float(torch.finfo(torch.float32).eps), (0.7, 1.3)
+    with _lib.use_library(oracle):
+        out, dce, dbp = _yaw_fused("cpu", c, wc, wb, eps, gw)
+        b0, c0 = c[1].clone().requires_grad_(True), c[2].clone().requires_grad_(True)
+        lc, lb = _yaw_torch_chain(head, c[0], b0, c0, *c[3:], wc, wb, eps)
+        (lc * gw[0] + lb * gw[1]).backward()
+    torch.testing.assert_close(out, torch.stack([lc, lb]).detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dce, c0.grad, rtol=1e-4, atol=1e-7)
+    pos = c[6]
+    d = (dbp[pos] - b0.grad[pos]).abs().max(1)[0]
+    ok = d <= 2e-3 * (1e-3 + b0.grad[pos].abs().max(1)[0])           # (central differences vs autograd; kinks of the polygon excluded by the quota)
+    assert float(ok.float().mean()) > 0.97, float(ok.float().mean())
+    other = torch.ones(dbp.shape[0], dtype=torch.bool); other[pos] = False
+    assert float(dbp[other].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_hip_yaw_positives_loss_matches_torch_autograd_on_the_device(hip):
+    head = _mini_head(10)
+    head.yaw_parametrization = "fcaf3d"
+    c = _yaw_pos_case(n=6000, seed=3)
+    wc, wb, eps, gw = 0.25, 0.25, float(torch.finfo(torch.float32).eps), (0.7, 1.3)
+    out, dce, dbp = _yaw_fused("cuda", c, wc, wb, eps, gw)
+    cd = [x.cuda() if torch.is_tensor(x) else x for x in c]
+    b0, c0 = cd[1].clone().requires_grad_(True), cd[2].clone().requires_grad_(True)
+    lc, lb = _yaw_torch_chain(head, cd[0], b0, c0, *cd[3:], wc, wb, eps)
+    (lc * gw[0] + lb * gw[1]).backward()
+    torch.testing.assert_close(out, torch.stack([lc, lb]).detach().cpu(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dce, c0.grad.cpu(), rtol=1e-4, atol=1e-7)
+    pos = c[6]
+    g0 = b0.grad.cpu()
+    d = (dbp[pos] - g0[pos]).abs().max(1)[0]
+    ok = d <= 1e-3 * (1e-3 + g0[pos].abs().max(1)[0])
+    assert float(ok.float().mean()) > 0.99, float(ok.float().mean())
