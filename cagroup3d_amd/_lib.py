@@ -117,6 +117,8 @@ _SIGNATURES = {
     "cg3d_pos_loss_yaw_nblocks": (c_int32, [c_int64]),
     "cg3d_pos_loss_yaw_fwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P]),
     "cg3d_pos_loss_yaw_bwd": (c_int32, [P, P, P, P, P, c_int32, P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, P]),
+    "cg3d_head_outputs_fwd": (c_int32, [P, c_int32, P, c_int64, c_int32, P, P, c_int32, c_float, P, P, P, P]),
+    "cg3d_head_outputs_bwd": (c_int32, [P, P, P, c_int32, P, c_int64, c_int32, P, c_int32, P, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
     "cg3d_event_create": (c_int32, [P]),

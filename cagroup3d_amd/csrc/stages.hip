@@ -1153,3 +1153,71 @@ extern "C" int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+
+// ================================================================================================ class-branch outputs
+__global__ __launch_bounds__(256) void k_head_outputs_fwd(const float *__restrict__ reg, int nd, const int32_t *__restrict__ coords,
+                                                          int64_t n, int nbatch, const float *__restrict__ scale,
+                                                          const float *__restrict__ vs_tab, int nc, float boost,
+                                                          float *__restrict__ cls, float *__restrict__ bbox_pred,
+                                                          float *__restrict__ points) {
+    const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 q = reinterpret_cast<const int4 *>(coords)[i];
+    const int c = q.x / nbatch;
+    const float sc = scale[c];
+    for (int k = 0; k < nd; k++) bbox_pred[i * nd + k] = k < 6 ? expf(reg[i * nd + k] * sc) : reg[i * nd + k];
+    points[i * 3] = (float)q.y * vs_tab[c * 3]; points[i * 3 + 1] = (float)q.z * vs_tab[c * 3 + 1];
+    points[i * 3 + 2] = (float)q.w * vs_tab[c * 3 + 2];
+    if (boost != 0.f && cls) cls[i * nc + c] = cls[i * nc + c] + boost;
+}
+__global__ __launch_bounds__(256) void k_head_outputs_bwd(const float *__restrict__ dbbox, const float *__restrict__ bbox_pred,
+                                                          const float *__restrict__ reg, int nd, const int32_t *__restrict__ coords,
+                                                          int64_t n, int nbatch, const float *__restrict__ scale, int nc,
+                                                          float *__restrict__ dreg, float *__restrict__ dscale) {
+    extern __shared__ float s_ds[];
+    for (int k = threadIdx.x; k < nc; k += 256) s_ds[k] = 0.f;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = coords[i * 4] / nbatch;
+        const float sc = scale[c];
+        float acc = 0.f;
+        for (int k = 0; k < nd; k++) {
+            const float g = dbbox[i * nd + k];
+            if (k < 6) {
+                const float gb = g * bbox_pred[i * nd + k];
+                dreg[i * nd + k] = gb * sc;
+                acc += gb * reg[i * nd + k];
+            } else {
+                dreg[i * nd + k] = g;
+            }
+        }
+        unsafeAtomicAdd(&s_ds[c], acc);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nc; k += 256)
+        if (s_ds[k] != 0.f) unsafeAtomicAdd(&dscale[k], s_ds[k]);
+}
+extern "C" int cg3d_head_outputs_fwd(const float *reg, int32_t nd, const int32_t *coords, int64_t n, int32_t nbatch,
+                                     const float *scale, const float *vs_tab, int32_t nc, float boost, float *cls, float *bbox_pred,
+                                     float *points, cg3d_stream_t stream) {
+    if (n < 0 || nd < 6 || nbatch <= 0 || nc <= 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!reg || !coords || !scale || !vs_tab || !bbox_pred || !points || ((uintptr_t)coords & 15)) return CG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_head_outputs_fwd, dim3((unsigned)cg3d_divup(n, 256)), dim3(256), 0, cg3d_hs(stream), reg, nd, coords, n, nbatch,
+                       scale, vs_tab, nc, boost, cls, bbox_pred, points);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+extern "C" int cg3d_head_outputs_bwd(const float *dbbox, const float *bbox_pred, const float *reg, int32_t nd, const int32_t *coords,
+                                     int64_t n, int32_t nbatch, const float *scale, int32_t nc, float *dreg, float *dscale,
+                                     cg3d_stream_t stream) {
+    if (n < 0 || nd < 6 || nbatch <= 0 || nc <= 0 || nc > 4096 || !dscale) return CG3D_ERR_ARG;
+    if (hipMemsetAsync(dscale, 0, (size_t)nc * 4, cg3d_hs(stream)) != hipSuccess) return CG3D_ERR_LAUNCH;
+    if (n == 0) return CG3D_OK;
+    if (!dbbox || !bbox_pred || !reg || !coords || !scale || !dreg) return CG3D_ERR_ARG;
+    const unsigned g = (unsigned)(cg3d_divup(n, 256) < 256 ? cg3d_divup(n, 256) : 256);
+    hipLaunchKernelGGL(k_head_outputs_bwd, dim3(g), dim3(256), (size_t)nc * 4, cg3d_hs(stream), dbbox, bbox_pred, reg, nd, coords, n,
+                       nbatch, scale, nc, dreg, dscale);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}

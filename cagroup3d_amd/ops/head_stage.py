@@ -92,3 +92,44 @@ def vote_targets(xyz, ins, sem, gt_ctr, n_gt, n_classes, n_ins, vox_xyz, vox_sce
     lib.call("cg3d_vote_targets", ptr(vox_xyz), ptr(vox_scene), ptr(nearest), c_int64(N), ptr(ins), c_int32(P), ptr(centers),
              c_int32(n_ins), ptr(off_t), ptr(off_m), lib.stream())
     return off_t, off_m
+
+
+class _HeadOutputs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reg, scale, coords, vs_tab, n_batch, cls, boost):
+        lib = _lib.get()
+        reg, scale = reg.contiguous(), scale.contiguous()
+        lib.check(reg, scale, coords, vs_tab, cls)
+        n, nd = reg.shape
+        assert coords.dtype == torch.int32 and coords.shape == (n, 4) and (cls is None or cls.is_contiguous())
+        bbox = torch.empty_like(reg)
+        points = torch.empty((n, 3), dtype=torch.float32, device=reg.device)
+        lib.call("cg3d_head_outputs_fwd", ptr(reg), c_int32(nd), ptr(coords), c_int64(n), c_int32(n_batch), ptr(scale), ptr(vs_tab),
+                 c_int32(scale.shape[0]), c_float(boost), ptr(cls), ptr(bbox), ptr(points), lib.stream())
+        ctx.save_for_backward(reg, scale, coords, bbox)
+        ctx.n_batch = n_batch
+        ctx.mark_non_differentiable(points)
+        ctx.set_materialize_grads(False)
+        return bbox, points
+
+    @staticmethod
+    def backward(ctx, dbbox, _dpoints):
+        if dbbox is None:
+            return (None,) * 7
+        reg, scale, coords, bbox = ctx.saved_tensors
+        lib = _lib.get()
+        dbbox = dbbox.contiguous()
+        dreg = torch.empty_like(reg)
+        dscale = torch.empty_like(scale)
+        lib.call("cg3d_head_outputs_bwd", ptr(dbbox), ptr(bbox), ptr(reg), c_int32(reg.shape[1]), ptr(coords), c_int64(reg.shape[0]),
+                 c_int32(ctx.n_batch), ptr(scale), c_int32(scale.shape[0]), ptr(dreg), ptr(dscale), lib.stream())
+        return dreg, dscale, None, None, None, None, None
+
+
+def head_outputs(reg, scale, coords, vs_tab, n_batch, cls=None, boost=0.0):
+    """Class-branch prediction outputs of all class maps (reference cagroup_head.py:627-652): bbox_pred = (exp(reg[:, :6] *
+    scale[class]), reg[:, 6:]) with gradients to `reg` and `scale`, points = coords * class voxel size; `boost` is added IN
+    PLACE to every row's own-class logit of `cls` (a constant: the gradient of `cls` is unchanged)."""
+    with torch.no_grad():
+        cls_raw = cls.detach() if cls is not None and boost else None
+    return _HeadOutputs.apply(reg, scale, coords, vs_tab, n_batch, cls_raw, float(boost))

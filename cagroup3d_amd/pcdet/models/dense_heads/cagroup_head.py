@@ -327,12 +327,17 @@ class CAGroup3DHead(nn.Module):
             rc = fb // B                                                   # class of every fine row
         centerness = ME.linear(f, self.centerness_conv.kernel)
         cls_score = ME.linear(f, self.cls_conv.kernel, self.cls_conv.bias.view(-1))
-        if self.force_class_logit_boost:
-            cls_score = cls_score + torch.nn.functional.one_hot(rc, C).float() * self.force_class_logit_boost
         reg = ME.linear(f, self.reg_conv.kernel)
         scale_vec = torch.stack([sc.scale for sc in self.scales])
-        bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
-        points = fine_C[:, 1:].float() * vs_tab[rc]
+        if FUSED_HEAD and fine_C.dtype == torch.int32 and fine_C.is_contiguous() and cls_score.is_contiguous():
+            # Scale + exp, the points and the bench's logit boost in one launch (ops/head_stage.head_outputs)
+            from ....ops.head_stage import head_outputs
+            bbox_pred, points = head_outputs(reg, scale_vec, fine_C, vs_tab, B, cls_score, self.force_class_logit_boost)
+        else:
+            if self.force_class_logit_boost:
+                cls_score = cls_score + torch.nn.functional.one_hot(rc, C).float() * self.force_class_logit_boost
+            bbox_pred = torch.cat((torch.exp(reg[:, :6] * scale_vec[rc].unsqueeze(1)), reg[:, 6:]), dim=1)
+            points = fine_C[:, 1:].float() * vs_tab[rc]
         if ME.MORTON_ROWS and cls_map.rows_batch_major:
             # rows of the class map are already (class, scene)-major (SparseTensor inserts in (batch, Morton) order): no sort,
             # no four gathers -- and none of their sort-based index_put backward passes

@@ -196,6 +196,20 @@ int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_pred, const
                           const float *ctr_denorm, const int64_t *pos, int64_t npos, float wc, float wb, float eps,
                           const float *gscale, float *dcenterness, float *dbbox_pred, cg3d_stream_t stream);
 
+/* Outputs of the class branches' prediction layers (CAGroup3DHead.forward_single, cagroup_head.py:627-652, for all class maps at
+ * once): row i belongs to class map c_i = coords[i,0] / nbatch (coords int32 [n,4] of the merged class map).
+ *   bbox_pred[i, 0:6] = exp(reg[i, 0:6] * scale[c_i]), bbox_pred[i, 6:] = reg[i, 6:]          (Scale + exp, :640-645)
+ *   points[i, :]      = coords[i, 1:4] * vs_tab[c_i, :]                                        (:647-650)
+ *   cls[i, c_i]      += boost (in place; the bench's forced-selection aid, 0 = off)
+ * reg float32 [n, nd] (nd = 6 or 8), scale float32 [nc], vs_tab float32 [nc,3].
+ * bwd: dreg[i, 0:6] = dbbox[i, 0:6] * bbox_pred[i, 0:6] * scale[c_i], dreg[i, 6:] = dbbox[i, 6:];
+ *      dscale float32 [nc] (zero-filled by the call) += sum_i sum_k dbbox[i,k] * bbox_pred[i,k] * reg[i,k], k < 6. */
+int cg3d_head_outputs_fwd(const float *reg, int32_t nd, const int32_t *coords, int64_t n, int32_t nbatch, const float *scale,
+                          const float *vs_tab, int32_t nc, float boost, float *cls, float *bbox_pred, float *points,
+                          cg3d_stream_t stream);
+int cg3d_head_outputs_bwd(const float *dbbox, const float *bbox_pred, const float *reg, int32_t nd, const int32_t *coords, int64_t n,
+                          int32_t nbatch, const float *scale, int32_t nc, float *dreg, float *dscale, cg3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -620,3 +620,44 @@ int cg3d_pos_loss_yaw_bwd(const float *centerness, const float *bbox_pred, const
     }
     return CG3D_OK;
 }
+
+/* ================================================================================================ class-branch outputs
+ * forward_single, cagroup_head.py:627-652 (Scale + exp :640-645, points :647-650) for all class maps at once */
+int cg3d_head_outputs_fwd(const float *reg, int32_t nd, const int32_t *coords, int64_t n, int32_t nbatch, const float *scale,
+                          const float *vs_tab, int32_t nc, float boost, float *cls, float *bbox_pred, float *points,
+                          cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || nd < 6 || nbatch <= 0 || nc <= 0) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    if (!reg || !coords || !scale || !vs_tab || !bbox_pred || !points) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int c = coords[i * 4] / nbatch;
+        for (int k = 0; k < nd; k++) bbox_pred[i * nd + k] = k < 6 ? expf(reg[i * nd + k] * scale[c]) : reg[i * nd + k];
+        for (int k = 0; k < 3; k++) points[i * 3 + k] = (float)coords[i * 4 + 1 + k] * vs_tab[c * 3 + k];
+        if (boost != 0.f && cls) cls[i * nc + c] = cls[i * nc + c] + boost;
+    }
+    return CG3D_OK;
+}
+int cg3d_head_outputs_bwd(const float *dbbox, const float *bbox_pred, const float *reg, int32_t nd, const int32_t *coords, int64_t n,
+                          int32_t nbatch, const float *scale, int32_t nc, float *dreg, float *dscale, cg3d_stream_t stream) {
+    (void)stream;
+    if (n < 0 || nd < 6 || nbatch <= 0 || nc <= 0 || nc > 4096 || !dscale) return CG3D_ERR_ARG;
+    double acc[4096];
+    for (int k = 0; k < nc; k++) acc[k] = 0.0;
+    if (n > 0 && (!dbbox || !bbox_pred || !reg || !coords || !scale || !dreg)) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        const int c = coords[i * 4] / nbatch;
+        for (int k = 0; k < nd; k++) {
+            const float g = dbbox[i * nd + k];
+            if (k < 6) {
+                const float gb = g * bbox_pred[i * nd + k];
+                dreg[i * nd + k] = gb * scale[c];
+                acc[c] += (double)gb * reg[i * nd + k];
+            } else {
+                dreg[i * nd + k] = g;
+            }
+        }
+    }
+    for (int k = 0; k < nc; k++) dscale[k] = (float)acc[k];
+    return CG3D_OK;
+}

@@ -662,3 +662,51 @@ def test_hip_yaw_positives_loss_matches_torch_autograd_on_the_device(hip):
     d = (dbp[pos] - g0[pos]).abs().max(1)[0]
     ok = d <= 1e-3 * (1e-3 + g0[pos].abs().max(1)[0])
     assert float(ok.float().mean()) > 0.99, float(ok.float().mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------- class-branch outputs
+def _head_out_case(dev, nd, C=10, B=3, n=4000, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    coords = torch.cat([torch.sort(torch.randint(0, C * B, (n, 1), generator=g), 0)[0], torch.randint(-60, 60, (n, 3), generator=g)], 1).int()
+    reg = torch.randn(n, nd, generator=g) * 0.5
+    cls = torch.randn(n, C, generator=g)
+    scale = torch.rand(C, generator=g) + 0.5
+    vs = torch.rand(C, 3, generator=g) * 0.3 + 0.04
+    w = torch.randn(n, nd, generator=g)
+    return [t.to(dev) for t in (coords, reg, cls, scale, vs, w)] + [B, C]
+
+
+def _head_out_run(case, fused, boost=6.0):
+    from cagroup3d_amd.ops.head_stage import head_outputs
+    coords, reg, cls, scale, vs, w, B, C = case
+    r, s_, c = reg.clone().requires_grad_(True), scale.clone().requires_grad_(True), cls.clone()
+    rc = coords[:, 0].long() // B
+    if fused:
+        bbox, pts = head_outputs(r, s_, coords.contiguous(), vs, B, c, boost)
+    else:
+        c = c + torch.nn.functional.one_hot(rc, C).float() * boost
+        bbox = torch.cat((torch.exp(r[:, :6] * s_[rc].unsqueeze(1)), r[:, 6:]), dim=1)
+        pts = coords[:, 1:].float() * vs[rc]
+    (bbox * w).sum().backward()
+    return [t.detach().cpu() for t in (bbox, pts, c, r.grad, s_.grad)]
+
+
+@pytest.mark.parametrize("nd", [6, 8])
+def test_oracle_head_outputs_equal_the_tensor_form(oracle, nd):
+    with _lib.use_library(oracle):
+        case = _head_out_case("cpu", nd)
+        a, b = _head_out_run(case, False), _head_out_run(case, True)
+    assert torch.equal(b[1], a[1]) and torch.equal(b[2], a[2])               # points and boosted logits: exact
+    for x, y, tol in ((b[0], a[0], 1e-6), (b[3], a[3], 1e-5), (b[4], a[4], 1e-4)):
+        torch.testing.assert_close(x, y, rtol=tol, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd", [6, 8])
+def test_hip_head_outputs_match_oracle(hip, oracle, nd):
+    with _lib.use_library(oracle):
+        want = _head_out_run(_head_out_case("cpu", nd, n=50000), True)
+    got = _head_out_run(_head_out_case("cuda", nd, n=50000), True)
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    for x, y, tol in ((got[0], want[0], 1e-5), (got[3], want[3], 1e-5), (got[4], want[4], 1e-3)):
+        torch.testing.assert_close(x, y, rtol=tol, atol=tol)
