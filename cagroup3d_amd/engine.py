@@ -19,6 +19,7 @@ the specification: `tests/test_engine.py` runs both and compares every output an
 
 Reference: pcdet/models/backbones_3d/biresnet.py:8-406 (the module tree `emit` walks is cagroup3d_amd's mirror of it).
 """
+import collections
 import os
 import struct
 import threading
@@ -45,11 +46,12 @@ WGRAD_ACC = 0x100
 # An address inside a program row is either absolute (< 2^60: weights, coordinate structures, module buffers) or an offset into
 # one of the regions below, tagged in the top bits and resolved when the pass is run.
 TAG = 60
-R_ACT, R_ZF, R_ZB, R_PG, R_DOUT, R_IN = (r << TAG for r in range(1, 7))
+R_ACT, R_ZF, R_ZB, R_PG, R_DOUT, R_IN, R_IN2 = (r << TAG for r in range(1, 8))
 #   R_ACT  activations, gradients, scratch          R_ZF  zero-filled at the start of the forward pass
 #   R_ZB   zero-filled at the start of the backward pass
 #   R_PG   the parameter-gradient buffer of a backward pass (fresh zeros per pass)
 #   R_DOUT the gradient of the backbone output (known when backward runs)       R_IN the input features
+#   R_IN2  the second input of a two-input program (the class branches: features on the coarse map)
 ALIGN = 256
 
 
@@ -152,7 +154,7 @@ class Builder:
         self.late = []                  # (program, row, column, fn() -> tensor): operands that exist only at run time
         self.marks = {}                 # name -> backward row index (callbacks between two parts of the backward pass)
         self.mark_at = {}               # tape position -> name
-        self.bf16 = ME.PRECISION == 1 and ME.BF16_ROWS
+        self.bf16 = ME._prec() == 1 and ME.BF16_ROWS
 
     # ---------------------------------------------------------------- memory
     def alloc(self, nbytes, region=R_ACT):
@@ -299,12 +301,12 @@ class Builder:
         prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, xb * n_in * cin + 4.0 * n_out * cout + wbytes + map_bytes,
                           (kind, K, cin, cout, P, n_out, nseg), xb * P * cin + 4.0 * n_out * cout + wbytes + map_bytes))
 
-    def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P):
+    def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P, ksplit=1, groups=1):
         def p(t):
             return t.data_ptr() if t is not None else 0
-        self._prof(prog, "tile_bf16", plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out)
+        self._prof(prog, "tile_bf16", plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups)
         prog.add(OP_TILE_FWD, x16, wf, p(plan.slots), p(plan.live), p(plan.pass_tab), p(plan.npass), p(plan.ulist), plan.maxpass,
-                 plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin, cout, 1,
+                 plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin, cout, ksplit,
                  1 if wrev else 0, stats)
 
     def _conv_bwd(self, x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b):
@@ -355,6 +357,114 @@ class Builder:
                               eb * P * (cin + cout) + 4.0 * K * cin * cout))
         prog.add(OP_PAIRS_WGRAD, xw, dyw, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), K, cin, cout,
                  wprec | WGRAD_ACC)
+
+    # ---------------------------------------------------------------- grouped layers (the class branches)
+    def hold(self, t):
+        self.keep.append(t)
+        return t
+
+    def pgrad_group(self, params):
+        """Address (in R_PG) of one contiguous block holding the gradients of G same-sized parameters, in order."""
+        off = self._pidx.get(id(params[0]))
+        if off is None:
+            n = params[0].numel()
+            off = self.alloc(len(params) * n * 4, R_PG)
+            for g, prm in enumerate(params):
+                self._pidx[id(prm)] = off + g * n * 4
+                self.params.append((prm, off - R_PG + g * n * 4))
+        return off
+
+    def gconv(self, x, weights, kmap, row_bounds, closed):
+        """me.GroupedConvFunction: G contiguous row groups with their own weights (one parameter per group)."""
+        GC = ME.GroupedConvFunction
+        w3s = [w.view(-1, w.shape[-2], w.shape[-1]) for w in weights]
+        G, (K, cin, cout) = len(w3s), w3s[0].shape
+        if not (self.bf16 and ME._use_bf16(cin) and ME._use_bf16(cout)):
+            raise NotReady("grouped convolution outside the bf16 mode")
+        pin, pout, _, P = kmap.pairs(row_bounds)
+        xg = self.rows16(x)
+        lds = GC._lds_tile(kmap, K, cin, cout, closed)
+        wt = self.hold(ME._prep_bf16_group(w3s, True, lds)).data_ptr()
+        wp = self.hold(ME._prep_bf16_group(w3s, False, lds)).data_ptr() if x.need else 0
+        n_in, n_out = kmap.n_in, kmap.n_out
+        if lds:
+            plan = kmap.tile_plan(False, row_bounds)
+            y = self.new(n_out, cout)
+            self._tile_row(self.f, xg, wt, plan, y.p, n_in, cin, cout, False, 0, P, GC._ksplit(plan, K), G)
+        elif GC._tiled(kmap, P, K, closed):
+            tl, ntl = kmap.tiles(row_bounds)
+            y = self.new(n_out, cout)
+            self.f.add(OP_SPCONV_FWD_TILED, xg, wt, kmap.nbr.data_ptr(), tl.data_ptr(), ntl, 0, y.p, n_in, n_out, K, cin, cout, 2)
+        else:
+            seg, nseg = kmap.segments(ME._seg_len_fwd(), row_bounds)
+            y = T(self.alloc(max(n_out, 1) * cout * 4, R_ZF), n_out, cout)          # atomic scatter into zeros
+            self.f.add(OP_PAIRS_FWD, xg, wt, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out, cin, cout, 2, 1)
+        self.tape.append(lambda: self._gconv_bwd(x, y, weights, kmap, row_bounds, closed, G, K, cin, cout, P, wp, lds))
+        return y
+
+    def _gconv_bwd(self, x, y, weights, kmap, rb, closed, G, K, cin, cout, P, wp, lds):
+        g = self.grad(y, want16=True)
+        if g is None:
+            return
+        GC = ME.GroupedConvFunction
+        dy16 = g[1]
+        pin, pout = kmap.pairs(rb)[:2]
+        if x.need:
+            if lds:
+                plan = kmap.tile_plan(True, rb)
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
+                self._tile_row(self.b, dy16, wp, plan, dx, kmap.n_out, cout, cin, kmap.symmetric, 0, P, GC._ksplit(plan, K), G)
+            elif GC._tiled(kmap, P, K, closed):
+                tl, ntl = kmap.tiles(rb)
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
+                self.b.add(OP_SPCONV_FWD_TILED, dy16, wp, kmap.nbrT.data_ptr(), tl.data_ptr(), ntl, 0, dx, kmap.n_out, kmap.n_in, K,
+                           cout, cin, 2)
+            else:
+                seg, nseg = kmap.segments(ME._seg_len_fwd(), rb)
+                dx = self.alloc(max(kmap.n_in, 1) * cin * 4, R_ZB)
+                self.b.add(OP_PAIRS_FWD, dy16, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin, 2, 1)
+            self.gadd(x, dx)
+        seg, nseg = kmap.segments(ME._wgrad_seg_len(P, cin, cout, 1, G * K), rb)
+        self.b.add(OP_PAIRS_WGRAD, self.rows16(x) if not x.p16 else x.p16, dy16, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg,
+                   self.pgrad_group(weights), G * K, cin, cout, 2 | WGRAD_ACC)
+
+    def gbn_act(self, x, bns, bounds, act):
+        """me.FusedBNActFunction over G row groups; the G modules' parameters and running statistics as [G, C] arrays (me.BNStack)."""
+        n, c, G = x.n, x.c, len(bns)
+        b0 = bns[0]
+        if not (b0.training and ME.GROUPED_BN_STACK and ME._stackable(bns) and c % 4 == 0) or ME._sync_group_of(b0) is not None:
+            raise NotReady("grouped BatchNorm form without a program counterpart")
+        st = self.hold(ME.BNStack.of(bns))
+        red, nred, _, group_n, app, napp, _ = self._hold(ME._bn_chunks(tuple(bounds), self.dev, c))
+        sums = self.alloc(ME.BN_SLOTS * 2 * G * c * 4, R_ZF)
+        self.f.add(OP_BN_SUMS, x.p, red.data_ptr(), nred, G, c, sums)
+        mv = self.alloc(2 * G * c * 4, R_ZF)
+        mean, var = mv, mv + G * c * 4
+        y = self.new(n, c)
+        if self.bf16 and ME._use_bf16(c):
+            y.p16 = self.alloc(max(n, 1) * c * 2)
+        self.f.add(OP_BN_APPLY_SUMS, x.p, 0, app.data_ptr(), napp, G, c, sums, group_n.data_ptr(), _fbits(b0.eps),
+                   st.weight.data_ptr(), st.bias.data_ptr(), act, y.p, y.p16, mean, var, st.running_mean.data_ptr(),
+                   st.running_var.data_ptr(), st.num_batches_tracked.data_ptr(), _fbits(b0.momentum))
+        self.tape.append(lambda: self._gbn_bwd(x, y, bns, st, act, mean, var, G, (red, nred, group_n, app, napp)))
+        return y
+
+    def _gbn_bwd(self, x, y, bns, st, act, mean, var, G, ch):
+        g = self.grad(y)
+        if g is None:
+            return
+        dy = g[0]
+        red, nred, group_n, app, napp = ch
+        n, c = x.n, x.c
+        eps = _fbits(bns[0].eps)
+        dsums = self.alloc(ME.BN_SLOTS * 2 * G * c * 4, R_ZB)
+        self.b.add(OP_BN_BWD_SUMS, dy, x.p, y.p, red.data_ptr(), nred, G, c, mean, var, eps, act, dsums)
+        dx = self.alloc(max(n, 1) * c * 4)
+        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.bf16 and ME._use_bf16(c)) else 0
+        self.b.add(OP_BN_BWD_APPLY_SUMS, dy, x.p, y.p, app.data_ptr(), napp, G, c, mean, var, eps, st.weight.data_ptr(), dsums,
+                   group_n.data_ptr(), act, 1, dx, dx16, 0, self.pgrad_group([b.bias for b in bns]),
+                   self.pgrad_group([b.weight for b in bns]))
+        self.gadd(x, dx, dx16)
 
     # ---------------------------------------------------------------- 1x1x1 convolution (me.LinearFunction)
     def linear(self, x, weight, cin, cout):
@@ -770,6 +880,37 @@ def _run(lib, P, nrows=None):
         raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, int(P[fail.value, 0]) if 0 <= fail.value < n else -1, rc))
 
 
+# ------------------------------------------------------------------------------------------------ parameter gradients
+# A backward table writes every parameter gradient of its pass into ONE zero-filled buffer.  Handing 200+ parameters a fresh
+# slice each (slice + view + attribute) cost the issuing thread ~1 ms per pass -- inside the stretch of the step where the
+# device waits for the host.  The buffer and its per-parameter views are therefore kept per layout and reused while that is
+# safe: every parameter's .grad must be None when the pass starts (the training loop's zero_grad(set_to_none=True)), else
+# -- gradient accumulation over several backward passes, a second backward through a retained graph -- the pass gets a
+# fresh buffer and adds, as before.
+PG_REUSE = os.environ.get("CG3D_PG_REUSE", "1") != "0"
+_PG_POOL = collections.OrderedDict()
+
+
+def _pg_views(comp, device):
+    """(buffer, views aligned with comp.params, fresh): a zero-filled buffer for the pass's parameter gradients."""
+    n = max(comp.size[R_PG] // 4, 1)
+    params = comp.params
+    if PG_REUSE and params and all(prm.grad is None for prm, _ in params):
+        key = (n, str(device), tuple((id(prm), off) for prm, off in params))
+        hit = _PG_POOL.get(key)
+        if hit is not None and all(a is b[0] for a, b in zip(hit[2], params)):
+            hit[0].zero_()
+            return hit[0], hit[1], False
+        pg = torch.zeros(n, dtype=torch.float32, device=device)
+        views = [pg[off // 4: off // 4 + prm.numel()].view_as(prm) for prm, off in params]
+        _PG_POOL[key] = (pg, views, [prm for prm, _ in params])
+        while len(_PG_POOL) > 6:
+            _PG_POOL.popitem(last=False)
+        return pg, views, False
+    pg = torch.zeros(n, dtype=torch.float32, device=device)
+    return pg, [pg[off // 4: off // 4 + prm.numel()].view_as(prm) for prm, off in params], True
+
+
 class BackboneFunction(torch.autograd.Function):
     """The whole backbone as ONE autograd node: forward = the forward table, backward = the backward table; the parameters'
     gradients are written to one fresh zero-filled buffer and handed to the parameters here (`p.grad = view`, added to an
@@ -816,7 +957,7 @@ class BackboneFunction(torch.autograd.Function):
         comp, lib, hooks = ctx.comp, ctx.comp.lib, ctx.hooks or {}
         dy = dy.contiguous()
         bases = dict(ctx.bases)
-        pg = torch.zeros(max(comp.size[R_PG] // 4, 1), dtype=torch.float32, device=dy.device)
+        pg, views, _ = _pg_views(comp, dy.device)
         bases[R_PG], bases[R_DOUT] = pg.data_ptr(), dy.data_ptr()
         P = _resolve(comp.bwd, bases)
         keep = []
@@ -837,11 +978,10 @@ class BackboneFunction(torch.autograd.Function):
         def give(ids):
             # hand the gradients written so far to their parameters (ids None: all that are left)
             with torch.no_grad():
-                for prm, off in comp.params:
+                for (prm, _), g in zip(comp.params, views):
                     k = id(prm)
                     if k in given or (ids is not None and k not in ids):
                         continue
-                    g = pg[off // 4: off // 4 + prm.numel()].view_as(prm)
                     prm.grad = g if prm.grad is None else prm.grad + g
                     given.add(k)
         first = True
@@ -858,6 +998,117 @@ class BackboneFunction(torch.autograd.Function):
         give(None)
         ctx.arena = ctx.keep = ctx.feats = None
         return None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ the class branches
+CLASS_PROGRAM = os.environ.get("CG3D_CLASS_PROGRAM", "1") != "0"
+CLASS_STATS = {"program_passes": 0, "not_ready": 0}
+
+
+def class_branches_applicable(head):
+    """Training step of the batched dense head in the bench precision on the device library (CG3D_ENGINE_ANY: tests)."""
+    if not (ENABLED and CLASS_PROGRAM and head.training and torch.is_grad_enabled()) or ME.coords_only():
+        return False
+    return _lib.get().is_device and ME._prec() == 1 and ME.BF16_ROWS and ME.GROUPED_BN_STACK
+
+
+def compile_class_branches(head, nf, nc, c, km9, km5, km_up, ident, fine_bounds, coarse_bounds, device):
+    """Program pair for the feature side of the class branches (reference cagroup_head.py:227-282, all classes at once as in
+    CAGroup3DHead._class_branches_batched): out conv 9^3 + BN + ELU on the fine map, expand conv 5^3 + BN + ELU on the coarse
+    map, generative transposed conv + BN + ELU back onto the fine voxels, concatenation, fuse conv + BN + ELU.  The maps are
+    the ones the caller built; compiling adds their pair lists / tile plans (with their host reads) as the per-layer path
+    does.  Inputs: R_IN = features on the fine map [nf, c], R_IN2 = features on the coarse map [nc, c]."""
+    lib = _lib.get()
+    b = Builder(lib, device, ME._WeightPlan.gen)
+    xf, xc = T(R_IN, nf, c, need=True), T(R_IN2, nc, c, need=True)
+    elu = ME.ACT_ELU
+    a = b.gconv(xf, [m[0].kernel for m in head.cls_individual_out], km9, fine_bounds, True)
+    a = b.gbn_act(a, [m[1].bn for m in head.cls_individual_out], fine_bounds, elu)
+    e = b.gconv(xc, [m[0].kernel for m in head.cls_individual_expand_out], km5, coarse_bounds, True)
+    e = b.gbn_act(e, [m[1].bn for m in head.cls_individual_expand_out], coarse_bounds, elu)
+    u = b.gconv(e, [m[0].kernel for m in head.cls_individual_up], km_up, fine_bounds, False)
+    u = b.gbn_act(u, [m[1][0].bn for m in head.cls_individual_up], fine_bounds, elu)
+    f = b.gconv(b.cat([u, a]), [m[0].kernel for m in head.cls_individual_fuse], ident, fine_bounds, False)
+    f = b.gbn_act(f, [m[1].bn for m in head.cls_individual_fuse], fine_bounds, elu)
+    b.emit_backward(f)
+    gin = (b.grad(xf), b.grad(xc))              # (may add the rows that sum several contributions: before the tables are cut)
+    comp = Compiled(b, f, None, nf, c)
+    comp.n_in2, comp.gin = nc, gin
+    # the rows address the maps' tables, pair lists, segment tables and tile plans (cached inside the KernelMap objects): the
+    # program owns them until its backward pass has run -- the caller's sparse tensors and managers die with its frame
+    comp.maps = (km9, km5, km_up, ident)
+    return comp
+
+
+def _arena_view(arena, bases, addr, n, c, dtype=torch.float32, width=4):
+    tag = (addr >> TAG) << TAG
+    off = bases[tag] + (addr - tag) - arena.data_ptr()
+    return arena[off:off + n * c * width].view(dtype).view(n, c)
+
+
+class ClassBranchFunction(torch.autograd.Function):
+    """The feature side of all class branches as ONE autograd node (two inputs, one output); the parameters' gradients are
+    slices of one zero-filled buffer handed to the parameters in backward, as in BackboneFunction."""
+
+    @staticmethod
+    def forward(ctx, xf, xc, comp):
+        lib = comp.lib
+        xf, xc = xf.contiguous(), xc.contiguous()
+        assert xf.shape == (comp.n_in, comp.c_in) and xc.shape == (comp.n_in2, comp.c_in) and xf.dtype == xc.dtype == torch.float32
+        sz = comp.size
+        zf, zb, act = sz[R_ZF], sz[R_ZB], sz[R_ACT]
+        arena = torch.empty(zf + zb + act + ALIGN, dtype=torch.uint8, device=xf.device)
+        base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
+        bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: xf.data_ptr(), R_IN2: xc.data_ptr()}
+        P = _resolve(comp.fwd, bases)
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, base, 0, zf)
+        prof = bool(ME.KernelProfile.enabled and lib.is_device)
+        if prof:
+            P, recs = _with_events(P, comp.fprof, lib)
+            ME.KernelProfile.records.extend(recs)
+        _run(lib, np.concatenate([head, P]))
+        ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (xf, xc), prof
+        p, n, c, p16 = comp.out
+        y = _arena_view(arena, bases, p, n, c)
+        if p16:
+            ME._ROWS16[y.data_ptr()] = (y, _arena_view(arena, bases, p16, n, c, torch.int16, 2))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        comp, lib = ctx.comp, ctx.comp.lib
+        dy = dy.contiguous()
+        bases = dict(ctx.bases)
+        pg, views, _ = _pg_views(comp, dy.device)
+        bases[R_PG], bases[R_DOUT] = pg.data_ptr(), dy.data_ptr()
+        P = _resolve(comp.bwd, bases)
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+        if ctx.prof:
+            P, recs = _with_events(P, comp.bprof, lib)
+            ME.KernelProfile.records.extend(recs)
+        _run(lib, np.concatenate([head, P]))
+        with torch.no_grad():
+            for (prm, _), g in zip(comp.params, views):
+                prm.grad = g if prm.grad is None else prm.grad + g
+        grads = []
+        for gi, (n, c) in zip(comp.gin, ((comp.n_in, comp.c_in), (comp.n_in2, comp.c_in))):
+            grads.append(_arena_view(ctx.arena, bases, gi[0], n, c) if gi is not None else None)
+        ctx.arena = ctx.inputs = None
+        return grads[0], grads[1], None
+
+
+def run_class_branches(head, xf, xc, km9, km5, km_up, ident, fine_bounds, coarse_bounds):
+    """Features [nf, c] after the fuse BatchNorm + ELU of all class branches.  Raises NotReady when a layer has no program form."""
+    try:
+        comp = compile_class_branches(head, xf.shape[0], xc.shape[0], xf.shape[1], km9, km5, km_up, ident, fine_bounds,
+                                      coarse_bounds, xf.device)
+    except NotReady:
+        CLASS_STATS["not_ready"] += 1
+        raise
+    CLASS_STATS["program_passes"] += 1
+    return ClassBranchFunction.apply(xf, xc, comp)
 
 
 def comp_prof_slice(prof, lo, hi):

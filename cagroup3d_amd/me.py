@@ -2011,6 +2011,52 @@ def _sync_group_of(bn):
     return (group,) if dist.get_world_size(group) > 1 else None
 
 
+class BNStack:
+    """The parameters and running statistics of G BatchNorm1d modules (the class branches: one module per class, reference
+    cagroup_head.py:183-188) as slices of ONE [G, C] tensor each, so that a grouped launch addresses them as a plain array
+    (no torch.stack per step, the running statistics of all groups updated inside the apply launch).  The modules keep their
+    own Parameter / buffer objects -- only their `.data` moves into the stacked storage; `state_dict` keys and shapes are
+    unchanged.  A `.to()` / `load` that gives a module fresh storage is noticed (address check) and the stack rebuilt."""
+    ATTRS = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+    __slots__ = ATTRS + ("first", "last", "C")
+
+    @staticmethod
+    def of(bns):
+        b0 = bns[0]
+        st = b0.__dict__.get("_cg3d_stack")
+        if st is not None and len(bns) == st.weight.shape[0] and st.valid(bns):
+            return st
+        st = BNStack(bns)
+        b0.__dict__["_cg3d_stack"] = st
+        return st
+
+    def valid(self, bns):
+        C, w0, m0 = self.C * 4, self.first[0], self.first[3]
+        for g, b in enumerate(bns):           # every module's weight and running mean; the other three of the last module
+            if b.weight.data_ptr() != w0 + g * C or b.running_mean.data_ptr() != m0 + g * C:
+                return False
+        b, g = bns[-1], self.last
+        return (b.running_var.data_ptr() == self.first[1] + g * C and b.bias.data_ptr() == self.first[2] + g * C
+                and b.num_batches_tracked.data_ptr() == self.first[4] + g * 8)
+
+    def __init__(self, bns):
+        with torch.no_grad():
+            for a in BNStack.ATTRS:
+                stacked = torch.stack([getattr(b, a).data for b in bns]).contiguous()
+                for g, b in enumerate(bns):
+                    getattr(b, a).data = stacked[g]
+                setattr(self, a, stacked)
+        self.C, self.last = self.weight.shape[1], len(bns) - 1
+        self.first = (self.weight.data_ptr(), self.running_var.data_ptr(), self.bias.data_ptr(), self.running_mean.data_ptr(),
+                      self.num_batches_tracked.data_ptr())
+
+
+def _stackable(bns):
+    b0 = bns[0]
+    return (len(bns) > 1 and b0.track_running_stats and b0.momentum is not None and b0.weight is not None
+            and all(type(b) is type(b0) and b.momentum == b0.momentum for b in bns))
+
+
 def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     """BatchNorm1d modules `bns` (one per contiguous row group of `bounds`) + residual + activation in
     two launches (statistics, apply); updates the modules' running statistics like nn.BatchNorm1d."""
@@ -2039,6 +2085,10 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     running = None
     if track and G == 1 and b0.momentum is not None:
         running = (b0.running_mean, b0.running_var, b0.num_batches_tracked, float(b0.momentum))
+    elif track and G > 1 and GROUPED_BN_STACK and _stackable(bns):
+        # all groups' running statistics as [G, C] arrays (BNStack): updated inside the apply launch like the single group's
+        st = BNStack.of(bns)
+        running = (st.running_mean, st.running_var, st.num_batches_tracked, float(b0.momentum))
     sync = _sync_group_of(b0) if use_batch else None
     y, mean, var, n_rows = FusedBNActFunction.apply(feats, gamma, beta, residual, tuple(bounds), act, use_batch, mean_in, var_in,
                                                     b0.eps, running, sync)
@@ -2057,6 +2107,7 @@ def fused_bn_act(feats, bns, bounds=None, act=ACT_NONE, residual=None):
     return y
 
 
+GROUPED_BN_STACK = __import__("os").environ.get("CG3D_BN_STACK", "1") != "0"
 _unit_cache = {}
 ADD_RELU = __import__("os").environ.get("CG3D_ADD_RELU", "1") != "0"
 

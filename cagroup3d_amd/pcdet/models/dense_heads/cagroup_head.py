@@ -39,6 +39,17 @@ def _conv_bn_elu(cin, cout, k):
                          ME.MinkowskiBatchNorm(cout), ME.MinkowskiELU())
 
 
+import time as _time
+TICKS = None         # list -> (name, host s, after-sync s) records
+
+
+def _tick(name):
+    if TICKS is not None:
+        a = _time.perf_counter()
+        torch.cuda.synchronize()
+        TICKS.append((name, a, _time.perf_counter()))
+
+
 class CAGroup3DHead(nn.Module):
     def __init__(self, model_cfg, yaw_parametrization="fcaf3d", predict_boxes=True, **kwargs):
         super().__init__()
@@ -272,6 +283,7 @@ class CAGroup3DHead(nn.Module):
         N, ch = out.F.shape
         elu = torch.nn.functional.elu
         vs_tab = self._vs_table(dev)
+        _tick("enter")
         if votes is not None:
             from ....ops import head_stage as HS
             with torch.no_grad():
@@ -293,9 +305,12 @@ class CAGroup3DHead(nn.Module):
             feat_tab = torch.cat([offset_features.reshape(N * n_vote, -1), out.F], dim=0)
             fuse_feat = ME.gather_rows(feat_tab, src)
 
+        _tick("class_rows+gather")
         avg = ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
         cls_map = ME.SparseTensor(coordinates=fine, features=fuse_feat, quantization_mode=avg)
+        _tick("fine tensor")
         cls_exp = ME.SparseTensor(coordinates=coarse, features=fuse_feat, tensor_stride=self.expand, quantization_mode=avg)
+        _tick("coarse tensor")
         fine_C = cls_map.C
         with torch.no_grad():                                             # ONE host read for all group sizes
             fb, cb = fine_C[:, 0].long(), cls_exp.C[:, 0].long()
@@ -304,24 +319,35 @@ class CAGroup3DHead(nn.Module):
         fine_bounds = (0,) + tuple(np.cumsum(sizes[:C]).tolist())
         coarse_bounds = (0,) + tuple(np.cumsum(sizes[C:2 * C]).tolist())
         per_scene = sizes[2 * C:].tolist()
+        _tick("sizes")
 
-        mgr = cls_map.coordinate_manager
+        mgr, emgr = cls_map.coordinate_manager, cls_exp.coordinate_manager
         km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, self.cls_kernel, 1, False)
-        a = ME.grouped_conv(cls_map.F, [m[0].kernel for m in self.cls_individual_out], km9, fine_bounds, closed=True)
-        a = self._grouped_bn_act(a, fine_bounds, [m[1] for m in self.cls_individual_out], elu)
-
-        emgr = cls_exp.coordinate_manager
         km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
-        e = ME.grouped_conv(cls_exp.F, [m[0].kernel for m in self.cls_individual_expand_out], km5, coarse_bounds, closed=True)
-        e = self._grouped_bn_act(e, coarse_bounds, [m[1] for m in self.cls_individual_expand_out], elu)
         tgt_key, _, _ = emgr.insert(fine_C, 1)                             # generative transposed conv onto the fine voxels
         km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, self.expand, 1, True)
-        u = ME.grouped_conv(e, [m[0].kernel for m in self.cls_individual_up], km_up, fine_bounds)
-        u = self._grouped_bn_act(u, fine_bounds, [m[1][0] for m in self.cls_individual_up], elu)
-
         ident = ME.KernelMap.identity(fine_C.shape[0], dev)
-        f = ME.grouped_conv(torch.cat([u, a], dim=1), [m[0].kernel for m in self.cls_individual_fuse], ident, fine_bounds)
-        f = self._grouped_bn_act(f, fine_bounds, [m[1] for m in self.cls_individual_fuse], elu)
+        _tick("maps")
+        f = None
+        from .... import engine
+        if engine.class_branches_applicable(self):
+            # the four (convolution, BatchNorm, ELU) stages of all classes as one launch program each way (engine.py): one
+            # autograd node and two foreign calls instead of ~16 nodes and ~60 calls issued from here
+            try:
+                f = engine.run_class_branches(self, cls_map.F, cls_exp.F, km9, km5, km_up, ident, fine_bounds, coarse_bounds)
+            except engine.NotReady:
+                f = None
+        _tick("program")
+        if f is None:
+            a = ME.grouped_conv(cls_map.F, [m[0].kernel for m in self.cls_individual_out], km9, fine_bounds, closed=True)
+            a = self._grouped_bn_act(a, fine_bounds, [m[1] for m in self.cls_individual_out], elu)
+            e = ME.grouped_conv(cls_exp.F, [m[0].kernel for m in self.cls_individual_expand_out], km5, coarse_bounds, closed=True)
+            e = self._grouped_bn_act(e, coarse_bounds, [m[1] for m in self.cls_individual_expand_out], elu)
+            u = ME.grouped_conv(e, [m[0].kernel for m in self.cls_individual_up], km_up, fine_bounds)
+            u = self._grouped_bn_act(u, fine_bounds, [m[1][0] for m in self.cls_individual_up], elu)
+            f = ME.grouped_conv(torch.cat([u, a], dim=1), [m[0].kernel for m in self.cls_individual_fuse], ident, fine_bounds)
+            f = self._grouped_bn_act(f, fine_bounds, [m[1] for m in self.cls_individual_fuse], elu)
+        _tick("layers")
 
         with torch.no_grad():
             rc = fb // B                                                   # class of every fine row
@@ -347,6 +373,7 @@ class CAGroup3DHead(nn.Module):
             merged, seg = [t[perm] for t in (centerness, bbox_pred, cls_score, points)], fb[perm]
         object.__setattr__(self, "_merged", {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2],
                                              "points": merged[3], "seg": seg, "per_scene": per_scene})
+        _tick("linears+outputs")
         pieces = [torch.split(t, per_scene) for t in merged]
         outs = []
         for c in range(C):
@@ -354,6 +381,7 @@ class CAGroup3DHead(nn.Module):
             for p in pieces[3][sl]:
                 assert len(p) > 0, "forward empty"
             outs.append((list(pieces[0][sl]), list(pieces[1][sl]), list(pieces[2][sl]), list(pieces[3][sl])))
+        _tick("split")
         return outs
 
     def forward_single(self, x, scale, voxel_size, cls_id=None):

@@ -181,3 +181,107 @@ def test_compiled_program_owns_the_cached_tables_it_points_into(oracle):
     assert len(used) > 10, "the program does not seem to use the cached tables at all"
     missing = [t.shape for t in used if t.data_ptr() not in kept_ptrs]
     assert not missing, "cached tables referenced by raw address only: %s" % missing[:5]
+
+
+# ------------------------------------------------------------------------------------------------ the class branches
+def _class_branch_step(head, fine, coarse, feat, up, use_program, B):
+    """The feature side of all class branches (four grouped convolution + BatchNorm + ELU stages) on given coordinates, through the
+    per-layer path or through the launch program; returns what both must agree on."""
+    C, dev = head.n_classes, feat.device
+    for p in head.parameters():
+        p.grad = None
+    x = feat.clone().requires_grad_(True)
+    avg = me.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
+    me.prepare_weights(True)
+    cls_map = me.SparseTensor(coordinates=fine, features=x, quantization_mode=avg)
+    cls_exp = me.SparseTensor(coordinates=coarse, features=x, tensor_stride=head.expand, quantization_mode=avg)
+    fb, cb = cls_map.C[:, 0].long(), cls_exp.C[:, 0].long()
+    fine_bounds = (0,) + tuple(np.cumsum(torch.bincount(fb // B, minlength=C).cpu().numpy()).tolist())
+    coarse_bounds = (0,) + tuple(np.cumsum(torch.bincount(cb // B, minlength=C).cpu().numpy()).tolist())
+    mgr, emgr = cls_map.coordinate_manager, cls_exp.coordinate_manager
+    km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, head.cls_kernel, 1, False)
+    km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
+    tgt_key, _, _ = emgr.insert(cls_map.C, 1)
+    km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, head.expand, 1, True)
+    ident = me.KernelMap.identity(cls_map.C.shape[0], dev)
+    elu = torch.nn.functional.elu
+    if use_program:
+        assert engine.class_branches_applicable(head)
+        f = engine.run_class_branches(head, cls_map.F, cls_exp.F, km9, km5, km_up, ident, fine_bounds, coarse_bounds)
+    else:
+        a = me.grouped_conv(cls_map.F, [m[0].kernel for m in head.cls_individual_out], km9, fine_bounds, closed=True)
+        a = head._grouped_bn_act(a, fine_bounds, [m[1] for m in head.cls_individual_out], elu)
+        e = me.grouped_conv(cls_exp.F, [m[0].kernel for m in head.cls_individual_expand_out], km5, coarse_bounds, closed=True)
+        e = head._grouped_bn_act(e, coarse_bounds, [m[1] for m in head.cls_individual_expand_out], elu)
+        u = me.grouped_conv(e, [m[0].kernel for m in head.cls_individual_up], km_up, fine_bounds)
+        u = head._grouped_bn_act(u, fine_bounds, [m[1][0] for m in head.cls_individual_up], elu)
+        f = me.grouped_conv(torch.cat([u, a], dim=1), [m[0].kernel for m in head.cls_individual_fuse], ident, fine_bounds)
+        f = head._grouped_bn_act(f, fine_bounds, [m[1] for m in head.cls_individual_fuse], elu)
+    me.finish_weights()
+    fout = f.detach().cpu()
+    loss = (f * up[:f.shape[0]]).sum()
+    # (the head's frame is gone when backward runs: the graph alone must keep alive what the backward pass reads)
+    del cls_map, cls_exp, mgr, emgr, km9, km5, km_up, ident, tgt_key, f, fb, cb
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    scratch = torch.full((64 << 20,), float("nan"), device=dev)      # what the allocator hands out next is poisoned
+    del scratch
+    loss.backward()
+    names = ("cls_individual_out", "cls_individual_expand_out", "cls_individual_up", "cls_individual_fuse")
+    grads = {n: p.grad.detach().clone().cpu() for n, p in head.named_parameters() if n.startswith(names)}
+    bufs = {n: b.detach().clone().cpu() for n, b in head.named_buffers() if n.startswith(names)}
+    return fout, x.grad.detach().cpu(), grads, bufs
+
+
+@pytest.mark.gpu
+def test_class_branch_program_equals_per_layer_path_on_the_device(hip):
+    """engine.run_class_branches (one autograd node, one launch program each way) against the sequence of grouped autograd
+    functions it replaces: same output rows, same gradient for the input rows and for every parameter of the four stages of
+    all 18 classes, same running statistics.  Yardstick as for the backbone: the run-to-run noise of the per-layer path."""
+    prec, me.PRECISION = me.PRECISION, 1
+    try:
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        head = model.dense_head.cuda().train()
+        C, B = head.n_classes, 2
+        g = torch.Generator().manual_seed(3)
+        rows = []
+        for c in range(C):
+            for b in range(B):
+                n = 150 + 40 * ((c + b) % 5)
+                # a surface patch (most rows have in-plane neighbours) with a few duplicate voxels for the averaging quantisation
+                xy = torch.randint(0, 24, (n, 2), generator=g)
+                z = torch.randint(0, 3, (n, 1), generator=g)
+                rows.append(torch.cat([torch.full((n, 1), c * B + b), xy, z], 1))
+        fine = torch.cat(rows).float().cuda()
+        coarse = fine.clone()
+        coarse[:, 1:] = torch.floor(fine[:, 1:] / head.expand) * head.expand
+        ch = head.cls_individual_out[0][0].kernel.shape[-1]
+        feat = torch.randn(fine.shape[0], ch, generator=g).cuda()
+        up = torch.randn(fine.shape[0], ch, generator=g).cuda()
+        state = {k: v.clone() for k, v in head.state_dict().items()}
+
+        def run(use_program):
+            head.load_state_dict(state)
+            return _class_branch_step(head, fine, coarse, feat, up, use_program, B)
+        for e in (False, False, True, True):       # both paths' weight variants enter the step's bf16 arena
+            run(e)
+        ref, ref2 = run(False), run(False)
+        before = engine.CLASS_STATS["program_passes"]
+        got = run(True)
+        assert engine.CLASS_STATS["program_passes"] == before + 1
+    finally:
+        me.PRECISION = prec
+    assert ref[0].shape == got[0].shape and len(ref[2]) == 18 * 12 and set(ref[2]) == set(got[2])
+    assert _l2(ref[0], got[0]) <= 3 * _l2(ref[0], ref2[0]) + 1e-4, (_l2(ref[0], got[0]), _l2(ref[0], ref2[0]))
+    assert _l2(ref[1], got[1]) <= 3 * _l2(ref[1], ref2[1]) + 1e-3, (_l2(ref[1], got[1]), _l2(ref[1], ref2[1]))
+    bad = {}
+    for k in ref[2]:
+        if float(ref[2][k].norm()) > 1e-3:
+            noise, err = _l2(ref[2][k], ref2[2][k]), _l2(ref[2][k], got[2][k])
+            if err > 3 * noise + 1e-3:
+                bad[k] = (err, noise)
+    assert not bad, bad
+    for k in ref[3]:
+        assert _l2(ref[3][k].float(), got[3][k].float()) <= 3 * _l2(ref[3][k].float(), ref2[3][k].float()) + 1e-3, k

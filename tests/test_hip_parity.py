@@ -610,9 +610,16 @@ def test_weight_plan_single_launch_equals_per_layer_conversion(hip):
         grp = [torch.randn(125, 64, 64, device="cuda") for _ in range(3)]
         first = [me._prep_bf16_both(w) for w in ws[:2]] + [(me._prep_bf16_t(ws[2]), None)]        # per-layer launches; recorded
         g_t, g_p = me._prep_bf16_group(grp, True), me._prep_bf16_group(grp, False)
+        wf = torch.randn(27, 128, 64, device="cuda")         # the tile kernel's operands: both copies in MFMA fragment order
+        f_t, f_p = me._prep_frag(wf, True, True)
+        gf_t, gf_p = me._prep_bf16_group(grp, True, True), me._prep_bf16_group(grp, False, True)
         assert me._WeightPlan.dirty and me._WeightPlan.table is None
         me.prepare_weights()
-        assert me._WeightPlan.nrows == 27 + 8 * 2 + 27 * 2 * 4 + 2 * 3 * 125
+        assert me._WeightPlan.nrows == 27 + 8 * 2 + 27 * 2 * 4 + 2 * 3 * 125 + 27 * 2 + 2 * 3 * 125
+        a_t, a_p = me._prep_frag(wf, True, True)
+        assert a_t.data_ptr() != f_t.data_ptr() and torch.equal(a_t.view(-1), f_t.view(-1)) and torch.equal(a_p.view(-1), f_p.view(-1))
+        assert torch.equal(me._prep_bf16_group(grp, True, True).view(-1), gf_t.view(-1))
+        assert torch.equal(me._prep_bf16_group(grp, False, True).view(-1), gf_p.view(-1))
         again = [me._prep_bf16_both(w) for w in ws[:2]] + [(me._prep_bf16_t(ws[2]), None)]
         for (a_t, a_p), (b_t, b_p), w in zip(first, again, ws):
             assert b_t.data_ptr() != a_t.data_ptr() and torch.equal(a_t, b_t)                 # answered from the arena

@@ -18,7 +18,7 @@ dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
-batch = build_model.synthetic_batch("S50k", 4, device=dev)
+batch = build_model.synthetic_batch("S50k", int(os.environ.get("CG3D_PROFILE_BATCH", "4")), device=dev)
 for _ in range(5):
     bench.train_step(model, opt, batch, 10.0)
 torch.cuda.synchronize()
