@@ -1024,14 +1024,18 @@ def compile_class_branches(head, nf, nc, c, km9, km5, km_up, ident, fine_bounds,
     b = Builder(lib, device, ME._WeightPlan.gen)
     xf, xc = T(R_IN, nf, c, need=True), T(R_IN2, nc, c, need=True)
     elu = ME.ACT_ELU
-    a = b.gconv(xf, [m[0].kernel for m in head.cls_individual_out], km9, fine_bounds, True)
-    a = b.gbn_act(a, [m[1].bn for m in head.cls_individual_out], fine_bounds, elu)
-    e = b.gconv(xc, [m[0].kernel for m in head.cls_individual_expand_out], km5, coarse_bounds, True)
-    e = b.gbn_act(e, [m[1].bn for m in head.cls_individual_expand_out], coarse_bounds, elu)
-    u = b.gconv(e, [m[0].kernel for m in head.cls_individual_up], km_up, fine_bounds, False)
-    u = b.gbn_act(u, [m[1][0].bn for m in head.cls_individual_up], fine_bounds, elu)
-    f = b.gconv(b.cat([u, a]), [m[0].kernel for m in head.cls_individual_fuse], ident, fine_bounds, False)
-    f = b.gbn_act(f, [m[1].bn for m in head.cls_individual_fuse], fine_bounds, elu)
+    L = head.__dict__.get("_cb_layers")
+    m0 = head.cls_individual_out[0]
+    if L is None or L[0][0][0] is not m0[0].kernel or L[0][1][0] is not m0[1].bn:      # (a replaced module, e.g. convert_sync_batchnorm)
+        # (216 module-tree look-ups per step otherwise; the lists hold the modules' own Parameter / BatchNorm1d objects)
+        L = head.__dict__["_cb_layers"] = tuple(
+            ([m[0].kernel for m in mods], [(m[1][0] if up else m[1]).bn for m in mods])
+            for mods, up in ((head.cls_individual_out, False), (head.cls_individual_expand_out, False),
+                             (head.cls_individual_up, True), (head.cls_individual_fuse, False)))
+    a = b.gbn_act(b.gconv(xf, L[0][0], km9, fine_bounds, True), L[0][1], fine_bounds, elu)
+    e = b.gbn_act(b.gconv(xc, L[1][0], km5, coarse_bounds, True), L[1][1], coarse_bounds, elu)
+    u = b.gbn_act(b.gconv(e, L[2][0], km_up, fine_bounds, False), L[2][1], fine_bounds, elu)
+    f = b.gbn_act(b.gconv(b.cat([u, a]), L[3][0], ident, fine_bounds, False), L[3][1], fine_bounds, elu)
     b.emit_backward(f)
     gin = (b.grad(xf), b.grad(xc))              # (may add the rows that sum several contributions: before the tables are cut)
     comp = Compiled(b, f, None, nf, c)

@@ -1876,12 +1876,27 @@ def _bn_chunks(bounds, device, C=64):
             rows = np.stack([g, r0, np.minimum(step[g], b[g + 1] - r0)], 1).astype(np.int32)
             if rows.shape[0] == 0:
                 rows = np.zeros((1, 3), np.int32)
-            return h2d(torch.from_numpy(rows), torch.int32, device).view(-1, 3), int(gco[-1]), h2d(torch.from_numpy(gco.astype(np.int32)), torch.int32, device)
+            return rows, int(gco[-1]), gco.astype(np.int32)
         red, nred, gco = table(np.maximum(step_rows, -(-ng // 1024)))
         app, napp, _ = table(np.full_like(ng, step_rows))
         ns = np.maximum(ng, 1).astype(np.float64)
-        unb = h2d(torch.from_numpy((ns / np.maximum(ns - 1, 1)).astype(np.float32)), torch.float32, device).view(-1, 1)   # biased -> unbiased variance
-        return (red, nred, gco, h2d(torch.from_numpy(ns.astype(np.float32)), torch.float32, device), app, napp, unb)
+        unb = (ns / np.maximum(ns - 1, 1)).astype(np.float32)          # biased -> unbiased variance
+        # ONE upload for the five tables (they were five: ~17 us of host time each, twice per step for the class branches'
+        # ever-changing bounds): 4-byte words, every piece at a 16-byte boundary
+        parts = [red.reshape(-1), app.reshape(-1), gco, ns.astype(np.float32).view(np.int32), unb.view(np.int32)]
+        offs, tot = [], 0
+        for q in parts:
+            offs.append(tot)
+            tot += (q.size + 3) & ~3
+        flat = np.zeros(tot, np.int32)
+        for q, o in zip(parts, offs):
+            flat[o:o + q.size] = q
+        dev_flat = h2d(torch.from_numpy(flat), torch.int32, device)
+
+        def piece(i):
+            return dev_flat[offs[i]:offs[i] + parts[i].size]
+        return (piece(0).view(-1, 3), nred, piece(2), piece(3).view(torch.float32), piece(1).view(-1, 3), napp,
+                piece(4).view(torch.float32).view(-1, 1))
     return _cached(_chunk_cache, ck, build, 512)
 
 

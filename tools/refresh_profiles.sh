@@ -32,6 +32,9 @@ python $R/tools/mb_roi_contract.py > $O/${RN}_roi_contract.txt 2>&1
 python $R/tools/torch_ops_by_site.py > $O/${RN}_ops_by_site.txt 2>&1
 ls -la $O
 python $R/tools/host_sections.py > $O/${RN}_host_sections.txt 2>&1; BATCH=4 python $R/tools/host_sections.py >> $O/${RN}_host_sections.txt 2>&1
+python $R/tools/sync_waits.py > $O/${RN}_sync_waits.txt 2>&1
+python $R/tools/backward_nodes.py 2>/dev/null > $O/${RN}_backward_nodes.txt
+python $R/tools/class_branch_sections.py > $O/${RN}_class_branch_sections.txt 2>&1
 # other configurations and inference, one line each
 ( echo "# other configurations at the end of round ${RN#r0} (bf16 operands; one box, one call)"
 for a in "--dataset sunrgbd --config S100k-yaw --batch 8" "--config S200k" "--natural" "--batch 8" "--batch 2" "--batch 1" "--head-precision fp32"; do
