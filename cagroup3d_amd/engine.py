@@ -1032,6 +1032,7 @@ def compile_class_branches(head, nf, nc, c, km9, km5, km_up, ident, fine_bounds,
             ([m[0].kernel for m in mods], [(m[1][0] if up else m[1]).bn for m in mods])
             for mods, up in ((head.cls_individual_out, False), (head.cls_individual_expand_out, False),
                              (head.cls_individual_up, True), (head.cls_individual_fuse, False)))
+    ME.pairs_many([(km9, fine_bounds), (km5, coarse_bounds), (km_up, fine_bounds), (ident, fine_bounds)])    # one host read for the four
     a = b.gbn_act(b.gconv(xf, L[0][0], km9, fine_bounds, True), L[0][1], fine_bounds, elu)
     e = b.gbn_act(b.gconv(xc, L[1][0], km5, coarse_bounds, True), L[1][1], coarse_bounds, elu)
     u = b.gbn_act(b.gconv(e, L[2][0], km_up, fine_bounds, False), L[2][1], fine_bounds, elu)

@@ -163,6 +163,47 @@ class KernelMap:
         nbr = torch.arange(n, dtype=torch.int32, device=device).view(1, n)
         return KernelMap(nbr, 1, n, n, lambda: nbr)
 
+    def _pairs_count(self, row_bounds):
+        """First half of `pairs`: the counting launch; returns what `_pairs_finish` needs (the offsets are still on the device)."""
+        lib = _lib.get()
+        dev = self.nbr.device
+        total = self.K * self.n_out
+        G = 1 if row_bounds is None else len(row_bounds) - 1
+        # ungrouped maps: the same launch also reports where every block of WGRAD_BLOCK_ROWS output rows starts in
+        # each offset's list (the blocks are "groups" to the counting kernel) -- `wgrad_segments` cuts along them
+        blocks = None
+        if WGRAD_ROW_BLOCKS and row_bounds is None and lib.is_device and self.n_out >= WGRAD_BLOCK_MIN_ROWS:
+            nb = -(-self.n_out // WGRAD_BLOCK_ROWS)
+            blocks = tuple(range(0, nb * WGRAD_BLOCK_ROWS, WGRAD_BLOCK_ROWS)) + (self.n_out,)
+            G = nb
+        rb = h2d(blocks if blocks is not None else row_bounds, torch.int32, dev) if (blocks is not None or row_bounds is not None) else None
+        ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
+        off = torch.empty(self.K * G + 1, dtype=torch.int32, device=dev)      # (zero-filled by the call)
+        lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
+                 ptr(off), lib.stream())
+        return (ws, off, G, blocks, rb)
+
+    def _pairs_finish(self, row_bounds, pending, off_h):
+        lib = _lib.get()
+        ws, _, G, blocks, _ = pending
+        any_hit = next(iter(self._pairs.values()), None)
+        off_h = off_h.astype(np.int64)
+        if blocks is not None:
+            self._blocks = (G, off_h)
+            off_h = np.concatenate([off_h[0:self.K * G:G], off_h[-1:]])
+        P = int(off_h[-1])
+        if any_hit is not None:
+            pin, pout = any_hit[0], any_hit[1]       # the lists do not depend on the grouping
+        else:
+            dev = self.nbr.device
+            pin = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+            pout = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+            lib.call("cg3d_pairs_fill", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(ws), ptr(pin),
+                     ptr(pout), lib.stream())
+        hit = (pin, pout, off_h, P)
+        self._pairs[row_bounds] = hit
+        return hit
+
     def pairs(self, row_bounds=None):
         """(pair_in, pair_out, pair_off host int64 [K*G+1], P).  row_bounds: host tuple of G+1 output-row
         boundaries (contiguous groups with their own weights) or None for a single group."""
@@ -170,37 +211,9 @@ class KernelMap:
             self._pairs = {}
         hit = self._pairs.get(row_bounds)
         if hit is None:
-            lib = _lib.get()
-            dev = self.nbr.device
-            total = self.K * self.n_out
-            G = 1 if row_bounds is None else len(row_bounds) - 1
-            # ungrouped maps: the same launch also reports where every block of WGRAD_BLOCK_ROWS output rows starts in
-            # each offset's list (the blocks are "groups" to the counting kernel) -- `wgrad_segments` cuts along them
-            blocks = None
-            if WGRAD_ROW_BLOCKS and row_bounds is None and lib.is_device and self.n_out >= WGRAD_BLOCK_MIN_ROWS:
-                nb = -(-self.n_out // WGRAD_BLOCK_ROWS)
-                blocks = tuple(range(0, nb * WGRAD_BLOCK_ROWS, WGRAD_BLOCK_ROWS)) + (self.n_out,)
-                G = nb
-            rb = h2d(blocks if blocks is not None else row_bounds, torch.int32, dev) if (blocks is not None or row_bounds is not None) else None
-            ws = torch.empty(max(int(lib.raw("cg3d_pairs_ws_bytes")(total)) // 4, 1), dtype=torch.int32, device=dev)
-            off = torch.empty(self.K * G + 1, dtype=torch.int32, device=dev)      # (zero-filled by the call)
-            lib.call("cg3d_pairs_count", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(rb), c_int32(G), ptr(ws),
-                     ptr(off), lib.stream())
-            any_hit = next(iter(self._pairs.values()), None)
-            off_h = off.cpu().numpy().astype(np.int64)  # host sync, once per kernel map (and grouping)
-            if blocks is not None:
-                self._blocks = (G, off_h)
-                off_h = np.concatenate([off_h[0:self.K * G:G], off_h[-1:]])
-            P = int(off_h[-1])
-            if any_hit is not None:
-                pin, pout = any_hit[0], any_hit[1]       # the lists do not depend on the grouping
-            else:
-                pin = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-                pout = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-                lib.call("cg3d_pairs_fill", ptr(self.nbr), c_int32(self.K), c_int64(self.n_out), ptr(ws), ptr(pin),
-                         ptr(pout), lib.stream())
-            hit = (pin, pout, off_h, P)
-            self._pairs[row_bounds] = hit
+            pending = self._pairs_count(row_bounds)
+            off_h = pending[1].cpu().numpy()          # host sync, once per kernel map (and grouping)
+            hit = self._pairs_finish(row_bounds, pending, off_h)
         return hit
 
     def wgrad_segments(self, maxlen, row_bounds=None):
@@ -661,6 +674,25 @@ TILE_SORT_ROWS = __import__("os").environ.get("CG3D_TILE_SORT_ROWS", "1") != "0"
 TILE_SORT_MAX_OCCUPANCY = 0.2       # pairs / (K * rows) below which a map's tiles are cut from signature-sorted rows
 # (window 128 = inside the tile: only useful to a kernel that skips dead 32-row blocks -- tried, not kept: spconv_tile2.hip)
 TILE_SORT_IN_TILE = __import__("os").environ.get("CG3D_TILE_SORT_IN_TILE", "0") != "0"
+
+
+def pairs_many(items):
+    """`kmap.pairs(row_bounds)` for several (kmap, row_bounds) at once: all counting launches first, ONE host read of all the
+    offset tables, then the fill launches -- the class branches need four lists in a row (one blocking read instead of four)."""
+    todo = []
+    for km, rb in items:
+        if km._pairs is None:
+            km._pairs = {}
+        if rb not in km._pairs and not any(k is km and r == rb for k, r, _ in todo):
+            todo.append((km, rb, km._pairs_count(rb)))
+    if todo:
+        host = torch.cat([p[1] for _, _, p in todo]).cpu().numpy() if len(todo) > 1 else todo[0][2][1].cpu().numpy()
+        o = 0
+        for km, rb, p in todo:
+            n = p[1].shape[0]
+            km._pairs_finish(rb, p, host[o:o + n])
+            o += n
+    return [km.pairs(rb) for km, rb in items]
 
 
 class TilePlan:
