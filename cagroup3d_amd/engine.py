@@ -43,15 +43,16 @@ STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_re
 STRIDE = 24
 WGRAD_ACC = 0x100
 
-# An address inside a program row is either absolute (< 2^60: weights, coordinate structures, module buffers) or an offset into
+# An address inside a program row is either absolute (< 2^56: weights, coordinate structures, module buffers) or an offset into
 # one of the regions below, tagged in the top bits and resolved when the pass is run.
-TAG = 60
-R_ACT, R_ZF, R_ZB, R_PG, R_DOUT, R_IN, R_IN2 = (r << TAG for r in range(1, 8))
+TAG = 56
+R_ACT, R_ZF, R_ZB, R_PG, R_DOUT, R_IN, R_IN2, R_DOUT2 = (r << TAG for r in range(1, 9))
 #   R_ACT  activations, gradients, scratch          R_ZF  zero-filled at the start of the forward pass
 #   R_ZB   zero-filled at the start of the backward pass
 #   R_PG   the parameter-gradient buffer of a backward pass (fresh zeros per pass)
 #   R_DOUT the gradient of the backbone output (known when backward runs)       R_IN the input features
-#   R_IN2  the second input of a two-input program (the class branches: features on the coarse map)
+#   R_IN2  the second input of a two-input program (the class branches: features on the coarse map; the head's first layers:
+#          the bf16 copy of the input rows)                R_DOUT2 the gradient of a second output
 ALIGN = 256
 
 
@@ -483,6 +484,14 @@ class Builder:
             elif ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 1024:
                 y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
             self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin, cout, max(ksplit, 1), y.stats, part)
+        elif self.bf16 and ME._use_bf16(cin) and ME.LinearFunction._skinny(n, cin, cout):
+            # many rows x few output channels in the bench precision (the vote offsets: 64 -> 3): me.LinearFunction._rows_gemm,
+            # i.e. the pair kernel on the identity map with fp32 rows rounded on the fly and the bf16 copy of the weights
+            wt, _ = self._planned(w2.view(1, cin, cout), False, False)
+            ar, seg, nseg = self._ident(n, 128)
+            y = T(self.alloc(max(n, 1) * cout * 4, R_ZF), n, cout)
+            self.f.add(OP_PAIRS_FWD, x.p, wt, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 1, 1)
+            wp = 0
         else:
             # generic form (fp32 parity mode / the oracle): the pair kernel on the identity map, me.LinearFunction._rows_gemm
             ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
@@ -656,7 +665,9 @@ class Builder:
         self.mark_at[len(self.tape)] = name
 
     def emit_backward(self, out):
-        out.gc = [(R_DOUT, 0)]
+        outs = out if isinstance(out, (list, tuple)) else [out]
+        for o, region in zip(outs, (R_DOUT, R_DOUT2)):
+            o.gc = [(region, 0)]
         for i in range(len(self.tape) - 1, -1, -1):
             self.tape[i]()
             name = self.mark_at.get(i)
@@ -739,8 +750,8 @@ class Emitter:
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if isinstance(m, ME.MinkowskiBatchNorm) and isinstance(nxt, ME.MinkowskiReLU):
-                x = self.bn(m, x, ME.ACT_RELU)
+            if isinstance(m, ME.MinkowskiBatchNorm) and isinstance(nxt, (ME.MinkowskiReLU, ME.MinkowskiELU)):
+                x = self.bn(m, x, ME.ACT_RELU if isinstance(nxt, ME.MinkowskiReLU) else ME.ACT_ELU)
                 i += 2
                 continue
             x = self.module(m, x)
@@ -1116,6 +1127,119 @@ def run_class_branches(head, xf, xc, km9, km5, km_up, ident, fine_bounds, coarse
         raise
     CLASS_STATS["program_passes"] += 1
     return ClassBranchFunction.apply(xf, xc, comp)
+
+
+# ------------------------------------------------------------------------------------------------ the head's first layers
+# Off by default: measured at 153.6 against 153.7 scenes/s over three alternating runs (the seven layers' backward nodes cost the
+# issuing thread 0.55 ms, the program's node 0.35 ms, and compiling it inline adds to the start of the step) -- kept for the
+# test that pins it and for a host slower than the bench boxes.
+HEAD_PROGRAM = os.environ.get("CG3D_HEAD_PROGRAM", "0") == "1"
+HEAD_STATS = {"program_passes": 0, "not_ready": 0}
+
+
+def head_pre_applicable(head):
+    """Training step in the bench precision on the device library."""
+    if not (ENABLED and HEAD_PROGRAM and head.training and torch.is_grad_enabled()) or ME.coords_only():
+        return False
+    return _lib.get().is_device and ME._prec() == 1 and ME.BF16_ROWS
+
+
+def compile_head_pre(head, sp, has16):
+    """Program pair for the two branches the dense head puts on the backbone output before anything data dependent
+    (reference cagroup_head.py:150-162, 196-199): the vote-offset block (1x1x1 conv, BN, ELU, twice, then the 1x1x1 conv to
+    3 n_vote offsets) and the feature-offset block (3^3 conv, BN, ELU).  One input (R_IN: the backbone output rows; R_IN2:
+    their bf16 copy when the backbone program left one), two outputs."""
+    lib = _lib.get()
+    b = Builder(lib, sp.F.device, ME._WeightPlan.gen)
+    n, c = sp.F.shape
+    xt = T(R_IN, n, c, need=True)
+    if has16:
+        xt.p16 = R_IN2
+    em = Emitter(b, sp.coordinate_manager)
+    x = _X(xt, sp.coordinate_map_key)
+    off = em.seq(head.offset_block, x)
+    fo = em.seq(head.feature_offset, x)
+    b.emit_backward([off.t, fo.t])
+    gin = b.grad(xt)
+    comp = Compiled(b, off.t, None, n, c, sp.coordinate_manager)
+    comp.out2 = (fo.t.p, fo.t.n, fo.t.c, fo.t.p16)
+    comp.gin = gin
+    return comp
+
+
+class HeadPreFunction(torch.autograd.Function):
+    """The head's two coordinate-independent branches as ONE autograd node (one input, two outputs)."""
+
+    @staticmethod
+    def forward(ctx, x, x16, comp):
+        lib = comp.lib
+        x = x.contiguous()
+        assert x.shape == (comp.n_in, comp.c_in) and x.dtype == torch.float32
+        sz = comp.size
+        zf, zb, act = sz[R_ZF], sz[R_ZB], sz[R_ACT]
+        arena = torch.empty(zf + zb + act + ALIGN, dtype=torch.uint8, device=x.device)
+        base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
+        bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: x.data_ptr(),
+                 R_IN2: x16.data_ptr() if x16 is not None else 0}
+        P = _resolve(comp.fwd, bases)
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, base, 0, zf)
+        prof = bool(ME.KernelProfile.enabled and lib.is_device)
+        if prof:
+            P, recs = _with_events(P, comp.fprof, lib)
+            ME.KernelProfile.records.extend(recs)
+        _run(lib, np.concatenate([head, P]))
+        ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (x, x16), prof
+        outs = []
+        for p, n, c, p16 in (comp.out, comp.out2):
+            y = _arena_view(arena, bases, p, n, c)
+            if p16:
+                ME._ROWS16[y.data_ptr()] = (y, _arena_view(arena, bases, p16, n, c, torch.int16, 2))
+            outs.append(y)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        comp, lib = ctx.comp, ctx.comp.lib
+        bases = dict(ctx.bases)
+        shapes = ((comp.out[1], comp.out[2]), (comp.out2[1], comp.out2[2]))
+        d0 = d0.contiguous() if d0 is not None else torch.zeros(shapes[0], dtype=torch.float32, device=ctx.arena.device)
+        d1 = d1.contiguous() if d1 is not None else torch.zeros(shapes[1], dtype=torch.float32, device=ctx.arena.device)
+        pg, views, _ = _pg_views(comp, d0.device)
+        bases[R_PG], bases[R_DOUT], bases[R_DOUT2] = pg.data_ptr(), d0.data_ptr(), d1.data_ptr()
+        P = _resolve(comp.bwd, bases)
+        keep = []
+        for r, c, fn in comp.late_b:
+            t = fn()
+            keep.append(t)
+            P[r, c] = t.data_ptr()
+        head = np.zeros((1, STRIDE), dtype=np.int64)
+        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+        if ctx.prof:
+            P, recs = _with_events(P, comp.bprof, lib)
+            ME.KernelProfile.records.extend(recs)
+        _run(lib, np.concatenate([head, P]))
+        with torch.no_grad():
+            for (prm, _), g in zip(comp.params, views):
+                prm.grad = g if prm.grad is None else prm.grad + g
+        dx = _arena_view(ctx.arena, bases, comp.gin[0], comp.n_in, comp.c_in) if comp.gin is not None else None
+        ctx.arena = ctx.inputs = None
+        return dx, None, None
+
+
+def run_head_pre(head, sp):
+    """(vote offsets [n, 3 n_vote], offset features [n, c n_vote]) of the dense head on the backbone output `sp`.
+    Raises NotReady when a layer has no program form (first steps: weights not in the step's arena yet)."""
+    x = sp.F
+    hit = ME._ROWS16.get(x.data_ptr())
+    x16 = hit[1] if (hit is not None and hit[0].shape == x.shape and hit[0].data_ptr() == x.data_ptr()) else None
+    try:
+        comp = compile_head_pre(head, sp, x16 is not None)
+    except NotReady:
+        HEAD_STATS["not_ready"] += 1
+        raise
+    HEAD_STATS["program_passes"] += 1
+    return HeadPreFunction.apply(x, x16, comp)
 
 
 def comp_prof_slice(prof, lo, hi):

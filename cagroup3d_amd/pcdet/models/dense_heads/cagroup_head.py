@@ -125,8 +125,23 @@ class CAGroup3DHead(nn.Module):
         out = input_dict["sp_tensor"]
         semantic_scores = self.semantic_conv(out)
         ts = out.coordinate_map_key.get_key()[0][0]
-        voxel_offsets = self.offset_block(out)
-        offset_features = self.feature_offset(out).F
+        pre = None
+        if FUSED_HEAD:
+            from .... import engine
+            if engine.head_pre_applicable(self):
+                # the vote-offset block and the feature-offset block as one launch program each way (engine.compile_head_pre):
+                # two foreign calls and one autograd node for seven layers
+                try:
+                    pre = engine.run_head_pre(self, out)
+                except engine.NotReady:
+                    pre = None
+        if pre is not None:
+            voxel_offsets = ME.SparseTensor(features=pre[0], coordinate_map_key=out.coordinate_map_key,
+                                            coordinate_manager=out.coordinate_manager)
+            offset_features = pre[1]
+        else:
+            voxel_offsets = self.offset_block(out)
+            offset_features = self.feature_offset(out).F
         n_vote = 3 if self.with_yaw else 1
         offset_features = offset_features.view(offset_features.shape[0], n_vote, -1)
         sem_prob = semantic_scores.F.detach().sigmoid()

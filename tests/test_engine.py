@@ -335,3 +335,79 @@ def test_class_branch_program_equals_per_layer_path_on_the_device(hip):
     assert not bad, bad
     for k in ref[3]:
         assert _l2(ref[3][k].float(), got[3][k].float()) <= 3 * _l2(ref[3][k].float(), ref2[3][k].float()) + 1e-3, k
+
+
+# ------------------------------------------------------------------------------------------------ the head's first layers
+def _head_pre_step(head, sp_args, feat, ups, use_program):
+    for p in head.parameters():
+        p.grad = None
+    x = feat.clone().requires_grad_(True)
+    me._ROWS16.clear()
+    me.prepare_weights(True)
+    me.WANT_BN_STATS = True
+    sp = me.SparseTensor(features=x, coordinate_map_key=sp_args[1], coordinate_manager=sp_args[0])
+    if use_program:
+        assert engine.head_pre_applicable(head)
+        off, fo = engine.run_head_pre(head, sp)
+    else:
+        off, fo = head.offset_block(sp).F, head.feature_offset(sp).F
+    me.finish_weights()
+    ((off * ups[0]).sum() + (fo * ups[1]).sum()).backward()
+    names = ("offset_block", "feature_offset")
+    grads = {n: p.grad.detach().clone().cpu() for n, p in head.named_parameters() if n.startswith(names)}
+    bufs = {n: b.detach().clone().cpu() for n, b in head.named_buffers() if n.startswith(names)}
+    return torch.cat([off.detach().cpu(), fo.detach().cpu()], 1), x.grad.detach().cpu(), grads, bufs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset,nrows", [("scannet", 20000), ("sunrgbd", 9000), ("scannet", 3000)])
+def test_head_pre_program_equals_per_layer_path_on_the_device(hip, dataset, nrows):
+    """engine.run_head_pre (the vote-offset block and the feature-offset block as one autograd node) against the module calls it
+    replaces; 20 000 rows: the 64 -> 3 layer takes the streaming pair kernel (me.LinearFunction._skinny), 3 000: the library."""
+    prec, me.PRECISION = me.PRECISION, 1
+    keep_flag, engine.HEAD_PROGRAM = engine.HEAD_PROGRAM, True
+    try:
+        model, _ = build_model.build_cagroup3d(dataset, seed=0)
+        head = model.dense_head.cuda().train()
+        g = torch.Generator().manual_seed(4)
+        coords = torch.cat([torch.randint(0, 2, (nrows * 2, 1), generator=g), torch.randint(0, 60, (nrows * 2, 2), generator=g),
+                            torch.randint(0, 6, (nrows * 2, 1), generator=g)], 1).float().cuda()
+        sp0 = me.SparseTensor(coordinates=coords, features=torch.zeros(coords.shape[0], 1, device="cuda"))
+        n = sp0.C.shape[0]
+        c = head.offset_block[0].kernel.shape[-2]
+        feat = torch.randn(n, c, generator=g).cuda()
+        n_vote = 3 if head.with_yaw else 1
+        ups = (torch.randn(n, 3 * n_vote, generator=g).cuda(), torch.randn(n, c * n_vote, generator=g).cuda())
+        state = {k: v.clone() for k, v in head.state_dict().items()}
+        args = (sp0.coordinate_manager, sp0.coordinate_map_key)
+
+        def run(use_program):
+            head.load_state_dict(state)
+            return _head_pre_step(head, args, feat, ups, use_program)
+        for e in (False, False):
+            run(e)
+        for e in (True, True, True):               # the program's weight variants enter the arena one refusal at a time
+            try:
+                run(e)
+            except engine.NotReady:
+                pass
+        ref, ref2 = run(False), run(False)
+        before = engine.HEAD_STATS["program_passes"]
+        got = run(True)
+        assert engine.HEAD_STATS["program_passes"] == before + 1
+    finally:
+        me.PRECISION = prec
+        engine.HEAD_PROGRAM = keep_flag
+        me._WeightPlan.reset()
+    assert ref[0].shape == got[0].shape and set(ref[2]) == set(got[2]) and len(ref[2]) == 10
+    assert _l2(ref[0], got[0]) <= 3 * _l2(ref[0], ref2[0]) + 2e-4, (_l2(ref[0], got[0]), _l2(ref[0], ref2[0]))
+    assert _l2(ref[1], got[1]) <= 3 * _l2(ref[1], ref2[1]) + 2e-3, (_l2(ref[1], got[1]), _l2(ref[1], ref2[1]))
+    bad = {}
+    for k in ref[2]:
+        if float(ref[2][k].norm()) > 1e-3:
+            noise, err = _l2(ref[2][k], ref2[2][k]), _l2(ref[2][k], got[2][k])
+            if err > 3 * noise + 4e-3:
+                bad[k] = (err, noise)
+    assert not bad, bad
+    for k in ref[3]:
+        assert _l2(ref[3][k].float(), got[3][k].float()) <= 3 * _l2(ref[3][k].float(), ref2[3][k].float()) + 1e-3, k
