@@ -1,0 +1,46 @@
+"""Per-step wall times of the bench loop (host clock around train_step; the step's own blocking reads keep the host within
+one step of the device): is the run-to-run scatter of bench.py made of outlier steps or of a shifted level?  dev tool; GPU box."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import bench  # noqa: E402
+from cagroup3d_amd import build_model, me  # noqa: E402
+from cagroup3d_amd.optim import ClippedAdamW  # noqa: E402
+
+me.PRECISION = 1
+dev = torch.device("cuda", 0)
+try:
+    from cagroup3d_amd.hostpin import pin_host_threads
+    if os.environ.get("CG3D_PIN", "1") != "0":
+        pin_host_threads(0)
+except Exception as e:  # noqa: BLE001
+    print("no pinning:", e)
+model, cfg = bench.make_model("scannet", True, dev)
+model.train()
+opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
+batch = build_model.synthetic_batch("S50k", 4, device=dev)
+for _ in range(6):
+    bench.train_step(model, opt, batch, 10.0)
+import gc
+gc.collect()
+gc.freeze()
+torch.cuda.synchronize()
+N = int(os.environ.get("STEPS", "80"))
+ts = []
+t_prev = time.perf_counter()
+for _ in range(N):
+    bench.train_step(model, opt, batch, 10.0)
+    t = time.perf_counter()
+    ts.append(1e3 * (t - t_prev))
+    t_prev = t
+torch.cuda.synchronize()
+bench.finish_prefetch(model)
+a = np.array(ts)
+print("mean %.2f  median %.2f  p10 %.2f  p90 %.2f  max %.2f  | first 10: %s" %
+      (a.mean(), np.median(a), np.percentile(a, 10), np.percentile(a, 90), a.max(), np.round(a[:10], 1)))
+print("by block of 10:", np.round(a[: N // 10 * 10].reshape(-1, 10).mean(1), 2))
