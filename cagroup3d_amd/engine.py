@@ -22,7 +22,6 @@ Reference: pcdet/models/backbones_3d/biresnet.py:8-406 (the module tree `emit` w
 import collections
 import os
 import struct
-import threading
 
 import numpy as np
 import torch
