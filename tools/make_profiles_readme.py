@@ -81,7 +81,11 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_other_configs.txt" % RN, "bench lines of the other configurations and inference"),
                    ("%s_roi_contract.txt" % RN, "the per-RoI 7^3 contraction alone: library form vs cg3d_linear_fwd (stored partial products / atomics, by number of workgroups)"),
                    ("%s_host_sections.txt" % RN, "host wall-clock per section of the step, batch 1 (no GPU wait) and batch 4"),
-                   ("%s_ops_by_site.txt" % RN, "framework ops, fills / copies, library GEMMs, reductions and sorts per source line; C-ABI calls per entry point (one step)")):
+                   ("%s_ops_by_site.txt" % RN, "framework ops, fills / copies, library GEMMs, reductions and sorts per source line; C-ABI calls per entry point (one step)"),
+                   ("%s_sync_waits.txt" % RN, "every blocking read of the issuing thread: position in the step, time inside it (long = the host was ahead of the device, tens of us = the device was idle)"),
+                   ("%s_gpu_gaps.txt" % RN, "kernel-trace timeline: launches per step, time with a kernel running on either queue, idle time by the launch that ended the gap"),
+                   ("%s_backward_nodes.txt" % RN, "host time of the backward pass per autograd node (torch.profiler)"),
+                   ("%s_class_branch_sections.txt" % RN, "host time and device tail per section of the class branches (a device sync per section)")):
     if os.path.exists(os.path.join(P, name)):
         out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
 open(os.path.join(P, "README.md"), "w").write("".join(out))
