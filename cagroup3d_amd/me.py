@@ -340,8 +340,10 @@ def _xcd_order(slot, start, cnt, off, G, row_bounds, n_out):
     return out[out >= 0]                                                # ... closed up (only the last few places shift)
 
 
-def _build_map(coords_i32, qstride):
-    """coords int32 [n,4] -> (out_coords [m,4], keys, vals, cap, unique_index [m], inverse [n])."""
+def _build_map(coords_i32, qstride, assume_unique=False):
+    """coords int32 [n,4] -> (out_coords [m,4], keys, vals, cap, unique_index [m], inverse [n]).
+    assume_unique: the caller vouches that the rows are distinct, in-range voxels (the rows of another map of this step):
+    m = n without the host read of the count."""
     lib = _lib.get()
     lib.check(coords_i32)
     n = coords_i32.shape[0]
@@ -356,6 +358,8 @@ def _build_map(coords_i32, qstride):
     n_out = torch.empty(2, dtype=torch.int32, device=dev)          # [row count, status], both written by the call
     lib.call("cg3d_coord_map_build", ptr(coords_i32), c_int64(n), c_int32(qstride), ptr(keys), ptr(vals),
              c_int64(cap), ptr(ws), ptr(out_coords), ptr(uniq), ptr(inv), ptr(n_out), lib.stream())
+    if assume_unique and qstride == 1:
+        return out_coords[:n], keys, vals, cap, uniq[:n], inv[:n]
     m, status = n_out.tolist()  # host sync: the row count sizes every later tensor on this map
     if status != 0:
         raise _lib.CG3DError("cg3d_coord_map_build: a coordinate or batch index does not fit the packed voxel key "
@@ -443,8 +447,9 @@ class CoordinateManager:
         self._uid = itertools.count()
 
     # -- maps
-    def insert(self, coords_i32, tensor_stride=1, sort=False):
-        """sort: build the map in (batch, Morton) row order (SparseTensor construction: the features are re-indexed through
+    def insert(self, coords_i32, tensor_stride=1, sort=False, assume_unique=False):
+        """assume_unique: the rows are the (distinct) rows of another map -- no host read of the row count.
+        sort: build the map in (batch, Morton) row order (SparseTensor construction: the features are re-indexed through
         `unique_index` / `inverse_mapping` anyway).  Maps at caller-given output coordinates (`conv(x, coordinates)`) keep
         the caller's order: row i of the result belongs to coordinate i."""
         coords_i32 = coords_i32.contiguous()
@@ -456,7 +461,7 @@ class CoordinateManager:
             inv = torch.empty_like(inv_s)
             inv[order] = inv_s
         else:
-            out, keys, vals, cap, uniq, inv = _build_map(coords_i32, 1)
+            out, keys, vals, cap, uniq, inv = _build_map(coords_i32, 1, assume_unique)
         key = CoordinateMapKey(tensor_stride, next(self._uid))
         self._maps[key] = _CoordMap(out, keys, vals, cap, out.shape[0], int(tensor_stride))
         return key, uniq, inv

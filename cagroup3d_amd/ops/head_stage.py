@@ -13,7 +13,7 @@ from .. import _lib
 from .._lib import ptr
 
 
-def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, expand, n_batch):
+def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, expand, n_batch, before_read=None):
     """hit bool / uint8 [N, C]; coords int32 [N,4]; pad_row int32 [B]; offsets float32 [N, n_vote*3]; vs_tab float32 [C,3].
     -> (src int32 [T], fine int32 [T,4], coarse int32 [T,4], sel list[C]) with T = (sum(sel) + C*B) * (n_vote + 1)."""
     lib = _lib.get()
@@ -27,6 +27,10 @@ def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, ex
     work = torch.empty((C + 6) * nblk + C + 6, dtype=torch.int32, device=dev)
     block_off, totals = work[:(C + 6) * nblk], work[(C + 6) * nblk:]
     lib.call("cg3d_class_count", ptr(hit8), c_int64(N), c_int32(C), ptr(coords), ptr(block_off), ptr(totals), lib.stream())
+    if before_read is not None:
+        # the caller's data-only host reads (ground-truth padding mask, scene sizes): behind the counting launch, so that THIS
+        # stage's read -- the first of the step that waits for the device -- finds its result ready when they return
+        before_read()
     sel = totals[:C].tolist()                                     # the stage's host read (the reference: torch.nonzero)
     T = (sum(sel) + C * n_batch) * (n_vote + 1)
     out = torch.empty((T, 9), dtype=torch.int32, device=dev)      # one allocation: fine | coarse | src (16-byte aligned rows first)

@@ -152,13 +152,25 @@ class CAGroup3DHead(nn.Module):
             if forced is None or forced.shape[0] != out.F.shape[0]:
                 forced = self._forced_selection(input_dict, out, out.C[:, 1:].float() * self.voxel_size)
 
+        # the ground-truth lists need one host read of the padding mask (and the detector's scene sizes another): taken right
+        # behind the class-row counting launch, inside the step's first wait for the device -- not after the class branches,
+        # where every blocking read leaves the device idle until the next launch arrives
+        gt_holder = []
+
+        def early_reads():
+            if self.predict_boxes and "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
+                gt_holder.append(split_gt_boxes(input_dict["gt_boxes"], torch.int))
+            early = input_dict.pop("early_host_reads", None)    # (the detector's own data-only host reads: same place, same reason)
+            if early is not None:
+                early()
         object.__setattr__(self, "_merged", None)
         fused = self.batched and FUSED_HEAD and out.F.shape[0] > 0
         if fused:
             # selection, pad voxels, voted positions (with the scene-bound clamp) and both quantisations: ops/head_stage.class_rows
             outs = self._class_branches_batched(out, sem_prob, forced, None, None, None, None, offset_features, n_vote, batch_size,
-                                                votes=voxel_offsets.F.detach(), ts=ts)
+                                                votes=voxel_offsets.F.detach(), ts=ts, before_read=early_reads)
         else:
+            early_reads()
             pad_id = torch.stack([p[0] for p in semantic_scores.decomposition_permutations]).long()  # first row of every scene
             xyz_vox = out.C[:, 1:]
             # (column reductions of the strided [N, 3] view run one workgroup chain per column: 100 + 52 us on 156 k rows;
@@ -184,8 +196,8 @@ class CAGroup3DHead(nn.Module):
             else:
                 out_dict["pred_bbox_list"] = self.get_bboxes(centernesses, bbox_preds, cls_scores, voxel_points,
                                                              [None] * batch_size, rescale=False)
-            if "gt_boxes" in input_dict and "gt_bboxes_3d" not in input_dict:
-                out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = split_gt_boxes(input_dict["gt_boxes"], torch.int)
+            if gt_holder:
+                out_dict["gt_bboxes_3d"], out_dict["gt_labels_3d"] = gt_holder[0]
         return out_dict
 
     def _vs_table(self, device):
@@ -288,7 +300,7 @@ class CAGroup3DHead(nn.Module):
         return src, fine, coarse
 
     def _class_branches_batched(self, out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote,
-                                batch_size, votes=None, ts=None):
+                                batch_size, votes=None, ts=None, before_read=None):
         """All class branches at once: rows of class c live at batch index c*B + b of ONE coordinate map,
         class-major, so every hash build / kernel map / convolution / NMS is a single (grouped) launch.
         Row order inside a class equals the loop version's, so results match it up to fp32 summation order.
@@ -309,7 +321,7 @@ class CAGroup3DHead(nn.Module):
                 else:
                     pad_row = ME.h2d(starts, torch.int32, dev)
                 src, fine, coarse, _ = HS.class_rows(hit, out.C, pad_row, votes, n_vote, self.voxel_size, int(ts),
-                                                     vs_tab, self.expand, B)
+                                                     vs_tab, self.expand, B, before_read=before_read)
             fuse_feat = HS.gather_rows2(offset_features.reshape(N * n_vote, -1), out.F, src)
         else:
             with torch.no_grad():
@@ -339,7 +351,7 @@ class CAGroup3DHead(nn.Module):
         mgr, emgr = cls_map.coordinate_manager, cls_exp.coordinate_manager
         km9 = mgr.kernel_map(cls_map.coordinate_map_key, cls_map.coordinate_map_key, self.cls_kernel, 1, False)
         km5 = emgr.kernel_map(cls_exp.coordinate_map_key, cls_exp.coordinate_map_key, 5, 1, False)
-        tgt_key, _, _ = emgr.insert(fine_C, 1)                             # generative transposed conv onto the fine voxels
+        tgt_key, _, _ = emgr.insert(fine_C, 1, assume_unique=True)         # generative transposed conv onto the fine voxels (rows of cls_map: distinct, no host read)
         km_up = emgr.kernel_map(cls_exp.coordinate_map_key, tgt_key, self.expand, 1, True)
         ident = ME.KernelMap.identity(fine_C.shape[0], dev)
         _tick("maps")

@@ -225,6 +225,14 @@ class CAGroup3D(Detector3DTemplate):
             # the two heads (and their losses) under ME.HEAD_PRECISION when that is set ("bf16 backbone", fp32 heads)
             with ME.precision_scope(ME.HEAD_PRECISION if i > 0 else None):
                 batch_dict.update(module(batch_dict))
+            if i == 0 and self.training:
+                # the per-scene views of the raw points (the losses' scene_points) cost one host read of the scene sizes.  The
+                # dense head takes it where its own first blocking read is -- after the backbone AND its coordinate-independent
+                # layers have been issued, the host ahead of the device -- instead of between the heads and the backward pass,
+                # where every blocking read leaves the device idle until the next launch arrives
+                def early_reads(bd=batch_dict):
+                    bd["scene_points"] = self.convert2list(bd["points"], bd["batch_size"])
+                batch_dict["early_host_reads"] = early_reads
             if i == 0 and self.training and getattr(self, "grad_sync", None) is not None:
                 self.grad_sync.attach(batch_dict["sp_tensor"].F)      # heads' gradients are complete when this one is
         if self.training:
@@ -276,7 +284,8 @@ class CAGroup3D(Detector3DTemplate):
         centernesses, bbox_preds, cls_scores, voxel_points = x
         loss_one, tb_dict = self.dense_head.loss(
             centernesses, bbox_preds, cls_scores, voxel_points, semantic_scores, voxel_offset,
-            batch_dict["gt_bboxes_3d"], batch_dict["gt_labels_3d"], self.convert2list(batch_dict["points"], bs),
+            batch_dict["gt_bboxes_3d"], batch_dict["gt_labels_3d"],
+            batch_dict["scene_points"] if batch_dict.get("scene_points") is not None else self.convert2list(batch_dict["points"], bs),
             [None] * bs, masks("semantic_mask"), masks("instance_mask"))
         loss_two, tb_two = self.roi_head.loss(batch_dict)
         loss_all = loss_one + loss_two

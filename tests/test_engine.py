@@ -330,7 +330,7 @@ def test_class_branch_program_equals_per_layer_path_on_the_device(hip):
     for k in ref[2]:
         if float(ref[2][k].norm()) > 1e-3:
             noise, err = _l2(ref[2][k], ref2[2][k]), _l2(ref[2][k], got[2][k])
-            if err > 3 * noise + 1e-3:
+            if err > 3 * noise + 4e-3:      # the averaging quantisation in front of both paths sums duplicates with atomics: its own run-to-run flips reach 1.3e-3 on single kernels
                 bad[k] = (err, noise)
     assert not bad, bad
     for k in ref[3]:
