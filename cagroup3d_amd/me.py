@@ -340,10 +340,8 @@ def _xcd_order(slot, start, cnt, off, G, row_bounds, n_out):
     return out[out >= 0]                                                # ... closed up (only the last few places shift)
 
 
-def _build_map(coords_i32, qstride, assume_unique=False):
-    """coords int32 [n,4] -> (out_coords [m,4], keys, vals, cap, unique_index [m], inverse [n]).
-    assume_unique: the caller vouches that the rows are distinct, in-range voxels (the rows of another map of this step):
-    m = n without the host read of the count."""
+def _build_map_begin(coords_i32, qstride):
+    """The launch half of `_build_map`: everything but the host read of the row count."""
     lib = _lib.get()
     lib.check(coords_i32)
     n = coords_i32.shape[0]
@@ -358,13 +356,26 @@ def _build_map(coords_i32, qstride, assume_unique=False):
     n_out = torch.empty(2, dtype=torch.int32, device=dev)          # [row count, status], both written by the call
     lib.call("cg3d_coord_map_build", ptr(coords_i32), c_int64(n), c_int32(qstride), ptr(keys), ptr(vals),
              c_int64(cap), ptr(ws), ptr(out_coords), ptr(uniq), ptr(inv), ptr(n_out), lib.stream())
-    if assume_unique and qstride == 1:
-        return out_coords[:n], keys, vals, cap, uniq[:n], inv[:n]
-    m, status = n_out.tolist()  # host sync: the row count sizes every later tensor on this map
+    return (n, cap, keys, vals, out_coords, uniq, inv, n_out)
+
+
+def _build_map_finish(state, m, status):
+    n, cap, keys, vals, out_coords, uniq, inv, _ = state
     if status != 0:
         raise _lib.CG3DError("cg3d_coord_map_build: a coordinate or batch index does not fit the packed voxel key "
                              "(|x|,|y|,|z| < %d, 0 <= batch < %d): the rows would be dropped silently" % (16384, 524288))
     return out_coords[:m], keys, vals, cap, uniq[:m], inv[:n]
+
+
+def _build_map(coords_i32, qstride, assume_unique=False):
+    """coords int32 [n,4] -> (out_coords [m,4], keys, vals, cap, unique_index [m], inverse [n]).
+    assume_unique: the caller vouches that the rows are distinct, in-range voxels (the rows of another map of this step):
+    m = n without the host read of the count."""
+    state = _build_map_begin(coords_i32, qstride)
+    if assume_unique and qstride == 1:
+        return _build_map_finish(state, state[0], 0)
+    m, status = state[7].tolist()  # host sync: the row count sizes every later tensor on this map
+    return _build_map_finish(state, m, status)
 
 
 # Row order of every map inserted from raw coordinates: (batch, Morton(x, y, z)) instead of the order the points arrive in
@@ -452,16 +463,33 @@ class CoordinateManager:
         sort: build the map in (batch, Morton) row order (SparseTensor construction: the features are re-indexed through
         `unique_index` / `inverse_mapping` anyway).  Maps at caller-given output coordinates (`conv(x, coordinates)`) keep
         the caller's order: row i of the result belongs to coordinate i."""
+        begun = self._insert_begin(coords_i32, sort)
+        state = begun[1]
+        if assume_unique:
+            m, status = state[0], 0
+        else:
+            m, status = state[7].tolist()  # host sync: the row count sizes every later tensor on this map
+        return self._insert_finish(begun, m, status, tensor_stride)
+
+    def _insert_begin(self, coords_i32, sort):
+        """Launch half of `insert` (ordering + map build); `_insert_finish` needs the map's (row count, status) from the host."""
         coords_i32 = coords_i32.contiguous()
+        order = None
         if sort and MORTON_ROWS and coords_i32.shape[0] > 1:
             _lib.get().check(coords_i32)
             order = _morton_order(coords_i32)
-            out, keys, vals, cap, uniq, inv_s = _build_map(coords_i32[order].contiguous(), 1)
+            coords_i32 = coords_i32[order].contiguous()
+        return (order, _build_map_begin(coords_i32, 1))
+
+    def _insert_finish(self, begun, m, status, tensor_stride):
+        order, state = begun
+        out, keys, vals, cap, uniq, inv_s = _build_map_finish(state, m, status)
+        if order is not None:
             uniq = order[uniq.long()].to(torch.int32)           # representative rows / inverse map in the caller's row numbering
             inv = torch.empty_like(inv_s)
             inv[order] = inv_s
         else:
-            out, keys, vals, cap, uniq, inv = _build_map(coords_i32, 1, assume_unique)
+            inv = inv_s
         key = CoordinateMapKey(tensor_stride, next(self._uid))
         self._maps[key] = _CoordMap(out, keys, vals, cap, out.shape[0], int(tensor_stride))
         return key, uniq, inv
@@ -2237,17 +2265,7 @@ class SparseTensor:
             if coordinates.dtype.is_floating_point:
                 coordinates = torch.floor(coordinates)
             ci = coordinates.to(torch.int32).contiguous()
-            key, uniq, inv = self.coordinate_manager.insert(ci, int(tensor_stride), sort=True)
-            self.rows_batch_major = bool(MORTON_ROWS and ci.shape[0] > 1)    # (batch, Morton) row order: the batch column ascends
-            self.coordinate_map_key = key
-            self.unique_index, self.inverse_mapping = uniq, inv
-            n_out = uniq.shape[0]
-            if n_out == ci.shape[0] and not (MORTON_ROWS and n_out > 1):
-                self.F = features                       # one row per voxel, rows in the caller's order
-            elif quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
-                self.F = ScatterMeanFunction.apply(features, inv.view(1, -1), n_out)
-            else:
-                self.F = gather_rows(features, uniq) if (features.dim() == 2 and features.dtype == torch.float32) else features[uniq.long()]
+            self._from_map(self.coordinate_manager.insert(ci, int(tensor_stride), sort=True), ci.shape[0], features, quantization_mode)
         else:
             assert coordinate_map_key is not None and coordinate_manager is not None
             self.coordinate_manager, self.coordinate_map_key = coordinate_manager, coordinate_map_key
@@ -2255,6 +2273,43 @@ class SparseTensor:
             self.unique_index = self.inverse_mapping = None
             self.rows_batch_major = False
         assert self.F.shape[0] == self._map.n, (self.F.shape, self._map.n)
+
+    def _from_map(self, inserted, n_rows, features, quantization_mode):
+        key, uniq, inv = inserted
+        self.rows_batch_major = bool(MORTON_ROWS and n_rows > 1)    # (batch, Morton) row order: the batch column ascends
+        self.coordinate_map_key = key
+        self.unique_index, self.inverse_mapping = uniq, inv
+        n_out = uniq.shape[0]
+        if n_out == n_rows and not (MORTON_ROWS and n_out > 1):
+            self.F = features                       # one row per voxel, rows in the caller's order
+        elif quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
+            self.F = ScatterMeanFunction.apply(features, inv.view(1, -1), n_out)
+        else:
+            self.F = gather_rows(features, uniq) if (features.dim() == 2 and features.dtype == torch.float32) else features[uniq.long()]
+
+    @classmethod
+    def build_many(cls, specs):
+        """Several tensors from raw coordinates -- each dict(features, coordinates, tensor_stride=1, quantization_mode=...) -- with
+        ONE host read for all their row counts: every map's ordering and build launches first, then the read, then the rest
+        (the class branches build the fine and the coarse tensor of all classes back to back)."""
+        begun = []
+        for sp in specs:
+            coordinates = sp["coordinates"]
+            if coordinates.dtype.is_floating_point:
+                coordinates = torch.floor(coordinates)
+            ci = coordinates.to(torch.int32).contiguous()
+            mgr = CoordinateManager()
+            begun.append((mgr, ci.shape[0], mgr._insert_begin(ci, True)))
+        host = torch.cat([b[2][1][7] for b in begun]).tolist()
+        out = []
+        for i, (sp, (mgr, n_rows, bg)) in enumerate(zip(specs, begun)):
+            t = cls.__new__(cls)
+            t.coordinate_manager = mgr
+            t._from_map(mgr._insert_finish(bg, host[2 * i], host[2 * i + 1], int(sp.get("tensor_stride", 1))), n_rows, sp["features"],
+                        sp.get("quantization_mode", SparseTensorQuantizationMode.RANDOM_SUBSAMPLE))
+            assert t.F.shape[0] == t._map.n
+            out.append(t)
+        return out
 
     # -- accessors
     @property

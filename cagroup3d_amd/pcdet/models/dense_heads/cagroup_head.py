@@ -334,10 +334,10 @@ class CAGroup3DHead(nn.Module):
 
         _tick("class_rows+gather")
         avg = ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
-        cls_map = ME.SparseTensor(coordinates=fine, features=fuse_feat, quantization_mode=avg)
-        _tick("fine tensor")
-        cls_exp = ME.SparseTensor(coordinates=coarse, features=fuse_feat, tensor_stride=self.expand, quantization_mode=avg)
-        _tick("coarse tensor")
+        cls_map, cls_exp = ME.SparseTensor.build_many([          # (one host read for the two maps' row counts)
+            dict(coordinates=fine, features=fuse_feat, quantization_mode=avg),
+            dict(coordinates=coarse, features=fuse_feat, tensor_stride=self.expand, quantization_mode=avg)])
+        _tick("fine + coarse tensor")
         fine_C = cls_map.C
         with torch.no_grad():                                             # ONE host read for all group sizes
             fb, cb = fine_C[:, 0].long(), cls_exp.C[:, 0].long()
