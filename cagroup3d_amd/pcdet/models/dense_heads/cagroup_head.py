@@ -2,6 +2,8 @@
 stage-1 losses (mirror of pcdet/models/dense_heads/cagroup_head.py:14-797) on the gfx950 engine.
 
 Data flow of one class branch: SURVEY.md Appendix B."""
+import collections.abc
+
 import numpy as np
 import torch
 from torch import nn
@@ -48,6 +50,35 @@ def _tick(name):
         a = _time.perf_counter()
         torch.cuda.synchronize()
         TICKS.append((name, a, _time.perf_counter()))
+
+
+class _LazyClassLists:
+    """The class branches' outputs as the reference returns them -- four lists (centre-ness, box, class score, points) of
+    n_classes lists of one tensor per scene -- cut from the (class, scene)-major merged rows on first use."""
+
+    def __init__(self, merged, per_scene, n_classes, n_batch):
+        self._args, self._lists = (list(merged), list(per_scene), n_classes, n_batch), None
+
+    def lists(self):
+        if self._lists is None:
+            merged, per_scene, C, B = self._args
+            pieces = [torch.split(t, per_scene) for t in merged]
+            self._lists = [[list(pieces[j][c * B:(c + 1) * B]) for c in range(C)] for j in range(4)]
+        return self._lists
+
+    def view(self, j):
+        return _LazyClassList(self, j)
+
+
+class _LazyClassList(collections.abc.Sequence):
+    def __init__(self, owner, j):
+        self._owner, self._j = owner, j
+
+    def __getitem__(self, i):
+        return self._owner.lists()[self._j][i]
+
+    def __len__(self):
+        return self._owner._args[2]
 
 
 class CAGroup3DHead(nn.Module):
@@ -184,7 +215,10 @@ class CAGroup3DHead(nn.Module):
             batch_col = out.C[:, :1].float()
             branch = self._class_branches_batched if self.batched else self._class_branches_loop
             outs = branch(out, sem_prob, forced, pad_id, batch_col, voted, ori_xyz, offset_features, n_vote, batch_size)
-        centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
+        if isinstance(outs, _LazyClassLists):
+            centernesses, bbox_preds, cls_scores, voxel_points = (outs.view(j) for j in range(4))
+        else:
+            centernesses, bbox_preds, cls_scores, voxel_points = [list(x) for x in zip(*outs)]
         out_dict = {"one_stage_results": [[centernesses, bbox_preds, cls_scores, voxel_points], semantic_scores, voxel_offsets],
                     "middle_feature_list": [None, None, None, out] if return_middle_feature else None}
         if self.predict_boxes:
@@ -401,13 +435,10 @@ class CAGroup3DHead(nn.Module):
         object.__setattr__(self, "_merged", {"centerness": merged[0], "bbox_pred": merged[1], "cls_score": merged[2],
                                              "points": merged[3], "seg": seg, "per_scene": per_scene})
         _tick("linears+outputs")
-        pieces = [torch.split(t, per_scene) for t in merged]
-        outs = []
-        for c in range(C):
-            sl = slice(c * B, (c + 1) * B)
-            for p in pieces[3][sl]:
-                assert len(p) > 0, "forward empty"
-            outs.append((list(pieces[0][sl]), list(pieces[1][sl]), list(pieces[2][sl]), list(pieces[3][sl])))
+        assert min(per_scene) > 0, "forward empty"
+        # the reference's per-class, per-scene lists are cut from the merged rows when somebody reads them: the batched loss and
+        # the batched proposal stage work on the merged rows themselves (288 views and their Python lists per step otherwise)
+        outs = _LazyClassLists(merged, per_scene, C, B)
         _tick("split")
         return outs
 
