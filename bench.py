@@ -63,9 +63,12 @@ def parse():
                          "accumulation, storage and the weight gradient are fp32 in both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="S50k:4", help="config:scenes per step timed on the CPU oracle (the GPU's own batch)")
-    ap.add_argument("--head-precision", choices=["bf16", "fp32"], default="bf16",
-                    help="operand type of the two heads' convolutions (class branches, RoI pooling, 1x1x1 layers) in the bf16 run: "
-                         "fp32 = BASELINE.json configs[1] read literally (\"bf16 backbone\"); the other one is timed as a sub-record")
+    ap.add_argument("--head-precision", choices=["split", "bf16", "fp32"], default="split",
+                    help="arithmetic of the two heads' convolutions (class branches, RoI pooling, 1x1x1 layers) in the bf16 run.  "
+                         "BASELINE.json configs[1] says \"bf16 backbone\" and the reference's heads are fp32: split (default) = "
+                         "fp32-accurate products from three bf16 MFMA passes on split operands (me.PREC_SPLIT), fp32 = fp32 MFMA "
+                         "operands, bf16 = bf16 operands in the heads too (a wider precision scope than configs[1] names).  The "
+                         "two modes not chosen are timed as sub-records")
     ap.add_argument("--cpu-sample-1t", default="S5k:1", help="config:scenes of the single-thread CPU leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
@@ -270,7 +273,8 @@ def main():
         dist.init_process_group(backend=os.environ.get("CG3D_DIST_BACKEND", "nccl"))   # "nccl" = RCCL on ROCm
     forced = not args.natural
     me.PRECISION = 1 if args.precision == "bf16" else 0
-    me.HEAD_PRECISION = 0 if (args.precision == "bf16" and args.head_precision == "fp32") else None
+    HEADS = {"split": me.PREC_SPLIT, "fp32": 0, "bf16": None}
+    me.HEAD_PRECISION = HEADS[args.head_precision] if args.precision == "bf16" else None
 
     model, cfg = make_model(args.dataset, forced, dev, build_model.VOXEL_SIZE_OF_CONFIG.get(args.config))
     model.train()
@@ -347,13 +351,33 @@ def main():
         "wgrad_bf16_fp32rows": ("k_spconv_pairs_wgrad_bf16 (weight gradient, fp32 rows rounded to bf16 operands)", "k_spconv_pairs_wgrad_bf16"),
         "wgrad": ("k_spconv_pairs_wgrad / _t128 (weight gradient, fp32 MFMA)", "k_spconv_pairs_wgrad"),
     }
+    # "...x3" kinds: the same kernels on split operands (the heads, me.PREC_SPLIT): a launch multiplies a three times longer
+    # contraction -- three bf16 products per fp32-accurate product.  Such a launch is priced at the bf16 peak for the 3 x flops
+    # it performs (equivalently: its 2 P Cin Cout at a third of the peak); `roofline.split_launches` states their share.
+
+    def base_kind(k):
+        return k[:-2] if k.endswith("x3") else k
+
+    def flops_of(k, f):
+        return 3.0 * f if k.endswith("x3") else f
 
     def roofline_of(dt_, profiled, steps, precision):
         """per launch flops = 2 P Cin Cout, bytes = every tensor once; bound = max(flops / MFMA peak, bytes / HBM peak)."""
         kinds = me.KernelProfile.summary()
-        fwd = {k: v for k, v in kinds.items() if not k.startswith("wgrad")}
+        # by KERNEL (the plain and the split-operand launches of one kernel are one line of a rocprofv3 kernel-stats table)
+        merged = {}
+        for k, v in kinds.items():
+            d = merged.setdefault(base_kind(k), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "bytes_per_pair": 0.0,
+                                                 "split_launches": 0, "split_ms": 0.0})
+            for f in ("launches", "ms", "bytes", "bytes_per_pair"):
+                d[f] += v[f]
+            d["flops"] += flops_of(k, v["flops"])
+            if k.endswith("x3"):
+                d["split_launches"] += v["launches"]
+                d["split_ms"] += v["ms"]
+        fwd = {k: v for k, v in merged.items() if not k.startswith("wgrad")}
         kind = max(fwd, key=lambda k: fwd[k]["ms"])                      # the dominant forward / data-gradient kernel of this run
-        prof = kinds[kind]
+        prof = merged[kind]
         secs = prof["ms"] * 1e-3
         bf16 = precision == 1
 
@@ -371,9 +395,10 @@ def main():
                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "achieved_tflops": tf}
         per_kind = {}
         for r in me.KernelProfile.records:
-            d = per_kind.setdefault(r[4][0], [0.0, 0.0])
-            d[0] += max(r[2] / peak_of(r[4][0]), r[3] / bw)
-            d[1] += r[0].elapsed_time(r[1]) * 1e-3
+            for key in {r[4][0], base_kind(r[4][0])}:
+                d = per_kind.setdefault(key, [0.0, 0.0])
+                d[0] += max(flops_of(r[4][0], r[2]) / peak_of(r[4][0]), r[3] / bw)
+                d[1] += r[0].elapsed_time(r[1]) * 1e-3
         roof.update(launches=prof["launches"], avg_launch_ms=prof["ms"] / max(prof["launches"], 1),
                     kernel_time_share=secs / (dt_ * profiled / steps), timed_steps=profiled,
                     algorithmic_bytes_per_launch=prof["bytes"] / max(prof["launches"], 1),
@@ -385,12 +410,15 @@ def main():
                     per_pair_gbytes_per_s=prof["bytes_per_pair"] / secs / 1e9 if secs > 0 else None,
                     conv_kernels={k: {"launches_per_step": v["launches"] / profiled, "ms_per_step": v["ms"] / profiled,
                                       "bound_over_measured": per_kind[k][0] / per_kind[k][1] if per_kind[k][1] > 0 else None,
-                                      "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
+                                      "tflops": flops_of(k, v["flops"]) / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
                                       "gbytes_per_s_8d": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None}
                                   for k, v in kinds.items()})
         roof["traffic"], roof["traffic_source"] = pmc_traffic(KNAMES[kind][1]) if bf16 else (None, None)
-        bound_all = sum(v[0] for v in per_kind.values())
-        meas_all = sum(v[1] for v in per_kind.values())
+        roof["split_launches"] = {"launches": prof["split_launches"], "ms_per_step": prof["split_ms"] / profiled,
+                                  "note": "launches of this kernel on split operands (the two heads): 3 bf16 products per fp32-accurate "
+                                          "product, counted as the 3 x 2 P Cin Cout bf16 flops the launch performs"}
+        bound_all = sum(v[0] for k, v in per_kind.items() if k in kinds)
+        meas_all = sum(v[1] for k, v in per_kind.items() if k in kinds)
         # every sparse convolution of the step (forward, data and weight gradient): their 8(d) bounds over their measured
         # time, and over the whole step (which also holds BN, the heads, losses, target assignment, AdamW, map building)
         roof["conv_bound_over_conv_time"] = bound_all / meas_all if meas_all > 0 else None
@@ -416,19 +444,22 @@ def main():
                     "roofline_unit": r32["unit"], "frac": r32["frac"], "frac_8d_per_layer": r32["frac_8d_per_layer"],
                     "avg_launch_ms": r32["avg_launch_ms"], "conv_bound_over_step_time": r32["conv_bound_over_step_time"]}
         me.PRECISION = 1
-    other_heads = None
+    other_heads = {}
     if me.PRECISION == 1 and not args.no_fp32 and os.environ.get("CG3D_BENCH_FP32", "1") != "0":
-        # the same bf16 backbone with the heads in the OTHER precision (fp32 heads = configs[1] read literally, bf16 heads = the
-        # wider scope), same process, model and batch
+        # the same bf16 backbone with the heads in the two OTHER arithmetics, same process, model and batch, as many steps as
+        # the headline (at most 20)
         keep = me.HEAD_PRECISION
-        me.HEAD_PRECISION = 0 if keep is None else None
-        n2 = max(3, min(args.steps, 6))
-        for _ in range(3):
-            train_step(net, opt, batch, clip)
-        dt2, _, _ = timed_run(n2)
-        if rank == 0:
-            other_heads = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2, "warmup": 3,
-                           "heads": "fp32" if keep is None else "bf16"}
+        for name, hp in HEADS.items():
+            if hp == keep:
+                continue
+            me.HEAD_PRECISION = hp
+            n2 = max(3, min(args.steps, 20))
+            for _ in range(3):
+                train_step(net, opt, batch, clip)
+            dt2, _, _ = timed_run(n2)
+            if rank == 0:
+                other_heads[name] = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+                                     "warmup": 3, "heads": name}
         me.HEAD_PRECISION = keep
     finish_prefetch(net)            # the worker thread is done and joined before anything else happens (cpu_baseline, exit)
 
@@ -444,7 +475,13 @@ def main():
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
                           "precision": (("bf16 MFMA operands (fp32 accumulate) in the convolutions (>= 16 input channels) of the BACKBONE "
                                          "only -- forward, data gradient and weight gradient; both heads (class branches, RoI pooling, "
-                                         "1x1x1 layers) run fp32 operands: BASELINE.json configs[1] read literally"
+                                         "1x1x1 layers) compute fp32-accurate products from three bf16 MFMA passes on split operands "
+                                         "(x = hi + lo: xhi whi + xlo whi + xhi wlo, ~1e-5 relative; tests/test_split_precision.py pins "
+                                         "them against the fp32 oracle at rtol 1e-4): BASELINE.json configs[1] (\"bf16 backbone\")"
+                                         if me.HEAD_PRECISION == me.PREC_SPLIT else
+                                         "bf16 MFMA operands (fp32 accumulate) in the convolutions (>= 16 input channels) of the BACKBONE "
+                                         "only -- forward, data gradient and weight gradient; both heads (class branches, RoI pooling, "
+                                         "1x1x1 layers) run fp32 MFMA operands: BASELINE.json configs[1] read literally"
                                          if me.HEAD_PRECISION == 0 else
                                          "bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
                                          "backbone, class branches, RoI pooling and the 1x1x1 layers; forward, data gradient AND weight "
@@ -456,8 +493,8 @@ def main():
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32
-        if other_heads is not None:
-            out["bf16_backbone_only" if other_heads["heads"] == "fp32" else "bf16_all_convolutions"] = other_heads
+        for name, rec in other_heads.items():
+            out[{"fp32": "bf16_backbone_fp32_heads", "bf16": "bf16_all_convolutions", "split": "bf16_backbone_split_heads"}[name]] = rec
         if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):
             out["comm"] = model.grad_sync.report()
         if use_dist:

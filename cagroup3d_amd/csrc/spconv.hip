@@ -394,6 +394,79 @@ extern "C" int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream
     return CG3D_OK;
 }
 
+// ---------------------------------------------------------------- split operands ("bf16x3": fp32-accurate products on the bf16 pipe)
+// x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi).  A product of two fp32 values is then
+//   x w = xhi whi + xlo whi + xhi wlo + O(2^-16 |x w|)
+// i.e. three bf16 MFMA products accumulated in fp32 -- 3/16 of the cost of v_mfma_f32_32x32x2_f32.  The split is done on the
+// OPERANDS, not in the kernels: rows become [hi | lo | hi] (3 c channels), the contraction side of the weights becomes
+// [Whi ; Whi ; Wlo], and every bf16 kernel of this library (tile, dense-map, pair, linear) runs unchanged on a three times
+// longer contraction.  BASELINE.json configs[1] words its precision as "bf16 backbone": this is how the two heads keep the
+// reference's fp32 arithmetic (cagroup_head.py:227-282, cagroup_roi_head.py:69-91) without the fp32 MFMA rate.
+__device__ static inline void split_bf(float v, uint32_t &hi, uint32_t &lo) {
+    hi = f2bf(v);
+    const float r = v - __uint_as_float(hi << 16);               // exact in fp32
+    lo = ((hi & 0x7f80u) == 0x7f80u) ? 0u : f2bf(r);             // inf / NaN stay in the hi part alone
+}
+__global__ void k_to_bf16_split(const float4 *__restrict__ X, uint2 *__restrict__ Xs, int64_t n_rows, int32_t c4) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n_rows * c4) return;
+    const int64_t row = t / c4;
+    const int32_t q = (int32_t)(t - row * c4);
+    const float4 v = X[t];
+    uint32_t h[4], l[4];
+    split_bf(v.x, h[0], l[0]); split_bf(v.y, h[1], l[1]); split_bf(v.z, h[2], l[2]); split_bf(v.w, h[3], l[3]);
+    const uint2 hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16)), lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    uint2 *dst = Xs + row * 3 * c4 + q;
+    dst[0] = hi;
+    dst[c4] = lo;
+    dst[2 * c4] = hi;
+}
+extern "C" int cg3d_to_bf16_split(const float *X, uint16_t *Xs, int64_t n_rows, int32_t c, cg3d_stream_t stream) {
+    if (n_rows < 0 || c < 4 || (c & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Xs & 7)) return CG3D_ERR_ARG;
+    if (n_rows == 0) return CG3D_OK;
+    const int64_t n4 = n_rows * (c / 4);
+    hipLaunchKernelGGL(k_to_bf16_split, dim3((unsigned)cg3d_divup(n4, 256)), dim3(256), 0, cg3d_hs(stream),
+                       reinterpret_cast<const float4 *>(X), reinterpret_cast<uint2 *>(Xs), n_rows, c / 4);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+// Split weights, element form: fp32 [slot][ci][co] -> the forward operand W_t over the contraction index ci' in [0, 3 cin)
+// (ci' = part * cin + ci; parts 0, 1 hold bf16(W), part 2 holds bf16(W - bf16(W))) and / or the data gradient's operand
+// W_p over co' in [0, 3 cout), each row-major ([slot][co][3 cin] / [slot][ci][3 cout]) or in MFMA fragment order
+// (cg3d_frag_index with kdim = 3 cin / 3 cout).
+__global__ __launch_bounds__(256) void k_prep_weights_split(const float *__restrict__ W0, const float *const *__restrict__ Ws,
+                                                            uint16_t *__restrict__ W_t, uint16_t *__restrict__ W_p,
+                                                            int64_t slots_per, int32_t cin, int32_t cout, int32_t frag) {
+    const int64_t slot = blockIdx.x;
+    const int64_t per = (int64_t)cin * cout;
+    const float *src = Ws ? Ws[slot / slots_per] + (slot % slots_per) * per : W0 + slot * per;
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.y * 256) {
+        const int ci = (int)(i / cout), co = (int)(i % cout);
+        uint32_t hi, lo;
+        split_bf(src[i], hi, lo);
+#pragma unroll
+        for (int part = 0; part < 3; part++) {
+            const uint16_t b = (uint16_t)(part < 2 ? hi : lo);
+            if (W_t) W_t[slot * 3 * per + (frag ? cg3d_frag_index(co, part * cin + ci, 3 * cin) : (int64_t)co * 3 * cin + part * cin + ci)] = b;
+            if (W_p) W_p[slot * 3 * per + (frag ? cg3d_frag_index(ci, part * cout + co, 3 * cout) : (int64_t)ci * 3 * cout + part * cout + co)] = b;
+        }
+    }
+}
+extern "C" int cg3d_spconv_prep_weights_split(const float *W0, const float *const *Ws, uint16_t *W_t, uint16_t *W_p, int32_t G,
+                                              int64_t slots_per, int32_t cin, int32_t cout, int32_t frag, cg3d_stream_t stream) {
+    if (G < 1 || slots_per < 0 || cin < 1 || cout < 1 || (!W0 && !Ws) || (!W_t && !W_p)) return CG3D_ERR_ARG;
+    if (frag && W_t && ((cin & 15) || (cout & 31))) return CG3D_ERR_ARG;
+    if (frag && W_p && ((cout & 15) || (cin & 31))) return CG3D_ERR_ARG;
+    const int64_t slots = (int64_t)G * slots_per;
+    if (slots == 0) return CG3D_OK;
+    if (slots > 0x7fffffffll) return CG3D_ERR_RANGE;
+    const unsigned gy = (unsigned)(cg3d_divup((int64_t)cin * cout, 2048) < 64 ? cg3d_divup((int64_t)cin * cout, 2048) : 64);
+    hipLaunchKernelGGL(k_prep_weights_split, dim3((unsigned)slots, gy), dim3(256), 0, cg3d_hs(stream), W0, Ws, W_t, W_p, slots_per,
+                       cin, cout, frag ? 1 : 0);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
 // fp32 weights [slot][ci][co] -> bf16 copies, transposed [slot][co][ci] (the MFMA B operand of forward) and/or plain
 // [slot][ci][co] (the B operand of the data gradient), 64 x 64 tiles through LDS so both sides stay coalesced.
 // The slots may come from G separate tensors (one per class branch, `Ws` = device array of G pointers): the grouped
@@ -438,13 +511,18 @@ extern "C" int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float 
 //   { address of the fp32 slot [cin][cout], address of its transposed bf16 copy or 0, address of its plain bf16 copy or
 //     0, cin, cout, tile index = ci_tile * ceil(cout / 64) + co_tile }
 __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__restrict__ table) {
-    __shared__ __attribute__((aligned(16))) uint16_t T[64][72];       // 144-byte rows: 16-byte aligned pieces
+    __shared__ __attribute__((aligned(16))) uint16_t T[2][64][72];       // 144-byte rows: 16-byte aligned pieces; [1]: the lo parts (split rows)
     const int64_t *row = table + (int64_t)blockIdx.x * 6;
     const float *src = reinterpret_cast<const float *>(row[0]);
     uint16_t *Wb_t = reinterpret_cast<uint16_t *>(row[1]);
     uint16_t *Wb = reinterpret_cast<uint16_t *>(row[2]);
     const int cin = (int)row[3], cout = (int)row[4], tile = (int)(row[5] & 0xfffffff);
     const bool frag_t = (row[5] >> 30) & 1, frag_p = (row[5] >> 29) & 1;       // copies in MFMA fragment order (cg3d_spconv_tile_fwd)
+    // split row (bit 28): the copies are the three-part operands of cg3d_spconv_prep_weights_split -- the transposed copy over
+    // the contraction index part * cin + ci, the plain copy over part * cout + co (parts 0, 1: bf16(W); part 2: the remainder)
+    const bool split = (row[5] >> 28) & 1;
+    const int NP = split ? 3 : 1;
+    const int kt = NP * cin, kp = NP * cout;                                   // contraction lengths of the two copies
     const int co_tiles = (cout + 63) / 64;
     const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
     // Full tiles of 16-byte aligned tensors (every layer of the model but the 3- / 6- / 18-channel ends): a thread moves 8
@@ -459,12 +537,23 @@ __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__res
             const int piece = threadIdx.x + 256 * j, r = piece >> 3, c8 = (piece & 7) * 8;     // r: input channel, c8: output channel
             const float4 *sp = reinterpret_cast<const float4 *>(src + (int64_t)(ci0 + r) * cout + co0 + c8);
             const float4 a = sp[0], b = sp[1];
-            uint4 o;
-            o.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16); o.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
-            o.z = (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16); o.w = (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16);
-            *reinterpret_cast<uint4 *>(&T[r][c8]) = o;
-            if (Wb)
-                *reinterpret_cast<uint4 *>(Wb + (frag_p ? cg3d_frag_index(ci0 + r, co0 + c8, cout) : (int64_t)(ci0 + r) * cout + co0 + c8)) = o;
+            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (split) split_bf(f[e], h[e], l[e]);
+                else { h[e] = f2bf(f[e]); l[e] = 0u; }
+            }
+            const uint4 o = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            const uint4 ol = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+            *reinterpret_cast<uint4 *>(&T[0][r][c8]) = o;
+            if (split) *reinterpret_cast<uint4 *>(&T[1][r][c8]) = ol;
+            if (Wb) {
+                for (int part = 0; part < NP; part++) {
+                    const int kc = part * cout + co0 + c8;
+                    *reinterpret_cast<uint4 *>(Wb + (frag_p ? cg3d_frag_index(ci0 + r, kc, kp) : (int64_t)(ci0 + r) * kp + kc)) = part < 2 ? o : ol;
+                }
+            }
         }
         __syncthreads();
         if (!Wb_t) return;
@@ -472,27 +561,43 @@ __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__res
         for (int j = 0; j < 2; j++) {
             // lanes of a wave: r (output channel) fastest, so the eight 2-byte LDS reads of a step hit 32 consecutive columns
             const int piece = threadIdx.x + 256 * j, r = piece & 63, c8 = (piece >> 6) * 8;    // c8: input channel
-            uint32_t w[4];
+            for (int part = 0; part < NP; part++) {
+                const int sel = part < 2 ? 0 : 1;
+                uint32_t w[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) w[e] = (uint32_t)T[c8 + 2 * e][r] | ((uint32_t)T[c8 + 2 * e + 1][r] << 16);
-            *reinterpret_cast<uint4 *>(Wb_t + (frag_t ? cg3d_frag_index(co0 + r, ci0 + c8, cin) : (int64_t)(co0 + r) * cin + ci0 + c8)) =
-                make_uint4(w[0], w[1], w[2], w[3]);
+                for (int e = 0; e < 4; e++) w[e] = (uint32_t)T[sel][c8 + 2 * e][r] | ((uint32_t)T[sel][c8 + 2 * e + 1][r] << 16);
+                const int kc = part * cin + ci0 + c8;
+                *reinterpret_cast<uint4 *>(Wb_t + (frag_t ? cg3d_frag_index(co0 + r, kc, kt) : (int64_t)(co0 + r) * kt + kc)) =
+                    make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
         return;
     }
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int r = i >> 6, c = i & 63;                       // r: input channel, c: output channel
         const bool ok = ci0 + r < cin && co0 + c < cout;
-        const uint16_t b = ok ? (uint16_t)f2bf(src[(int64_t)(ci0 + r) * cout + co0 + c]) : (uint16_t)0;
-        T[r][c] = b;
-        if (Wb && ok) Wb[frag_p ? cg3d_frag_index(ci0 + r, co0 + c, cout) : (int64_t)(ci0 + r) * cout + co0 + c] = b;
+        uint32_t hi = 0u, lo = 0u;
+        if (ok) {
+            const float v = src[(int64_t)(ci0 + r) * cout + co0 + c];
+            if (split) split_bf(v, hi, lo); else hi = f2bf(v);
+        }
+        T[0][r][c] = (uint16_t)hi;
+        T[1][r][c] = (uint16_t)lo;
+        if (Wb && ok)
+            for (int part = 0; part < NP; part++) {
+                const int kc = part * cout + co0 + c;
+                Wb[frag_p ? cg3d_frag_index(ci0 + r, kc, kp) : (int64_t)(ci0 + r) * kp + kc] = (uint16_t)(part < 2 ? hi : lo);
+            }
     }
     __syncthreads();
     if (!Wb_t) return;
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int r = i >> 6, c = i & 63;                       // r: output channel, c: input channel
         if (co0 + r < cout && ci0 + c < cin)
-            Wb_t[frag_t ? cg3d_frag_index(co0 + r, ci0 + c, cin) : (int64_t)(co0 + r) * cin + ci0 + c] = T[c][r];
+            for (int part = 0; part < NP; part++) {
+                const int kc = part * cin + ci0 + c;
+                Wb_t[frag_t ? cg3d_frag_index(co0 + r, kc, kt) : (int64_t)(co0 + r) * kt + kc] = T[part < 2 ? 0 : 1][c][r];
+            }
     }
 }
 extern "C" int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream) {
@@ -1436,7 +1541,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void k_spconv_pairs_wgrad
                                                                       const int32_t *__restrict__ pout,
                                                                       const int32_t *__restrict__ seg,
                                                                       float *__restrict__ dW, int32_t cin, int32_t cout,
-                                                                      int32_t co_tiles) {
+                                                                      int32_t co_tiles, int32_t ldx, int32_t ldy) {
+    // ldx / ldy: row pitch of X / dY in elements (cin / cout for plain rows; 3 cin / 3 cout when the operands are the hi or
+    // lo part of split rows, cg3d_to_bf16_split)
     __shared__ __attribute__((aligned(16))) uint16_t Xs[2][TM * WB_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Ds[2][TN * WB_LD];
     constexpr int WJ = NW / 2;                           // waves along the output-channel direction (2 along the input channels)
@@ -1491,13 +1598,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void k_spconv_pairs_wgrad
 #pragma unroll
         for (int i = 0; i < XPQ; i++) {
             const int32_t p = p0 + xp0 + i;
-            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + (int64_t)ix.xi[i] * cin);
+            const uint4 a = *reinterpret_cast<const uint4 *>(xbase + (int64_t)ix.xi[i] * ldx);
             xr.v[i] = (p < count && xin) ? a : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < DPQ; i++) {
             const int32_t p = p0 + dp0 + i;
-            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + (int64_t)ix.di[i] * cout);
+            const uint4 b = *reinterpret_cast<const uint4 *>(dbase + (int64_t)ix.di[i] * ldy);
             dr.v[i] = (p < count && din) ? b : make_uint4(0u, 0u, 0u, 0u);
         }
     };
@@ -1664,7 +1771,7 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
     // CG3D_WGRAD_ACCUMULATE: dW += ... (the caller initialised dW -- e.g. one zero-fill for every weight gradient of a pass)
     const bool accumulate = (precision & CG3D_WGRAD_ACCUMULATE) != 0;
     precision &= ~CG3D_WGRAD_ACCUMULATE;
-    if (precision < 0 || precision > 2) return CG3D_ERR_ARG;
+    if (precision < 0 || precision > 3) return CG3D_ERR_ARG;
     hipStream_t s = cg3d_hs(stream);
     if (!accumulate && hipMemsetAsync(dW, 0, (int64_t)K * cin * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     if (nseg == 0) return CG3D_OK;
@@ -1683,23 +1790,27 @@ extern "C" int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const in
         else if (n128) LAUNCH_WB(64, 128, ST);                                                                     \
         else LAUNCH_WB(64, 64, ST);                                                                                \
     } while (0)
-        if (precision == 2) {   // rows stored as bf16: 16-byte gathers need 8-channel multiples
+        if (precision >= 2) {   // rows stored as bf16: 16-byte gathers need 8-channel multiples
             if (cin % 8 != 0 || cout % 8 != 0) return CG3D_ERR_ARG;
-#define LAUNCH_WR(TM, TN)                                                                                          \
-    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN, 4>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(256), 0, s, \
-                       reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg, \
-                       dW, cin, cout, ot)
+            // precision 3: split rows [hi | lo | hi] of 3 cin / 3 cout channels (cg3d_to_bf16_split):
+            //   dW = Xhi^T dYhi + Xlo^T dYhi + Xhi^T dYlo   -- three accumulating launches on the parts of the same rows
+            const int npass = precision == 3 ? 3 : 1;
+            const int32_t ldx = precision == 3 ? 3 * cin : cin, ldy = precision == 3 ? 3 * cout : cout;
             static const bool w8 = !(getenv("CG3D_WGRAD_W8") && atoi(getenv("CG3D_WGRAD_W8")) == 0);
-            if (m128 && n128 && w8)
-                hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<128, 128, 8>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(512), 0, s,
-                                   reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(dY), pair_in, pair_out, seg,
-                                   dW, cin, cout, ot);
-            else if (m128 && n128) LAUNCH_WR(128, 128);
-            else if (m128) LAUNCH_WR(128, 64);
-            else if (n128) LAUNCH_WR(64, 128);
-            else LAUNCH_WR(64, 64);
+            for (int pass = 0; pass < npass; pass++) {
+                const uint16_t *Xp = reinterpret_cast<const uint16_t *>(X) + (pass == 1 ? cin : 0);
+                const uint16_t *Dp = reinterpret_cast<const uint16_t *>(dY) + (pass == 2 ? cout : 0);
+#define LAUNCH_WR(TM, TN, NW)                                                                                      \
+    hipLaunchKernelGGL((k_spconv_pairs_wgrad_rows16<TM, TN, NW>), dim3((unsigned)nseg, (unsigned)(ct * ot)), dim3(NW * 64), 0, s, \
+                       Xp, Dp, pair_in, pair_out, seg, dW, cin, cout, ot, ldx, ldy)
+                if (m128 && n128 && w8) LAUNCH_WR(128, 128, 8);
+                else if (m128 && n128) LAUNCH_WR(128, 128, 4);
+                else if (m128) LAUNCH_WR(128, 64, 4);
+                else if (n128) LAUNCH_WR(64, 128, 4);
+                else LAUNCH_WR(64, 64, 4);
 #undef LAUNCH_WR
-            CG3D_CHECK_LAUNCH();
+                CG3D_CHECK_LAUNCH();
+            }
             return CG3D_OK;
         }
         LAUNCH_WB_ALL(float);

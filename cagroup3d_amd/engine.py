@@ -38,7 +38,7 @@ STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_re
 (OP_NOP, OP_MEMSET, OP_COPY2D, OP_TO_BF16, OP_TILE_FWD, OP_SPCONV_FWD, OP_SPCONV_FWD_TILED, OP_PAIRS_FWD, OP_PAIRS_WGRAD,
  OP_LINEAR_FWD, OP_BN_SUMS, OP_BN_APPLY_SUMS, OP_BN_APPLY, OP_BN_BWD_SUMS, OP_BN_BWD_APPLY_SUMS, OP_BN_BWD_APPLY, OP_INTERP_MAP,
  OP_INTERP_FWD, OP_INTERP_BWD, OP_GATHER_ROWS, OP_SCATTER_ADD_ROWS, OP_SCATTER_MEAN_FWD, OP_SCATTER_MEAN_BWD,
- OP_EVENT_RECORD) = range(24)
+ OP_EVENT_RECORD, OP_TO_BF16_SPLIT) = range(25)
 STRIDE = 24
 WGRAD_ACC = 0x100
 
@@ -154,7 +154,11 @@ class Builder:
         self.late = []                  # (program, row, column, fn() -> tensor): operands that exist only at run time
         self.marks = {}                 # name -> backward row index (callbacks between two parts of the backward pass)
         self.mark_at = {}               # tape position -> name
-        self.bf16 = ME._prec() == 1 and ME.BF16_ROWS
+        self.bf16 = ME._prec() in (1, 3) and ME.BF16_ROWS
+        # split precision (ME.PREC_SPLIT, the two heads): operand rows are [hi | lo | hi] of 3 c channels written by their own
+        # pass (the BatchNorm kernels' bf16 copies are not used), weights are three-part, contractions three times as long
+        self.kx = ME._kx()
+        self.prec = ME._prec()
 
     # ---------------------------------------------------------------- memory
     def alloc(self, nbytes, region=R_ACT):
@@ -177,9 +181,19 @@ class Builder:
     def rows16(self, t):
         """bf16 copy of the rows of `t` (written by its producer, or by one conversion pass)."""
         if not t.p16:
-            t.p16 = self.alloc(max(t.n, 1) * t.c * 2)
-            self.f.add(OP_TO_BF16, t.p, t.p16, t.n * t.c)
+            t.p16 = self.alloc(max(t.n, 1) * t.c * 2 * self.kx)
+            self._to16(self.f, t.p, t.p16, t.n, t.c)
         return t.p16
+
+    def _to16(self, prog, p, p16, n, c):
+        if self.kx == 3:
+            prog.add(OP_TO_BF16_SPLIT, p, p16, n, c)
+        else:
+            prog.add(OP_TO_BF16, p, p16, n * c)
+
+    def want16(self, c):
+        """Whether an apply kernel should leave the plain bf16 copy of its output (never in the split precision)."""
+        return self.bf16 and self.kx == 1 and ME._use_bf16(c)
 
     def host_table(self, data, dtype):
         t = ME.h2d(data, dtype, self.dev)
@@ -209,8 +223,8 @@ class Builder:
                     acc = out
                 t.gsum, t.gsum16 = acc, 0
         if want16 and not t.gsum16:
-            t.gsum16 = self.alloc(max(t.n, 1) * t.c * 2)
-            self.b.add(OP_TO_BF16, t.gsum, t.gsum16, t.n * t.c)
+            t.gsum16 = self.alloc(max(t.n, 1) * t.c * 2 * self.kx)
+            self._to16(self.b, t.gsum, t.gsum16, t.n, t.c)
         return t.gsum, t.gsum16
 
     # The chunk / identity-pair / unit tables come out of me.py's host caches, which are CLEARED when they grow past their
@@ -243,7 +257,7 @@ class Builder:
     # ---------------------------------------------------------------- weights of the step's arena
     def _planned(self, w3, frag, need_plain):
         P = ME._WeightPlan
-        e = P.singles.get((w3.data_ptr(), frag))
+        e = P.singles.get((w3.data_ptr(), ME._wkind(frag)))
         if e is None or e[0].shape != w3.shape or (need_plain and not e[1]) or e[3] is None or P.dirty or P.gen != self.gen:
             ME._planned_single(w3, need_plain, frag)          # records it: converted from the next forward on
             raise NotReady("weight not in the step's arena yet")
@@ -282,17 +296,19 @@ class Builder:
             self._tile_row(prog, xg, wt, plan, y.p, n_in, cin, cout, False, y.stats, P)
         elif implicit_f:
             y = self.new(n_out, cout)
-            self._prof(prog, "implicit_bf16", K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 4.0 * K * n_out)
-            prog.add(OP_SPCONV_FWD, xg, wt, kmap.nbr.data_ptr(), 0, y.p, n_in, n_out, K, cin, cout, 2 if rows16 else 1)
+            self._prof(prog, "implicit_bf16" + ME._ksuffix(), K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 4.0 * K * n_out)
+            prog.add(OP_SPCONV_FWD, xg, wt, kmap.nbr.data_ptr(), 0, y.p, n_in, n_out, K, cin * (self.kx if rows16 else 1), cout, 2 if rows16 else 1)
         else:
             seg, nseg = kmap.segments(ME._seg_len_fwd(), None)
             y = T(self.alloc(max(n_out, 1) * cout * 4, R_ZF), n_out, cout)          # atomic scatter into zeros
             prec = 1 if ME._use_bf16(cin) else 0
+            if prec and self.kx == 3 and not rows16:
+                raise NotReady("split operands without row copies")
             wptr = wt if prec else w3.data_ptr()
-            self._prof(prog, "pairs_bf16" if prec else "pairs", K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 8.0 * P,
+            self._prof(prog, ("pairs_bf16" + ME._ksuffix()) if prec else "pairs", K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 8.0 * P,
                        wb=2.0 if prec else 4.0, nseg=nseg)
-            prog.add(OP_PAIRS_FWD, xg, wptr, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out, cin, cout,
-                     2 if rows16 else prec, 1)
+            prog.add(OP_PAIRS_FWD, xg, wptr, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out,
+                     cin * (self.kx if prec else 1), cout, 2 if rows16 else prec, 1)
         self.tape.append(lambda: self._conv_bwd(x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b))
         return y
 
@@ -304,9 +320,9 @@ class Builder:
     def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P, ksplit=1, groups=1):
         def p(t):
             return t.data_ptr() if t is not None else 0
-        self._prof(prog, "tile_bf16", plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups)
+        self._prof(prog, "tile_bf16" + ME._ksuffix(), plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups)
         prog.add(OP_TILE_FWD, x16, wf, p(plan.slots), p(plan.live), p(plan.pass_tab), p(plan.npass), p(plan.ulist), plan.maxpass,
-                 plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin, cout, ksplit,
+                 plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin * self.kx, cout, ksplit,
                  1 if wrev else 0, stats)
 
     def _conv_bwd(self, x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b):
@@ -327,16 +343,18 @@ class Builder:
                 dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
                 if not wp:
                     raise NotReady("plain bf16 copy missing")
-                self._prof(prog, "implicit_bf16", K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 4.0 * K * kmap.n_in)
-                prog.add(OP_SPCONV_FWD, dyg, wp, kmap.nbrT.data_ptr(), 0, dx, kmap.n_out, kmap.n_in, K, cout, cin, 2 if use16 else 1)
+                self._prof(prog, "implicit_bf16" + ME._ksuffix(), K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 4.0 * K * kmap.n_in)
+                prog.add(OP_SPCONV_FWD, dyg, wp, kmap.nbrT.data_ptr(), 0, dx, kmap.n_out, kmap.n_in, K, cout * (self.kx if use16 else 1), cin, 2 if use16 else 1)
             else:
                 seg, nseg = kmap.segments(ME._seg_len_fwd(), None)
                 dx = self.alloc(max(kmap.n_in, 1) * cin * 4, R_ZB)
                 if ME._use_bf16(cout):
                     if not wp:
                         raise NotReady("plain bf16 copy missing")
-                    self._prof(prog, "pairs_bf16", K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 8.0 * P, nseg=nseg)
-                    prog.add(OP_PAIRS_FWD, dyg, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin,
+                    if self.kx == 3 and not use16:
+                        raise NotReady("split operands without row copies")
+                    self._prof(prog, "pairs_bf16" + ME._ksuffix(), K, cout, cin, P, kmap.n_out, kmap.n_in, 2.0 if use16 else 4.0, 8.0 * P, nseg=nseg)
+                    prog.add(OP_PAIRS_FWD, dyg, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout * self.kx, cin,
                              2 if use16 else 1, 1)
                 else:
                     # fp32 operands: W^T as its own tensor, formed when the pass runs (the weights may change until then)
@@ -345,15 +363,15 @@ class Builder:
                     prog.add(OP_PAIRS_FWD, dy, 0, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin, 0, 1)
             self.gadd(x, dx)
         # weight gradient
-        wprec = 1 if (ME._use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+        wprec = ME._wgrad_prec(cin, cout, bool(x.p16) and self.bf16)
         xw, dyw = x.p, dy
-        if wprec and x.p16 and cout % 8 == 0 and self.bf16:
-            xw, dyw, wprec = x.p16, (dy16 if dy16 else self.grad(y, want16=True)[1]), 2
+        if wprec >= 2:
+            xw, dyw = x.p16, (dy16 if dy16 else self.grad(y, want16=True)[1])
         seg, nseg = (kmap.wgrad_segments if wprec else kmap.segments)(ME._wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), None)
-        eb = 2.0 if wprec == 2 else 4.0
+        eb = 2.0 if wprec >= 2 else 4.0
         if ME.KernelProfile.wgrad:
             prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, eb * (kmap.n_in * cin + kmap.n_out * cout) + 4.0 * K * cin * cout + 8.0 * P,
-                              ("wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"), K, cin, cout, P, kmap.n_out, nseg),
+                              ("wgrad_bf16x3" if wprec == 3 else "wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"), K, cin, cout, P, kmap.n_out, nseg),
                               eb * P * (cin + cout) + 4.0 * K * cin * cout))
         prog.add(OP_PAIRS_WGRAD, xw, dyw, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), K, cin, cout,
                  wprec | WGRAD_ACC)
@@ -394,11 +412,11 @@ class Builder:
         elif GC._tiled(kmap, P, K, closed):
             tl, ntl = kmap.tiles(row_bounds)
             y = self.new(n_out, cout)
-            self.f.add(OP_SPCONV_FWD_TILED, xg, wt, kmap.nbr.data_ptr(), tl.data_ptr(), ntl, 0, y.p, n_in, n_out, K, cin, cout, 2)
+            self.f.add(OP_SPCONV_FWD_TILED, xg, wt, kmap.nbr.data_ptr(), tl.data_ptr(), ntl, 0, y.p, n_in, n_out, K, cin * self.kx, cout, 2)
         else:
             seg, nseg = kmap.segments(ME._seg_len_fwd(), row_bounds)
             y = T(self.alloc(max(n_out, 1) * cout * 4, R_ZF), n_out, cout)          # atomic scatter into zeros
-            self.f.add(OP_PAIRS_FWD, xg, wt, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out, cin, cout, 2, 1)
+            self.f.add(OP_PAIRS_FWD, xg, wt, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n_out, cin * self.kx, cout, 2, 1)
         self.tape.append(lambda: self._gconv_bwd(x, y, weights, kmap, row_bounds, closed, G, K, cin, cout, P, wp, lds))
         return y
 
@@ -418,15 +436,15 @@ class Builder:
                 tl, ntl = kmap.tiles(rb)
                 dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
                 self.b.add(OP_SPCONV_FWD_TILED, dy16, wp, kmap.nbrT.data_ptr(), tl.data_ptr(), ntl, 0, dx, kmap.n_out, kmap.n_in, K,
-                           cout, cin, 2)
+                           cout * self.kx, cin, 2)
             else:
                 seg, nseg = kmap.segments(ME._seg_len_fwd(), rb)
                 dx = self.alloc(max(kmap.n_in, 1) * cin * 4, R_ZB)
-                self.b.add(OP_PAIRS_FWD, dy16, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin, 2, 1)
+                self.b.add(OP_PAIRS_FWD, dy16, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout * self.kx, cin, 2, 1)
             self.gadd(x, dx)
         seg, nseg = kmap.segments(ME._wgrad_seg_len(P, cin, cout, 1, G * K), rb)
         self.b.add(OP_PAIRS_WGRAD, self.rows16(x) if not x.p16 else x.p16, dy16, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg,
-                   self.pgrad_group(weights), G * K, cin, cout, 2 | WGRAD_ACC)
+                   self.pgrad_group(weights), G * K, cin, cout, (3 if self.kx == 3 else 2) | WGRAD_ACC)
 
     def gbn_act(self, x, bns, bounds, act):
         """me.FusedBNActFunction over G row groups; the G modules' parameters and running statistics as [G, C] arrays (me.BNStack)."""
@@ -441,7 +459,7 @@ class Builder:
         mv = self.alloc(2 * G * c * 4, R_ZF)
         mean, var = mv, mv + G * c * 4
         y = self.new(n, c)
-        if self.bf16 and ME._use_bf16(c):
+        if self.want16(c):
             y.p16 = self.alloc(max(n, 1) * c * 2)
         self.f.add(OP_BN_APPLY_SUMS, x.p, 0, app.data_ptr(), napp, G, c, sums, group_n.data_ptr(), _fbits(b0.eps),
                    st.weight.data_ptr(), st.bias.data_ptr(), act, y.p, y.p16, mean, var, st.running_mean.data_ptr(),
@@ -460,7 +478,7 @@ class Builder:
         dsums = self.alloc(ME.BN_SLOTS * 2 * G * c * 4, R_ZB)
         self.b.add(OP_BN_BWD_SUMS, dy, x.p, y.p, red.data_ptr(), nred, G, c, mean, var, eps, act, dsums)
         dx = self.alloc(max(n, 1) * c * 4)
-        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.bf16 and ME._use_bf16(c)) else 0
+        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.want16(c)) else 0
         self.b.add(OP_BN_BWD_APPLY_SUMS, dy, x.p, y.p, app.data_ptr(), napp, G, c, mean, var, eps, st.weight.data_ptr(), dsums,
                    group_n.data_ptr(), act, 1, dx, dx16, 0, self.pgrad_group([b.bias for b in bns]),
                    self.pgrad_group([b.weight for b in bns]))
@@ -475,15 +493,15 @@ class Builder:
             wt, wp = self._planned(w2.view(1, cin, cout), True, x.need)
             x16 = self.rows16(x)
             y = self.new(n, cout)
-            units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin // 64
+            units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin * self.kx // 64
             ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
             part = 0
             if ksplit > 1:
                 part = self.alloc(ksplit * max(n, 1) * cout * 4)
             elif ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 1024:
                 y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
-            self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin, cout, max(ksplit, 1), y.stats, part)
-        elif self.bf16 and ME._use_bf16(cin) and ME.LinearFunction._skinny(n, cin, cout):
+            self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin * self.kx, cout, max(ksplit, 1), y.stats, part)
+        elif self.bf16 and self.kx == 1 and ME._use_bf16(cin) and ME.LinearFunction._skinny(n, cin, cout):
             # many rows x few output channels in the bench precision (the vote offsets: 64 -> 3): me.LinearFunction._rows_gemm,
             # i.e. the pair kernel on the identity map with fp32 rows rounded on the fly and the bf16 copy of the weights
             wt, _ = self._planned(w2.view(1, cin, cout), False, False)
@@ -509,20 +527,20 @@ class Builder:
         if x.need:
             if own:
                 dx = self.alloc(max(n, 1) * cin * 4)
-                units, nchunk = -(-n // 128) * (cin // (128 if cin % 128 == 0 else 64)), cout // 64
+                units, nchunk = -(-n // 128) * (cin // (128 if cin % 128 == 0 else 64)), cout * self.kx // 64
                 ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
                 part = self.alloc(ksplit * max(n, 1) * cin * 4) if ksplit > 1 else 0
-                prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx, n, cout, cin, max(ksplit, 1), 0, part)
+                prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx, n, cout * self.kx, cin, max(ksplit, 1), 0, part)
             else:
                 ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
                 dx = self.alloc(max(n, 1) * cin * 4, R_ZB)
                 self.late.append((prog, len(prog.rows), 2, lambda w=w2: w.detach().t().contiguous()))
                 prog.add(OP_PAIRS_FWD, dy, 0, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, dx, n, cout, cin, 0, 1)
             self.gadd(x, dx)
-        wprec = 1 if (ME._use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+        wprec = ME._wgrad_prec(cin, cout, bool(own and x.p16 and dy16))
         xc, dyc = x.p, dy
-        if wprec and own and x.p16 and dy16 and cout % 8 == 0:
-            xc, dyc, wprec = x.p16, dy16, 2
+        if wprec >= 2:
+            xc, dyc = x.p16, dy16
         ar, seg, nseg = self._ident(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1))
         prog.add(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
                  wprec | WGRAD_ACC)
@@ -541,7 +559,7 @@ class Builder:
         mv = self.alloc(2 * c * 4, R_ZF)
         mean, var = mv, mv + c * 4
         y = self.new(n, c)
-        if self.bf16 and ME._use_bf16(c):
+        if self.want16(c):
             y.p16 = self.alloc(max(n, 1) * c * 2)
         gamma, beta = bn.weight, bn.bias
         prog.add(OP_BN_APPLY_SUMS, x.p, res.p if res is not None else 0, app.data_ptr(), napp, 1, c, sums, group_n.data_ptr(),
@@ -561,7 +579,7 @@ class Builder:
         eps = _fbits(bn.eps)
         prog.add(OP_BN_BWD_SUMS, dy, x.p, y.p, red.data_ptr(), nred, 1, c, mean, var, eps, act, dsums)
         dx = self.alloc(max(n, 1) * c * 4) if x.need else 0
-        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.bf16 and ME._use_bf16(c)) else 0
+        dx16 = self.alloc(max(n, 1) * c * 2) if (x.need and self.want16(c)) else 0
         dres = self.alloc(max(n, 1) * c * 4) if (res is not None and res.need) else 0
         if not dx:
             dx = self.alloc(max(n, 1) * c * 4)          # (the kernel always writes dX)
@@ -574,7 +592,7 @@ class Builder:
     # ---------------------------------------------------------------- relu(a [+ b]) / a + b
     def add_act(self, a, b, act):
         y = self.new(a.n, a.c, need=a.need or (b is not None and b.need))
-        if act == ME.ACT_RELU and self.bf16 and ME._use_bf16(a.c):
+        if act == ME.ACT_RELU and self.want16(a.c):
             y.p16 = self.alloc(max(a.n, 1) * a.c * 2)
         self._add_rows(self.f, a.p, b.p if b is not None else 0, y.p, a.n, a.c, act, y.p16)
         self.tape.append(lambda: self._add_act_bwd(a, b, y, act))
@@ -1019,7 +1037,7 @@ def class_branches_applicable(head):
     """Training step of the batched dense head in the bench precision on the device library (CG3D_ENGINE_ANY: tests)."""
     if not (ENABLED and CLASS_PROGRAM and head.training and torch.is_grad_enabled()) or ME.coords_only():
         return False
-    if not (ME._prec() == 1 and ME.BF16_ROWS and ME.GROUPED_BN_STACK):
+    if not (ME._prec() in (1, 3) and ME.BF16_ROWS and ME.GROUPED_BN_STACK):
         return False
     return _lib.get().is_device or os.environ.get("CG3D_ENGINE_ANY") == "1"
 
@@ -1140,7 +1158,7 @@ def head_pre_applicable(head):
     """Training step in the bench precision on the device library."""
     if not (ENABLED and HEAD_PROGRAM and head.training and torch.is_grad_enabled()) or ME.coords_only():
         return False
-    return _lib.get().is_device and ME._prec() == 1 and ME.BF16_ROWS
+    return _lib.get().is_device and ME._prec() in (1, 3) and ME.BF16_ROWS
 
 
 def compile_head_pre(head, sp, has16):
@@ -1231,7 +1249,7 @@ def run_head_pre(head, sp):
     Raises NotReady when a layer has no program form (first steps: weights not in the step's arena yet)."""
     x = sp.F
     hit = ME._ROWS16.get(x.data_ptr())
-    x16 = hit[1] if (hit is not None and hit[0].shape == x.shape and hit[0].data_ptr() == x.data_ptr()) else None
+    x16 = hit[1] if (hit is not None and hit[0].shape == x.shape and hit[0].data_ptr() == x.data_ptr() and ME._prec() == 1) else None
     try:
         comp = compile_head_pre(head, sp, x16 is not None)
     except NotReady:
@@ -1273,6 +1291,6 @@ def applicable(net, compiling=False):
     if not ENABLED or not net.training or ME.coords_only() or not (compiling or torch.is_grad_enabled()):
         return False
     lib = _lib.get()
-    if lib.is_device and ME.PRECISION == 1 and ME.BF16_ROWS:
+    if lib.is_device and ME.PRECISION in (1, 3) and ME.BF16_ROWS:
         return True
     return os.environ.get("CG3D_ENGINE_ANY") == "1" and ME.PRECISION == 0

@@ -571,9 +571,15 @@ FWD_SEG = 128  # pairs per workgroup of cg3d_spconv_pairs_fwd
 
 # Operand precision of the sparse convolutions' forward / data-gradient MFMAs:
 #   0 = fp32 operands (v_mfma_f32_32x32x2_f32, exact products) -- the parity configuration;
-#   1 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[1] "bf16 backbone".
-# Features, weights, gradients and the weight-gradient kernel stay fp32 in both modes.
+#   1 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- BASELINE.json configs[1] "bf16 backbone";
+#   3 = SPLIT bf16 operands ("bf16x3"): x = hi + lo, x w = xhi whi + xlo whi + xhi wlo -- three bf16 MFMA products per fp32
+#       product, fp32-accurate to ~1e-5 relative (include/cagroup3d_hip.h, cg3d_to_bf16_split).  Rows become [hi | lo | hi]
+#       (3 c channels), the contraction side of the weights [Whi ; Whi ; Wlo], and every bf16 kernel runs unchanged on the three
+#       times longer contraction.  The two heads run under it (HEAD_PRECISION = 3): configs[1] words its precision as "bf16
+#       backbone", the reference's heads are fp32 (cagroup_head.py:227-282), and fp32 MFMA operands cost 16 x the bf16 rate.
+# Features, weights, gradients stay fp32 in all modes.
 PRECISION = 0
+PREC_SPLIT = 3
 # Precision of a PART of the step: `precision_scope(p)` overrides PRECISION for the calling thread (the detector runs the two
 # heads under `HEAD_PRECISION` when that is set: BASELINE.json configs[1] words its precision as "bf16 backbone").  A Function
 # records the precision its forward ran under and its backward runs under the same one, whichever thread the autograd
@@ -615,7 +621,23 @@ def _ctx_precision(fn):
 
 
 def _use_bf16(cin):
-    return _prec() == 1 and cin % 8 == 0 and cin >= 16
+    """bf16 MFMA operands (plain or split) for a contraction over `cin` channels."""
+    return _prec() in (1, 3) and cin % 8 == 0 and cin >= 16
+
+
+def _split():
+    return _prec() == 3
+
+
+def _kx():
+    """Length of the contraction the kernels see, in units of the layer's own: 3 in the split precision."""
+    return 3 if _prec() == 3 else 1
+
+
+def _want_rows16(c):
+    """Whether the BatchNorm / ReLU apply kernels should leave the PLAIN bf16 copy of their output rows (the operand of the
+    next convolution in the bf16 precision; split operands are written by their own pass, cg3d_to_bf16_split)."""
+    return BF16_ROWS and _prec() == 1 and c % 8 == 0 and c >= 16
 
 
 # bf16 mode: maps whose neighbourhood occupancy P / (K * n_out) is at least this run the output-stationary
@@ -636,12 +658,13 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs, tiles
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rows16 = x.dtype == torch.int16
+    kc = cin * _kx() if rows16 else cin        # the contraction the kernel sees (split rows: 3 cin)
     if tiles is None:
         lib.call("cg3d_spconv_fwd", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(bias), ptr(y), c_int64(x.shape[0]), c_int64(n_out),
-                 c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1), lib.stream())
+                 c_int32(K), c_int32(kc), c_int32(cout), c_int32(2 if rows16 else 1), lib.stream())
     else:       # row groups with their own weights: w_bf16_t stacks G sets of K slots
         lib.call("cg3d_spconv_fwd_tiled", ptr(x), ptr(w_bf16_t), ptr(nbr), ptr(tiles[0]), c_int64(tiles[1]), ptr(bias), ptr(y),
-                 c_int64(x.shape[0]), c_int64(n_out), c_int32(K), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else 1),
+                 c_int64(x.shape[0]), c_int64(n_out), c_int32(K), c_int32(kc), c_int32(cout), c_int32(2 if rows16 else 1),
                  lib.stream())
     if prof:
         ev1.record()
@@ -650,7 +673,7 @@ def _conv_implicit_bf16(x, w_bf16_t, nbr, bias, n_out, cin, cout, n_pairs, tiles
         # figure (a gathered row counted once per pair it takes part in) round 1 reported
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
                                       xb * x.shape[0] * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out,
-                                      ("implicit_bf16", K, cin, cout, n_pairs, n_out, 0),
+                                      ("implicit_bf16" + _ksuffix(), K, cin, cout, n_pairs, n_out, 0),
                                       xb * n_pairs * cin + 4.0 * n_out * cout + 2.0 * K * cin * cout + 4.0 * K * n_out))
     return y
 
@@ -788,7 +811,7 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
         ev0.record()
     lib.call("cg3d_spconv_tile_fwd", ptr(x16), ptr(wf), ptr(plan.slots), ptr(plan.live), ptr(plan.pass_tab), ptr(plan.npass),
              ptr(plan.ulist), c_int32(plan.maxpass), c_int32(plan.ucap), ptr(plan.tiles), c_int64(plan.ntile), ptr(plan.order), ptr(bias), ptr(y),
-             c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin), c_int32(cout), c_int32(ksplit),
+             c_int64(n_in), c_int64(plan.n_out), c_int32(plan.K), c_int32(cin * _kx()), c_int32(cout), c_int32(ksplit),
              c_int32(1 if wrev else 0), ptr(stats), lib.stream())
     if prof:
         ev1.record()
@@ -796,7 +819,7 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
         wbytes = 2.0 * groups * plan.K * cin * cout
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
                                       2.0 * n_in * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out,
-                                      ("tile_bf16", plan.K, cin, cout, n_pairs, plan.n_out, 0),
+                                      ("tile_bf16" + _ksuffix(), plan.K, cin, cout, n_pairs, plan.n_out, 0),
                                       2.0 * n_pairs * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out))
     return y
 
@@ -809,10 +832,15 @@ def _prep_frag(w3, want_t=True, want_p=False):
         return (e[3] if want_t else None), (e[4] if want_p else None)
     lib = _lib.get()
     K, cin, cout = w3.shape
-    wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device) if want_t else None
-    wp = torch.empty((K, cin, cout), dtype=torch.int16, device=w3.device) if want_p else None
-    lib.call("cg3d_spconv_prep_weights_frag", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K), c_int32(cin),
-             c_int32(cout), lib.stream())
+    x = _kx()
+    wt = torch.empty((K, cout, cin * x), dtype=torch.int16, device=w3.device) if want_t else None
+    wp = torch.empty((K, cin, cout * x), dtype=torch.int16, device=w3.device) if want_p else None
+    if x == 3:
+        lib.call("cg3d_spconv_prep_weights_split", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K), c_int32(cin),
+                 c_int32(cout), c_int32(1), lib.stream())
+    else:
+        lib.call("cg3d_spconv_prep_weights_frag", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K), c_int32(cin),
+                 c_int32(cout), lib.stream())
     return wt, wp
 
 
@@ -893,9 +921,32 @@ def rows16_of(x, keep=False):
     return e[1] if (e is not None and e[0].shape == x.shape and e[0].dtype == x.dtype) else None
 
 
+_ROWS48 = {}       # split operand rows of forward activations of THIS forward (cleared with _ROWS16): data_ptr -> (x, rows)
+
+
+def _to_split(x, keep=False):
+    """fp32 [N, C] -> int16 [N, 3 C] split operand rows [hi | lo | hi] (cg3d_to_bf16_split).  keep: remember the copy for the
+    other layers that read the same activation in this forward."""
+    e = _ROWS48.get(x.data_ptr())
+    if e is not None and e[0].shape == x.shape and e[0].dtype == x.dtype:
+        return e[1]
+    lib = _lib.get()
+    n, c = x.shape
+    out = torch.empty((n, 3 * c), dtype=torch.int16, device=x.device)
+    lib.call("cg3d_to_bf16_split", ptr(x), ptr(out), c_int64(n), c_int32(c), lib.stream())
+    if keep:
+        if len(_ROWS48) > 64:
+            _ROWS48.clear()
+        _ROWS48[x.data_ptr()] = (x, out)
+    return out
+
+
 def _to_bf16(x, keep=False):
     """fp32 [N, C] -> int16 view of the bf16 rows (cg3d_to_bf16; one streaming pass, halves every later gather).
-    keep: leave a BatchNorm-written copy registered (forward activations may feed several convolutions)."""
+    keep: leave a BatchNorm-written copy registered (forward activations may feed several convolutions).
+    Split precision: the [N, 3 C] split operand rows instead."""
+    if _prec() == 3:
+        return _to_split(x, keep)
     ready = rows16_of(x, keep)
     if ready is not None:
         return ready
@@ -912,8 +963,9 @@ class _WeightPlan:
     spot and recorded; from then on `prepare_weights()` -- called by the detector at the start of every forward --
     converts every recorded weight whose tensor version changed (i.e. after every optimizer step, never in inference)
     into one persistent arena with a single launch, and the per-layer requests are answered from the arena."""
-    singles = {}        # (data_ptr, frag) -> [w3, need_plain, version, wt_view, wp_view]; frag: MFMA fragment order (tile kernel)
-    groups = {}         # (ptrs, transposed, frag) -> [weights, versions, out_view]
+    singles = {}        # (data_ptr, kind) -> [w3, need_plain, version, wt_view, wp_view]; kind bit 0: MFMA fragment order (tile kernel),
+    #                     bit 1: split operands (three-part contraction, cg3d_spconv_prep_weights_split)
+    groups = {}         # (ptrs, transposed, kind) -> [weights, versions, out_view]
     table = None        # device int64 [nrows, 6]
     nrows = 0
     dirty = False
@@ -932,46 +984,51 @@ class _WeightPlan:
     @classmethod
     def _rebuild(cls, device):
         import numpy as _np
-        n_t = sum(e[0].numel() for e in cls.singles.values()) + sum(sum(w.numel() for w in g[0]) for k, g in cls.groups.items() if k[1])
-        n_p = sum(e[0].numel() for e in cls.singles.values() if e[1]) + sum(sum(w.numel() for w in g[0]) for k, g in cls.groups.items() if not k[1])
+        def kx(kind):
+            return 3 if kind & 2 else 1
+        n_t = sum(e[0].numel() * kx(k[1]) for k, e in cls.singles.items()) + sum(sum(w.numel() for w in g[0]) * kx(k[2]) for k, g in cls.groups.items() if k[1])
+        n_p = sum(e[0].numel() * kx(k[1]) for k, e in cls.singles.items() if e[1]) + sum(sum(w.numel() for w in g[0]) * kx(k[2]) for k, g in cls.groups.items() if not k[1])
         arena_t = torch.empty(max(n_t, 1), dtype=torch.int16, device=device)
         arena_p = torch.empty(max(n_p, 1), dtype=torch.int16, device=device)
         rows, ot, op = [], 0, 0
 
-        def add(w, off_t, off_p, frag=False):
+        def add(w, off_t, off_p, kind=0):
             K, cin, cout = w.shape
             per = cin * cout
+            x = kx(kind)                                  # a slot's copies are 3 cin cout elements each in the split form
             tiles = -(-cin // 64) * -(-cout // 64)
             k = _np.repeat(_np.arange(K, dtype=_np.int64), tiles)
             t = _np.tile(_np.arange(tiles, dtype=_np.int64), K)
             r = _np.empty((K * tiles, 6), dtype=_np.int64)
             r[:, 0] = w.data_ptr() + k * per * 4
-            r[:, 1] = 0 if off_t is None else arena_t.data_ptr() + (off_t + k * per) * 2
-            r[:, 2] = 0 if off_p is None else arena_p.data_ptr() + (off_p + k * per) * 2
-            r[:, 3], r[:, 4], r[:, 5] = cin, cout, t | ((3 << 29) if frag else 0)
+            r[:, 1] = 0 if off_t is None else arena_t.data_ptr() + (off_t + k * per * x) * 2
+            r[:, 2] = 0 if off_p is None else arena_p.data_ptr() + (off_p + k * per * x) * 2
+            r[:, 3], r[:, 4], r[:, 5] = cin, cout, t | ((3 << 29) if kind & 1 else 0) | ((1 << 28) if kind & 2 else 0)
             rows.append(r)
-        for (_, frag), e in cls.singles.items():
+        for (_, kind), e in cls.singles.items():
             w = e[0]
             K, cin, cout = w.shape
-            add(w, ot, op if e[1] else None, frag)
-            e[3] = arena_t[ot:ot + w.numel()].view(K, cout, cin)
-            ot += w.numel()
+            x = kx(kind)
+            add(w, ot, op if e[1] else None, kind)
+            e[3] = arena_t[ot:ot + w.numel() * x].view(K, cout, cin * x)
+            ot += w.numel() * x
             if e[1]:
-                e[4] = arena_p[op:op + w.numel()].view(K, cin, cout)
-                op += w.numel()
+                e[4] = arena_p[op:op + w.numel() * x].view(K, cin, cout * x)
+                op += w.numel() * x
             e[2] = -1
-        for (ptrs, transposed, frag), g in cls.groups.items():
+        for (ptrs, transposed, kind), g in cls.groups.items():
             ws = g[0]
             K, cin, cout = ws[0].shape
+            x = kx(kind)
             base = ot if transposed else op
             for i, w in enumerate(ws):
-                add(w, base + i * w.numel() if transposed else None, None if transposed else base + i * w.numel(), frag)
-            tot = sum(w.numel() for w in ws)
+                add(w, base + i * w.numel() * x if transposed else None, None if transposed else base + i * w.numel() * x, kind)
+            tot = sum(w.numel() for w in ws) * x
             if transposed:
-                g[2] = arena_t[ot:ot + tot].view(len(ws) * K, cout, cin)
+                g[2] = arena_t[ot:ot + tot].view(len(ws) * K, cout, cin * x)
                 ot += tot
             else:
-                g[2] = arena_p[op:op + tot].view(len(ws) * K, cin, cout)
+                g[2] = arena_p[op:op + tot].view(len(ws) * K, cin, cout * x)
                 op += tot
             g[1] = None
         tab = _np.concatenate(rows) if rows else _np.zeros((0, 6), dtype=_np.int64)
@@ -991,7 +1048,7 @@ def prepare_weights(training=True):
     lib = _lib.get()
     P = _WeightPlan
     P.live = False
-    if not lib.is_device or PRECISION != 1 or not (P.singles or P.groups):
+    if not lib.is_device or (PRECISION not in (1, 3) and HEAD_PRECISION not in (1, 3)) or not (P.singles or P.groups):
         return
     if len(P.singles) + len(P.groups) > 512:
         P.reset()
@@ -1018,16 +1075,22 @@ def finish_weights():
     _WeightPlan.live = False
 
 
+def _wkind(frag):
+    """Key of a weight's prepared copies: bit 0 fragment order, bit 1 split operands (this thread's precision)."""
+    return (1 if frag else 0) | (2 if _prec() == 3 else 0)
+
+
 def _planned_single(w3, need_plain, frag=False):
     P = _WeightPlan
-    e = P.singles.get((w3.data_ptr(), frag))
+    kind = _wkind(frag)
+    e = P.singles.get((w3.data_ptr(), kind))
     if e is not None and e[0].shape == w3.shape and (e[1] or not need_plain):
         if P.live and e[3] is not None and e[2] == w3._version:
             return e
         return None
     if _lib.get().is_device and w3.dim() == 3:
         with _CACHE_LOCK:
-            P.singles[(w3.data_ptr(), frag)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
+            P.singles[(w3.data_ptr(), kind)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
             P.dirty = True
     return None
 
@@ -1039,6 +1102,11 @@ def _prep_bf16_t(w3):
         return e[3]
     lib = _lib.get()
     K, cin, cout = w3.shape
+    if _prec() == 3:
+        out = torch.empty((K, cout, 3 * cin), dtype=torch.int16, device=w3.device)
+        lib.call("cg3d_spconv_prep_weights_split", ptr(w3), ptr(None), ptr(out), ptr(None), c_int32(1), c_int64(K), c_int32(cin),
+                 c_int32(cout), c_int32(0), lib.stream())
+        return out
     out = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
     lib.call("cg3d_spconv_prep_weights_bf16", ptr(w3), ptr(out), c_int64(K), c_int32(cin), c_int32(cout), lib.stream())
     return out
@@ -1051,10 +1119,15 @@ def _prep_bf16_both(w3):
         return e[3], e[4]
     lib = _lib.get()
     K, cin, cout = w3.shape
-    wt = torch.empty((K, cout, cin), dtype=torch.int16, device=w3.device)
-    wp = torch.empty((K, cin, cout), dtype=torch.int16, device=w3.device)
-    lib.call("cg3d_spconv_prep_weights_bf16_multi", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K),
-             c_int32(cin), c_int32(cout), lib.stream())
+    x = _kx()
+    wt = torch.empty((K, cout, cin * x), dtype=torch.int16, device=w3.device)
+    wp = torch.empty((K, cin, cout * x), dtype=torch.int16, device=w3.device)
+    if x == 3:
+        lib.call("cg3d_spconv_prep_weights_split", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K), c_int32(cin),
+                 c_int32(cout), c_int32(0), lib.stream())
+    else:
+        lib.call("cg3d_spconv_prep_weights_bf16_multi", ptr(w3), ptr(None), ptr(wt), ptr(wp), c_int32(1), c_int64(K),
+                 c_int32(cin), c_int32(cout), lib.stream())
     return wt, wp
 
 
@@ -1068,16 +1141,23 @@ def _prep_bf16_group(weights, transposed, frag=False):
     lib = _lib.get()
     G, (K, cin, cout) = len(weights), weights[0].shape
     key = tuple(w.data_ptr() for w in weights)
-    g = _WeightPlan.groups.get((key, transposed, frag))
+    kind = _wkind(frag)
+    g = _WeightPlan.groups.get((key, transposed, kind))
     if g is not None:
         if _WeightPlan.live and g[2] is not None and g[1] == tuple(w._version for w in weights):
             return g[2]
     elif lib.is_device:
-        _WeightPlan.groups[(key, transposed, frag)] = [[w.detach() for w in weights], None, None]
-        _WeightPlan.dirty = True
+        with _CACHE_LOCK:
+            _WeightPlan.groups[(key, transposed, kind)] = [[w.detach() for w in weights], None, None]
+            _WeightPlan.dirty = True
     tab = _cached(_wptr_cache, key, lambda: h2d(list(key), torch.int64, weights[0].device) if lib.is_device
                   else torch.tensor(key, dtype=torch.int64), 64)
-    out = torch.empty((G * K, cout, cin) if transposed else (G * K, cin, cout), dtype=torch.int16, device=weights[0].device)
+    x = _kx()
+    out = torch.empty((G * K, cout, cin * x) if transposed else (G * K, cin, cout * x), dtype=torch.int16, device=weights[0].device)
+    if x == 3:
+        lib.call("cg3d_spconv_prep_weights_split", ptr(None), ptr(tab), ptr(out if transposed else None), ptr(None if transposed else out),
+                 c_int32(G), c_int64(K), c_int32(cin), c_int32(cout), c_int32(1 if frag else 0), lib.stream())
+        return out
     lib.call("cg3d_spconv_prep_weights_frag" if frag else "cg3d_spconv_prep_weights_bf16_multi", ptr(None), ptr(tab),
              ptr(out if transposed else None), ptr(None if transposed else out), c_int32(G), c_int64(K), c_int32(cin),
              c_int32(cout), lib.stream())
@@ -1086,6 +1166,11 @@ def _prep_bf16_group(weights, transposed, frag=False):
 
 def _seg_len_fwd():
     return FWD_SEG if _lib.get().is_device else (1 << 30)
+
+
+def _ksuffix():
+    """Kind suffix of a profiled launch that runs split operands (three bf16 products per algorithmic product)."""
+    return "x3" if _prec() == 3 else ""
 
 
 class KernelProfile:
@@ -1126,12 +1211,20 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
     # host-side op fewer per launch than a torch fill -- 34 of them per step
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     prec = 1 if _use_bf16(cin) else 0
+    if prec and _split() and x.dtype != torch.int16:
+        x = _to_split(x)                      # (no rounding-on-the-fly form of the split: the rows are always expanded)
     wptr = w3
+    kc = cin
     if prec == 1:
-        if w_bf16_t is None:
-            w_bf16_t = torch.empty((K, cout, cin), dtype=torch.int16, device=x.device)
-            lib.call("cg3d_spconv_prep_weights_bf16", ptr(w3), ptr(w_bf16_t), c_int64(K), c_int32(cin), c_int32(cout),
-                     lib.stream())
+        kc = cin * _kx()
+        if w_bf16_t is None:                  # converted on the spot (temporaries: not recorded in the step's weight plan)
+            w_bf16_t = torch.empty((K, cout, kc), dtype=torch.int16, device=x.device)
+            if _split():
+                lib.call("cg3d_spconv_prep_weights_split", ptr(w3), ptr(None), ptr(w_bf16_t), ptr(None), c_int32(1), c_int64(K),
+                         c_int32(cin), c_int32(cout), c_int32(0), lib.stream())
+            else:
+                lib.call("cg3d_spconv_prep_weights_bf16", ptr(w3), ptr(w_bf16_t), c_int64(K), c_int32(cin), c_int32(cout),
+                         lib.stream())
         wptr = w_bf16_t
     prof = KernelProfile.enabled and lib.is_device
     if prof:
@@ -1139,7 +1232,7 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
         ev0.record()
     rows16 = x.dtype == torch.int16
     lib.call("cg3d_spconv_pairs_fwd", ptr(x), ptr(wptr), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(bias), ptr(y),
-             c_int64(n_out), c_int32(cin), c_int32(cout), c_int32(2 if rows16 else prec), c_int32(0), lib.stream())
+             c_int64(n_out), c_int32(kc), c_int32(cout), c_int32(2 if rows16 else prec), c_int32(0), lib.stream())
     if prof:
         ev1.record()
         # algorithmic work of one launch: 2*P*cin*cout flops; bytes = every gathered input row and every
@@ -1149,7 +1242,7 @@ def _conv_pairs(x, w3, pin, pout, seg, nseg, bias, n_out, n_pairs=0, w_bf16_t=No
         xb = 2.0 if rows16 else 4.0
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
                                       xb * x.shape[0] * cin + 4.0 * n_out * cout + wb * K * cin * cout + 8.0 * n_pairs,
-                                      ("pairs_bf16" if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg),
+                                      (("pairs_bf16" + _ksuffix()) if prec else "pairs", K, cin, cout, n_pairs, n_out, nseg),
                                       n_pairs * (xb * cin + 4.0 * cout) + wb * K * cin * cout + 8.0 * n_pairs))
     return y
 
@@ -1195,8 +1288,20 @@ def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
     covers (64-channel chunks in, 64 or multiples of 128 out), enough rows to give every CU a tile.  Since the rows reach
     LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
     transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
-    return (TILE_KERNEL and _lib.get().is_device and _prec() == 1 and BF16_ROWS and row_bounds is None
+    return (TILE_KERNEL and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS and row_bounds is None
             and 1 < K <= 32 and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
+
+
+def _wgrad_prec(cin, cout, have_rows16):
+    """Precision argument of cg3d_spconv_pairs_wgrad for a layer of this thread's precision: 0 fp32 operands, 1 bf16 operands
+    rounded on the fly from fp32 rows, 2 rows stored as bf16, 3 split rows (three accumulating bf16 passes).  The split
+    precision never rounds an operand to a single bf16: without 8-channel multiples on both sides it is the fp32 kernel."""
+    wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+    if _prec() == 3:
+        return 3 if (wprec and have_rows16 and cout % 8 == 0) else 0
+    if wprec and have_rows16 and cout % 8 == 0:
+        return 2
+    return wprec
 
 
 class SparseConvFunction(torch.autograd.Function):
@@ -1228,7 +1333,7 @@ class SparseConvFunction(torch.autograd.Function):
                 _ = kmap.nbrT
             else:
                 kmap.segments(_seg_len_fwd(), row_bounds)
-            wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+            wprec = _wgrad_prec(cin, cout, True)
             (kmap.wgrad_segments if wprec else kmap.segments)(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), row_bounds)
 
     @staticmethod
@@ -1284,22 +1389,22 @@ class SparseConvFunction(torch.autograd.Function):
                 dx = _conv_tile(dyg, wp, kmap.tile_plan(True), None, cout, cin, kmap.n_out, P, wrev=kmap.symmetric)
             elif SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, rb):
                 # the swapped problem's bf16 [K, cout'=cin, cin'=cout] weights are W itself, cast
-                dx = _conv_implicit_bf16(dyg, wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16),
+                dx = _conv_implicit_bf16(dyg, wp if wp is not None else _prep_bf16_both(w3)[1],
                                          kmap.nbrT, None, kmap.n_in, cout, cin, P)
             else:
                 seg, nseg = kmap.segments(_seg_len_fwd(), rb)
                 if _use_bf16(cout):
                     dx = _conv_pairs(dyg, (KK, cout, cin), pout, pin, seg, nseg, None, kmap.n_in, P,
-                                     w_bf16_t=wp if wp is not None else w3.to(torch.bfloat16).view(torch.int16))
+                                     w_bf16_t=wp if wp is not None else _prep_bf16_both(w3)[1])
                 else:
                     wt = w3.transpose(1, 2).contiguous()
                     dx = _conv_pairs(dy, wt, pout, pin, seg, nseg, None, kmap.n_in, P)   # lists swapped
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w3)
-            wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
+            wprec = _wgrad_prec(cin, cout, xb is not None)
             xw, dyw = x, dy
-            if wprec and xb is not None and cout % 8 == 0:
-                xw, dyw, wprec = xb, (dyg if dyg is not dy else _to_bf16(dy)), 2
+            if wprec >= 2:
+                xw, dyw = xb, (dyg if dyg is not dy else _to_bf16(dy))
             seg, nseg = (kmap.wgrad_segments if wprec else kmap.segments)(_wgrad_seg_len(P, cin, cout, 1 if wprec else 0, KK), rb)
             lib.check(xw, dyw, pin, pout, seg)
             prof = KernelProfile.enabled and KernelProfile.wgrad and lib.is_device
@@ -1310,10 +1415,10 @@ class SparseConvFunction(torch.autograd.Function):
                      c_int32(KK), c_int32(cin), c_int32(cout), c_int32(wprec), lib.stream())
             if prof:
                 ev1.record()
-                eb = 2.0 if wprec == 2 else 4.0
+                eb = 2.0 if wprec >= 2 else 4.0
                 KernelProfile.records.append((ev0, ev1, 2.0 * P * cin * cout,
                                               eb * (kmap.n_in * cin + kmap.n_out * cout) + 4.0 * KK * cin * cout + 8.0 * P,
-                                              ("wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"),
+                                              ("wgrad_bf16x3" if wprec == 3 else "wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"),
                                                KK, cin, cout, P, kmap.n_out, nseg),
                                               eb * P * (cin + cout) + 4.0 * KK * cin * cout))
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1338,7 +1443,7 @@ class GroupedConvFunction(torch.autograd.Function):
         row groups), bf16 row copies, channel counts the kernel's register tile covers.  The rows of a pass are staged once
         for all of its slot-table blocks, so the 5^3 / 9^3 class convolutions (K = 125 / 729) gather each distinct
         neighbour row once per pass instead of once per offset."""
-        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and _prec() == 1 and BF16_ROWS
+        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and (cin == 64 or cin % 128 == 0) and (cout == 64 or cout % 128 == 0))
 
     @staticmethod
@@ -1354,7 +1459,7 @@ class GroupedConvFunction(torch.autograd.Function):
         G, (K, cin, cout) = len(weights), weights[0].shape
         ctx.kmap, ctx.row_bounds, ctx.shape, ctx.closed = kmap, row_bounds, (G, K, cin, cout), closed
         pin, pout, _, P = kmap.pairs(row_bounds)
-        xg = _to_bf16(x, keep=True) if BF16_ROWS else x
+        xg = _to_bf16(x, keep=True) if (BF16_ROWS or _split()) else x
         ctx.save_for_backward(x, xg if xg is not x else None, *weights)
         lds_tile = ctx.lds_tile = GroupedConvFunction._lds_tile(kmap, K, cin, cout, closed)
         wt = _prep_bf16_group(weights, True, lds_tile)
@@ -1378,7 +1483,7 @@ class GroupedConvFunction(torch.autograd.Function):
         lib = _lib.get()
         dy = dy.contiguous()
         pin, pout, _, P = kmap.pairs(rb)
-        dyg = _to_bf16(dy) if BF16_ROWS else dy
+        dyg = _to_bf16(dy) if (BF16_ROWS or _split()) else dy
         dx = None
         if ctx.needs_input_grad[0]:
             wp = ctx.wp_plain if ctx.wp_plain is not None else _prep_bf16_group(weights, False, ctx.lds_tile)
@@ -1394,8 +1499,8 @@ class GroupedConvFunction(torch.autograd.Function):
         dws = [None] * G
         if any(ctx.needs_input_grad[4:]):
             dw = torch.empty((G * K, cin, cout), dtype=torch.float32, device=x.device)
-            wprec = 2 if (xb is not None and dyg is not dy) else 1
-            xw, dyw = (xb, dyg) if wprec == 2 else (x, dy)
+            wprec = (3 if _split() else 2) if (xb is not None and dyg is not dy) else 1
+            xw, dyw = (xb, dyg) if wprec >= 2 else (x, dy)
             seg, nseg = kmap.segments(_wgrad_seg_len(P, cin, cout, 1, G * K), rb)
             lib.check(xw, dyw, pin, pout, seg)
             lib.call("cg3d_spconv_pairs_wgrad", ptr(xw), ptr(dyw), ptr(pin), ptr(pout), ptr(seg), c_int64(nseg), ptr(dw),
@@ -1455,19 +1560,24 @@ class LinearFunction(torch.autograd.Function):
     def _rows_gemm(x, w, bias):
         n, (cin, cout) = x.shape[0], w.shape
         ar, seg, nseg = _identity_pairs(n, 128, x.device)
+        if _split():
+            # a narrow side: the fp32 pair kernel is cheap here (and exact) -- no split copy of 150 k rows for 3 output channels
+            with precision_scope(0):
+                return _conv_pairs(x.contiguous(), w.contiguous().view(1, cin, cout), ar, ar, seg, nseg, bias, n, n)
         return _conv_pairs(x.contiguous(), w.contiguous().view(1, cin, cout), ar, ar, seg, nseg, bias, n, n)
 
     @staticmethod
     def _own(n, cin, cout):
         """The hand-written streaming kernel (cg3d_linear_fwd, csrc/linear.hip): bench precision, bf16 row copies, channel
         counts in multiples of 64 on both sides (the data gradient is the same kernel with the roles swapped)."""
-        return (LINEAR_KERNEL and _prec() == 1 and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
+        return (LINEAR_KERNEL and _prec() in (1, 3) and BF16_ROWS and n >= LinearFunction.OWN_MIN_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and cin >= 64 and cout >= 64)
 
     @staticmethod
     def _own_gemm(x16, wf, bias, n, cin, cout, want_stats=False):
         lib = _lib.get()
         y = torch.empty((n, cout), dtype=torch.float32, device=x16.device)
+        cin = cin * _kx()                      # the contraction the kernel sees (split rows: [hi | lo | hi])
         # few rows x a long contraction (DAPPM: 32-284 rows x 1024 channels): one workgroup would walk 16 chunks one latency
         # at a time -- the chunks go to separate workgroups instead, partial products stored and summed by the same call
         units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin // 64
@@ -1527,9 +1637,9 @@ class LinearFunction(torch.autograd.Function):
                 dw = x.t() @ dy
             else:
                 xc, dyc = x.contiguous(), dy.contiguous()
-                wprec = 1 if (_use_bf16(cin) and cout % 4 == 0 and cout >= 16) else 0
-                if wprec and x16 is not None and dy16 is not None and cout % 8 == 0:
-                    xc, dyc, wprec = x16, dy16, 2           # both operands as bf16 rows: half the gather traffic
+                wprec = _wgrad_prec(cin, cout, x16 is not None and dy16 is not None)
+                if wprec >= 2:
+                    xc, dyc = x16, dy16                     # both operands as bf16 rows: half the gather traffic
                 ar, seg, nseg = _identity_pairs(n, _wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1), x.device)
                 dw = torch.empty_like(w)
                 lib.check(xc, dyc, ar, seg, dw)
@@ -1579,7 +1689,7 @@ class LinearTFunction(torch.autograd.Function):
             dw = torch.empty_like(w)
             lib.check(x16, dy16, ar, seg, dw)
             lib.call("cg3d_spconv_pairs_wgrad", ptr(dy16), ptr(x16), ptr(ar), ptr(ar), ptr(seg), c_int64(nseg), ptr(dw),
-                     c_int32(1), c_int32(cout), c_int32(cin), c_int32(2), lib.stream())
+                     c_int32(1), c_int32(cout), c_int32(cin), c_int32(3 if _split() else 2), lib.stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -1751,6 +1861,8 @@ class RoiContractFunction(torch.autograd.Function):
     @staticmethod
     def available(feats, w):
         G, C, C2 = w.shape
+        # (plain bf16 operands only: the split rows of the gathered grid points would interleave [hi | lo | hi] per point,
+        # not per contraction -- the split precision gathers fp32 rows and runs `linear` on the flattened product)
         return ROI_CONTRACT and _prec() == 1 and BF16_ROWS and C % 64 == 0 and C2 % 64 == 0 and feats.shape[1] == C
 
     @staticmethod
@@ -1807,6 +1919,8 @@ def roi_contract(feats, idx, w):
     if RoiContractFunction.available(feats, w):
         return RoiContractFunction.apply(feats, idx, w)
     G, C, C2 = w.shape
+    if _split() and LinearFunction._own(idx.shape[0] // G, G * C, C2):
+        return linear(gather_rows(feats, idx).view(-1, G * C), w.view(G * C, C2))
     return gather_rows(feats, idx).view(-1, G * C) @ w.view(G * C, C2)
 
 
@@ -1985,7 +2099,7 @@ class FusedBNActFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         # bf16 mode: the apply kernels also write the bf16 row copy the neighbouring convolution gathers from
         # (forward: y16 -> its input; backward: dx16 -> its output gradient), instead of separate cg3d_to_bf16 passes
-        want16 = BF16_ROWS and _use_bf16(C)
+        want16 = _want_rows16(C)
         y16 = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want16 else None
         if use_batch:
             # (from the zero block: an EMPTY group has no chunk, hence no workgroup that writes its mean / variance)
@@ -2215,7 +2329,7 @@ class AddReluFunction(torch.autograd.Function):
         zeros, ones = _unit_bn(C, a.device)
         _, _, _, _, achunks, nachunk, _ = _bn_chunks((0, N), a.device, C)
         y = torch.empty_like(a)
-        want16 = BF16_ROWS and _use_bf16(C)
+        want16 = _want_rows16(C)
         y16 = torch.empty(a.shape, dtype=torch.int16, device=a.device) if want16 else None
         lib.check(a, b, achunks)
         lib.call("cg3d_bn_apply", ptr(a), ptr(b), ptr(achunks), c_int64(nachunk), c_int32(C), ptr(zeros), ptr(ones), c_float(0.0),

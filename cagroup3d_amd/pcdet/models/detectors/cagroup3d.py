@@ -202,6 +202,7 @@ class CAGroup3D(Detector3DTemplate):
         cur_epoch = batch_dict.get("cur_epoch", None)
         assert cur_epoch is not None
         ME._ROWS16.clear()
+        ME._ROWS48.clear()
         ME._STATS.clear()
         ME.zero_arena().reset()                     # a fresh zero block for this step's statistics tables
         ME.WANT_BN_STATS = bool(self.training)      # evaluation: no BatchNorm takes the conv epilogue's partial sums

@@ -198,6 +198,30 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pair
                             int32_t precision, cg3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Split operands ("bf16x3"): fp32-accurate products on the bf16 matrix pipe, for the parts of the path that keep the
+ * reference's fp32 arithmetic (the two heads: cagroup_head.py:227-282, cagroup_roi_head.py:69-91) while BASELINE.json
+ * configs[1] runs the backbone in bf16.  With hi = bf16(x) and lo = bf16(x - hi),
+ *     x w = xhi whi + xlo whi + xhi wlo + O(2^-16 |x w|),
+ * three bf16 products accumulated in fp32.  The split lives in the OPERANDS: every bf16 kernel of this library then runs
+ * unchanged on a three times longer contraction (pass 3 cin where it asks for cin).
+ *
+ * cg3d_to_bf16_split: Xs uint16 [n_rows, 3 c] = [ bf16(X) | bf16(X - bf16(X)) | bf16(X) ] row by row (c % 4 == 0).
+ * cg3d_spconv_prep_weights_split: float32 [slot][cin][cout] (W0, or G tensors Ws as in ..._bf16_multi) ->
+ *     W_t: the forward operand over the contraction index ci' = part * cin + ci in [0, 3 cin): parts 0 and 1 hold
+ *          bf16(W), part 2 holds bf16(W - bf16(W)); uint16 [slot][cout][3 cin], or (frag != 0) in the MFMA fragment order
+ *          of cg3d_spconv_prep_weights_frag with kdim = 3 cin;
+ *     W_p: the data gradient's operand over co' = part * cout + co in [0, 3 cout): uint16 [slot][cin][3 cout] or fragment
+ *          order with kdim = 3 cout.  Either may be NULL.
+ *   Bit 28 of the tile field of a cg3d_spconv_prep_weights_bf16_table row writes the same two operands (the row's
+ *   destination addresses are those of the slot's 3 cin cout-element blocks).
+ * cg3d_spconv_pairs_wgrad with precision 3: X and dY are split rows (uint16 [n, 3 cin] / [n, 3 cout]);
+ *     dW = Xhi^T dYhi + Xlo^T dYhi + Xhi^T dYlo     (cin % 8 == 0, cout % 8 == 0).
+ * ---------------------------------------------------------------------------------------- */
+int cg3d_to_bf16_split(const float *X, uint16_t *Xs, int64_t n_rows, int32_t c, cg3d_stream_t stream);
+int cg3d_spconv_prep_weights_split(const float *W0, const float *const *Ws, uint16_t *W_t, uint16_t *W_p, int32_t G,
+                                   int64_t slots_per, int32_t cin, int32_t cout, int32_t frag, cg3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Sparse convolution on LDS-staged neighbour tiles (forward and data gradient of every MinkowskiConvolution with
  * K > 1, cin % 64 == 0, cout % 64 == 0 in the bf16 mode; ME ConvolutionForwardGPU / BackwardGPU, call sites
  * backbones_3d/biresnet.py:358-406, dense_heads/cagroup_head.py:259-275).

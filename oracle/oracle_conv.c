@@ -64,6 +64,53 @@ int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t s) {
     return CG3D_OK;
 }
 
+/* Split operands (include/cagroup3d_hip.h, "bf16x3"): hi = bf16(v), lo = bf16(v - hi); inf / NaN keep lo = 0. */
+static inline void os_split(float v, uint16_t *hi, uint16_t *lo) {
+    float h = os_bf16(v);
+    uint32_t u; memcpy(&u, &h, 4);
+    *hi = (uint16_t)(u >> 16);
+    if ((*hi & 0x7f80u) == 0x7f80u) { *lo = 0; return; }
+    float r = os_bf16(v - h);
+    memcpy(&u, &r, 4);
+    *lo = (uint16_t)(u >> 16);
+}
+int cg3d_to_bf16_split(const float *X, uint16_t *Xs, int64_t n_rows, int32_t c, cg3d_stream_t s) {
+    (void)s;
+    if (n_rows < 0 || c < 4 || (c & 3)) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n_rows; r++)
+        for (int32_t a = 0; a < c; a++) {
+            uint16_t hi, lo;
+            os_split(X[r * c + a], &hi, &lo);
+            Xs[r * 3 * c + a] = hi;
+            Xs[r * 3 * c + c + a] = lo;
+            Xs[r * 3 * c + 2 * c + a] = hi;
+        }
+    return CG3D_OK;
+}
+int cg3d_spconv_prep_weights_split(const float *W0, const float *const *Ws, uint16_t *W_t, uint16_t *W_p, int32_t G,
+                                   int64_t slots_per, int32_t cin, int32_t cout, int32_t frag, cg3d_stream_t s) {
+    (void)s;
+    if (G < 1 || slots_per < 0 || cin < 1 || cout < 1 || (!W0 && !Ws) || (!W_t && !W_p)) return CG3D_ERR_ARG;
+    if (frag && W_t && ((cin & 15) || (cout & 31))) return CG3D_ERR_ARG;
+    if (frag && W_p && ((cout & 15) || (cin & 31))) return CG3D_ERR_ARG;
+    int64_t per = (int64_t)cin * cout;
+    for (int64_t slot = 0; slot < (int64_t)G * slots_per; slot++) {
+        const float *src = Ws ? Ws[slot / slots_per] + (slot % slots_per) * per : W0 + slot * per;
+        for (int32_t ci = 0; ci < cin; ci++)
+            for (int32_t co = 0; co < cout; co++) {
+                uint16_t hi, lo;
+                os_split(src[(int64_t)ci * cout + co], &hi, &lo);
+                for (int part = 0; part < 3; part++) {
+                    uint16_t b = part < 2 ? hi : lo;
+                    if (W_t) W_t[slot * 3 * per + (frag ? os_frag_index(co, part * cin + ci, 3 * cin) : (int64_t)co * 3 * cin + part * cin + ci)] = b;
+                    if (W_p) W_p[slot * 3 * per + (frag ? os_frag_index(ci, part * cout + co, 3 * cout) : (int64_t)ci * 3 * cout + part * cout + co)] = b;
+                }
+            }
+    }
+    return CG3D_OK;
+}
+
 /* `tiles` (may be NULL): int32 [ntile,3] = (group, first row, row count): the output rows of a tile use the weights of
  * that group (W holds G stacked weight sets of K slots each); rows not covered by a tile are not written. */
 int cg3d_spconv_fwd_tiled(const float *X, const float *W, const int32_t *nbr, const int32_t *tiles, int64_t ntile,
@@ -177,15 +224,25 @@ int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3
         uint16_t *wt = (uint16_t *)(uintptr_t)row[1], *wp = (uint16_t *)(uintptr_t)row[2];
         const int cin = (int)row[3], cout = (int)row[4], tile = (int)(row[5] & 0xfffffff);
         const int frag_t = (int)((row[5] >> 30) & 1), frag_p = (int)((row[5] >> 29) & 1);   /* MFMA fragment order */
+        const int split = (int)((row[5] >> 28) & 1);                                        /* three-part split operands */
+        const int np = split ? 3 : 1;
         const int co_tiles = (cout + 63) / 64;
         const int ci0 = (tile / co_tiles) * 64, co0 = (tile % co_tiles) * 64;
         for (int r = ci0; r < ci0 + 64 && r < cin; r++)
             for (int c = co0; c < co0 + 64 && c < cout; c++) {
-                const float f = os_bf16(src[(int64_t)r * cout + c]);
-                uint32_t u; memcpy(&u, &f, 4);
-                const uint16_t v = (uint16_t)(u >> 16);
-                if (wp) wp[frag_p ? os_frag_index(r, c, cout) : (int64_t)r * cout + c] = v;
-                if (wt) wt[frag_t ? os_frag_index(c, r, cin) : (int64_t)c * cin + r] = v;
+                uint16_t hi, lo = 0;
+                if (split) os_split(src[(int64_t)r * cout + c], &hi, &lo);
+                else {
+                    const float f = os_bf16(src[(int64_t)r * cout + c]);
+                    uint32_t u; memcpy(&u, &f, 4);
+                    hi = (uint16_t)(u >> 16);
+                }
+                for (int part = 0; part < np; part++) {
+                    const uint16_t v = part < 2 ? hi : lo;
+                    const int kc_p = part * cout + c, kc_t = part * cin + r;
+                    if (wp) wp[frag_p ? os_frag_index(r, kc_p, np * cout) : (int64_t)r * np * cout + kc_p] = v;
+                    if (wt) wt[frag_t ? os_frag_index(c, kc_t, np * cin) : (int64_t)c * np * cin + kc_t] = v;
+                }
             }
     }
     return CG3D_OK;
@@ -246,7 +303,34 @@ int cg3d_spconv_pairs_wgrad(const float *X, const float *dY, const int32_t *pin,
     if (nseg < 0 || K < 1 || cin < 1 || cout < 1) return CG3D_ERR_ARG;
     const int accumulate = (precision & CG3D_WGRAD_ACCUMULATE) != 0;
     precision &= ~CG3D_WGRAD_ACCUMULATE;
+    if (precision < 0 || precision > 3) return CG3D_ERR_ARG;
     if (!accumulate) memset(dW, 0, (size_t)K * cin * cout * sizeof(float));
+    if (precision == 3) {
+        /* split rows [hi | lo | hi]: dW = Xhi^T dYhi + Xlo^T dYhi + Xhi^T dYlo, each product of two bf16 values exact in fp32 */
+        const uint16_t *Xs = (const uint16_t *)X, *Ds = (const uint16_t *)dY;
+        const int32_t AB3 = 16;
+        int32_t nab3 = (cin + AB3 - 1) / AB3;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int32_t ab = 0; ab < nab3; ab++) {
+            int32_t a0 = ab * AB3, a1 = a0 + AB3 < cin ? a0 + AB3 : cin;
+            for (int64_t g = 0; g < nseg; g++) {
+                int32_t k = seg[g * 3], start = seg[g * 3 + 1], count = seg[g * 3 + 2];
+                float *w = dW + (int64_t)k * cin * cout;
+                for (int32_t p = start; p < start + count; p++) {
+                    const uint16_t *xr = Xs + (int64_t)pin[p] * 3 * cin, *dr = Ds + (int64_t)pout[p] * 3 * cout;
+                    for (int32_t a = a0; a < a1; a++) {
+                        const float xh = os_bf16_bits(xr[a]), xl = os_bf16_bits(xr[cin + a]);
+                        float *wr = w + (int64_t)a * cout;
+                        for (int32_t c = 0; c < cout; c++) {
+                            const float dh = os_bf16_bits(dr[c]), dl = os_bf16_bits(dr[cout + c]);
+                            wr[c] += xh * dh + xl * dh + xh * dl;
+                        }
+                    }
+                }
+            }
+        }
+        return CG3D_OK;
+    }
     const int32_t AB = 16;
     int32_t nab = (cin + AB - 1) / AB;
 #pragma omp parallel for schedule(dynamic, 1)
