@@ -71,6 +71,9 @@ def parse():
                          "two modes not chosen are timed as sub-records")
     ap.add_argument("--cpu-sample-1t", default="S5k:1", help="config:scenes of the single-thread CPU leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="sub-record `rotate`: K DIFFERENT synthetic batches cycled inside the timed region (the headline repeats one "
+                         "fixed batch; sizes, cache keys and allocator requests then never change) -- 0 skips it")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     return ap.parse_args()
 
@@ -97,19 +100,24 @@ PREFETCH = os.environ.get("CG3D_PREFETCH", "1") != "0"
 PREFETCH_THREAD = os.environ.get("CG3D_PREFETCH_THREAD", "1") != "0"     # the dry run of the next batch on a worker thread
 
 
-def train_step(model, opt, batch, clip):
+def train_step(model, opt, batch, clip, next_batch=None):
+    """next_batch: the batch the FOLLOWING step will run (--rotate): its coordinate dry run is submitted here."""
     params = _PARAMS.get(id(model))
     if params is None:                      # walking the module tree every step costs ~2 ms of host time
         params = _PARAMS[id(model)] = [p for p in model.parameters() if p.requires_grad]
     opt.zero_grad(set_to_none=True)
     b = fresh(batch)
     core = model.module if hasattr(model, "module") else model
+    nxt = batch if next_batch is None else next_batch
     if PREFETCH and _PREPARED.get(id(core)) is not None:
-        b["prepared"] = _PREPARED.pop(id(core)).result()
+        handle, owner = _PREPARED.pop(id(core))
+        prepared = handle.result()
+        if owner is batch:                      # (a dry run made for another batch is dropped: this step builds its own)
+            b["prepared"] = prepared
     if PREFETCH and PREFETCH_THREAD and batch["points"].is_cuda:
-        # the NEXT batch's coordinate structures (here: the same synthetic scenes again -- every step builds them anew,
-        # nothing is reused) on the worker thread and the side stream, while this step is issued and runs
-        _PREPARED[id(core)] = core.prefetch_coordinates_async(batch)
+        # the NEXT batch's coordinate structures (fixed-batch runs: the same synthetic scenes again -- every step builds them
+        # anew, nothing is reused) on the worker thread and the side stream, while this step is issued and runs
+        _PREPARED[id(core)] = (core.prefetch_coordinates_async(nxt), nxt)
     ret, tb, disp = model(b)
     ret["loss"].backward()
     if getattr(core, "grad_sync", None) is not None:
@@ -122,7 +130,7 @@ def train_step(model, opt, batch, clip):
     if PREFETCH and not (PREFETCH_THREAD and batch["points"].is_cuda):
         # single-threaded variant: on the side stream while the GPU still works through the backward just queued
         from cagroup3d_amd.pcdet.models.detectors.cagroup3d import _Done
-        _PREPARED[id(core)] = _Done(core.prefetch_coordinates(batch))
+        _PREPARED[id(core)] = (_Done(core.prefetch_coordinates(nxt)), nxt)
     return tb
 
 
@@ -132,7 +140,7 @@ def finish_prefetch(model):
     core = model.module if hasattr(model, "module") else model
     h = _PREPARED.pop(id(core), None)
     if h is not None:
-        h.result()
+        h[0].result()
     w = getattr(core, "_prefetch_worker", None)
     if w is not None:
         w.close()
@@ -312,7 +320,8 @@ def main():
     # in a 100-step run slowed the run itself).  3 steps x 67 launches of the dominant kernel is plenty for an average.
     rank_ms = []
 
-    def timed_run(steps):
+    def timed_run(steps, batches=None):
+        batches = batches or [batch]
         me.KernelProfile.reset()
         me.KernelProfile.wgrad = True               # the weight gradient is part of the step's 8(d) work
         stride = max(1, -(-steps // int(os.environ.get("CG3D_BENCH_PROFILE_STEPS", "3"))))
@@ -322,10 +331,10 @@ def main():
         for i in range(steps):
             me.KernelProfile.enabled = i % stride == 0
             profiled += int(me.KernelProfile.enabled)
-            tb_ = train_step(net, opt, batch, clip)
+            tb_ = train_step(net, opt, batches[i % len(batches)], clip, batches[(i + 1) % len(batches)])
         pending = _PREPARED.get(id(net.module if hasattr(net, "module") else net))
         if pending is not None:
-            pending.result()                        # the worker thread's dry run of the next batch belongs to the timed work
+            pending[0].result()                     # the worker thread's dry run of the next batch belongs to the timed work
         barrier()
         dt_ = time.perf_counter() - t0
         me.KernelProfile.enabled = False
@@ -461,6 +470,22 @@ def main():
                 other_heads[name] = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
                                      "warmup": 3, "heads": name}
         me.HEAD_PRECISION = keep
+    rotate = None
+    if args.rotate > 1:
+        # K different batches cycled inside the timed region (same precision as the headline): map sizes, cache keys and
+        # allocator requests change from step to step, and so does the forced selection's load on the class branches
+        K = args.rotate
+        batches = [build_model.synthetic_batch(args.config, args.batch, first_scene=(rank + world * (j + 1)) * args.batch, device=dev)
+                   for j in range(K)]
+        nrot = max(3, min(args.steps, 20))
+        for j in range(K):                                      # every batch once: its cache entries and allocator sizes exist
+            train_step(net, opt, batches[j], clip, batches[(j + 1) % K])
+        dtr, _, _ = timed_run(nrot, batches)
+        if rank == 0:
+            rotate = {"value": world * args.batch * nrot / dtr, "unit": "scenes/s", "ms_per_step": dtr / nrot * 1e3, "steps": nrot,
+                      "warmup": K, "batches": K, "voxels_per_batch": None,
+                      "note": "%d different synthetic batches of %d x %s scenes cycled inside the timed region, next batch's "
+                              "coordinate dry run on the worker thread as in training" % (K, args.batch, args.config)}
     finish_prefetch(net)            # the worker thread is done and joined before anything else happens (cpu_baseline, exit)
 
     if rank == 0:
@@ -493,6 +518,9 @@ def main():
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32
+        if rotate is not None:
+            rotate.pop("voxels_per_batch", None)
+            out["rotate"] = rotate
         for name, rec in other_heads.items():
             out[{"fp32": "bf16_backbone_fp32_heads", "bf16": "bf16_all_convolutions", "split": "bf16_backbone_split_heads"}[name]] = rec
         if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):

@@ -43,6 +43,9 @@ __device__ static inline bool quantised_key(const int32_t *__restrict__ coords, 
 // same-address atomics per step serialised at the L2 atomic unit (0.47 ms in the RoI stage's map build).
 __global__ __launch_bounds__(256) void k_insert(const int32_t *__restrict__ coords, int64_t n, int32_t qs, unsigned long long *keys,
                                                 int32_t *vals, uint64_t capm1, int32_t *slot_of, int32_t *status) {
+    // wave64 only (gfx950): the lane index, the 64-bit ballot masks and the default-width shuffles below assume it -- on a
+    // 32-lane target lane 32 would read a slot out of another wave's ballot bits and the map would be silently corrupt
+    // (cg3d_coord_map_build refuses a device whose wavefronts are not 64 lanes wide)
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int4 c;
@@ -178,6 +181,15 @@ extern "C" int cg3d_coord_map_build(const int32_t *coords, int64_t n, int32_t qs
                                     int32_t *inverse, int32_t *n_out, cg3d_stream_t stream) {
     if (n < 0 || qstride < 1 || cap < 2 * n || (cap & (cap - 1)) || cap > (1LL << 30)) return CG3D_ERR_ARG;
     if (((uintptr_t)coords & 15) || ((uintptr_t)out_coords & 15)) return CG3D_ERR_ARG;
+    {   // k_insert's ballots and shuffles are written for 64-lane wavefronts: checked once per process, not assumed
+        static int wave = 0;
+        if (!wave) {
+            int dev = 0, w = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&w, hipDeviceAttributeWarpSize, dev) != hipSuccess) return CG3D_ERR_LAUNCH;
+            wave = w;
+        }
+        if (wave != 64) return CG3D_ERR_LAUNCH;
+    }
     hipStream_t s = cg3d_hs(stream);
     hipLaunchKernelGGL(k_table_init, dim3((unsigned)cg3d_divup(cap, 256)), dim3(256), 0, s, (unsigned long long *)keys, vals, cap,
                        n_out);                        // empty keys (all ones), "no row" values, row count and status = 0: one launch

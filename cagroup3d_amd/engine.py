@@ -150,6 +150,7 @@ class Builder:
         # completed, and what frees one is this reference going away -- no stream hand-over needed: `keep` gets one)
         self.keep_cached, self._held = [], set()
         self.params = []                # (parameter, offset in R_PG)
+        self.uses_arena = False         # some row addresses a bf16 weight copy of the step's arena (me._WeightPlan)
         self._pidx = {}
         self.late = []                  # (program, row, column, fn() -> tensor): operands that exist only at run time
         self.marks = {}                 # name -> backward row index (callbacks between two parts of the backward pass)
@@ -261,6 +262,7 @@ class Builder:
         if e is None or e[0].shape != w3.shape or (need_plain and not e[1]) or e[3] is None or P.dirty or P.gen != self.gen:
             ME._planned_single(w3, need_plain, frag)          # records it: converted from the next forward on
             raise NotReady("weight not in the step's arena yet")
+        self.uses_arena = True
         return e[3].data_ptr(), (e[4].data_ptr() if e[4] is not None else 0)
 
     # ---------------------------------------------------------------- convolution (me.SparseConvFunction)
@@ -848,10 +850,19 @@ class Compiled:
         self.lib = b.lib
         self.dev = b.dev
         self.stream_device = None
+        self.uses_arena = b.uses_arena
 
     def usable(self):
         P = ME._WeightPlan
         return (not P.dirty) and P.gen == self.gen and _lib.get() is self.lib
+
+    def check_weights_live(self):
+        """The rows address the bf16 weight copies of the step's arena, which `me.prepare_weights()` refreshes at the start of a
+        detector forward and `me.finish_weights()` declares stale at its end (an optimizer step may follow).  A pass issued
+        outside such a forward -- BiResNet.forward called directly after optimizer.step(), a profiling tool -- would multiply by
+        the PREVIOUS step's weights while the per-layer path converts on the spot: refuse, the caller takes that path."""
+        if self.uses_arena and not ME._WeightPlan.live:
+            raise NotReady("the step's weight arena is not live (no detector forward in progress)")
 
 
 def compile_backbone(net, sp, mid_mark=False):
@@ -939,6 +950,16 @@ def _pg_views(comp, device):
     return pg, [pg[off // 4: off // 4 + prm.numel()].view_as(prm) for prm, off in params], True
 
 
+def _arena_alive(ctx):
+    """A program node's backward runs ONCE: it releases the arena its rows point into (activations, statistics, scratch: the
+    largest allocation of the step).  These nodes save nothing through save_for_backward, so autograd itself would not object
+    to a second backward (retain_graph=True, or autograd.grad followed by backward) -- which would re-run the whole table on
+    freed or reused memory and write parameter gradients from it."""
+    if ctx.arena is None:
+        raise RuntimeError("engine program: backward already ran for this node and its arena has been released "
+                           "(a launch program's backward pass can run once; recompute the forward for another one)")
+
+
 class BackboneFunction(torch.autograd.Function):
     """The whole backbone as ONE autograd node: forward = the forward table, backward = the backward table; the parameters'
     gradients are written to one fresh zero-filled buffer and handed to the parameters here (`p.grad = view`, added to an
@@ -982,6 +1003,7 @@ class BackboneFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _arena_alive(ctx)
         comp, lib, hooks = ctx.comp, ctx.comp.lib, ctx.hooks or {}
         dy = dy.contiguous()
         bases = dict(ctx.bases)
@@ -1010,7 +1032,8 @@ class BackboneFunction(torch.autograd.Function):
                     k = id(prm)
                     if k in given or (ids is not None and k not in ids):
                         continue
-                    prm.grad = g if prm.grad is None else prm.grad + g
+                    if prm.requires_grad:          # (a frozen layer's gradient is computed by the table but not handed out)
+                        prm.grad = g if prm.grad is None else prm.grad + g
                     given.add(k)
         first = True
         for rows, prof, name in parts:
@@ -1112,6 +1135,7 @@ class ClassBranchFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _arena_alive(ctx)
         comp, lib = ctx.comp, ctx.comp.lib
         dy = dy.contiguous()
         bases = dict(ctx.bases)
@@ -1126,7 +1150,8 @@ class ClassBranchFunction(torch.autograd.Function):
         _run(lib, np.concatenate([head, P]))
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
-                prm.grad = g if prm.grad is None else prm.grad + g
+                if prm.requires_grad:
+                    prm.grad = g if prm.grad is None else prm.grad + g
         grads = []
         for gi, (n, c) in zip(comp.gin, ((comp.n_in, comp.c_in), (comp.n_in2, comp.c_in))):
             grads.append(_arena_view(ctx.arena, bases, gi[0], n, c) if gi is not None else None)
@@ -1139,6 +1164,11 @@ def run_class_branches(head, xf, xc, km9, km5, km_up, ident, fine_bounds, coarse
     try:
         comp = compile_class_branches(head, xf.shape[0], xc.shape[0], xf.shape[1], km9, km5, km_up, ident, fine_bounds,
                                       coarse_bounds, xf.device)
+    except NotReady:
+        CLASS_STATS["not_ready"] += 1
+        raise
+    try:
+        comp.check_weights_live()
     except NotReady:
         CLASS_STATS["not_ready"] += 1
         raise
@@ -1217,6 +1247,7 @@ class HeadPreFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d0, d1):
+        _arena_alive(ctx)
         comp, lib = ctx.comp, ctx.comp.lib
         bases = dict(ctx.bases)
         shapes = ((comp.out[1], comp.out[2]), (comp.out2[1], comp.out2[2]))
@@ -1238,7 +1269,8 @@ class HeadPreFunction(torch.autograd.Function):
         _run(lib, np.concatenate([head, P]))
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
-                prm.grad = g if prm.grad is None else prm.grad + g
+                if prm.requires_grad:
+                    prm.grad = g if prm.grad is None else prm.grad + g
         dx = _arena_view(ctx.arena, bases, comp.gin[0], comp.n_in, comp.c_in) if comp.gin is not None else None
         ctx.arena = ctx.inputs = None
         return dx, None, None
@@ -1252,6 +1284,11 @@ def run_head_pre(head, sp):
     x16 = hit[1] if (hit is not None and hit[0].shape == x.shape and hit[0].data_ptr() == x.data_ptr() and ME._prec() == 1) else None
     try:
         comp = compile_head_pre(head, sp, x16 is not None)
+    except NotReady:
+        HEAD_STATS["not_ready"] += 1
+        raise
+    try:
+        comp.check_weights_live()
     except NotReady:
         HEAD_STATS["not_ready"] += 1
         raise
@@ -1272,6 +1309,7 @@ def run_backbone(net, sp, comp=None, hooks=None):
             STATS["compiled_inline"] += 1
         else:
             STATS["compiled_ahead"] += 1
+        comp.check_weights_live()
     except NotReady:
         STATS["not_ready"] += 1
         raise

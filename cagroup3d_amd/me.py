@@ -416,14 +416,26 @@ def _cached(cache, key, build, limit=None):
     the table on ITS stream with nothing ordering it after the copy.  (The wait blocks only the worker, once per key.)"""
     with _CACHE_LOCK:
         hit = cache.get(key)
-        if hit is None:
-            hit = build()
-            if __import__("threading").current_thread() is not __import__("threading").main_thread() \
-                    and torch.cuda.is_available() and _lib.get().is_device:
-                torch.cuda.current_stream().synchronize()
+        if hit is not None:
+            return hit
+        hit = build()
+        worker = (__import__("threading").current_thread() is not __import__("threading").main_thread()
+                  and torch.cuda.is_available() and _lib.get().is_device)
+        if not worker:
             if limit is not None and len(cache) > limit:
                 cache.clear()
             cache[key] = hit
+            return hit
+    # worker thread: wait for its uploads OUTSIDE the lock (every cache lookup of the main thread would stall behind the
+    # wait otherwise), then publish; if the main thread built the same key meanwhile, its entry stays
+    torch.cuda.current_stream().synchronize()
+    with _CACHE_LOCK:
+        other = cache.get(key)
+        if other is not None:
+            return other
+        if limit is not None and len(cache) > limit:
+            cache.clear()
+        cache[key] = hit
         return hit
 
 
@@ -1053,21 +1065,23 @@ def prepare_weights(training=True):
     if len(P.singles) + len(P.groups) > 512:
         P.reset()
         return
-    if P.dirty:
-        with _CACHE_LOCK:           # (the prefetch worker records weights too: engine.Builder._planned)
+    # (the prefetch worker records weights too -- engine.Builder._planned -> _planned_single inserts into P.singles while it
+    # compiles the next batch's program: the scans and updates below run under the lock the inserts take)
+    with _CACHE_LOCK:
+        if P.dirty:
             dev = next(iter(P.singles.values()))[0].device if P.singles else next(iter(P.groups.values()))[0][0].device
             P._rebuild(dev)
-        P.pending = True
-    need = training or P.pending or any(e[2] != e[0]._version for e in P.singles.values()) or \
-        any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
-    if need:
-        lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
-        for e in P.singles.values():
-            e[2] = e[0]._version
-        for g in P.groups.values():
-            g[1] = tuple(w._version for w in g[0])
-    P.pending = bool(training)          # after a training forward the weights change behind our back
-    P.live = True
+            P.pending = True
+        need = training or P.pending or any(e[2] != e[0]._version for e in P.singles.values()) or \
+            any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
+        if need:
+            lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
+            for e in P.singles.values():
+                e[2] = e[0]._version
+            for g in P.groups.values():
+                g[1] = tuple(w._version for w in g[0])
+        P.pending = bool(training)          # after a training forward the weights change behind our back
+        P.live = True
 
 
 def finish_weights():

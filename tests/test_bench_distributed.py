@@ -51,3 +51,21 @@ def test_bench_refuses_a_world_size_other_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_plain_bench_gpus_8_refuses_on_a_smaller_node():
+    """`python bench.py --gpus 8` (no launcher) where fewer than eight devices are visible -- this container, a 1-GPU box --
+    must stop with the message the driver will read and print NO JSON line: an 8-GPU figure is never made up from fewer
+    devices (reference tools/scripts/dist_train.sh:1-18 simply fails in torch.distributed.launch there)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have >= 8:
+        pytest.skip("eight devices visible: the run would be real")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CG3D_SINGLE_DEVICE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert "--gpus 8: only %d GPU(s) visible" % have in out.stderr and "refusing" in out.stderr, out.stderr[-500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -105,6 +105,93 @@ def test_program_table_is_plain_data(oracle):
     assert comp.size[engine.R_PG] >= 4 * sum(p.numel() for p in model.backbone_3d.parameters())
 
 
+def test_a_program_node_refuses_a_second_backward(oracle):
+    """The node's backward releases the arena its rows point into; nothing is saved through save_for_backward, so autograd
+    would let a second backward (retain_graph=True) re-run the table on freed memory.  It must raise instead."""
+    with _lib.use_library(oracle):
+        prec, me.PRECISION = me.PRECISION, 0
+        os.environ["CG3D_ENGINE_ANY"] = "1"
+        try:
+            model, _ = build_model.build_cagroup3d("scannet", seed=0)
+            model.train()
+            batch = build_model.synthetic_batch("S5k", 1, device="cpu")
+            pts = batch["points"].clone()
+            pts[:, -3:] = pts[:, -3:] / 255.
+            sp = model.voxelization(pts)
+            out = engine.run_backbone(model.backbone_3d, sp)
+            loss = out.F.sum()
+            loss.backward(retain_graph=True)
+            first = {n: p.grad.clone() for n, p in model.backbone_3d.named_parameters() if p.grad is not None}
+            with pytest.raises(RuntimeError, match="backward already ran"):
+                loss.backward()
+            # ... and the first pass's gradients are untouched by the refused one
+            for n, p in model.backbone_3d.named_parameters():
+                if n in first:
+                    assert torch.equal(p.grad, first[n]), n
+        finally:
+            me.PRECISION = prec
+            os.environ.pop("CG3D_ENGINE_ANY", None)
+
+
+def test_frozen_parameters_get_no_gradient_from_a_program(oracle):
+    """requires_grad = False on a layer: the per-layer autograd path leaves its .grad None; so must the program's backward
+    (clip_grad_norm_ over model.parameters() would otherwise see gradients the optimizer never asked for)."""
+    with _lib.use_library(oracle):
+        prec, me.PRECISION = me.PRECISION, 0
+        os.environ["CG3D_ENGINE_ANY"] = "1"
+        try:
+            model, _ = build_model.build_cagroup3d("scannet", seed=0)
+            model.train()
+            net = model.backbone_3d
+            frozen = [p for n, p in net.named_parameters() if n.startswith("layer1.")]
+            assert frozen
+            for p in frozen:
+                p.requires_grad_(False)
+            batch = build_model.synthetic_batch("S5k", 1, device="cpu")
+            pts = batch["points"].clone()
+            pts[:, -3:] = pts[:, -3:] / 255.
+            out = engine.run_backbone(net, model.voxelization(pts))
+            out.F.sum().backward()
+            assert all(p.grad is None for p in frozen)
+            assert sum(p.grad is not None for p in net.parameters()) > 100
+        finally:
+            me.PRECISION = prec
+            os.environ.pop("CG3D_ENGINE_ANY", None)
+
+
+@pytest.mark.gpu
+def test_a_program_is_not_run_on_a_stale_weight_arena(hip):
+    """Detector step, optimizer step, then the backbone ALONE (no prepare_weights: the arena still holds the pre-step bf16
+    weights).  The program must step aside (NotReady -> per-layer path, which converts on the spot), so the output follows
+    the UPDATED weights."""
+    prec, me.PRECISION = me.PRECISION, 1
+    try:
+        model, _ = build_model.build_cagroup3d("scannet", seed=0)
+        model = model.cuda().train()
+        net = model.backbone_3d
+        batch = build_model.synthetic_batch("S5k", 2, device="cuda")
+        for e in (False, False, True, True):
+            _backbone_step(model, batch, e, "cuda")                    # every weight variant enters the arena
+        pts = batch["points"].clone()
+        pts[:, -3:] = pts[:, -3:] / 255.
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.5)                                            # "optimizer.step()": in place, version-blind as fused AdamW
+        os.environ["CG3D_ENGINE_ANY"] = "1"
+        before = dict(engine.STATS)
+        assert not me._WeightPlan.live
+        out_prog = net({"sp_tensor": model.voxelization(pts.clone()), "batch_size": 2})["sp_tensor"].F.detach().clone()
+        assert engine.STATS["not_ready"] == before["not_ready"] + 1 and engine.STATS["program_passes"] == before["program_passes"]
+        engine.ENABLED = False
+        out_ref = net({"sp_tensor": model.voxelization(pts.clone()), "batch_size": 2})["sp_tensor"].F.detach().clone()
+        engine.ENABLED = True
+        assert _l2(out_prog, out_ref) < 0.05, _l2(out_prog, out_ref)   # (atomics' run-to-run noise; stale weights are O(1) off)
+    finally:
+        engine.ENABLED = True
+        os.environ.pop("CG3D_ENGINE_ANY", None)
+        me.PRECISION = prec
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfgname,n", [("S5k", 2), ("S50k", 1)])
 def test_program_equals_per_layer_path_on_the_device(hip, cfgname, n):

@@ -128,6 +128,74 @@ def test_collective_order_does_not_depend_on_which_hooks_fire(tmp_path):
     assert open(out).read() == "ok"
 
 
+def _worker_eight(rank, world, port, out):
+    """Eight ranks (the node the bench scales to: reference tools/train.py:143-144, tools/scripts/dist_train.sh:1-18) with
+    UNEVEN shards and one rank whose scenes hold no ground truth: its loss never reaches the roi head (zero gradients travel
+    in the early bucket), its normaliser row is all zeros.  Checked on every rank: the collectives leave in the order early,
+    mid, late; every parameter gradient equals the locally computed average over the eight ranks' losses; the (B, 3) loss
+    normaliser of cagroup_utils.reduce_mean (cagroup_utils.py:6-12) is the mean over ranks, zeros included."""
+    from cagroup3d_amd.pcdet.models.model_utils.cagroup_utils import reduce_mean
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    ref = Toy()
+    torch.manual_seed(0)
+    mine = Toy()
+    # ranks start from rank 0's parameters whatever they were initialised with (broadcast in the constructor)
+    if rank != 0:
+        with torch.no_grad():
+            for p in mine.parameters():
+                p.add_(float(rank))
+    mine.grad_sync = TwoBucketGradSync(mine)
+    for (n, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
+        torch.testing.assert_close(b.detach(), a.detach(), rtol=0, atol=0, msg=lambda m: "broadcast of %s: %s" % (n, m))
+    gs = mine.grad_sync
+    order = []
+    real_reduce = gs._reduce
+    gs._reduce = lambda flat, async_op: (order.append(next(k for k, v in gs._buf.items() if v[0] is flat)), real_reduce(flat, async_op))[1]
+    no_gt = 5
+    rows = [3 + (r * 5) % 4 for r in range(world)]                     # 3..6 rows per rank
+    for step in range(2):
+        xs = [torch.randn(rows[r], 8, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+
+        def loss_of(m, r, x):
+            f = m.backbone_3d(x)
+            if m.grad_sync is not None:
+                m.grad_sync.attach(f)
+            out = m.dense_head(f).pow(2).sum()
+            return out if r == no_gt else out + m.roi_head(f).abs().sum()
+        ref.zero_grad(set_to_none=True)
+        for r, x in enumerate(xs):
+            (loss_of(ref, r, x) / world).backward()
+        mine.zero_grad(set_to_none=True)
+        del order[:]
+        loss_of(mine, rank, xs[rank]).backward()
+        gs.finish()
+        assert order == ["early", "mid", "late"], (rank, step, order)
+        for (n, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
+            if a.grad is None:
+                assert b.grad is None or float(b.grad.abs().max()) == 0.0, n
+            else:
+                torch.testing.assert_close(b.grad, a.grad, rtol=1e-5, atol=1e-6, msg=lambda m: "%s rank %d step %d: %s" % (n, rank, step, m))
+        # the loss normalisers: one (B, 3) all-reduce per step (positives, centerness sum, vote count per scene); the
+        # ground-truth-free rank contributes zeros and still takes part
+        B = 4
+        stats = [torch.zeros(B, 3) if r == no_gt else torch.arange(B * 3, dtype=torch.float32).view(B, 3) * (r + 1) + step for r in range(world)]
+        got = reduce_mean(stats[rank])
+        torch.testing.assert_close(got, torch.stack(stats).mean(0), rtol=1e-6, atol=1e-6)
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_shards_and_a_rank_without_ground_truth(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_eight, args=(8, 29541, out), nprocs=8, join=True)
+    assert open(out).read() == "ok"
+
+
 def _worker_gpu(rank, world, port, out):
     """Both ranks on cuda:0 over gloo (RCCL refuses two ranks on one device): the bucket packing, the asynchronous
     exchange started inside backward and finish() run on device tensors and streams."""
