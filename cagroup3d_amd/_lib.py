@@ -53,6 +53,7 @@ _SIGNATURES = {
     "cg3d_scatter_mean_bwd": (c_int32, [P, P, P, c_int32, P, c_int64, c_int64, c_int32, P]),
     "cg3d_to_bf16": (c_int32, [P, P, c_int64, P]),
     "cg3d_to_bf16_split": (c_int32, [P, P, c_int64, c_int32, P]),
+    "cg3d_from_bf16": (c_int32, [P, P, c_int64, P]),
     "cg3d_spconv_prep_weights_split": (c_int32, [P, P, P, P, c_int32, c_int64, c_int32, c_int32, c_int32, P]),
     "cg3d_points_in_boxes": (c_int32, [P, c_int64, P, c_int32, P, P, P, P]),
     "cg3d_focal_loss_nblocks": (c_int32, [c_int64, c_int32]),

@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ A,
 }
 
 static bool bad(const void *p) { return ((uintptr_t)p & 15) != 0; }
+// bf16 storage: a thread column per channel oct, power-of-two column counts (the reductions meet by xor-shuffles), <= 1024 channels
+static bool bn16_ok(int32_t c) { return c >= 64 && c <= 1024 && !(c & (c - 1)); }
+__global__ void k_bn16_partial_bwd(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ X, const uint16_t *__restrict__ Yv,
+                                   const int32_t *__restrict__ chunks, int32_t c, const float *__restrict__ mean,
+                                   const float *__restrict__ var, float eps, int act, float *__restrict__ sums, int G);
 
 // sums[slot][0][g][:] += sum over the rows of group g of x, sums[slot][1][g][:] += sum of x^2 (the caller zero-fills `sums`)
 extern "C" int cg3d_bn_sums(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, float *sums,
@@ -123,10 +128,70 @@ extern "C" int cg3d_bn_bwd_sums(const float *dY, const float *X, const float *Y,
                                 cg3d_stream_t stream) {
     if (nchunk < 0 || G < 1 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || !dsums) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
+    if (act & CG3D_BN_STORE_BF16) {          // dY, X, Y are bf16 rows
+        if (!bn16_ok(c)) return CG3D_ERR_ARG;
+        hipLaunchKernelGGL(k_bn16_partial_bwd, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), reinterpret_cast<const uint16_t *>(dY),
+                           reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(Y), chunks, c, mean, var, eps,
+                           act & ~CG3D_BN_STORE_BF16, dsums, G);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     hipLaunchKernelGGL(k_bn_partial<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var, eps,
                        act, dsums, G);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
+}
+
+// The slot table of a layer, added up ONCE per workgroup.  Every thread used to add the 16 slots of its own channels up
+// itself: 0.5-1 KB of table loads per thread, 128-256 KB per workgroup out of the L1 for an 8 KB table -- more bytes than the
+// rows the workgroup then moves (a 128-row chunk of 64 channels is 16-32 KB), and 1 200 workgroups per launch do it.  Here
+// thread t adds up channel t (t + 256, ...) of both statistics in fp64, in slot order as before (same bits), and leaves the two
+// per-channel results in LDS; the row loop reads its channels' constants from there.
+#define BN_LDS_C 1024
+__device__ static inline void bn_slot_pair_to_lds(const float *__restrict__ table, int G, int g, int c, float *s0, float *s1,
+                                                  bool write_out, float *__restrict__ out0, float *__restrict__ out1) {
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+            a0 += table[((int64_t)(sl * 2) * G + g) * c + ch];
+            a1 += table[((int64_t)(sl * 2 + 1) * G + g) * c + ch];
+        }
+        s0[ch] = (float)a0;
+        s1[ch] = (float)a1;
+        if (write_out) { out0[(int64_t)g * c + ch] = (float)a0; out1[(int64_t)g * c + ch] = (float)a1; }
+    }
+}
+// forward: mean / biased variance of channel ch from the slot sums (fp64), written to LDS -- and, by the first chunk of a
+// group, to mean / var and the running statistics
+__device__ static inline void bn_mean_var_to_lds(const float *__restrict__ sums, const float *__restrict__ group_n, int G, int g, int c,
+                                                 float *s_mu, float *s_var, bool first_of_group, float *__restrict__ mean,
+                                                 float *__restrict__ var, float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                 long long *__restrict__ nbt, float momentum) {
+    const double n = group_n[g] > 0.f ? (double)group_n[g] : 1.0;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+            a0 += sums[((int64_t)(sl * 2) * G + g) * c + ch];
+            a1 += sums[((int64_t)(sl * 2 + 1) * G + g) * c + ch];
+        }
+        const double m = a0 / n, v = a1 / n - m * m;
+        const float mu = (float)m, vv = (float)(v > 0 ? v : 0);
+        s_mu[ch] = mu;
+        s_var[ch] = vv;
+        if (first_of_group) {
+            mean[(int64_t)g * c + ch] = mu;
+            var[(int64_t)g * c + ch] = vv;
+            if (run_mean && run_var) {
+                const float unb = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
+                float *rm = run_mean + (int64_t)g * c + ch, *rv = run_var + (int64_t)g * c + ch;
+                *rm = (1.f - momentum) * *rm + momentum * mu;
+                *rv = (1.f - momentum) * *rv + momentum * (vv * unb);
+            }
+            if (nbt && ch == 0) nbt[g] += 1;
+        }
+    }
 }
 
 // four fp32 -> four bf16, round-to-nearest-even (v_cvt_pk_bf16_f32): the copy the next convolution gathers from
@@ -136,6 +201,292 @@ __device__ static inline uint2 bn_pack4bf(float4 v) {
     const bn_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
     return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bn_bf16x2)),
                       __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bn_bf16x2)));
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 storage
+// CG3D_BN_STORE_BF16: every row matrix of the call is stored as bf16.  Same structure as the kernels above with EIGHT channels
+// per thread (one 16-byte access = 8 bf16): a row of C channels is covered by C / 8 lanes, the per-channel constants live in
+// registers, rows are walked four at a time with all loads issued before the first use.  Operands are widened to fp32 (a
+// shift), everything is computed in fp32 as above, results are rounded to nearest even on the store (v_cvt_pk_bf16_f32).
+struct bn_v8 { float v[8]; };
+__device__ static inline bn_v8 bn_ld8(const uint16_t *base, int64_t off8) {
+    const uint4 u = reinterpret_cast<const uint4 *>(base)[off8];
+    bn_v8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ static inline bn_v8 bn_unpack8(const uint4 u) {
+    bn_v8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ static inline uint4 bn_pack8(const bn_v8 &a) {
+    const uint2 lo = bn_pack4bf(make_float4(a.v[0], a.v[1], a.v[2], a.v[3])), hi = bn_pack4bf(make_float4(a.v[4], a.v[5], a.v[6], a.v[7]));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ static inline void bn_st8(uint16_t *base, int64_t off8, const bn_v8 &a) {
+    const uint2 lo = bn_pack4bf(make_float4(a.v[0], a.v[1], a.v[2], a.v[3])), hi = bn_pack4bf(make_float4(a.v[4], a.v[5], a.v[6], a.v[7]));
+    reinterpret_cast<uint4 *>(base)[off8] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ static inline bn_v8 bn_ldf8(const float *p) {          // 8 consecutive per-channel constants
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    bn_v8 r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+__device__ static inline void bn_stf8(float *p, const bn_v8 &a) {
+    reinterpret_cast<float4 *>(p)[0] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    reinterpret_cast<float4 *>(p)[1] = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+// sum over the CG3D_BN_SLOTS slots of one statistics row (fp64), 8 channels
+__device__ static inline void bn_slot_sums8(const float *table, int G, int g, int c, int o8, int which, double out[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) out[e] = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
+        const bn_v8 u = bn_ldf8(table + ((int64_t)(sl * 2 + which) * G + g) * c + 8 * o8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) out[e] += u.v[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn16_partial_bwd(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ X,
+                                                          const uint16_t *__restrict__ Yv, const int32_t *__restrict__ chunks,
+                                                          int32_t c, const float *__restrict__ mean, const float *__restrict__ var,
+                                                          float eps, int act, float *__restrict__ sums, int G) {
+    // c / 8 <= 256 channel octs (the entry point checks): one oct per thread column, no loop over octs
+    __shared__ float red[4][2][64][9];                   // [wave][statistic][oct of the wave][8 (+1: bank spread)]
+    const int co = c >> 3;
+    const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
+    const int tpr = co < 256 ? co : 256, rpb = 256 / tpr;          // tpr: a power of two (8 .. 256)
+    const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x % CG3D_BN_SLOTS;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s0[e] = s1[e] = 0.f;
+    {
+        const int q = tq;
+        // rows first: their addresses do not depend on the per-channel constants, whose loads then hide behind them
+        constexpr int U = 4;
+        uint4 a[U], x[U], y[U];
+        bool ok[U];
+        auto load = [&](int r) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int rr = r + u * rpb;
+                ok[u] = rr < nr;
+                const int64_t off = (int64_t)(r0 + (ok[u] ? rr : (r < nr ? r : 0))) * co + q;      // clamped, unconditional load
+                a[u] = reinterpret_cast<const uint4 *>(dY)[off];
+                x[u] = reinterpret_cast<const uint4 *>(X)[off];
+                if (act) y[u] = reinterpret_cast<const uint4 *>(Yv)[off];
+            }
+        };
+        load(tr);
+        const bn_v8 mu = bn_ldf8(mean + (int64_t)g * c + 8 * q), vv = bn_ldf8(var + (int64_t)g * c + 8 * q);
+        float is[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) is[e] = rsqrtf(vv.v[e] + eps);
+        for (int r = tr; r < nr; r += U * rpb) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!ok[u]) continue;
+                const bn_v8 av = bn_unpack8(a[u]), xv = bn_unpack8(x[u]);
+                bn_v8 yv;
+                if (act) yv = bn_unpack8(y[u]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float d = av.v[e];
+                    if (act) d *= act_bwd(yv.v[e], act);
+                    s0[e] += d;
+                    s1[e] += d * (xv.v[e] - mu.v[e]) * is[e];
+                }
+            }
+            if (r + U * rpb < nr) load(r + U * rpb);
+        }
+    }
+    // lanes of a wave that own the same oct (stride tpr) meet by xor-shuffles; the waves meet in LDS
+    for (int off = tpr; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { s0[e] += __shfl_xor(s0[e], off); s1[e] += __shfl_xor(s1[e], off); }
+    const int wo = tpr < 64 ? tpr : 64;                  // octs a wave covers
+    if (lane < wo) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { red[wave][0][lane][e] = s0[e]; red[wave][1][lane][e] = s1[e]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tpr) {
+        const int t = threadIdx.x;
+        float f0[8], f1[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) f0[e] = f1[e] = 0.f;
+        for (int w = 0; w < 4; w++) {
+            // wave w covers the octs (64 w) % tpr ... + wo - 1
+            const int first = (64 * w) % tpr;
+            if (t >= first && t < first + wo) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) { f0[e] += red[w][0][t - first][e]; f1[e] += red[w][1][t - first][e]; }
+            }
+        }
+        float *w0 = sums + ((int64_t)(slot * 2) * G + g) * c + 8 * t, *w1 = sums + ((int64_t)(slot * 2 + 1) * G + g) * c + 8 * t;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { unsafeAtomicAdd(w0 + e, f0[e]); unsafeAtomicAdd(w1 + e, f1[e]); }
+    }
+}
+
+template <bool SUMS>
+__global__ __launch_bounds__(256) void k_bn16_apply(const uint16_t *__restrict__ X, const uint16_t *__restrict__ R,
+                                                    const int32_t *__restrict__ chunks, int32_t c, float *__restrict__ mean,
+                                                    float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, int act, uint16_t *__restrict__ Y,
+                                                    const float *__restrict__ sums, const float *__restrict__ group_n, int G,
+                                                    float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                    long long *__restrict__ nbt, float momentum) {
+    // c / 8 <= 256 octs, c <= BN_LDS_C with SUMS (the entry points check): one oct per thread column
+    const int co = c >> 3;
+    const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
+    const bool first_of_group = SUMS && (blockIdx.x == 0 || chunks[(blockIdx.x - 1) * 3] != g);
+    const int tpr = co < 256 ? co : 256, rpb = 256 / tpr;
+    const int q = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const bool active = tr < rpb;
+    __shared__ __attribute__((aligned(16))) float s_mu[SUMS ? BN_LDS_C : 8], s_var[SUMS ? BN_LDS_C : 8];
+    // the first rows are requested BEFORE the statistics are derived: their addresses do not depend on them, and a chunk is
+    // one or two trips long -- the table loads, the fp64 sums and the barrier hide behind the rows' round trip
+    uint4 xv[4], rv[4];                                  // (packed: 8 bf16 per register quad, widened where they are used)
+    int64_t off[4];
+    bool ok[4];
+    auto load = [&](int r) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int rr = r + u * rpb;
+            ok[u] = active && rr < nr;
+            off[u] = (int64_t)(r0 + (ok[u] ? rr : 0)) * co + q;
+            xv[u] = reinterpret_cast<const uint4 *>(X)[off[u]];
+            if (R) rv[u] = reinterpret_cast<const uint4 *>(R)[off[u]];
+        }
+    };
+    load(tr);
+    bn_v8 mu, vv;
+    if (SUMS) {
+        bn_mean_var_to_lds(sums, group_n, G, g, c, s_mu, s_var, first_of_group, mean, var, run_mean, run_var, nbt, momentum);
+        __syncthreads();
+        mu = bn_ldf8(&s_mu[8 * q]);
+        vv = bn_ldf8(&s_var[8 * q]);
+    } else {
+        mu = bn_ldf8(mean + (int64_t)g * c + 8 * q);
+        vv = bn_ldf8(var + (int64_t)g * c + 8 * q);
+    }
+    if (!active) return;
+    const bn_v8 ga = bn_ldf8(gamma + (int64_t)g * c + 8 * q), be = bn_ldf8(beta + (int64_t)g * c + 8 * q);
+    float sc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) sc[e] = rsqrtf(vv.v[e] + eps);
+    for (int r = tr; r < nr; r += 4 * rpb) {
+        uint4 yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bn_v8 x = bn_unpack8(xv[u]);
+            bn_v8 rr, y;
+            if (R) rr = bn_unpack8(rv[u]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float t = (x.v[e] - mu.v[e]) * sc[e] * ga.v[e] + be.v[e];
+                if (R) t += rr.v[e];
+                y.v[e] = act_fwd(t, act);
+            }
+            yv[u] = bn_pack8(y);
+        }
+        bool okc[4];
+        int64_t offc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { okc[u] = ok[u]; offc[u] = off[u]; }
+        if (r + 4 * rpb < nr) load(r + 4 * rpb);         // the next trip's rows, ahead of this trip's stores
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (okc[u]) reinterpret_cast<uint4 *>(Y)[offc[u]] = yv[u];
+    }
+}
+
+template <bool SUMS>
+__global__ __launch_bounds__(256) void k_bn16_bwd_apply(const uint16_t *__restrict__ dY, const uint16_t *__restrict__ X,
+                                                        const uint16_t *__restrict__ Yv, const int32_t *__restrict__ chunks,
+                                                        int32_t c, const float *__restrict__ mean, const float *__restrict__ var,
+                                                        float eps, const float *__restrict__ gamma, float *__restrict__ dbeta,
+                                                        float *__restrict__ dgamma, const float *__restrict__ group_n, int act,
+                                                        int use_batch, uint16_t *__restrict__ dX, uint16_t *__restrict__ dR,
+                                                        const float *__restrict__ dsums, int G) {
+    const int co = c >> 3;
+    const int g = chunks[blockIdx.x * 3], r0 = chunks[blockIdx.x * 3 + 1], nr = chunks[blockIdx.x * 3 + 2];
+    const bool first_of_group = SUMS && (blockIdx.x == 0 || chunks[(blockIdx.x - 1) * 3] != g);
+    const float inv_n = use_batch ? 1.f / group_n[g] : 0.f;
+    const int tpr = co < 256 ? co : 256, rpb = 256 / tpr;
+    const int q = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const bool active = tr < rpb;
+    __shared__ __attribute__((aligned(16))) float s_b[SUMS ? BN_LDS_C : 8], s_g[SUMS ? BN_LDS_C : 8];
+    constexpr int U = 2;                                 // rows per trip (three input streams: 6 x 16 bytes in flight per thread)
+    uint4 dv[U], xv[U], yv[U];
+    int64_t off[U];
+    bool ok[U];
+    auto load = [&](int r) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int rr = r + u * rpb;
+            ok[u] = active && rr < nr;
+            off[u] = (int64_t)(r0 + (ok[u] ? rr : 0)) * co + q;
+            dv[u] = reinterpret_cast<const uint4 *>(dY)[off[u]];
+            xv[u] = reinterpret_cast<const uint4 *>(X)[off[u]];
+            if (act) yv[u] = reinterpret_cast<const uint4 *>(Yv)[off[u]];
+        }
+    };
+    load(tr);                                            // (before the slot sums: see k_bn16_apply)
+    bn_v8 sb, sg;
+    if (SUMS) {
+        bn_slot_pair_to_lds(dsums, G, g, c, s_b, s_g, first_of_group, dbeta, dgamma);
+        __syncthreads();
+        sb = bn_ldf8(&s_b[8 * q]);
+        sg = bn_ldf8(&s_g[8 * q]);
+    } else {
+        sb = bn_ldf8(dbeta + (int64_t)g * c + 8 * q);
+        sg = bn_ldf8(dgamma + (int64_t)g * c + 8 * q);
+    }
+    if (!active) return;
+    const bn_v8 mu = bn_ldf8(mean + (int64_t)g * c + 8 * q), vv = bn_ldf8(var + (int64_t)g * c + 8 * q);
+    const bn_v8 ga = bn_ldf8(gamma + (int64_t)g * c + 8 * q);
+    float is[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) is[e] = rsqrtf(vv.v[e] + eps);
+    for (int r = tr; r < nr; r += U * rpb) {
+        uint4 dp[U], op[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bn_v8 dyv = bn_unpack8(dv[u]), x = bn_unpack8(xv[u]);
+            bn_v8 y, d, o;
+            if (act) y = bn_unpack8(yv[u]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                d.v[e] = dyv.v[e] * (act ? act_bwd(y.v[e], act) : 1.f);
+                o.v[e] = ga.v[e] * is[e] * (d.v[e] - (sb.v[e] + (x.v[e] - mu.v[e]) * is[e] * sg.v[e]) * inv_n);
+            }
+            dp[u] = bn_pack8(d);
+            op[u] = bn_pack8(o);
+        }
+        bool okc[U];
+        int64_t offc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { okc[u] = ok[u]; offc[u] = off[u]; }
+        if (r + U * rpb < nr) load(r + U * rpb);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (okc[u]) {
+                if (dR) reinterpret_cast<uint4 *>(dR)[offc[u]] = dp[u];
+                reinterpret_cast<uint4 *>(dX)[offc[u]] = op[u];
+            }
+    }
 }
 
 // SUMS: mean / variance are not inputs but derived from the zero-based statistics table sums[2][G][C] of the layer
@@ -158,10 +509,20 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ X, c
     // are walked four at a time with all loads issued before the first use (memory-level parallelism)
     const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    __shared__ float s_mu[SUMS ? BN_LDS_C : 4], s_var[SUMS ? BN_LDS_C : 4];
+    const bool lds = SUMS && c <= BN_LDS_C;
+    if (lds) {
+        bn_mean_var_to_lds(sums, group_n, G, g, c, s_mu, s_var, first_of_group, mean, var, run_mean, run_var, nbt, momentum);
+        __syncthreads();
+    }
     if (tr >= rpb) return;
     for (int q = tq; q < cq; q += tpr) {
         float4 mu, vv;
-        if (SUMS) {
+        if (lds) {
+            mu = *reinterpret_cast<const float4 *>(&s_mu[4 * q]);
+            vv = *reinterpret_cast<const float4 *>(&s_var[4 * q]);
+        } else if (SUMS) {
+            // (more than BN_LDS_C channels: every thread adds the slots of its own channels up)
             // the 16 slot sums are added up in fp64 (each slot is an fp32 atomic chain over ~1/16 of the rows; the slot sums
             // themselves are large and nearly equal, so their sum is where fp32 would lose the low bits E[x^2] - mean^2 needs)
             double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
@@ -231,6 +592,15 @@ extern "C" int cg3d_bn_apply(const float *X, const float *residual, const int32_
                              int32_t act, float *Y, uint16_t *Y16, cg3d_stream_t stream) {
     if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(Y) || bad(residual) || ((uintptr_t)Y16 & 7)) return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
+    if (act & CG3D_BN_STORE_BF16) {          // X, residual, Y are bf16 rows
+        if (!bn16_ok(c) || Y16) return CG3D_ERR_ARG;
+        hipLaunchKernelGGL(k_bn16_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), reinterpret_cast<const uint16_t *>(X),
+                           reinterpret_cast<const uint16_t *>(residual), chunks, c, const_cast<float *>(mean), const_cast<float *>(var), eps,
+                           gamma, beta, act & ~CG3D_BN_STORE_BF16, reinterpret_cast<uint16_t *>(Y), nullptr, nullptr, 1, nullptr, nullptr,
+                           nullptr, 0.f);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     hipLaunchKernelGGL(k_bn_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c,
                        const_cast<float *>(mean), const_cast<float *>(var), eps, gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16),
                        nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0.f);
@@ -246,6 +616,15 @@ extern "C" int cg3d_bn_apply_sums(const float *X, const float *residual, const i
         bad(var) || bad(running_mean) || bad(running_var) || !sums || !group_n || !mean || !var)
         return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
+    if (act & CG3D_BN_STORE_BF16) {
+        if (!bn16_ok(c) || Y16) return CG3D_ERR_ARG;
+        hipLaunchKernelGGL(k_bn16_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), reinterpret_cast<const uint16_t *>(X),
+                           reinterpret_cast<const uint16_t *>(residual), chunks, c, mean, var, eps, gamma, beta, act & ~CG3D_BN_STORE_BF16,
+                           reinterpret_cast<uint16_t *>(Y), sums, group_n, G, running_mean, running_var,
+                           reinterpret_cast<long long *>(num_batches_tracked), momentum);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     hipLaunchKernelGGL(k_bn_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), X, residual, chunks, c, mean, var, eps,
                        gamma, beta, act, Y, reinterpret_cast<uint2 *>(Y16), sums, group_n, G, running_mean, running_var,
                        reinterpret_cast<long long *>(num_batches_tracked), momentum);
@@ -271,13 +650,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     const float inv_n = use_batch ? 1.f / group_n[g] : 0.f;
     const int tpr = cq < 256 ? cq : 256, rpb = 256 / tpr;
     const int tq = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    __shared__ float s_b[SUMS ? BN_LDS_C : 4], s_g[SUMS ? BN_LDS_C : 4];
+    const bool lds = SUMS && c <= BN_LDS_C;
+    if (lds) {
+        bn_slot_pair_to_lds(dsums, G, g, c, s_b, s_g, first_of_group, dbeta, dgamma);
+        __syncthreads();
+    }
     if (tr >= rpb) return;
     for (int q = tq; q < cq; q += tpr) {
         const float4 mu = reinterpret_cast<const float4 *>(mean + (int64_t)g * c)[q];
         const float4 vv = reinterpret_cast<const float4 *>(var + (int64_t)g * c)[q];
         const float4 ga = reinterpret_cast<const float4 *>(gamma + (int64_t)g * c)[q];
         float4 sb, sg;
-        if (SUMS) {
+        if (lds) {
+            sb = *reinterpret_cast<const float4 *>(&s_b[4 * q]);
+            sg = *reinterpret_cast<const float4 *>(&s_g[4 * q]);
+        } else if (SUMS) {
             double b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};            // slot sums added in fp64, as in the forward
 #pragma unroll
             for (int sl = 0; sl < CG3D_BN_SLOTS; sl++) {
@@ -338,6 +726,15 @@ extern "C" int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y
     if (nchunk < 0 || c < 4 || (c & 3) || bad(X) || bad(dY) || bad(Y) || bad(dX) || bad(dRes) || ((uintptr_t)dX16 & 7))
         return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
+    if (act & CG3D_BN_STORE_BF16) {          // dY, X, Y, dX, dRes are bf16 rows
+        if (!bn16_ok(c) || dX16) return CG3D_ERR_ARG;
+        hipLaunchKernelGGL(k_bn16_bwd_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), reinterpret_cast<const uint16_t *>(dY),
+                           reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(Y), chunks, c, mean, var, eps, gamma,
+                           const_cast<float *>(dbeta), const_cast<float *>(dgamma), group_n, act & ~CG3D_BN_STORE_BF16, use_batch_stats,
+                           reinterpret_cast<uint16_t *>(dX), reinterpret_cast<uint16_t *>(dRes), nullptr, 1);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var,
                        eps, gamma, const_cast<float *>(dbeta), const_cast<float *>(dgamma), group_n, act, use_batch_stats, dX,
                        reinterpret_cast<uint2 *>(dX16), dRes, nullptr, 1);
@@ -353,8 +750,18 @@ extern "C" int cg3d_bn_bwd_apply_sums(const float *dY, const float *X, const flo
         bad(dsums) || bad(dbeta) || bad(dgamma) || !dsums || !dbeta || !dgamma)
         return CG3D_ERR_ARG;
     if (nchunk == 0) return CG3D_OK;
+    if (act & CG3D_BN_STORE_BF16) {
+        if (!bn16_ok(c) || dX16) return CG3D_ERR_ARG;
+        hipLaunchKernelGGL(k_bn16_bwd_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), reinterpret_cast<const uint16_t *>(dY),
+                           reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(Y), chunks, c, mean, var, eps, gamma,
+                           dbeta, dgamma, group_n, act & ~CG3D_BN_STORE_BF16, use_batch_stats, reinterpret_cast<uint16_t *>(dX),
+                           reinterpret_cast<uint16_t *>(dRes), dsums, G);
+        CG3D_CHECK_LAUNCH();
+        return CG3D_OK;
+    }
     hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)nchunk), dim3(256), 0, cg3d_hs(stream), dY, X, Y, chunks, c, mean, var, eps,
                        gamma, dbeta, dgamma, group_n, act, use_batch_stats, dX, reinterpret_cast<uint2 *>(dX16), dRes, dsums, G);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
+

@@ -27,7 +27,7 @@ template <int NCO>                  // output channels of a workgroup = NCO * 64
 __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf,
                                                         const float *__restrict__ bias, float *__restrict__ Y, int64_t n,
                                                         int32_t cin, int32_t cout, int32_t ny, int32_t gz,
-                                                        float *__restrict__ stats, float *__restrict__ part) {
+                                                        float *__restrict__ stats, float *__restrict__ part, int32_t out16) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NB = NCO * 2;                          // 32-channel output blocks of the workgroup
     constexpr int NC = NCO * 64;
@@ -109,7 +109,14 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (wave * 32 + rr < rows) {
                 float *dst = (part ? part + (int64_t)zi * n * cout : Y) + (row0 + wave * 32 + rr) * (int64_t)cout + col0;
-                if (gz == 1 || part) *reinterpret_cast<float4 *>(dst) = v;
+                if (out16) {                              // Y holds bf16 rows (CG3D_LINEAR_OUT_BF16; gz == 1, no partials)
+                    typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
+                    const ln_f32x2 p0 = {v.x, v.y}, p1 = {v.z, v.w};
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(Y) + (row0 + wave * 32 + rr) * (int64_t)cout + col0) =
+                        make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, ln_bf16x2)),
+                                   __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, ln_bf16x2)));
+                } else if (gz == 1 || part) *reinterpret_cast<float4 *>(dst) = v;
                 else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
                 t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
@@ -151,6 +158,9 @@ __global__ __launch_bounds__(256) void k_linear_reduce(const float4 *__restrict_
 
 extern "C" int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin,
                                int32_t cout, int32_t ksplit, float *stats, float *partials, cg3d_stream_t stream) {
+    const int32_t out16 = (ksplit & CG3D_LINEAR_OUT_BF16) ? 1 : 0;          // Y: uint16 [n, cout] bf16 rows (ksplit == 1 only)
+    ksplit &= ~CG3D_LINEAR_OUT_BF16;
+    if (out16 && ksplit != 1) return CG3D_ERR_ARG;
     if (n < 0 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || ksplit < 1 || ksplit > 256 || ksplit > (cin >> 6)) return CG3D_ERR_ARG;
     if (((uintptr_t)X & 15) || ((uintptr_t)Wf & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)partials & 15) || (stats && ksplit != 1)) return CG3D_ERR_ARG;
     if (n == 0) return CG3D_OK;
@@ -171,7 +181,7 @@ extern "C" int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const floa
             attr = true;                                                                                                          \
         }                                                                                                                         \
         hipLaunchKernelGGL((k_linear_tile<NCO>), dim3((unsigned)nunit), dim3(256), LN_LDS, s, X, Wf, bias, Y, n, cin, cout, ny,   \
-                           ksplit, stats, partials);                                                                              \
+                           ksplit, stats, partials, out16);                                                                       \
     } while (0)
     if (nco == 2) LN_LAUNCH(2); else LN_LAUNCH(1);
 #undef LN_LAUNCH

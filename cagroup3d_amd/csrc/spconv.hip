@@ -394,6 +394,24 @@ extern "C" int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream
     return CG3D_OK;
 }
 
+__global__ void k_from_bf16(const uint4 *__restrict__ Xb, float4 *__restrict__ X, int64_t n8) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n8) return;
+    const uint4 u = Xb[t];
+    X[2 * t] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    X[2 * t + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                               __uint_as_float(u.w & 0xffff0000u));
+}
+extern "C" int cg3d_from_bf16(const uint16_t *Xb, float *X, int64_t n, cg3d_stream_t stream) {
+    if (n < 0 || (n & 7) || ((uintptr_t)X & 15) || ((uintptr_t)Xb & 15)) return CG3D_ERR_ARG;
+    if (n == 0) return CG3D_OK;
+    hipLaunchKernelGGL(k_from_bf16, dim3((unsigned)cg3d_divup(n / 8, 256)), dim3(256), 0, cg3d_hs(stream),
+                       reinterpret_cast<const uint4 *>(Xb), reinterpret_cast<float4 *>(X), n / 8);
+    CG3D_CHECK_LAUNCH();
+    return CG3D_OK;
+}
+
 // ---------------------------------------------------------------- split operands ("bf16x3": fp32-accurate products on the bf16 pipe)
 // x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi).  A product of two fp32 values is then
 //   x w = xhi whi + xlo whi + xhi wlo + O(2^-16 |x w|)

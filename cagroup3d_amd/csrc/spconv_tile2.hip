@@ -204,9 +204,9 @@ __device__ __forceinline__ void t2_unit(
                 if (nstep > 0) {
                     // weight fragments of (offset kk, 16-channel group ks, output block n): Wf[slot][nt][ks][lane][8]
                     // (wrev: offset k reads weight slot K-1-k -- the data gradient of a map onto itself walks the FORWARD plan)
-                    const uint16_t *wbase = Wf + ((wslot0 + (wrev ? K - 1 - kb : kb)) * nt_total + nt0) * (int64_t)ks_total * 512 +
+                    const uint16_t *wbase = Wf + ((wslot0 + ((wrev & 1) ? K - 1 - kb : kb)) * nt_total + nt0) * (int64_t)ks_total * 512 +
                                             (int64_t)c * 4 * 512 + lane * 8;
-                    const int64_t wstride = (wrev ? -1 : 1) * (int64_t)nt_total * ks_total * 512;       // per offset
+                    const int64_t wstride = ((wrev & 1) ? -1 : 1) * (int64_t)nt_total * ks_total * 512;       // per offset
                     const int64_t wn = (int64_t)ks_total * 512;                        // per 32-channel output block
                     // LDS byte address of (row block m, ks = 0) for this lane's channel half; granule g of slot s sits at
                     // g ^ ((s >> 1) & 7) and g = 2 ks + kg, so the address of ks is  a0 ^ (kg << 4) ^ (ks << 5)
@@ -418,7 +418,14 @@ __device__ __forceinline__ void t2_unit(
             if (pos < rows) {
                 const int64_t orow = order ? (int64_t)order[row0 + pos] : row0 + pos;
                 float *dst = Y + orow * cout + col0;
-                if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
+                if (wrev & CG3D_TILE_OUT_BF16) {          // Y holds bf16 rows: 8 bytes per lane, a row's 64 channels are one 128-byte line
+                    typedef float t2_f32x2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 t2_bf16x2 __attribute__((ext_vector_type(2)));
+                    const t2_f32x2 p0 = {v.x, v.y}, p1 = {v.z, v.w};
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(Y) + orow * cout + col0) =
+                        make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, t2_bf16x2)),
+                                   __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, t2_bf16x2)));
+                } else if (gz == 1) *reinterpret_cast<float4 *>(dst) = v;
                 else { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
                 t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
                 t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
@@ -494,6 +501,8 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
         return CG3D_ERR_ARG;
     if (ucap < T2_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
+    if ((wrev & CG3D_TILE_OUT_BF16) && (ksplit != 1 || ((uintptr_t)Y & 7))) return CG3D_ERR_ARG;      // bf16 rows are stored, not added
+    wrev &= 3;
     if (ntile == 0) return CG3D_OK;
     hipStream_t s = cg3d_hs(stream);
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
@@ -519,7 +528,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
             }                                                                                                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spconv_tile2<NW>), dim3(grid), dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist,    \
-                           maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev ? 1 : 0, stats, stagger); \
+                           maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev, stats, stagger); \
     } while (0)
     // tail in half units (see k_spconv_tile2_mix): only when the last round is at most half full
     static const int tail_env = getenv("CG3D_TILE_TAIL") ? atoi(getenv("CG3D_TILE_TAIL")) : 1;
@@ -538,7 +547,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
         const int32_t grid2 = (nunit2 + 7) / 8 * 8;
         hipLaunchKernelGGL(k_spconv_tile2_mix, dim3((unsigned)(grid2 + (nunit1 + 7) / 8 * 8)), dim3(256), lds, s, X, Wf, slots, live,
                            pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, grid2, nunit2, ny, nunit1,
-                           ny1, tile_split, wrev ? 1 : 0, stats, stagger);
+                           ny1, tile_split, wrev, stats, stagger);
     } else if (cout >= 128) T2_LAUNCH(2); else T2_LAUNCH(1);
 #undef T2_LAUNCH
     CG3D_CHECK_LAUNCH();

@@ -38,7 +38,16 @@ STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_re
 (OP_NOP, OP_MEMSET, OP_COPY2D, OP_TO_BF16, OP_TILE_FWD, OP_SPCONV_FWD, OP_SPCONV_FWD_TILED, OP_PAIRS_FWD, OP_PAIRS_WGRAD,
  OP_LINEAR_FWD, OP_BN_SUMS, OP_BN_APPLY_SUMS, OP_BN_APPLY, OP_BN_BWD_SUMS, OP_BN_BWD_APPLY_SUMS, OP_BN_BWD_APPLY, OP_INTERP_MAP,
  OP_INTERP_FWD, OP_INTERP_BWD, OP_GATHER_ROWS, OP_SCATTER_ADD_ROWS, OP_SCATTER_MEAN_FWD, OP_SCATTER_MEAN_BWD,
- OP_EVENT_RECORD, OP_TO_BF16_SPLIT) = range(25)
+ OP_EVENT_RECORD, OP_TO_BF16_SPLIT, OP_FROM_BF16) = range(26)
+S16 = 0x100                 # CG3D_BN_STORE_BF16: the row matrices of a BatchNorm call are bf16 rows
+TILE_OUT16 = 2              # CG3D_TILE_OUT_BF16 (bit of cg3d_spconv_tile_fwd's wrev argument)
+LIN_OUT16 = 0x10000         # CG3D_LINEAR_OUT_BF16 (bit of cg3d_linear_fwd's ksplit argument)
+# Activations and activation gradients of the BACKBONE program stored as bf16 only (BASELINE.json configs[1], "bf16 backbone"):
+# the tile / linear convolutions write bf16 rows (+ fp32 statistics), the BatchNorm kernels read and write bf16 and compute in
+# fp32, gradient contributions are summed from bf16 rows in fp32 registers.  A layer moves 6-8 bytes per element in the forward
+# instead of 14-18 and 12-16 in the backward instead of 30-34 (include/cagroup3d_hip.h, CG3D_BN_STORE_BF16).  CG3D_ACT_BF16=0:
+# fp32 storage with bf16 operand copies, the arithmetic of rounds 1-4 (and what the per-layer path of me.py computes).
+ACT_BF16 = os.environ.get("CG3D_ACT_BF16", "1") != "0"
 STRIDE = 24
 WGRAD_ACC = 0x100
 
@@ -67,13 +76,15 @@ class NotReady(Exception):
 class T:
     """A feature matrix inside a program: fp32 rows [n, c] at `p` (+ optional bf16 copy, + the BatchNorm statistics table its
     producer filled) and, during backward emission, the list of its gradient contributions."""
-    __slots__ = ("p", "n", "c", "p16", "stats", "need", "gc", "gsum", "gsum16")
+    __slots__ = ("p", "n", "c", "p16", "stats", "need", "gc", "gsum", "gsum16", "gdone")
 
     def __init__(self, p, n, c, need=True):
         self.p, self.n, self.c, self.p16, self.stats, self.need = p, n, c, 0, 0, need
-        self.gc = None          # [(address, bf16 address or 0)] gradient contributions (backward emission)
-        self.gsum = None        # address of their sum once it has been formed
+        # (bf16 storage, Builder.act16: p may be 0 -- the rows exist as bf16 only, at p16)
+        self.gc = None          # [(address or 0, bf16 address or 0)] gradient contributions (backward emission)
+        self.gsum = None        # address of their sum once it has been formed (0: the sum exists as bf16 rows only)
         self.gsum16 = 0
+        self.gdone = False
 
 
 class _Events:
@@ -160,6 +171,7 @@ class Builder:
         # pass (the BatchNorm kernels' bf16 copies are not used), weights are three-part, contractions three times as long
         self.kx = ME._kx()
         self.prec = ME._prec()
+        self.act16 = False              # set by compile_backbone: activations / gradients stored as bf16 only
 
     # ---------------------------------------------------------------- memory
     def alloc(self, nbytes, region=R_ACT):
@@ -169,6 +181,28 @@ class Builder:
 
     def new(self, n, c, need=True):
         return T(self.alloc(max(n, 1) * c * 4), n, c, need)
+
+    def new16(self, n, c, need=True):
+        """A feature matrix stored as bf16 rows only (act16)."""
+        t = T(0, n, c, need)
+        t.p16 = self.alloc(max(n, 1) * c * 2)
+        return t
+
+    def s16ok(self, c):
+        """bf16 row storage of a c-channel matrix in the BatchNorm kernels (CG3D_BN_STORE_BF16: power-of-two channel counts
+        64 .. 1024 -- the rest of the backbone, DAPPM's 640-channel join, stays on fp32 rows)."""
+        return self.act16 and 64 <= c <= 1024 and (c & (c - 1)) == 0
+
+    def out(self, n, c, need=True):
+        """Where a kernel with both output forms puts a layer's rows: bf16 rows under act16, fp32 rows otherwise."""
+        return self.new16(n, c, need) if self.act16 else self.new(n, c, need)
+
+    def f32(self, t):
+        """fp32 rows of `t` (forward pass): its own, or one widening pass over the bf16 rows (cg3d_from_bf16)."""
+        if not t.p:
+            t.p = self.alloc(max(t.n, 1) * t.c * 4)
+            self.f.add(OP_FROM_BF16, t.p16, t.p, t.n * t.c)
+        return t.p
 
     def pgrad(self, param):
         """Address (in R_PG) of the gradient of `param`."""
@@ -207,25 +241,50 @@ class Builder:
             if t.gc is None:
                 t.gc = []
             t.gc.append((p, p16))
-            t.gsum = None
+            t.gsum, t.gdone = None, False
 
-    def grad(self, t, want16=False):
-        """(address, bf16 address or 0) of the complete gradient of `t`, or None when no contribution arrived."""
+    def grad(self, t, want16=False, want32=False):
+        """(address or 0, bf16 address or 0) of the complete gradient of `t`, or None when no contribution arrived.
+        want16 / want32: make sure that form exists (act16: a gradient may exist as bf16 rows only)."""
         if not t.gc:
             return None
-        if t.gsum is None:
+        if not t.gdone:
             if len(t.gc) == 1:
                 t.gsum, t.gsum16 = t.gc[0]
+            elif self.s16ok(t.c):
+                # every contribution as bf16 rows, added pairwise in fp32 registers (one rounding per sum)
+                c16 = []
+                for p, p16 in t.gc:
+                    if not p16:
+                        p16 = self.alloc(max(t.n, 1) * t.c * 2)
+                        self.b.add(OP_TO_BF16, p, p16, t.n * t.c)
+                    c16.append(p16)
+                acc = c16[0]
+                for q in c16[1:]:
+                    out = self.alloc(max(t.n, 1) * t.c * 2)
+                    self._add_rows(self.b, acc, q, out, t.n, t.c, ME.ACT_NONE, 0, s16=True)
+                    acc = out
+                t.gsum, t.gsum16 = 0, acc
             else:
-                acc = t.gc[0][0]
-                for p, _ in t.gc[1:]:
+                c32 = []
+                for p, p16 in t.gc:
+                    if not p:                                   # (act16, a channel count the bf16 kernels do not take)
+                        p = self.alloc(max(t.n, 1) * t.c * 4)
+                        self.b.add(OP_FROM_BF16, p16, p, t.n * t.c)
+                    c32.append(p)
+                acc = c32[0]
+                for p in c32[1:]:
                     out = self.alloc(max(t.n, 1) * t.c * 4)
                     self._add_rows(self.b, acc, p, out, t.n, t.c, ME.ACT_NONE, 0)
                     acc = out
                 t.gsum, t.gsum16 = acc, 0
+            t.gdone = True
         if want16 and not t.gsum16:
             t.gsum16 = self.alloc(max(t.n, 1) * t.c * 2 * self.kx)
             self._to16(self.b, t.gsum, t.gsum16, t.n, t.c)
+        if want32 and not t.gsum:
+            t.gsum = self.alloc(max(t.n, 1) * t.c * 4)
+            self.b.add(OP_FROM_BF16, t.gsum16, t.gsum, t.n * t.c)
         return t.gsum, t.gsum16
 
     # The chunk / identity-pair / unit tables come out of me.py's host caches, which are CLEARED when they grow past their
@@ -249,11 +308,12 @@ class Builder:
     def _ident(self, n, seglen):
         return self._hold(ME._identity_pairs(n, seglen, self.dev))
 
-    def _add_rows(self, prog, a, b, y, n, c, act, y16):
-        """y = act(a + b) (b may be 0): cg3d_bn_apply with the identity normalisation, as me.AddReluFunction does."""
+    def _add_rows(self, prog, a, b, y, n, c, act, y16, s16=False):
+        """y = act(a + b) (b may be 0): cg3d_bn_apply with the identity normalisation, as me.AddReluFunction does.
+        s16: a, b, y are bf16 rows (act16)."""
         z, o = self._unit(c)
         ch = self._chunks(n, c)
-        prog.add(OP_BN_APPLY, a, b, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, act, y, y16)
+        prog.add(OP_BN_APPLY, a, b, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, act | (S16 if s16 else 0), y, y16)
 
     # ---------------------------------------------------------------- weights of the step's arena
     def _planned(self, w3, frag, need_plain):
@@ -286,16 +346,16 @@ class Builder:
             _, wp = self._planned(w3, True, True)
         if x.need and not tile_b and ME._use_bf16(cout):
             _, wp = self._planned(w3, False, True)                # (the per-layer path converts this one on the spot when missing)
-        xg = self.rows16(x) if use16 else x.p
+        xg = self.rows16(x) if use16 else self.f32(x)
         rows16 = bool(use16)
         n_in, n_out = kmap.n_in, kmap.n_out
         prog = self.f
         if tile_f:
             plan = kmap.tile_plan(False)
-            y = self.new(n_out, cout)
+            y = self.out(n_out, cout)
             if ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 512 and plan.ntile > 0:
                 y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
-            self._tile_row(prog, xg, wt, plan, y.p, n_in, cin, cout, False, y.stats, P)
+            self._tile_row(prog, xg, wt, plan, y.p or y.p16, n_in, cin, cout, False, y.stats, P, out16=not y.p)
         elif implicit_f:
             y = self.new(n_out, cout)
             self._prof(prog, "implicit_bf16" + ME._ksuffix(), K, cin, cout, P, n_in, n_out, 2.0 if rows16 else 4.0, 4.0 * K * n_out)
@@ -319,28 +379,34 @@ class Builder:
         prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, xb * n_in * cin + 4.0 * n_out * cout + wbytes + map_bytes,
                           (kind, K, cin, cout, P, n_out, nseg), xb * P * cin + 4.0 * n_out * cout + wbytes + map_bytes))
 
-    def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P, ksplit=1, groups=1):
+    def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P, ksplit=1, groups=1, out16=False):
         def p(t):
             return t.data_ptr() if t is not None else 0
         self._prof(prog, "tile_bf16" + ME._ksuffix(), plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups)
         prog.add(OP_TILE_FWD, x16, wf, p(plan.slots), p(plan.live), p(plan.pass_tab), p(plan.npass), p(plan.ulist), plan.maxpass,
                  plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin * self.kx, cout, ksplit,
-                 1 if wrev else 0, stats)
+                 (1 if wrev else 0) | (TILE_OUT16 if out16 else 0), stats)
 
     def _conv_bwd(self, x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b):
-        g = self.grad(y, want16=self.bf16 and ME._use_bf16(cout))
+        use16 = self.bf16 and ME._use_bf16(cout)
+        wprec = ME._wgrad_prec(cin, cout, bool(x.p16) and self.bf16)
+        # (fp32 rows of dY: the fp32-operand kernels -- the stem's data / weight gradient -- read them)
+        g = self.grad(y, want16=use16, want32=(not use16) or wprec < 2)
         if g is None:
             return
         dy, dy16 = g
         prog = self.b
         pin, pout = kmap.pairs(None)[:2]
-        use16 = self.bf16 and ME._use_bf16(cout)
         dyg = dy16 if use16 else dy
+        dx16 = 0
         if x.need:
             if tile_b:
                 plan = kmap.tile_plan(True)
-                dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
-                self._tile_row(prog, dyg, wp, plan, dx, kmap.n_out, cout, cin, kmap.symmetric, 0, P)
+                if self.act16:
+                    dx, dx16 = 0, self.alloc(max(kmap.n_in, 1) * cin * 2)
+                else:
+                    dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
+                self._tile_row(prog, dyg, wp, plan, dx or dx16, kmap.n_out, cout, cin, kmap.symmetric, 0, P, out16=not dx)
             elif ME.SparseConvFunction._implicit(kmap, P, cout, cin, kmap.n_in, None):
                 dx = self.alloc(max(kmap.n_in, 1) * cin * 4)
                 if not wp:
@@ -363,12 +429,13 @@ class Builder:
                     self._prof(prog, "pairs", K, cout, cin, P, kmap.n_out, kmap.n_in, 4.0, 8.0 * P, wb=4.0, nseg=nseg)
                     self.late.append((prog, len(prog.rows), 2, lambda w=w3: w.detach().transpose(1, 2).contiguous()))
                     prog.add(OP_PAIRS_FWD, dy, 0, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout, cin, 0, 1)
-            self.gadd(x, dx)
+            self.gadd(x, dx, dx16)
         # weight gradient
-        wprec = ME._wgrad_prec(cin, cout, bool(x.p16) and self.bf16)
         xw, dyw = x.p, dy
         if wprec >= 2:
             xw, dyw = x.p16, (dy16 if dy16 else self.grad(y, want16=True)[1])
+        elif not xw:
+            raise NotReady("fp32 rows of a bf16-stored input are not kept for the backward pass")
         seg, nseg = (kmap.wgrad_segments if wprec else kmap.segments)(ME._wgrad_seg_len(P, cin, cout, 1 if wprec else 0, K), None)
         eb = 2.0 if wprec >= 2 else 4.0
         if ME.KernelProfile.wgrad:
@@ -494,55 +561,62 @@ class Builder:
         if own:
             wt, wp = self._planned(w2.view(1, cin, cout), True, x.need)
             x16 = self.rows16(x)
-            y = self.new(n, cout)
             units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin * self.kx // 64
             ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
+            # (a split contraction meets in fp32 partial products: its output stays fp32 rows)
+            y = self.out(n, cout) if ksplit == 1 else self.new(n, cout)
             part = 0
             if ksplit > 1:
                 part = self.alloc(ksplit * max(n, 1) * cout * 4)
             elif ME.WANT_BN_STATS and ME.FUSED_BN_STATS and cout <= 1024:
                 y.stats = self.alloc(ME.BN_SLOTS * 2 * cout * 4, R_ZF)
-            self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p, n, cin * self.kx, cout, max(ksplit, 1), y.stats, part)
+            self.f.add(OP_LINEAR_FWD, x16, wt, 0, y.p or y.p16, n, cin * self.kx, cout, max(ksplit, 1) | (0 if y.p else LIN_OUT16), y.stats, part)
         elif self.bf16 and self.kx == 1 and ME._use_bf16(cin) and ME.LinearFunction._skinny(n, cin, cout):
             # many rows x few output channels in the bench precision (the vote offsets: 64 -> 3): me.LinearFunction._rows_gemm,
             # i.e. the pair kernel on the identity map with fp32 rows rounded on the fly and the bf16 copy of the weights
             wt, _ = self._planned(w2.view(1, cin, cout), False, False)
             ar, seg, nseg = self._ident(n, 128)
             y = T(self.alloc(max(n, 1) * cout * 4, R_ZF), n, cout)
-            self.f.add(OP_PAIRS_FWD, x.p, wt, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 1, 1)
+            self.f.add(OP_PAIRS_FWD, self.f32(x), wt, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 1, 1)
             wp = 0
         else:
             # generic form (fp32 parity mode / the oracle): the pair kernel on the identity map, me.LinearFunction._rows_gemm
             ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
             y = T(self.alloc(max(n, 1) * cout * 4, R_ZF), n, cout)
-            self.f.add(OP_PAIRS_FWD, x.p, w2.data_ptr(), ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 0, 1)
+            self.f.add(OP_PAIRS_FWD, self.f32(x), w2.data_ptr(), ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, y.p, n, cin, cout, 0, 1)
             wp = 0
         self.tape.append(lambda: self._linear_bwd(x, y, weight, w2, cin, cout, own, wp))
         return y
 
     def _linear_bwd(self, x, y, weight, w2, cin, cout, own, wp):
-        g = self.grad(y, want16=own)
+        wprec = ME._wgrad_prec(cin, cout, bool(own and x.p16))
+        g = self.grad(y, want16=own, want32=(not own) or wprec < 2)
         if g is None:
             return
         dy, dy16 = g
         n, prog = x.n, self.b
+        dx16 = 0
         if x.need:
             if own:
-                dx = self.alloc(max(n, 1) * cin * 4)
                 units, nchunk = -(-n // 128) * (cin // (128 if cin % 128 == 0 else 64)), cout * self.kx // 64
                 ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
+                if self.act16 and ksplit == 1:
+                    dx, dx16 = 0, self.alloc(max(n, 1) * cin * 2)
+                else:
+                    dx = self.alloc(max(n, 1) * cin * 4)
                 part = self.alloc(ksplit * max(n, 1) * cin * 4) if ksplit > 1 else 0
-                prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx, n, cout * self.kx, cin, max(ksplit, 1), 0, part)
+                prog.add(OP_LINEAR_FWD, dy16, wp, 0, dx or dx16, n, cout * self.kx, cin, max(ksplit, 1) | (0 if dx else LIN_OUT16), 0, part)
             else:
                 ar, seg, nseg = self._ident(n, 128 if self.lib.is_device else (1 << 30))
                 dx = self.alloc(max(n, 1) * cin * 4, R_ZB)
                 self.late.append((prog, len(prog.rows), 2, lambda w=w2: w.detach().t().contiguous()))
                 prog.add(OP_PAIRS_FWD, dy, 0, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, 0, dx, n, cout, cin, 0, 1)
-            self.gadd(x, dx)
-        wprec = ME._wgrad_prec(cin, cout, bool(own and x.p16 and dy16))
+            self.gadd(x, dx, dx16)
         xc, dyc = x.p, dy
         if wprec >= 2:
             xc, dyc = x.p16, dy16
+        elif not xc:
+            raise NotReady("fp32 rows of a bf16-stored input are not kept for the backward pass")
         ar, seg, nseg = self._ident(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1))
         prog.add(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
                  wprec | WGRAD_ACC)
@@ -554,24 +628,53 @@ class Builder:
             raise NotReady("BatchNorm form without a program counterpart (evaluation statistics, --sync_bn)")
         red, nred, _, group_n, app, napp, _ = self._chunks(n, c)
         prog = self.f
+        s16 = self.s16ok(c)
         sums = x.stats
         if not sums:
+            # (the statistics pass reads fp32 rows: a convolution that left none also left its statistics; what remains are
+            # the few small tensors of DAPPM that a BatchNorm reads straight from a join)
             sums = self.alloc(ME.BN_SLOTS * 2 * c * 4, R_ZF)
-            prog.add(OP_BN_SUMS, x.p, red.data_ptr(), nred, 1, c, sums)
+            prog.add(OP_BN_SUMS, self.f32(x), red.data_ptr(), nred, 1, c, sums)
         mv = self.alloc(2 * c * 4, R_ZF)
         mean, var = mv, mv + c * 4
+        gamma, beta = bn.weight, bn.bias
+        if s16:
+            y = self.new16(n, c)
+            prog.add(OP_BN_APPLY_SUMS, self.rows16(x), self.rows16(res) if res is not None else 0, app.data_ptr(), napp, 1, c, sums,
+                     group_n.data_ptr(), _fbits(bn.eps), gamma.data_ptr(), beta.data_ptr(), act | S16, y.p16, 0, mean, var,
+                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), _fbits(bn.momentum))
+            self.tape.append(lambda: self._bn_bwd16(x, y, res, bn, act, mean, var, (red, nred, group_n, app, napp)))
+            return y
         y = self.new(n, c)
         if self.want16(c):
             y.p16 = self.alloc(max(n, 1) * c * 2)
-        gamma, beta = bn.weight, bn.bias
-        prog.add(OP_BN_APPLY_SUMS, x.p, res.p if res is not None else 0, app.data_ptr(), napp, 1, c, sums, group_n.data_ptr(),
+        prog.add(OP_BN_APPLY_SUMS, self.f32(x), self.f32(res) if res is not None else 0, app.data_ptr(), napp, 1, c, sums, group_n.data_ptr(),
                  _fbits(bn.eps), gamma.data_ptr(), beta.data_ptr(), act, y.p, y.p16, mean, var, bn.running_mean.data_ptr(),
                  bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), _fbits(bn.momentum))
         self.tape.append(lambda: self._bn_bwd(x, y, res, bn, act, mean, var, (red, nred, group_n, app, napp)))
         return y
 
+    def _bn_bwd16(self, x, y, res, bn, act, mean, var, ch):
+        """bf16 storage: dY, X, Y in, dX (and dResidual) out as bf16 rows; statistics and parameter gradients fp32."""
+        g = self.grad(y, want16=True)
+        if g is None:
+            return
+        dy16 = g[1]
+        red, nred, group_n, app, napp = ch
+        n, c, prog = x.n, x.c, self.b
+        dsums = self.alloc(ME.BN_SLOTS * 2 * c * 4, R_ZB)
+        eps = _fbits(bn.eps)
+        prog.add(OP_BN_BWD_SUMS, dy16, x.p16, y.p16, red.data_ptr(), nred, 1, c, mean, var, eps, act | S16, dsums)
+        dx16 = self.alloc(max(n, 1) * c * 2)               # (the kernel always writes dX)
+        dres16 = self.alloc(max(n, 1) * c * 2) if (res is not None and res.need) else 0
+        prog.add(OP_BN_BWD_APPLY_SUMS, dy16, x.p16, y.p16, app.data_ptr(), napp, 1, c, mean, var, eps, bn.weight.data_ptr(), dsums,
+                 group_n.data_ptr(), act | S16, 1, dx16, 0, dres16, self.pgrad(bn.bias), self.pgrad(bn.weight))
+        self.gadd(x, 0, dx16)
+        if dres16:
+            self.gadd(res, 0, dres16)
+
     def _bn_bwd(self, x, y, res, bn, act, mean, var, ch):
-        g = self.grad(y)
+        g = self.grad(y, want32=True)
         if g is None:
             return
         dy = g[0]
@@ -593,15 +696,22 @@ class Builder:
 
     # ---------------------------------------------------------------- relu(a [+ b]) / a + b
     def add_act(self, a, b, act):
-        y = self.new(a.n, a.c, need=a.need or (b is not None and b.need))
+        need = a.need or (b is not None and b.need)
+        if self.s16ok(a.c):
+            y = self.new16(a.n, a.c, need=need)
+            self._add_rows(self.f, self.rows16(a), self.rows16(b) if b is not None else 0, y.p16, a.n, a.c, act, 0, s16=True)
+            self.tape.append(lambda: self._add_act_bwd(a, b, y, act))
+            return y
+        y = self.new(a.n, a.c, need=need)
         if act == ME.ACT_RELU and self.want16(a.c):
             y.p16 = self.alloc(max(a.n, 1) * a.c * 2)
-        self._add_rows(self.f, a.p, b.p if b is not None else 0, y.p, a.n, a.c, act, y.p16)
+        self._add_rows(self.f, self.f32(a), self.f32(b) if b is not None else 0, y.p, a.n, a.c, act, y.p16)
         self.tape.append(lambda: self._add_act_bwd(a, b, y, act))
         return y
 
     def _add_act_bwd(self, a, b, y, act):
-        g = self.grad(y)
+        s16 = not y.p                                    # the join was made on bf16 rows
+        g = self.grad(y, want16=s16, want32=not s16)
         if g is None:
             return
         dy = g[0]
@@ -614,6 +724,13 @@ class Builder:
         n, c = a.n, a.c
         z, o = self._unit(c)
         ch = self._chunks(n, c)
+        if s16:
+            dz16 = self.alloc(max(n, 1) * c * 2)
+            self.b.add(OP_BN_BWD_APPLY, g[1], y.p16, y.p16, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, z, o, act | S16, 0, dz16, 0, 0)
+            self.gadd(a, 0, dz16)
+            if b is not None:
+                self.gadd(b, 0, dz16)
+            return
         dz = self.alloc(max(n, 1) * c * 4)
         self.b.add(OP_BN_BWD_APPLY, dy, y.p, y.p, ch[4].data_ptr(), ch[5], c, z, o, _fbits(0.0), o, z, z, o, act, 0, dz, 0, 0)
         self.gadd(a, dz)
@@ -623,12 +740,12 @@ class Builder:
     # ---------------------------------------------------------------- interpolation (SparseTensor.features_at_coordinates)
     def interp(self, x, idx, w, nq):
         y = self.new(nq, x.c, need=x.need)
-        self.f.add(OP_INTERP_FWD, x.p, idx.data_ptr(), w.data_ptr(), y.p, nq, x.c)
+        self.f.add(OP_INTERP_FWD, self.f32(x), idx.data_ptr(), w.data_ptr(), y.p, nq, x.c)
         self.tape.append(lambda: self._interp_bwd(x, y, idx, w, nq))
         return y
 
     def _interp_bwd(self, x, y, idx, w, nq):
-        g = self.grad(y)
+        g = self.grad(y, want32=True)
         if g is None or not x.need:
             return
         df = self.alloc(max(x.n, 1) * x.c * 4, R_ZB)
@@ -641,12 +758,12 @@ class Builder:
         y = self.new(n_out, x.c, need=x.need)
         cnt = self.alloc(max(n_out, 1) * 4)
         # (the call zero-fills `out` and `cnt` itself)
-        self.f.add(OP_SCATTER_MEAN_FWD, x.p, smap.data_ptr(), J, y.p, cnt, n_in, n_out, x.c)
+        self.f.add(OP_SCATTER_MEAN_FWD, self.f32(x), smap.data_ptr(), J, y.p, cnt, n_in, n_out, x.c)
         self.tape.append(lambda: self._scatter_mean_bwd(x, y, smap, cnt, n_out))
         return y
 
     def _scatter_mean_bwd(self, x, y, smap, cnt, n_out):
-        g = self.grad(y)
+        g = self.grad(y, want32=True)
         if g is None or not x.need:
             return
         J, n_in = smap.shape
@@ -657,24 +774,28 @@ class Builder:
     # ---------------------------------------------------------------- channel concatenation
     def cat(self, ts):
         n, c = ts[0].n, sum(t.c for t in ts)
-        y = self.new(n, c, need=any(t.need for t in ts))
+        s16 = self.act16 and all(t.c % 8 == 0 for t in ts)
+        w = 2 if s16 else 4                                # bytes per element of the rows that are joined
+        y = self.new16(n, c, need=any(t.need for t in ts)) if s16 else self.new(n, c, need=any(t.need for t in ts))
         o = 0
         for t in ts:
-            self.f.add(OP_COPY2D, y.p + o * 4, c * 4, t.p, t.c * 4, t.c * 4, n)
+            self.f.add(OP_COPY2D, (y.p16 if s16 else y.p) + o * w, c * w, self.rows16(t) if s16 else self.f32(t), t.c * w, t.c * w, n)
             o += t.c
         self.tape.append(lambda: self._cat_bwd(ts, y))
         return y
 
     def _cat_bwd(self, ts, y):
-        g = self.grad(y)
+        s16 = not y.p
+        g = self.grad(y, want16=s16, want32=not s16)
         if g is None:
             return
-        o, c = 0, y.c
+        o, c, w = 0, y.c, (2 if s16 else 4)
+        src = g[1] if s16 else g[0]
         for t in ts:
             if t.need:
-                d = self.alloc(max(t.n, 1) * t.c * 4)
-                self.b.add(OP_COPY2D, d, t.c * 4, g[0] + o * 4, c * 4, t.c * 4, t.n)
-                self.gadd(t, d)
+                d = self.alloc(max(t.n, 1) * t.c * w)
+                self.b.add(OP_COPY2D, d, t.c * w, src + o * w, c * w, t.c * w, t.n)
+                self.gadd(t, 0 if s16 else d, d if s16 else 0)
             o += t.c
 
     # ---------------------------------------------------------------- backward emission
@@ -871,9 +992,11 @@ def compile_backbone(net, sp, mid_mark=False):
     Raises NotReady when something is missing (first steps: weights not yet in the step's arena)."""
     lib = _lib.get()
     b = Builder(lib, sp.F.device if sp.F is not None else sp.C.device, ME._WeightPlan.gen)
+    b.act16 = bool(ACT_BF16 and b.bf16 and b.kx == 1)
     n, c = sp.F.shape
     x = _X(T(R_IN, n, c, need=False), sp.coordinate_map_key)
     out = Emitter(b, sp.coordinate_manager).biresnet(net, x, mid_mark)
+    b.f32(out.t)                 # the pass hands fp32 rows to the head (and, next to them, the bf16 rows it computed them from)
     b.emit_backward(out.t)
     return Compiled(b, out.t, out.key, n, c, sp.coordinate_manager)
 

@@ -598,6 +598,12 @@ PREC_SPLIT = 3
 # engine calls it on; the coordinate-prefetch worker never sees another thread's override.
 HEAD_PRECISION = None
 _tls_prec = __import__("threading").local()
+HEAD_MODES = {"split": 3, "fp32": 0, "bf16": None}
+
+
+def heads_from_env(default="split"):
+    """HEAD_PRECISION for a bf16 run from CG3D_HEADS = split | fp32 | bf16 (the dev tools: the bench's default is split)."""
+    return HEAD_MODES[__import__("os").environ.get("CG3D_HEADS", default)]
 
 
 def _prec():
@@ -1291,6 +1297,9 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
 
 WGRAD_SKINNY_WGS = int(__import__("os").environ.get("CG3D_WGRAD_SKINNY_WGS", "64"))      # measured at cout = 18: 58 / 66 / 88 us at 64 / 128 / 256
 TILE_MIN_ROWS = int(__import__("os").environ.get("CG3D_TILE_MIN_ROWS", "4096"))
+# largest kernel volume of an ungrouped map on the tile kernel (the plan builder cuts K > 32 into runs of offsets, one wave each;
+# the RoI head's 5^3 convolution at given coordinates, cagroup_roi_head.py:69, is the K = 125 case)
+TILE_MAX_K = int(__import__("os").environ.get("CG3D_TILE_MAX_K", "32"))
 LINEAR_KERNEL = __import__("os").environ.get("CG3D_LINEAR_KERNEL", "1") != "0"
 LINEAR_WGRAD_SMALL = __import__("os").environ.get("CG3D_LINEAR_WGRAD_SMALL", "1") != "0"   # 1 k - 8 k rows: bf16-rows pair kernel, not the library
 TILE_KERNEL = __import__("os").environ.get("CG3D_TILE_KERNEL", "1") != "0"
@@ -1303,7 +1312,7 @@ def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
     LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
     transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
     return (TILE_KERNEL and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS and row_bounds is None
-            and 1 < K <= 32 and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
+            and 1 < K <= TILE_MAX_K and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
 
 
 def _wgrad_prec(cin, cout, have_rows16):
@@ -2042,6 +2051,9 @@ class ScatterMeanFunction(torch.autograd.Function):
 # ----------------------------------------------------------------------------- fused BatchNorm (+res) (+act)
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 _BN_CHUNK = 256
+# most chunks (= workgroups, = atomic additions per address of the statistics table / CG3D_BN_SLOTS) of a reduce launch
+# (measured on MI355X, 155 773 x 64 bf16 rows: 23.8 / 19.2 / 22.0 / 31.3 us per backward-statistics launch at 1024 / 512 / 256 / 128)
+BN_RED_CHUNKS = int(__import__("os").environ.get("CG3D_BN_RED_CHUNKS", "512"))
 _chunk_cache = {}
 
 
@@ -2070,7 +2082,7 @@ def _bn_chunks(bounds, device, C=64):
             if rows.shape[0] == 0:
                 rows = np.zeros((1, 3), np.int32)
             return rows, int(gco[-1]), gco.astype(np.int32)
-        red, nred, gco = table(np.maximum(step_rows, -(-ng // 1024)))
+        red, nred, gco = table(np.maximum(step_rows, -(-ng // BN_RED_CHUNKS)))
         app, napp, _ = table(np.full_like(ng, step_rows))
         ns = np.maximum(ng, 1).astype(np.float64)
         unb = (ns / np.maximum(ns - 1, 1)).astype(np.float32)          # biased -> unbiased variance

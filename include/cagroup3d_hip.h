@@ -129,6 +129,9 @@ int cg3d_kernel_map_transpose(const int32_t *nbr, int32_t K, int64_t n_out, int6
  *   dW is overwritten (the callee zero-fills it when it accumulates with atomics).
  * ---------------------------------------------------------------------------------------- */
 int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t stream);
+/* X[i] = float(Xb[i]) for n elements (n % 8 == 0, 16-byte aligned): the fp32 copy of rows stored as bf16, for the few
+ * consumers of a bf16-stored pass that compute on fp32 rows (interpolation, pooling, the pass's fp32 output). */
+int cg3d_from_bf16(const uint16_t *Xb, float *X, int64_t n, cg3d_stream_t stream);
 int cg3d_spconv_fwd(const float *X, const float *W, const int32_t *nbr, const float *bias,
                     float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout,
                     int32_t precision, cg3d_stream_t stream);
@@ -270,6 +273,12 @@ int cg3d_tile_plan_build(const int32_t *nbr, int32_t K, int64_t n_out, const int
                          int32_t ucap, int32_t maxpass, uint16_t *slots, uint8_t *live, int32_t *pass_tab,
                          int32_t *npass, int32_t *ulist, int64_t ulist_cap, int32_t *cursor, const int32_t *order,
                          cg3d_stream_t stream);
+/* cg3d_spconv_tile_fwd, `wrev` argument: bit 0 = the weight slots are walked in reverse (data gradient of a symmetric map on
+ * the forward plan); bit 1 (CG3D_TILE_OUT_BF16, needs ksplit == 1) = Y is uint16 [n_out, cout]: the fp32 sums (+ bias)
+ * rounded to bf16 on the store (half the output stream; `stats` still sums the fp32 values).
+ * cg3d_linear_fwd, `ksplit` argument: bit 16 (CG3D_LINEAR_OUT_BF16, with ksplit == 1) = the same for its Y. */
+#define CG3D_TILE_OUT_BF16 2
+#define CG3D_LINEAR_OUT_BF16 0x10000
 int cg3d_spconv_prep_weights_frag(const float *W0, const float *const *Ws, uint16_t *Wf_t, uint16_t *Wf, int32_t G,
                                   int64_t slots_per, int32_t cin, int32_t cout, cg3d_stream_t stream);
 int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap);
@@ -383,6 +392,13 @@ int cg3d_scatter_mean_bwd(const float *dout, const float *cnt, const int32_t *ma
  *                 dgamma float32 [G,C] (the parameters' gradients)
  * ---------------------------------------------------------------------------------------- */
 #define CG3D_BN_SLOTS 16
+/* Activations stored as bf16 (the BiResNet launch program of BASELINE.json configs[1], "bf16 backbone"): with this bit set in
+ * the `act` argument of cg3d_bn_apply / _apply_sums / _bwd_sums / _bwd_apply / _bwd_apply_sums EVERY row matrix of the call
+ * -- X, residual, Y, dY, dX, dRes -- is uint16 [n, c] bf16 rows instead of float32 (c % 8 == 0; Y16 / dX16 must be NULL:
+ * Y / dX are the bf16 rows themselves).  The arithmetic is unchanged: operands widened to fp32, statistics and per-channel
+ * constants in fp32 / fp64, results rounded to nearest even on the store.  A layer then moves 6-8 bytes per element in the
+ * forward (x, residual in; y out) instead of 14-18, and 6 + 8-10 in the backward instead of 12 + 18-22. */
+#define CG3D_BN_STORE_BF16 0x100
 int cg3d_bn_sums(const float *X, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c, float *sums,
                  cg3d_stream_t stream);
 int cg3d_bn_apply_sums(const float *X, const float *residual, const int32_t *chunks, int64_t nchunk, int32_t G, int32_t c,

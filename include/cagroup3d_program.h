@@ -51,6 +51,7 @@ enum {
     CG3D_OP_SCATTER_MEAN_BWD = 22, /* cg3d_scatter_mean_bwd                                                           */
     CG3D_OP_EVENT_RECORD = 23,     /* event handle from cg3d_event_create                       (hipEventRecord)      */
     CG3D_OP_TO_BF16_SPLIT = 24,    /* cg3d_to_bf16_split                                                              */
+    CG3D_OP_FROM_BF16 = 25,        /* cg3d_from_bf16                                                                  */
     CG3D_OP_COUNT
 };
 
@@ -173,6 +174,7 @@ static int cg3d_program_dispatch(const int64_t *row, cg3d_stream_t s) {
         return cg3d_scatter_mean_bwd(CG3D_A_P(const float *, 0), CG3D_A_P(const float *, 1), CG3D_A_P(const int32_t *, 2),
                                      CG3D_A_I(3), CG3D_A_P(float *, 4), CG3D_A_L(5), CG3D_A_L(6), CG3D_A_I(7), s);
     case CG3D_OP_EVENT_RECORD: return CG3D_PROG_EVENT_RECORD(CG3D_A_L(0), s);
+    case CG3D_OP_FROM_BF16: return cg3d_from_bf16(CG3D_A_P(const uint16_t *, 0), CG3D_A_P(float *, 1), CG3D_A_L(2), s);
     case CG3D_OP_TO_BF16_SPLIT:
         return cg3d_to_bf16_split(CG3D_A_P(const float *, 0), CG3D_A_P(uint16_t *, 1), CG3D_A_L(2), CG3D_A_I(3), s);
     default: return CG3D_ERR_ARG;

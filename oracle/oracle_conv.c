@@ -64,6 +64,14 @@ int cg3d_to_bf16(const float *X, uint16_t *Xb, int64_t n, cg3d_stream_t s) {
     return CG3D_OK;
 }
 
+int cg3d_from_bf16(const uint16_t *Xb, float *X, int64_t n, cg3d_stream_t s) {
+    (void)s;
+    if (n < 0) return CG3D_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) X[i] = os_bf16_bits(Xb[i]);
+    return CG3D_OK;
+}
+
 /* Split operands (include/cagroup3d_hip.h, "bf16x3"): hi = bf16(v), lo = bf16(v - hi); inf / NaN keep lo = 0. */
 static inline void os_split(float v, uint16_t *hi, uint16_t *lo) {
     float h = os_bf16(v);

@@ -365,8 +365,25 @@ static inline float os_act_bwd(float y, int act) {
     if (act == 2) return y > 0.f ? 1.f : y + 1.f;
     return 1.f;
 }
+/* fp32 -> bf16 bits, round-to-nearest-even (the copy the next convolution gathers from; cg3d_to_bf16's rounding) */
+static inline uint16_t os_bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+/* CG3D_BN_STORE_BF16 (a bit of the `act` argument): the row matrices of the call are stored as bf16 (uint16) instead of
+ * float32 -- element o of such a matrix, read / written through these two */
+static inline float os_ld(const void *base, int64_t o, int s16) {
+    if (!s16) return ((const float *)base)[o];
+    uint32_t u = (uint32_t)((const uint16_t *)base)[o] << 16; float f; memcpy(&f, &u, 4); return f;
+}
+static inline void os_st(void *base, int64_t o, float v, int s16) {
+    if (s16) ((uint16_t *)base)[o] = os_bf16_rne(v); else ((float *)base)[o] = v;
+}
 static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, const int32_t *chunks, int64_t nchunk,
                        int32_t G, int32_t c, const float *mean, const float *var, float eps, int32_t act, double *sums) {
+    const int s16 = (act & CG3D_BN_STORE_BF16) != 0;
+    act &= ~CG3D_BN_STORE_BF16;
     const size_t ns = 2 * (size_t)G * c;
     memset(sums, 0, sizeof(double) * ns);
 #pragma omp parallel
@@ -379,13 +396,13 @@ static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, 
                 for (int32_t a = 0; a < c; a++) {
                     int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
                     if (!bwd) {
-                        double v = A[o];
+                        double v = os_ld(A, o, s16);
                         loc[p] += v;
                         loc[(int64_t)(G + g) * c + a] += v * v;
                     } else {
-                        float d = A[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
+                        float d = os_ld(A, o, s16) * (act ? os_act_bwd(os_ld(Y, o, s16), act) : 1.f);
                         loc[p] += d;
-                        loc[(int64_t)(G + g) * c + a] += (double)(d * (X[o] - mean[p]) * (1.0f / sqrtf(var[p] + eps)));
+                        loc[(int64_t)(G + g) * c + a] += (double)(d * (os_ld(X, o, s16) - mean[p]) * (1.0f / sqrtf(var[p] + eps)));
                     }
                 }
         }
@@ -393,12 +410,6 @@ static void os_bn_sums(int bwd, const float *A, const float *X, const float *Y, 
         for (size_t i = 0; i < ns; i++) sums[i] += loc[i];
         free(loc);
     }
-}
-/* fp32 -> bf16 bits, round-to-nearest-even (the copy the next convolution gathers from; cg3d_to_bf16's rounding) */
-static inline uint16_t os_bf16_rne(float f) {
-    uint32_t u; memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
 }
 /* The statistics tables are float32 [CG3D_BN_SLOTS][2][G][C] (include/cagroup3d_hip.h); this restatement adds everything to
  * slot 0 and the consumers add the slots up.
@@ -426,16 +437,20 @@ int cg3d_bn_apply(const float *X, const float *R, const int32_t *chunks, int64_t
                   const float *var, float eps, const float *gamma, const float *beta, int32_t act, float *Y,
                   uint16_t *Y16, cg3d_stream_t s) {
     (void)s;
+    const int s16 = (act & CG3D_BN_STORE_BF16) != 0;
+    act &= ~CG3D_BN_STORE_BF16;
+    if (s16 && Y16) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < nchunk; k++) {
         int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
         for (int32_t r = r0; r < r0 + nr; r++)
             for (int32_t a = 0; a < c; a++) {
                 int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
-                float y = (X[o] - mean[p]) * (1.0f / sqrtf(var[p] + eps)) * gamma[p] + beta[p];
-                if (R) y += R[o];
-                Y[o] = os_act_fwd(y, act);
-                if (Y16) Y16[o] = os_bf16_rne(Y[o]);
+                float y = (os_ld(X, o, s16) - mean[p]) * (1.0f / sqrtf(var[p] + eps)) * gamma[p] + beta[p];
+                if (R) y += os_ld(R, o, s16);
+                y = os_act_fwd(y, act);
+                os_st(Y, o, y, s16);
+                if (Y16) Y16[o] = os_bf16_rne(y);
             }
     }
     return CG3D_OK;
@@ -495,6 +510,9 @@ int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int
                       const float *dgamma, const float *group_n, int32_t act, int32_t use_batch, float *dX,
                       uint16_t *dX16, float *dR, cg3d_stream_t s) {
     (void)s;
+    const int s16 = (act & CG3D_BN_STORE_BF16) != 0;
+    act &= ~CG3D_BN_STORE_BF16;
+    if (s16 && dX16) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < nchunk; k++) {
         int32_t g = chunks[k * 3], r0 = chunks[k * 3 + 1], nr = chunks[k * 3 + 2];
@@ -502,12 +520,13 @@ int cg3d_bn_bwd_apply(const float *dY, const float *X, const float *Y, const int
         for (int32_t r = r0; r < r0 + nr; r++)
             for (int32_t a = 0; a < c; a++) {
                 int64_t o = (int64_t)r * c + a, p = (int64_t)g * c + a;
-                float d = dY[o] * (act ? os_act_bwd(Y[o], act) : 1.f);
-                if (dR) dR[o] = d;
+                float d = os_ld(dY, o, s16) * (act ? os_act_bwd(os_ld(Y, o, s16), act) : 1.f);
+                if (dR) os_st(dR, o, d, s16);
                 float is = 1.0f / sqrtf(var[p] + eps);
-                float xh = (X[o] - mean[p]) * is;
-                dX[o] = gamma[p] * is * (d - (dbeta[p] + xh * dgamma[p]) * inv_n);
-                if (dX16) dX16[o] = os_bf16_rne(dX[o]);
+                float xh = (os_ld(X, o, s16) - mean[p]) * is;
+                float dx = gamma[p] * is * (d - (dbeta[p] + xh * dgamma[p]) * inv_n);
+                os_st(dX, o, dx, s16);
+                if (dX16) dX16[o] = os_bf16_rne(dx);
             }
     }
     return CG3D_OK;

@@ -134,6 +134,16 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
                          float *stats, cg3d_stream_t s) {
     (void)s; (void)n_in; (void)ucap;
     if ((stats && (ksplit != 1 || tiles || cout > 512)) || (order && tiles)) return CG3D_ERR_ARG;
+    /* CG3D_TILE_OUT_BF16: Y is uint16 [n_out, cout] = bf16(fp32 sums + bias); the statistics are those of the fp32 sums */
+    uint16_t *Y16 = NULL;
+    if (wrev & CG3D_TILE_OUT_BF16) {
+        if (ksplit != 1) return CG3D_ERR_ARG;
+        Y16 = (uint16_t *)Y;
+        Y = (float *)malloc(sizeof(float) * (size_t)(n_out > 0 ? n_out : 1) * cout);
+        /* rows no tile covers keep what the caller left there */
+        for (int64_t i = 0; i < n_out * cout; i++) Y[i] = ot_bf16_bits(Y16[i]);
+    }
+    wrev &= 1;
     if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127))) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t t = 0; t < ntile; t++) {
@@ -177,6 +187,10 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
         for (int c = 0; c < 2 * cout; c++) stats[c] += (float)acc[c];
         free(acc);
     }
+    if (Y16) {
+        for (int64_t i = 0; i < n_out * cout; i++) Y16[i] = ot_bf16(Y[i]);
+        free(Y);
+    }
     return CG3D_OK;
 }
 int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
@@ -191,6 +205,14 @@ int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
 int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, float *Y, int64_t n, int32_t cin, int32_t cout,
                     int32_t ksplit, float *stats, float *partials, cg3d_stream_t s) {
     (void)s; (void)partials;          /* scratch of the device's split contraction: the restatement sums in one pass */
+    /* CG3D_LINEAR_OUT_BF16 (a bit of `ksplit`, with ksplit == 1): Y is uint16 [n, cout] = bf16(fp32 sums + bias) */
+    uint16_t *Y16 = NULL;
+    if (ksplit & CG3D_LINEAR_OUT_BF16) {
+        ksplit &= ~CG3D_LINEAR_OUT_BF16;
+        if (ksplit != 1) return CG3D_ERR_ARG;
+        Y16 = (uint16_t *)Y;
+        Y = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * cout);
+    }
     if (n < 0 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || ksplit < 1 || ksplit > 256 || ksplit > (cin >> 6)) return CG3D_ERR_ARG;
     if (stats && ksplit != 1) return CG3D_ERR_ARG;
     float *w = (float *)malloc(sizeof(float) * (size_t)cin * cout);          /* [cout][cin] */
@@ -220,6 +242,10 @@ int cg3d_linear_fwd(const uint16_t *X, const uint16_t *Wf, const float *bias, fl
             }
         for (int c = 0; c < 2 * cout; c++) stats[c] += (float)acc[c];
         free(acc);
+    }
+    if (Y16) {
+        for (int64_t i = 0; i < n * cout; i++) Y16[i] = ot_bf16(Y[i]);
+        free(Y);
     }
     return CG3D_OK;
 }

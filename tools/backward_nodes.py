@@ -12,6 +12,8 @@ from cagroup3d_amd import build_model, me  # noqa: E402
 from cagroup3d_amd.optim import ClippedAdamW  # noqa: E402
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()

@@ -7,6 +7,7 @@ import bench
 from cagroup3d_amd import build_model, me
 from cagroup3d_amd.pcdet.models.dense_heads import cagroup_head as H
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()

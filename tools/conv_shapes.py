@@ -8,6 +8,8 @@ import bench
 from cagroup3d_amd import me, build_model
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()

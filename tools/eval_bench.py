@@ -5,6 +5,7 @@ import torch
 from cagroup3d_amd import build_model, me
 import bench
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 model, cfg = bench.make_model("scannet", True, "cuda")
 model.eval()
 batch = build_model.synthetic_batch("S50k", 4, device="cuda")

@@ -7,6 +7,8 @@ from cagroup3d_amd import me, synthetic
 from microbench_conv import timeit
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 batch = synthetic.make_batch("S50k", 4)
 pts = torch.from_numpy(batch["points"]).cuda()
 coords = pts[:, :4].clone()

@@ -48,6 +48,7 @@ if os.environ.get("UNITS"):          # one configuration (under rocprofv3 --kern
 me.PRECISION = 0
 print("fp32 library form:            fwd %7.1f us   fwd+bwd %7.1f us" % (timed(fwd), timed(both)))
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 for partials in (True, False):
     for units in (128, 256, 512, 1024, 2048):
         me.ROI_CONTRACT_PARTIALS, me.ROI_CONTRACT_UNITS = partials, units

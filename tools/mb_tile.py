@@ -7,6 +7,8 @@ from cagroup3d_amd import me, synthetic
 from microbench_conv import timeit
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 cfg = os.environ.get("CFG", "S50k")
 batch = synthetic.make_batch(cfg, 4)
 pts = torch.from_numpy(batch["points"]).cuda()

@@ -9,6 +9,8 @@ import torch
 from cagroup3d_amd import me, build_model, _lib
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 ts, cin, cout = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (4, 128, 128)
 nunits = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 pts = build_model.synthetic_batch("S50k", 4, device="cuda")["points"]

@@ -8,6 +8,7 @@ from cagroup3d_amd import me, synthetic, _lib
 from cagroup3d_amd._lib import ptr
 from microbench_conv import timeit
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 ts, cin, cout = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (2, 128, 128)
 batch = synthetic.make_batch("S50k", 4)
 pts = torch.from_numpy(batch["points"]).cuda()

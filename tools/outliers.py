@@ -6,6 +6,7 @@ import torch
 from cagroup3d_amd import build_model, me
 import bench
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 model, cfg = bench.make_model("scannet", True, "cuda")
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)

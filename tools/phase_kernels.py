@@ -19,6 +19,7 @@ if sys.argv[1] == "run":
     import bench
     from cagroup3d_amd import build_model, me
     me.PRECISION = 1
+    me.HEAD_PRECISION = me.heads_from_env()
     dev = torch.device("cuda", 0)
     model, cfg = bench.make_model("scannet", True, dev)
     model.train()

@@ -6,6 +6,7 @@ import torch
 from cagroup3d_amd import build_model, me
 import bench
 me.PRECISION = 1
+me.HEAD_PRECISION = me.heads_from_env()
 model, cfg = bench.make_model("scannet", True, "cuda")
 model.train()
 lr = float(os.environ.get("LR", cfg.OPTIMIZATION.LR))

@@ -13,6 +13,8 @@ from cagroup3d_amd import build_model, me  # noqa: E402
 from cagroup3d_amd.optim import ClippedAdamW  # noqa: E402
 
 me.PRECISION = 1
+
+me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
 try:
     from cagroup3d_amd.hostpin import pin_host_threads

@@ -55,6 +55,9 @@ class Count(TorchDispatchMode):
 
 
 me.PRECISION = 1
+
+
+me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()
