@@ -288,10 +288,15 @@ def main(argv=None):
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32")
+    ap.add_argument("--head-precision", choices=["split", "bf16", "fp32"], default="split",
+                    help="with --precision bf16 (\"bf16 backbone\", BASELINE.json configs[1]): arithmetic of the two heads' convolutions -- "
+                         "split = fp32-accurate products from three bf16 MFMA passes (me.PREC_SPLIT), fp32 = fp32 MFMA operands, bf16 = "
+                         "bf16 operands in the heads too")
     ap.add_argument("--sync_bn", action="store_true", help="BatchNorm statistics over every rank's rows (reference tools/train.py:33,118-119)")
     args = ap.parse_args(argv)
     from . import me
     me.PRECISION = 1 if args.precision == "bf16" else 0
+    me.HEAD_PRECISION = me.HEAD_MODES[args.head_precision] if args.precision == "bf16" else None
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device(args.device, int(os.environ.get("LOCAL_RANK", "0"))) if args.device == "cuda" else torch.device("cpu")
     if dev.type == "cuda":

@@ -13,9 +13,19 @@ import torch
 from cagroup3d_amd import build_model, me, train
 
 
+# precision legs: operand type of the backbone's convolutions, arithmetic of the two heads, storage of the backbone's rows
+#   fp32            fp32 everywhere (the reference's arithmetic)
+#   bench           bf16 backbone (activations / gradients stored as bf16) + split heads (fp32-accurate: three bf16 passes) -- bench.py's default
+#   bf16-fp32rows   the same with the backbone's rows stored as fp32 (the arithmetic of rounds 1-4)
+#   bf16            bf16 operands in the heads too (rows as in `bench`)
+#   bf16-backbone   bf16 backbone, fp32 MFMA operands in the heads
+LEGS = {"fp32": (0, None, True), "bench": (1, me.PREC_SPLIT, True), "bf16-fp32rows": (1, me.PREC_SPLIT, False),
+        "bf16": (1, None, True), "bf16-backbone": (1, 0, True)}
+
+
 def run(precision, args):
-    me.PRECISION = 1 if precision.startswith("bf16") else 0
-    me.HEAD_PRECISION = 0 if precision == "bf16-backbone" else None      # "bf16 backbone" read literally: fp32 heads
+    from cagroup3d_amd import engine
+    me.PRECISION, me.HEAD_PRECISION, engine.ACT_BF16 = LEGS[precision]
     me._WeightPlan.reset()
     np.random.seed(0)
     torch.manual_seed(0)
@@ -57,7 +67,7 @@ def main():
     out = {"what": "CAGroup3D trained from seed 0 on %d synthetic %s scenes (classes learnable from shape), %d epochs x %d iterations, "
                    "batch %d, AdamW 1e-3, decay x0.1 at 70%% / 90%%, clip 10; evaluated on %d held-out scenes with indoor_eval"
                    % (args.scenes, args.config, args.epochs, -(-args.scenes // args.batch), args.batch, args.val),
-           "runs": [run(p, args) for p in os.environ.get("CG3D_CONV_RUNS", "fp32,bf16,bf16-backbone").split(",")]}
+           "runs": [run(p, args) for p in os.environ.get("CG3D_CONV_RUNS", "fp32,bench,bf16-fp32rows,bf16").split(",")]}
     if args.repeat_fp32:
         out["runs"].append(dict(run("fp32", args), precision="fp32 (second run, same seed)"))
     a, b = out["runs"][0], out["runs"][min(1, len(out["runs"]) - 1)]
