@@ -196,6 +196,9 @@ def test_a_program_is_not_run_on_a_stale_weight_arena(hip):
 @pytest.mark.parametrize("cfgname,n", [("S5k", 2), ("S50k", 1)])
 def test_program_equals_per_layer_path_on_the_device(hip, cfgname, n):
     prec, me.PRECISION = me.PRECISION, 1
+    # (the per-layer path stores fp32 rows: it is the specification of the program with fp32 row storage; the bf16-storage
+    # program is compared with THAT program in tests/test_act_bf16.py)
+    act16, engine.ACT_BF16 = engine.ACT_BF16, False
     try:
         model, _ = build_model.build_cagroup3d("scannet", seed=0)
         model = model.cuda()
@@ -215,6 +218,7 @@ def test_program_equals_per_layer_path_on_the_device(hip, cfgname, n):
         assert engine.STATS["program_passes"] == before + 1, "the engine path did not run on the device"
     finally:
         me.PRECISION = prec
+        engine.ACT_BF16 = act16
     # Same kernels, same operands: what differs is the order of fp32 atomic additions -- which this untrained BatchNorm-heavy
     # net amplifies enormously (two runs of the per-layer path itself differ by up to 0.2 in relative L2 on the small scenes).
     # The yardstick is therefore that run-to-run noise: the program may deviate from a per-layer run by no more than a
