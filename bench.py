@@ -190,7 +190,7 @@ def pmc_traffic(kernel_substr):
     guide prescribes), so the figure is read from the newest pair of CSVs committed under profiles/ and `traffic_source`
     names them.  gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
     import csv
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         names = [os.path.join("profiles", "%s_pmc_%s.csv" % (rnd, c)) for c in ("FETCH_SIZE", "WRITE_SIZE")]
         if not all(os.path.exists(os.path.join(ROOT, n)) for n in names):
             continue

@@ -374,15 +374,19 @@ class Builder:
         self.tape.append(lambda: self._conv_bwd(x, y, weight, w3, kmap, K, cin, cout, P, wp, tile_b))
         return y
 
-    def _prof(self, prog, kind, K, cin, cout, P, n_in, n_out, xb, map_bytes, wb=2.0, nseg=0, groups=1):
-        wbytes = wb * groups * K * cin * cout
-        prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, xb * n_in * cin + 4.0 * n_out * cout + wbytes + map_bytes,
-                          (kind, K, cin, cout, P, n_out, nseg), xb * P * cin + 4.0 * n_out * cout + wbytes + map_bytes))
+    def _prof(self, prog, kind, K, cin, cout, P, n_in, n_out, xb, map_bytes, wb=2.0, nseg=0, groups=1, yb=4.0):
+        """SURVEY 8(d) work of a conv launch: 2 P cin cout flops; every tensor once (yb: bytes per stored output element)."""
+        kx = 3.0 if kind.endswith("x3") else 1.0          # split operands: rows and weights three times as long
+        wbytes = wb * kx * groups * K * cin * cout
+        xb = xb * kx
+        prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, xb * n_in * cin + yb * n_out * cout + wbytes + map_bytes,
+                          (kind, K, cin, cout, P, n_out, nseg), xb * P * cin + yb * n_out * cout + wbytes + map_bytes))
 
     def _tile_row(self, prog, x16, wf, plan, y, n_in, cin, cout, wrev, stats, P, ksplit=1, groups=1, out16=False):
         def p(t):
             return t.data_ptr() if t is not None else 0
-        self._prof(prog, "tile_bf16" + ME._ksuffix(), plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups)
+        self._prof(prog, "tile_bf16" + ME._ksuffix(), plan.K, cin, cout, P, n_in, plan.n_out, 2.0, 2.0 * plan.K * plan.n_out, groups=groups,
+                   yb=2.0 if out16 else 4.0)
         prog.add(OP_TILE_FWD, x16, wf, p(plan.slots), p(plan.live), p(plan.pass_tab), p(plan.npass), p(plan.ulist), plan.maxpass,
                  plan.ucap, p(plan.tiles), plan.ntile, p(plan.order), 0, y, n_in, plan.n_out, plan.K, cin * self.kx, cout, ksplit,
                  (1 if wrev else 0) | (TILE_OUT16 if out16 else 0), stats)

@@ -834,11 +834,12 @@ def _conv_tile(x16, wf, plan, bias, cin, cout, n_in, n_pairs=0, ksplit=1, groups
     if prof:
         ev1.record()
         # SURVEY 8(d) bytes: every input row once, every output row once, the weights once, the map once (2-byte slots)
-        wbytes = 2.0 * groups * plan.K * cin * cout
+        kx = _kx()          # (split operands: the rows and the weights the launch reads are three times as long)
+        wbytes = 2.0 * kx * groups * plan.K * cin * cout
         KernelProfile.records.append((ev0, ev1, 2.0 * n_pairs * cin * cout,
-                                      2.0 * n_in * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out,
+                                      2.0 * kx * n_in * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out,
                                       ("tile_bf16" + _ksuffix(), plan.K, cin, cout, n_pairs, plan.n_out, 0),
-                                      2.0 * n_pairs * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out))
+                                      2.0 * kx * n_pairs * cin + 4.0 * plan.n_out * cout + wbytes + 2.0 * plan.K * plan.n_out))
     return y
 
 

@@ -11,10 +11,13 @@ me.PRECISION = 1
 
 me.HEAD_PRECISION = me.heads_from_env()
 dev = torch.device("cuda", 0)
-model, cfg = bench.make_model("scannet", True, dev)
+DATASET, CFG, BATCH = os.environ.get("DATASET", "scannet"), os.environ.get("CFG", "S50k"), int(os.environ.get("BATCH", "4"))
+print("# %s, %d x %s scenes per step, heads: %s, backbone rows: %s" % (DATASET, BATCH, CFG, os.environ.get("CG3D_HEADS", "split"),
+                                                                   "bf16" if os.environ.get("CG3D_ACT_BF16", "1") != "0" else "fp32"))
+model, cfg = bench.make_model(DATASET, True, dev, build_model.VOXEL_SIZE_OF_CONFIG.get(CFG))
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
-batch = build_model.synthetic_batch("S50k", 4, device=dev)
+batch = build_model.synthetic_batch(CFG, BATCH, device=dev)
 for _ in range(4):
     bench.train_step(model, opt, batch, 10.0)
 me.KernelProfile.reset()
@@ -34,6 +37,8 @@ tot = collections.Counter()
 for key, (n, ms, fl, by, pairs) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     kind, K, cin, cout, rows = key
     s = ms * 1e-3
+    if kind.endswith("x3"):
+        fl = 3.0 * fl                 # split operands: three bf16 products per fp32-accurate product (bench.py prices them the same way)
     bound = max(fl / (157.3e12 if kind in ("pairs", "wgrad") else 2.5e15), by / 8e12)
     tot[kind] += ms / STEPS
     print("%-14s %3d %5d %5d %8d %9d %5.1f %8.3f %8.1f %7.0f %7.1f %6.1f" % (

@@ -4,7 +4,7 @@ import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-RN = os.environ.get("ROUND", "r04")
+RN = os.environ.get("ROUND", "r05")
 
 
 def rd(name):
@@ -20,8 +20,12 @@ out = ["# profiles/ — round %s (MI355X, 1 GPU, ROCm 7.2)\n\n" % RN[1:].lstrip(
        "python tools/conv_shapes.py --wgrad  # %s_conv_shapes.txt: every conv launch shape, time, SURVEY 8(d) bound\n"
        "bash tools/pmc_sq.sh k_spconv_tile tools/mb_tile_one.py 4 128 128     # SQ counters, 128->128 layer (82 107 rows)\n"
        "bash tools/pmc_sq.sh wgrad_rows16 tools/mb_wgrad_one.py 4 128 128; bash tools/pmc_wgrad.sh 4 128 128   # weight gradient: SQ and L2 / memory-side counters\n"
-       "python tools/mb_tile.py; python tools/mb_bn.py; python tools/host_profile.py; python tools/stream_bw.py\n```\n\n" % (RN, RN),
-       "Earlier rounds' files (`r01_*` ... `r03_*`) are kept for comparison; `%s_synthetic_convergence.json` (and `r02_*`): `tools/synthetic_convergence.py` (fp32 / bf16 in every convolution / bf16 in the backbone only / fp32 again from one seed, 1 008 iterations; indoor_eval mAP / recall and the loss curves).\n\n" % RN,
+       "python tools/mb_tile.py; python tools/mb_bn16.py; python tools/host_profile.py; python tools/stream_bw.py\n"
+       "# the other configurations at the one-GPU size (BASELINE.json configs[3] / [4]): the same kernel-stats, conv-shape and FETCH / WRITE passes with\n"
+       "#   --dataset sunrgbd --config S100k-yaw --batch 8   (%s_s100kyaw8_*)    and    --config S200k   (%s_s200k4_*, 0.01 m voxels)\n```\n\n" % (RN, RN, RN, RN),
+       "Default precision of every run here: bf16 backbone with its rows stored as bf16 + split (fp32-accurate) heads -- `bench.py`'s default, BASELINE.json configs[1].  "
+       "Earlier rounds' files (`r01_*` ... `r04_*`) are kept for comparison; `%s_synthetic_convergence.json`: `tools/synthetic_convergence.py` (fp32 / the bench precision / "
+       "the same with fp32 rows / bf16 in every convolution / fp32 again, one seed, 1 008 iterations; indoor_eval mAP / recall and the loss curves).\n\n" % RN,
        "Device copy rate on the box: " + rd("%s_stream_bw.txt" % RN).strip().splitlines()[-1] + ".\n\n"]
 import bench as _b
 for tag in ("bf16", "fp32"):
@@ -69,9 +73,75 @@ for tag in ("bf16", "fp32"):
     for x in sorted(rows, key=lambda x: -int(x["TotalDurationNs"]))[:28]:
         out.append("| %.2f | %.1f | %.1f | `%s` |\n" % (int(x["TotalDurationNs"]) / steps / 1e6, int(x["Calls"]) / steps, float(x["AverageNs"]) / 1e3,
                                                    re.sub(r"\(.*", "", x["Name"])[:90].replace("|", "/")))
+
+
+def _counters(fname):
+    d = {}
+    f = os.path.join(P, fname)
+    if os.path.exists(f):
+        for ln in open(f):
+            m = re.match(r"(\S+)\s+([0-9.e+]+) per launch", ln)
+            if m:
+                d[m.group(1)] = float(m.group(2))
+    return d
+
+
+def _pmc_per_kernel(tag):
+    """{kernel name prefix: (launches, 2 x FETCH + WRITE bytes per launch)} of a FETCH_SIZE / WRITE_SIZE pair of passes."""
+    tot = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(P, "%s_%spmc_%s.csv" % (RN, tag, c))
+        if not os.path.exists(f):
+            return {}
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:48]
+            d = tot.setdefault(k, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            d[c][0] += float(r["Counter_Value"]) * 1024.0
+            d[c][1] += 1
+    return {k: (v["FETCH_SIZE"][1], 2.0 * v["FETCH_SIZE"][0] / max(v["FETCH_SIZE"][1], 1) + v["WRITE_SIZE"][0] / max(v["WRITE_SIZE"][1], 1))
+            for k, v in tot.items()}
+
+
+def _avg_us(stats_csv):
+    d = {}
+    f = os.path.join(P, stats_csv)
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            d[re.sub(r"\(.*", "", r["Name"]).replace("void ", "")[:48]] = float(r["AverageNs"]) / 1e3
+    return d
+
+
+out.append("\n## Matrix-pipe occupancy and memory-side rate per kernel class\n\n")
+for label, fn in (("`k_spconv_tile2` (128 -> 128 @ 82 107 rows, alone)", "%s_pmc_sq_tile_128.txt" % RN),
+                  ("`k_spconv_pairs_wgrad_rows16` (same layer)", "%s_pmc_sq_wgrad_128.txt" % RN)):
+    c = _counters(fn)
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0            # the counter sums the 8 XCDs
+        busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+        wait = c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1)
+        conf = c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1)
+        out.append("* %s: **MFMA pipe busy %.1f %%** of the SIMD cycles of the launch (`SQ_VALU_MFMA_BUSY_CYCLES` %.3g / (1 024 SIMDs x %.0f k cycles per XCD)), "
+                   "waves waiting %.0f %% of their cycles, LDS bank-conflict cycles %.0f %% of the LDS cycles (`%s`)\n"
+                   % (label, 100 * busy, c["SQ_VALU_MFMA_BUSY_CYCLES"], cyc / 1e3, 100 * wait, 100 * conf, fn))
+out.append("\nMemory-side traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) over the "
+           "kernel's average duration in the kernel-stats table of the same configuration -- the HBM / Infinity-Fabric side rate of the conv kernels:\n\n")
+for tag, cfgname, stats in (("", "ScanNet S50k x 4 (the benchmark)", "%s_bench_bf16_kernel_stats.csv" % RN),
+                            ("s100kyaw8_", "SUN RGB-D S100k-yaw x 8", "%s_s100kyaw8_kernel_stats.csv" % RN),
+                            ("s200k4_", "S200k x 4 @ 0.01 m", "%s_s200k4_kernel_stats.csv" % RN)):
+    pk, av = _pmc_per_kernel(tag), _avg_us(stats)
+    if not pk:
+        continue
+    out.append("| %s | launches (PMC pass) | MB / launch | avg us | GB/s |\n|---|---:|---:|---:|---:|\n" % cfgname)
+    for k, (n, by) in sorted(pk.items(), key=lambda kv: -kv[1][1] * kv[1][0]):
+        us = av.get(k)
+        out.append("| `%s` | %d | %.1f | %s | %s |\n" % (k, n, by / 1e6, "%.1f" % us if us else "-", "%.0f" % (by / us / 1e3) if us else "-"))
+    out.append("\n")
+
 for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc_sq_tile_128.txt" % RN, "SQ counters, tile kernel, 128->128 @ 82 107 rows"),
                    ("%s_pmc_sq_wgrad_128.txt" % RN, "SQ counters, weight gradient, same layer"), ("%s_pmc_l2_wgrad_128.txt" % RN, "L2 / memory-side counters, weight gradient"),
-                   ("%s_tile_vs_dense_map.txt" % RN, "tile kernel vs the dense-map kernel per layer shape"), ("%s_bn_shapes.txt" % RN, "BatchNorm launches per shape"),
+                   ("%s_tile_vs_dense_map.txt" % RN, "tile kernel vs the dense-map kernel per layer shape"), ("%s_bn_shapes.txt" % RN, "BatchNorm launches per shape, fp32 and bf16 row storage (tools/mb_bn16.py)"),
+                   ("%s_s100kyaw8_conv_shapes.txt" % RN, "per-shape conv table, SUN RGB-D S100k-yaw x 8"),
+                   ("%s_s200k4_conv_shapes.txt" % RN, "per-shape conv table, S200k x 4 at 0.01 m"),
                    ("%s_host_issue.txt" % RN, "host issue time vs step time"),
                    ("%s_tile_trace.txt" % RN, "per-workgroup trace of the tile kernel (dev build): effective clock, co-residency, time per phase, for 256 / 512 / 642 units"),
                    ("%s_tile_units_scaling.txt" % RN, "tile kernel time against the number of units in flight (one / two workgroups per CU, the tail round)"),
