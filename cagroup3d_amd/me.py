@@ -1281,7 +1281,11 @@ def _wgrad_seg_len(P, cin, cout, precision=0, K=27):
         # rounds, so the segment length is chosen to land just under a whole number of rounds (every offset adds one
         # short tail segment).  Measured optimum: ~4 rounds when several channel tiles share the gathered rows
         # through L2, 1-2 rounds (fewer 64 KB atomic epilogues) when a single tile covers the layer.
-        rounds = 4 if tiles > 1 else (2 if max(cin, cout) <= 64 else 1)
+        # Round 5, the 8-wave 128 x 128 kernel (profiles/r05_wgrad_segments.txt): ONE round also when several channel tiles
+        # share the rows -- 256 -> 256 @ 23 015 rows 136.6 -> 99.6 us, 128 -> 256 @ 82 107 rows 160.7 -> 126.6 us, 512 -> 512 @ 5 330 rows
+        # 132.1 -> 114.3 us at 512 instead of 2 048 workgroups: every extra workgroup of a multi-tile layer repeats the
+        # gather of its pairs' rows and ends with another 64 KB of atomics
+        rounds = 1 if tiles > 1 else (2 if max(cin, cout) <= 64 else 1)
         slots = max(512 * rounds * _WGRAD_BF16_WGS // 2048 - K * tiles, 64)
         per = -(-P * tiles // slots)
         return max(_WGRAD_BF16_MIN, -(-per // 64) * 64)
