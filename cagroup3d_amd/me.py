@@ -2058,6 +2058,7 @@ ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 _BN_CHUNK = 256
 # most chunks (= workgroups, = atomic additions per address of the statistics table / CG3D_BN_SLOTS) of a reduce launch
 # (measured on MI355X, 155 773 x 64 bf16 rows: 23.8 / 19.2 / 22.0 / 31.3 us per backward-statistics launch at 1024 / 512 / 256 / 128)
+BN_CHUNK_SCALE = int(__import__("os").environ.get("CG3D_BN_CHUNK_SCALE", "1"))       # rows per apply chunk, in units of the round-3 rule
 BN_RED_CHUNKS = int(__import__("os").environ.get("CG3D_BN_RED_CHUNKS", "512"))
 _chunk_cache = {}
 
@@ -2070,7 +2071,7 @@ def _bn_chunks(bounds, device, C=64):
     128 rows at C = 64 down to 8 at C = 1024 -- with 128-row chunks for every C the 5330 x 512 and 1229 x 1024 layers
     ran 42 / 10 workgroups, each thread walking 64 / 128 rows one latency at a time (23 / 41 us for 11 / 5 MB)."""
     rpb = 256 // max(1, min(C // 4, 256))
-    step_rows = max(8, min(128, 8 * rpb))
+    step_rows = max(8, min(128 * BN_CHUNK_SCALE, 8 * rpb * BN_CHUNK_SCALE))
     ck = (bounds, device, step_rows)
 
     def build():
