@@ -334,8 +334,13 @@ __global__ __launch_bounds__(256) void k_bn16_partial_bwd(const uint16_t *__rest
             }
         }
         float *w0 = sums + ((int64_t)(slot * 2) * G + g) * c + 8 * t, *w1 = sums + ((int64_t)(slot * 2 + 1) * G + g) * c + 8 * t;
+#ifdef CG3D_BN_DBG_NOATOM          // dev build only (tools/_r05_y.sh): plain stores, wrong sums -- what the atomic chains cost
+#pragma unroll
+        for (int e = 0; e < 8; e++) { w0[e] = f0[e]; w1[e] = f1[e]; }
+#else
 #pragma unroll
         for (int e = 0; e < 8; e++) { unsafeAtomicAdd(w0 + e, f0[e]); unsafeAtomicAdd(w1 + e, f1[e]); }
+#endif
     }
 }
 

@@ -498,7 +498,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
                                     const float *bias, float *Y, int64_t n_in, int64_t n_out, int32_t K, int32_t cin,
                                     int32_t cout, int32_t ksplit, int32_t wrev, float *stats, cg3d_stream_t stream) {
     if ((stats && (ksplit != 1 || tiles || cout > 512)) || (order && tiles)) return CG3D_ERR_ARG;
-    if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127)))
+    if (n_out < 0 || n_in < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63))
         return CG3D_ERR_ARG;
     if (ucap < T2_TM || ucap > 511 || ksplit < 1 || ksplit > 8 || ((uintptr_t)X & 15) || ((uintptr_t)Wf & 15)) return CG3D_ERR_ARG;
     if ((wrev & CG3D_TILE_OUT_BF16) && (ksplit != 1 || ((uintptr_t)Y & 7))) return CG3D_ERR_ARG;      // bf16 rows are stored, not added
@@ -507,7 +507,10 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     hipStream_t s = cg3d_hs(stream);
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
     const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap);
-    const int32_t ny = cout >= 128 ? cout / 128 : 1;
+    // units of 128 output channels, or of 64 when the count is not a multiple of 128 (64, 192: the 64 -> 3 x 64 feature-offset
+    // convolution of the yaw datasets, cagroup_head.py:170-172)
+    const bool wide = (cout & 127) == 0;
+    const int32_t ny = wide ? cout / 128 : cout / 64;
     const int64_t nunit = ntile * ny * ksplit;
     if (nunit > 0x7ffffff0ll) return CG3D_ERR_ARG;
     const unsigned grid = (unsigned)((nunit + 7) / 8 * 8);
@@ -533,7 +536,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     // tail in half units (see k_spconv_tile2_mix): only when the last round is at most half full
     static const int tail_env = getenv("CG3D_TILE_TAIL") ? atoi(getenv("CG3D_TILE_TAIL")) : 1;
     const int64_t SLOTS = 512, rem = nunit % SLOTS;
-    const int64_t tail_tiles = (tail_env && cout >= 128 && ksplit == 1 && nunit > SLOTS && rem > 0 && 2 * rem <= SLOTS) ? rem / ny : 0;
+    const int64_t tail_tiles = (tail_env && wide && ksplit == 1 && nunit > SLOTS && rem > 0 && 2 * rem <= SLOTS) ? rem / ny : 0;
     if (tail_tiles > 0) {
         static bool attr_mix = false;
         if (!attr_mix) {
@@ -548,7 +551,7 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
         hipLaunchKernelGGL(k_spconv_tile2_mix, dim3((unsigned)(grid2 + (nunit1 + 7) / 8 * 8)), dim3(256), lds, s, X, Wf, slots, live,
                            pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, grid2, nunit2, ny, nunit1,
                            ny1, tile_split, wrev, stats, stagger);
-    } else if (cout >= 128) T2_LAUNCH(2); else T2_LAUNCH(1);
+    } else if (wide) T2_LAUNCH(2); else T2_LAUNCH(1);
 #undef T2_LAUNCH
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;

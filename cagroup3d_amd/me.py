@@ -1317,7 +1317,7 @@ def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
     LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
     transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
     return (TILE_KERNEL and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS and row_bounds is None
-            and 1 < K <= TILE_MAX_K and cin % 64 == 0 and (cout == 64 or cout % 128 == 0) and n_rows >= TILE_MIN_ROWS)
+            and 1 < K <= TILE_MAX_K and cin % 64 == 0 and cout % 64 == 0 and n_rows >= TILE_MIN_ROWS)
 
 
 def _wgrad_prec(cin, cout, have_rows16):
@@ -2058,6 +2058,7 @@ ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 _BN_CHUNK = 256
 # most chunks (= workgroups, = atomic additions per address of the statistics table / CG3D_BN_SLOTS) of a reduce launch
 # (measured on MI355X, 155 773 x 64 bf16 rows: 23.8 / 19.2 / 22.0 / 31.3 us per backward-statistics launch at 1024 / 512 / 256 / 128)
+BN_RED_DIV = int(__import__("os").environ.get("CG3D_BN_RED_DIV", "0"))
 BN_CHUNK_SCALE = int(__import__("os").environ.get("CG3D_BN_CHUNK_SCALE", "1"))       # rows per apply chunk, in units of the round-3 rule
 BN_RED_CHUNKS = int(__import__("os").environ.get("CG3D_BN_RED_CHUNKS", "512"))
 _chunk_cache = {}
@@ -2072,7 +2073,7 @@ def _bn_chunks(bounds, device, C=64):
     ran 42 / 10 workgroups, each thread walking 64 / 128 rows one latency at a time (23 / 41 us for 11 / 5 MB)."""
     rpb = 256 // max(1, min(C // 4, 256))
     step_rows = max(8, min(128 * BN_CHUNK_SCALE, 8 * rpb * BN_CHUNK_SCALE))
-    ck = (bounds, device, step_rows)
+    ck = (bounds, device, step_rows, C if BN_RED_DIV else 0)
 
     def build():
         b = np.asarray(bounds, dtype=np.int64)
@@ -2088,7 +2089,9 @@ def _bn_chunks(bounds, device, C=64):
             if rows.shape[0] == 0:
                 rows = np.zeros((1, 3), np.int32)
             return rows, int(gco[-1]), gco.astype(np.int32)
-        red, nred, gco = table(np.maximum(step_rows, -(-ng // BN_RED_CHUNKS)))
+        # (wide layers: a reduce workgroup ends with 2 C atomics whatever its rows -- at 8 rows per chunk the 1 229 x 1 024 layer
+        # issued 315 k atomics for 1.3 M elements: at least C / BN_RED_DIV rows per chunk)
+        red, nred, gco = table(np.maximum(max(step_rows, C // BN_RED_DIV if BN_RED_DIV else 0), -(-ng // BN_RED_CHUNKS)))
         app, napp, _ = table(np.full_like(ng, step_rows))
         ns = np.maximum(ng, 1).astype(np.float64)
         unb = (ns / np.maximum(ns - 1, 1)).astype(np.float32)          # biased -> unbiased variance

@@ -144,7 +144,7 @@ int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const uint16_t *
         for (int64_t i = 0; i < n_out * cout; i++) Y[i] = ot_bf16_bits(Y16[i]);
     }
     wrev &= 1;
-    if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63) || (cout > 64 && (cout & 127))) return CG3D_ERR_ARG;
+    if (n_out < 0 || K < 1 || cin < 64 || (cin & 63) || cout < 64 || (cout & 63)) return CG3D_ERR_ARG;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t t = 0; t < ntile; t++) {
         const int64_t row0 = tiles ? tiles[t * 3 + 1] : t * TP_TM;

@@ -79,7 +79,7 @@ def test_benchmark_layer_matches_oracle(oracle, hip, monkeypatch, name, in_strid
 # convolution, cagroup_head.py:170-172) and configs[4] (4 x 200 k points at 0.01 m: 2 500+ tiles per launch, five rounds of
 # tile-kernel units and more): the layers that carry those runs, on THEIR maps.
 OTHER = [
-    ("S100k-yaw x 8: feature_offset 64->192 @2", "S100k-yaw", 8, 0.02, 2, 3, 1, False, 64, 192, False),
+    ("S100k-yaw x 8: feature_offset 64->192 @2", "S100k-yaw", 8, 0.02, 2, 3, 1, False, 64, 192, True),
     ("S100k-yaw x 8: layer3_ 128->128 @4", "S100k-yaw", 8, 0.02, 4, 3, 1, False, 128, 128, True),
     ("S100k-yaw x 8: down3 128->256 @4->8", "S100k-yaw", 8, 0.02, 4, 3, 2, False, 128, 256, True),
     ("S200k x 4 @0.01: layer1 64->64 @2", "S200k", 4, 0.01, 2, 3, 1, False, 64, 64, True),

@@ -147,7 +147,7 @@ def _tile_conv(coords, x, w, bias, ks, stride, ucap, ksplit, transposed):
     return y, yref
 
 
-@pytest.mark.parametrize("cin,cout,n,ks,stride", [(64, 64, 2500, 3, 1), (64, 128, 2000, 3, 2), (128, 128, 1500, 3, 1)])
+@pytest.mark.parametrize("cin,cout,n,ks,stride", [(64, 64, 2500, 3, 1), (64, 128, 2000, 3, 2), (128, 128, 1500, 3, 1), (64, 192, 1200, 3, 1)])
 def test_oracle_plan_conv_equals_dense_map_conv(oracle, cin, cout, n, ks, stride):
     """CPU: the oracle's plan-driven convolution reads neighbours only through the plan == its dense-map convolution."""
     torch.manual_seed(cin + cout)
@@ -306,7 +306,7 @@ def test_hip_self_map_by_half_the_lookups_is_bit_identical(hip, ks, dil, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,n", [(64, 64, 9000), (128, 128, 45000), (128, 256, 30000), (256, 512, 3000)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 9000), (128, 128, 45000), (128, 256, 30000), (256, 512, 3000), (64, 192, 12000)])
 def test_hip_bn_statistics_from_the_conv_epilogue(hip, cin, cout, n):
     """The loader waves of the tile kernel sum every output channel while they store a tile (one to three tiles per
     workgroup, 1-4 channel blocks): the BatchNorm that follows gets the same mean / variance / running statistics / output
@@ -350,6 +350,7 @@ def test_hip_plan_grouped_tiles_and_empty(hip):
     (64, 64, 9000, 3, 1, 511, 1), (64, 128, 6000, 3, 2, 511, 1), (128, 128, 4000, 3, 1, 511, 1), (128, 128, 4000, 3, 1, 128, 1),
     (256, 256, 1500, 3, 1, 511, 1), (256, 256, 1500, 3, 1, 511, 3), (128, 256, 3000, 3, 2, 300, 2), (512, 512, 600, 3, 1, 511, 4),
     (64, 64, 700, 9, 1, 511, 1), (64, 128, 1500, 5, 1, 200, 1), (128, 64, 3000, 3, 1, 511, 1), (64, 64, 100, 3, 1, 511, 1),
+    (64, 192, 5000, 3, 1, 511, 1), (192, 64, 5000, 3, 1, 511, 1), (128, 320, 2000, 3, 1, 511, 2),
 ])
 def test_hip_tile_conv_matches_oracle(oracle, hip, cin, cout, n, ks, stride, ucap, ksplit):
     """forward and data-gradient problem through the HIP plan + LDS-staged kernel == the oracle's dense-map bf16
