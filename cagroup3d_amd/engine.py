@@ -48,6 +48,7 @@ LIN_OUT16 = 0x10000         # CG3D_LINEAR_OUT_BF16 (bit of cg3d_linear_fwd's ksp
 # instead of 14-18 and 12-16 in the backward instead of 30-34 (include/cagroup3d_hip.h, CG3D_BN_STORE_BF16).  CG3D_ACT_BF16=0:
 # fp32 storage with bf16 operand copies, the arithmetic of rounds 1-4 (and what the per-layer path of me.py computes).
 ACT_BF16 = os.environ.get("CG3D_ACT_BF16", "1") != "0"
+ACT16_MIN_ROWS = int(os.environ.get("CG3D_ACT16_MIN_ROWS", "4096"))
 STRIDE = 24
 WGRAD_ACC = 0x100
 
@@ -188,10 +189,13 @@ class Builder:
         t.p16 = self.alloc(max(n, 1) * c * 2)
         return t
 
-    def s16ok(self, c):
-        """bf16 row storage of a c-channel matrix in the BatchNorm kernels (CG3D_BN_STORE_BF16: power-of-two channel counts
-        64 .. 1024 -- the rest of the backbone, DAPPM's 640-channel join, stays on fp32 rows)."""
-        return self.act16 and 64 <= c <= 1024 and (c & (c - 1)) == 0
+    def s16ok(self, c, n=1 << 30):
+        """bf16 row storage of an n x c matrix in the BatchNorm kernels (CG3D_BN_STORE_BF16: power-of-two channel counts
+        64 .. 1024 -- the rest of the backbone, DAPPM's 640-channel join, stays on fp32 rows).  Matrices of fewer than ACT16_MIN_ROWS
+        rows stay fp32 as well: the stride-32 end of the net (layer5, DAPPM: 150-1 300 rows) is made of pooling, interpolation
+        and pair-kernel layers that compute on fp32 rows -- bf16 storage there saves no time (every launch sits on its ~7 us
+        floor) and cost ~40 conversion launches per step at the seams."""
+        return self.act16 and n >= ACT16_MIN_ROWS and 64 <= c <= 1024 and (c & (c - 1)) == 0
 
     def out(self, n, c, need=True):
         """Where a kernel with both output forms puts a layer's rows: bf16 rows under act16, fp32 rows otherwise."""
@@ -251,7 +255,7 @@ class Builder:
         if not t.gdone:
             if len(t.gc) == 1:
                 t.gsum, t.gsum16 = t.gc[0]
-            elif self.s16ok(t.c):
+            elif self.s16ok(t.c, t.n):
                 # every contribution as bf16 rows, added pairwise in fp32 registers (one rounding per sum)
                 c16 = []
                 for p, p16 in t.gc:
@@ -568,7 +572,7 @@ class Builder:
             units, nchunk = -(-n // 128) * (cout // (128 if cout % 128 == 0 else 64)), cin * self.kx // 64
             ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
             # (a split contraction meets in fp32 partial products: its output stays fp32 rows)
-            y = self.out(n, cout) if ksplit == 1 else self.new(n, cout)
+            y = self.out(n, cout) if (ksplit == 1 and n >= ACT16_MIN_ROWS) else self.new(n, cout)
             part = 0
             if ksplit > 1:
                 part = self.alloc(ksplit * max(n, 1) * cout * 4)
@@ -604,7 +608,7 @@ class Builder:
             if own:
                 units, nchunk = -(-n // 128) * (cin // (128 if cin % 128 == 0 else 64)), cout * self.kx // 64
                 ksplit = min(nchunk, 64 // max(units, 1)) if (units <= 16 and nchunk >= 4) else 1
-                if self.act16 and ksplit == 1:
+                if self.act16 and ksplit == 1 and n >= ACT16_MIN_ROWS:
                     dx, dx16 = 0, self.alloc(max(n, 1) * cin * 2)
                 else:
                     dx = self.alloc(max(n, 1) * cin * 4)
@@ -632,7 +636,7 @@ class Builder:
             raise NotReady("BatchNorm form without a program counterpart (evaluation statistics, --sync_bn)")
         red, nred, _, group_n, app, napp, _ = self._chunks(n, c)
         prog = self.f
-        s16 = self.s16ok(c)
+        s16 = self.s16ok(c, n)
         sums = x.stats
         if not sums:
             # (the statistics pass reads fp32 rows: a convolution that left none also left its statistics; what remains are
@@ -701,7 +705,7 @@ class Builder:
     # ---------------------------------------------------------------- relu(a [+ b]) / a + b
     def add_act(self, a, b, act):
         need = a.need or (b is not None and b.need)
-        if self.s16ok(a.c):
+        if self.s16ok(a.c, a.n):
             y = self.new16(a.n, a.c, need=need)
             self._add_rows(self.f, self.rows16(a), self.rows16(b) if b is not None else 0, y.p16, a.n, a.c, act, 0, s16=True)
             self.tape.append(lambda: self._add_act_bwd(a, b, y, act))
@@ -778,7 +782,7 @@ class Builder:
     # ---------------------------------------------------------------- channel concatenation
     def cat(self, ts):
         n, c = ts[0].n, sum(t.c for t in ts)
-        s16 = self.act16 and all(t.c % 8 == 0 for t in ts)
+        s16 = self.act16 and n >= ACT16_MIN_ROWS and all(t.c % 8 == 0 for t in ts)
         w = 2 if s16 else 4                                # bytes per element of the rows that are joined
         y = self.new16(n, c, need=any(t.need for t in ts)) if s16 else self.new(n, c, need=any(t.need for t in ts))
         o = 0
