@@ -195,12 +195,18 @@ def pmc_traffic(kernel_substr):
         if not all(os.path.exists(os.path.join(ROOT, n)) for n in names):
             continue
         try:
-            tot = []
-            for n in names:
+            tot, variants = [], {}
+            for i, n in enumerate(names):
                 rows = [r for r in csv.DictReader(open(os.path.join(ROOT, n))) if kernel_substr in r["Kernel_Name"]]
                 if not rows:
                     raise KeyError(kernel_substr)
                 tot.append(sum(float(r["Counter_Value"]) for r in rows) * 1024.0 / len(rows))
+                for r in rows:          # per template instance of the kernel (its launches differ in what they read: see DESIGN.md section 5)
+                    v = variants.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), [[0.0, 0], [0.0, 0]])
+                    v[i][0] += float(r["Counter_Value"]) * 1024.0
+                    v[i][1] += 1
+            pmc_traffic.by_variant = {k: {"launches_in_pass": v[0][1], "bytes_per_launch": 2.0 * v[0][0] / max(v[0][1], 1) + v[1][0] / max(v[1][1], 1)}
+                                      for k, v in variants.items()}
             return 2.0 * tot[0] + tot[1], ("%s + %s (committed rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1`, builder-side; "
                                            "2 x FETCH_SIZE + WRITE_SIZE averaged over the kernel's launches)" % tuple(names))
         except Exception:
@@ -423,6 +429,7 @@ def main():
                                       "gbytes_per_s_8d": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None}
                                   for k, v in kinds.items()})
         roof["traffic"], roof["traffic_source"] = pmc_traffic(KNAMES[kind][1]) if bf16 else (None, None)
+        roof["traffic_by_variant"] = getattr(pmc_traffic, "by_variant", None) if bf16 else None
         roof["split_launches"] = {"launches": prof["split_launches"], "ms_per_step": prof["split_ms"] / profiled,
                                   "note": "launches of this kernel on split operands (the two heads): 3 bf16 products per fp32-accurate "
                                           "product, counted as the 3 x 2 P Cin Cout bf16 flops the launch performs"}
