@@ -509,7 +509,10 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap);
     // units of 128 output channels, or of 64 when the count is not a multiple of 128 (64, 192: the 64 -> 3 x 64 feature-offset
     // convolution of the yaw datasets, cagroup_head.py:170-172)
-    const bool wide = (cout & 127) == 0;
+    // A launch of at most CG3D_TILE_NARROW units of 128 channels (fewer than one per CU: the 512-channel layers at tensor stride
+    // 16, 5 330 rows = 42 tiles x 4) is cut into twice as many units of 64 channels instead.
+    static const int narrow_env = getenv("CG3D_TILE_NARROW") ? atoi(getenv("CG3D_TILE_NARROW")) : 0;
+    const bool wide = (cout & 127) == 0 && !(ksplit == 1 && ntile * (cout / 128) <= narrow_env);
     const int32_t ny = wide ? cout / 128 : cout / 64;
     const int64_t nunit = ntile * ny * ksplit;
     if (nunit > 0x7ffffff0ll) return CG3D_ERR_ARG;
