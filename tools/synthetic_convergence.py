@@ -27,9 +27,9 @@ def run(precision, args):
     from cagroup3d_amd import engine
     me.PRECISION, me.HEAD_PRECISION, engine.ACT_BF16 = LEGS[precision]
     me._WeightPlan.reset()
-    np.random.seed(0)
-    torch.manual_seed(0)
-    model, cfg = build_model.build_cagroup3d("scannet", seed=0)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    model, cfg = build_model.build_cagroup3d("scannet", seed=args.seed)
     model = model.cuda()
     oc = cfg.OPTIMIZATION
     oc["DECAY_STEP_LIST"] = [int(args.epochs * 0.7), int(args.epochs * 0.9)]     # the reference's 7 / 9 of 10 epochs
@@ -62,9 +62,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--epochs", type=int, default=30)
     ap.add_argument("--thr-epochs", type=int, default=5, help="epochs over which the semantic threshold falls (0.15 -> 0.05), as in the 10-epoch recipe")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the weights' initialisation and of the host RNG streams")
     ap.add_argument("--repeat-fp32", action="store_true", help="a second fp32 run from the same seed: the run-to-run noise (fp32 atomics)")
     args = ap.parse_args()
-    out = {"what": "CAGroup3D trained from seed 0 on %d synthetic %s scenes (classes learnable from shape), %d epochs x %d iterations, "
+    out = {"what": "CAGroup3D trained from seed " + str(args.seed) + " on %d synthetic %s scenes (classes learnable from shape), %d epochs x %d iterations, "
                    "batch %d, AdamW 1e-3, decay x0.1 at 70%% / 90%%, clip 10; evaluated on %d held-out scenes with indoor_eval"
                    % (args.scenes, args.config, args.epochs, -(-args.scenes // args.batch), args.batch, args.val),
            "runs": [run(p, args) for p in os.environ.get("CG3D_CONV_RUNS", "fp32,bench,bf16-fp32rows,bf16").split(",")]}
