@@ -1056,7 +1056,9 @@ def _run(lib, P, nrows=None):
 # device waits for the host.  The buffer and its per-parameter views are therefore kept per layout and reused while that is
 # safe: every parameter's .grad must be None when the pass starts (the training loop's zero_grad(set_to_none=True)), else
 # -- gradient accumulation over several backward passes, a second backward through a retained graph -- the pass gets a
-# fresh buffer and adds, as before.
+# fresh buffer and adds, as before.  The contract that follows from the reuse: a .grad handed out by one pass is a view of
+# the pooled buffer, and the NEXT pass zero-fills and rewrites that buffer -- whoever keeps a gradient beyond
+# zero_grad(set_to_none=True) (gradient logging, EMA of gradients) must clone it, or run with CG3D_PG_REUSE=0.
 PG_REUSE = os.environ.get("CG3D_PG_REUSE", "1") != "0"
 _PG_POOL = collections.OrderedDict()
 
