@@ -124,7 +124,9 @@ _SIGNATURES = {
     "cg3d_head_outputs_bwd": (c_int32, [P, P, P, c_int32, P, c_int64, c_int32, P, c_int32, P, P, P]),
     # include/cagroup3d_program.h
     "cg3d_run_program": (c_int32, [P, c_int64, P, P]),
+    "cg3d_run_program_lanes": (c_int32, [P, c_int64, P, c_int32, P]),
     "cg3d_event_create": (c_int32, [P]),
+    "cg3d_event_create_sync": (c_int32, [P]),
     "cg3d_event_destroy": (c_int32, [c_int64]),
     "cg3d_event_elapsed_ms": (c_int32, [c_int64, c_int64, P]),
 }

@@ -1,4 +1,5 @@
-// program.hip -- cg3d_run_program: a table of C-ABI calls issued back to back on one stream (include/cagroup3d_program.h).
+// program.hip -- cg3d_run_program / cg3d_run_program_lanes: a table of C-ABI calls issued back to back on one stream, or on one
+// stream per lane with event edges between them (include/cagroup3d_program.h).
 // The host language then pays for ONE foreign call per network pass instead of one per launch; see engine.py.
 #include "cg3d_common.h"
 
@@ -19,14 +20,30 @@ static inline int prog_event_record(int64_t handle, cg3d_stream_t s) {
     if (!handle) return CG3D_ERR_ARG;
     return hipEventRecord((hipEvent_t)(intptr_t)handle, cg3d_hs(s)) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
 }
+static inline int prog_event_wait(int64_t handle, cg3d_stream_t s) {
+    if (!handle) return CG3D_ERR_ARG;
+    return hipStreamWaitEvent(cg3d_hs(s), (hipEvent_t)(intptr_t)handle, 0) == hipSuccess ? CG3D_OK : CG3D_ERR_LAUNCH;
+}
 #define CG3D_PROG_MEMSET prog_memset
 #define CG3D_PROG_COPY2D prog_copy2d
 #define CG3D_PROG_EVENT_RECORD prog_event_record
+#define CG3D_PROG_EVENT_WAIT prog_event_wait
 #define CG3D_PROGRAM_IMPL
 #include "../../include/cagroup3d_program.h"
 
 extern "C" int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, int64_t *fail_at) {
     return cg3d_program_run(prog, nops, stream, fail_at);
+}
+extern "C" int cg3d_run_program_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams,
+                                      int64_t *fail_at) {
+    return cg3d_program_run_lanes(prog, nops, streams, nstreams, fail_at);
+}
+extern "C" int cg3d_event_create_sync(int64_t *handle) {
+    if (!handle) return CG3D_ERR_ARG;
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CG3D_ERR_LAUNCH;
+    *handle = (int64_t)(intptr_t)e;
+    return CG3D_OK;
 }
 extern "C" int cg3d_event_create(int64_t *handle) {
     if (!handle) return CG3D_ERR_ARG;

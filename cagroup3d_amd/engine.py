@@ -38,7 +38,29 @@ STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_re
 (OP_NOP, OP_MEMSET, OP_COPY2D, OP_TO_BF16, OP_TILE_FWD, OP_SPCONV_FWD, OP_SPCONV_FWD_TILED, OP_PAIRS_FWD, OP_PAIRS_WGRAD,
  OP_LINEAR_FWD, OP_BN_SUMS, OP_BN_APPLY_SUMS, OP_BN_APPLY, OP_BN_BWD_SUMS, OP_BN_BWD_APPLY_SUMS, OP_BN_BWD_APPLY, OP_INTERP_MAP,
  OP_INTERP_FWD, OP_INTERP_BWD, OP_GATHER_ROWS, OP_SCATTER_ADD_ROWS, OP_SCATTER_MEAN_FWD, OP_SCATTER_MEAN_BWD,
- OP_EVENT_RECORD, OP_TO_BF16_SPLIT, OP_FROM_BF16) = range(26)
+ OP_EVENT_RECORD, OP_TO_BF16_SPLIT, OP_FROM_BF16, OP_EVENT_WAIT) = range(27)
+# Lanes (include/cagroup3d_program.h): the two chains of the bilateral backbone -- and the two independent branches of the class
+# program -- are issued on two queues, ordered by event edges that `_schedule` derives from what every row reads and writes.
+# CG3D_LANES=0: everything on the one stream, as until round 5.
+LANES = os.environ.get("CG3D_LANES", "1") != "0"
+LANES_RUN = os.environ.get("CG3D_LANES_RUN", "1") != "0"     # 0: tables WITH their event edges, every lane on the one stream (A/B runs)
+LANE_SHIFT = 32
+OPCODE_MASK = (1 << LANE_SHIFT) - 1
+# Pointer arguments of every opcode as (columns read, columns written) of a row (column 0 is the opcode): the `const T *` and the
+# `T *` parameters of the entry point the opcode names (tests/test_engine.py checks this table against include/cagroup3d_hip.h).
+# A written column counts as read too (accumulating kernels).
+ROLES = {
+    OP_NOP: ((), ()), OP_MEMSET: ((), (1,)), OP_COPY2D: ((3,), (1,)), OP_TO_BF16: ((1,), (2,)),
+    OP_TILE_FWD: ((1, 2, 3, 4, 5, 6, 7, 10, 12, 13), (14, 22)), OP_SPCONV_FWD: ((1, 2, 3, 4), (5,)),
+    OP_SPCONV_FWD_TILED: ((1, 2, 3, 4, 6), (7,)), OP_PAIRS_FWD: ((1, 2, 3, 4, 5, 7), (8,)),
+    OP_PAIRS_WGRAD: ((1, 2, 3, 4, 5), (7,)), OP_LINEAR_FWD: ((1, 2, 3), (4, 9, 10)), OP_BN_SUMS: ((1, 2), (6,)),
+    OP_BN_APPLY_SUMS: ((1, 2, 3, 7, 8, 10, 11), (13, 14, 15, 16, 17, 18, 19)), OP_BN_APPLY: ((1, 2, 3, 6, 7, 9, 10), (12, 13)),
+    OP_BN_BWD_SUMS: ((1, 2, 3, 4, 8, 9), (12,)), OP_BN_BWD_APPLY_SUMS: ((1, 2, 3, 4, 8, 9, 11, 12, 13), (16, 17, 18, 19, 20)),
+    OP_BN_BWD_APPLY: ((1, 2, 3, 4, 7, 8, 10, 11, 12, 13), (16, 17, 18)), OP_INTERP_MAP: ((1, 4, 5), (7, 8)),
+    OP_INTERP_FWD: ((1, 2, 3), (4,)), OP_INTERP_BWD: ((1, 2, 3), (4,)), OP_GATHER_ROWS: ((1, 2), (3,)),
+    OP_SCATTER_ADD_ROWS: ((1, 2), (3,)), OP_SCATTER_MEAN_FWD: ((1, 2), (4, 5)), OP_SCATTER_MEAN_BWD: ((1, 2, 3), (5,)),
+    OP_EVENT_RECORD: ((), ()), OP_TO_BF16_SPLIT: ((1,), (2,)), OP_FROM_BF16: ((1,), (2,)), OP_EVENT_WAIT: ((), ()),
+}
 S16 = 0x100                 # CG3D_BN_STORE_BF16: the row matrices of a BatchNorm call are bf16 rows
 TILE_OUT16 = 2              # CG3D_TILE_OUT_BF16 (bit of cg3d_spconv_tile_fwd's wrev argument)
 LIN_OUT16 = 0x10000         # CG3D_LINEAR_OUT_BF16 (bit of cg3d_linear_fwd's ksplit argument)
@@ -139,24 +161,43 @@ class Program:
 
     def __init__(self):
         self.rows = []
+        self.lanes = []         # lane of every row
+        self.lane = 0           # lane of the rows being added (Builder.set_lane)
         self.prof = []          # (row index, flops, bytes, meta, per-pair bytes): conv launches (KernelProfile)
+        self.nevents = 0        # ordering events the scheduled table refers to by slot number (_schedule)
 
     def add(self, *row):
         self.rows.append(row)
+        self.lanes.append(self.lane)
 
     def table(self):
         P = np.zeros((len(self.rows), STRIDE), dtype=np.int64)
         for i, r in enumerate(self.rows):
             P[i, :len(r)] = r
+        if any(self.lanes):
+            P[:, 0] |= np.asarray(self.lanes, dtype=np.int64) << LANE_SHIFT
         return P
+
+
+class _Tape(list):
+    """The backward closures of a pass, each with the lane its forward rows were put on."""
+
+    def __init__(self, builder):
+        list.__init__(self)
+        self.builder = builder
+
+    def append(self, fn):
+        list.append(self, (self.builder.lane, fn))
 
 
 class Builder:
     def __init__(self, lib, device, gen):
         self.lib, self.dev, self.gen = lib, device, gen
         self.f, self.b = Program(), Program()
-        self.tape = []
+        self.lane = 0
+        self.tape = _Tape(self)
         self.size = {R_ACT: 0, R_ZF: 0, R_ZB: 0, R_PG: 0}
+        self.starts = {R_ACT: [], R_ZF: [], R_ZB: [], R_PG: []}     # block starts per region, ascending (_schedule)
         self.keep = []                  # tensors the rows point into (tables built at emission time)
         # tables out of me.py's host caches: held for their lifetime only (the caches publish an entry after its upload has
         # completed, and what frees one is this reference going away -- no stream hand-over needed: `keep` gets one)
@@ -178,7 +219,14 @@ class Builder:
     def alloc(self, nbytes, region=R_ACT):
         off = self.size[region]
         self.size[region] = off + ((int(nbytes) + ALIGN - 1) & ~(ALIGN - 1))
+        self.starts[region].append(off)
         return region + off
+
+    def set_lane(self, lane):
+        """Rows added from here on (to either table) go to `lane`; returns the lane that was current."""
+        prev = self.lane
+        self.lane = self.f.lane = self.b.lane = lane if LANES else 0
+        return prev
 
     def new(self, n, c, need=True):
         return T(self.alloc(max(n, 1) * c * 4), n, c, need)
@@ -817,10 +865,13 @@ class Builder:
         for o, region in zip(outs, (R_DOUT, R_DOUT2)):
             o.gc = [(region, 0)]
         for i in range(len(self.tape) - 1, -1, -1):
-            self.tape[i]()
+            lane, fn = self.tape[i]
+            self.set_lane(lane)                     # a layer's backward rows run on the lane of its forward rows
+            fn()
             name = self.mark_at.get(i)
             if name is not None:
                 self.marks[name] = len(self.b.rows)
+        self.set_lane(0)
         self.tape = None
 
 
@@ -944,19 +995,188 @@ class Emitter:
         if mid_mark:
             self.b.mark("mid")           # every deeper layer's gradient is complete when the backward pass is back here
         r2 = self.relu(l2)
+        # From here to the last join the net is two chains that meet three times: the stride-8 / 16 / 32 layers (lane 1: 23 k, 5 k
+        # and 1 k voxels for 4 x S50k -- launches of 40-360 workgroup units and DAPPM's ~60 launches of a few microseconds) and
+        # the stride-4 layers (lane 0: 82 k voxels, 640 units per launch).  Every cross term sits on the lane of its CONSUMER's
+        # chain: down3 / down4 read the stride-4 rows and feed the coarse chain (lane 1), the interpolations read the coarse
+        # rows and feed the stride-4 chain (lane 0).
+        lane = self.b.set_lane
+        lane(1)
         l3 = self.module(net.layer3, r2)
+        r3 = self.relu(l3)
+        c3 = self.module(net.compression3, r3)
+        lane(0)
         hi = self.module(net.layer3_, r2)
-        r3, rh = self.relu(l3), self.relu(hi)
+        rh = self.relu(hi)
+        lane(1)
         lo_r = self.add_relu(l3, self.module(net.down3, rh))
-        hi_r = self.add_relu(hi, self.at_coordinates(self.module(net.compression3, r3), hi.key))
         l4 = self.module(net.layer4, lo_r)
+        r4 = self.relu(l4)
+        c4 = self.module(net.compression4, r4)
+        lane(0)
+        hi_r = self.add_relu(hi, self.at_coordinates(c3, hi.key))
         hi = self.module(net.layer4_, hi_r)
-        r4, rh = self.relu(l4), self.relu(hi)
+        rh = self.relu(hi)
+        lane(1)
         lo_r = self.add_relu(l4, self.module(net.down4, rh))
-        hi_r = self.add_relu(hi, self.at_coordinates(self.module(net.compression4, r4), hi.key))
+        sp = self.module(net.spp, self.module(net.layer5, lo_r))
+        lane(0)
+        hi_r = self.add_relu(hi, self.at_coordinates(c4, hi.key))
         hi = self.module(net.layer5_, hi_r)
-        hi = self.add(hi, self.at_coordinates(self.module(net.spp, self.module(net.layer5, lo_r)), hi.key))
+        hi = self.add(hi, self.at_coordinates(sp, hi.key))
         return self.module(net.out, hi)
+
+
+# ------------------------------------------------------------------------------------------------ lanes
+def _schedule(prog, starts, cuts=()):
+    """Event edges between the lanes of `prog` (rows still with region-relative addresses), in place.
+
+    Rows of one lane run in table order on their queue; a row needs an edge from the OTHER lane when it reads a block that lane
+    wrote last, or writes a block that lane read or wrote (ROLES).  A block is what one `Builder.alloc` returned (`starts`) or,
+    outside the regions (module buffers such as running statistics), an address.  An edge is an EVENT_RECORD right behind the
+    producing row on its lane and an EVENT_WAIT in front of the consuming row on its lane; a lane that already waited for a
+    later row of the other one needs none.  Every part of the table (cuts: row indices where the caller splits it to run a
+    callback between two halves of a backward pass) starts with lane 1 waiting for lane 0's position and ends with lane 0
+    waiting for the end of lane 1: what precedes the table on the stream (the zero-fill of its regions) and what follows it
+    (the framework's reads of the outputs) see one queue.
+
+    Events are numbered slots (row = opcode, slot, 1): `_bind_events` puts the handles in when the pass is run.
+    Returns (old -> new row index, cut -> new row index at which the table is split there: behind the join of the part that
+    ends at the cut, in front of what the next part starts with)."""
+    import bisect
+    rows, lanes = prog.rows, prog.lanes
+    n = len(rows)
+    if not any(lanes):
+        return list(range(n)), {c: c for c in cuts}
+    assert max(lanes) <= 1, "two lanes"
+    before = [[] for _ in range(n + 1)]          # rows put in front of old row i
+    after = [[] for _ in range(n)]               # rows put right behind old row i
+    tail = [[] for _ in range(n + 1)]            # the join of the part that ends in front of old row i (index n: end of table)
+    nev = 0
+
+    def block(addr):
+        tag = addr >> TAG
+        if not tag:
+            return addr
+        lst = starts.get(tag << TAG)
+        off = addr - (tag << TAG)
+        if not lst:
+            return (tag, 0)
+        return (tag, lst[bisect.bisect_right(lst, off) - 1])
+
+    bounds = [0] + sorted(set(c for c in cuts if 0 < c < n)) + [n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        lastw, lastr = {}, {}                    # block -> [sequence number of the last writer / reader on lane 0, lane 1]
+        cnt = [0, 0]                             # rows seen per lane
+        where = [[None], [None]]                 # lane, sequence number -> old row index
+        seen = [0, 0]                            # seen[L]: lane L has waited for the other lane's row number seen[L]
+        forked = False
+        for i in range(lo, hi):
+            row, L = rows[i], lanes[i]
+            M = 1 - L
+            rd, wr = ROLES[int(row[0]) & OPCODE_MASK]
+            need = 0
+            blocks_r, blocks_w = [], []
+            for c in rd:
+                if c < len(row) and row[c]:
+                    bk = block(row[c])
+                    blocks_r.append(bk)
+                    w = lastw.get(bk)
+                    if w is not None and w[M] > need:
+                        need = w[M]
+            for c in wr:
+                if c < len(row) and row[c]:
+                    bk = block(row[c])
+                    blocks_w.append(bk)
+                    w, r = lastw.get(bk), lastr.get(bk)
+                    if w is not None and w[M] > need:
+                        need = w[M]
+                    if r is not None and r[M] > need:
+                        need = r[M]
+            if L == 1 and not forked:
+                # the lane's first row of this part: behind everything lane 0 was given before the part (and the zero-fill)
+                before[lo].insert(0, ((OP_EVENT_RECORD, nev, 1), 0))
+                before[i].append(((OP_EVENT_WAIT, nev, 1), 1))
+                nev += 1
+                forked = True
+            if need > seen[L]:
+                after[where[M][need]].append(((OP_EVENT_RECORD, nev, 1), M))
+                before[i].append(((OP_EVENT_WAIT, nev, 1), L))
+                nev += 1
+                seen[L] = need
+            cnt[L] += 1
+            where[L].append(i)
+            q = cnt[L]
+            for bk in blocks_r:
+                lastr.setdefault(bk, [0, 0])[L] = q
+            for bk in blocks_w:
+                lastw.setdefault(bk, [0, 0])[L] = q
+                lastr.setdefault(bk, [0, 0])[L] = q
+        if cnt[1] > seen[0]:                     # the join: lane 0 behind the last row of lane 1
+            after[where[1][cnt[1]]].append(((OP_EVENT_RECORD, nev, 1), 1))
+            tail[hi].append(((OP_EVENT_WAIT, nev, 1), 0))
+            nev += 1
+    out_rows, out_lanes, index, cutmap = [], [], [], {}
+    for i in range(n + 1):
+        for r, l in tail[i]:
+            out_rows.append(r)
+            out_lanes.append(l)
+        cutmap[i] = len(out_rows)
+        if i == n:
+            break
+        for r, l in before[i]:
+            out_rows.append(r)
+            out_lanes.append(l)
+        index.append(len(out_rows))
+        out_rows.append(rows[i])
+        out_lanes.append(lanes[i])
+        for r, l in after[i]:
+            out_rows.append(r)
+            out_lanes.append(l)
+    prog.rows, prog.lanes, prog.nevents = out_rows, out_lanes, nev
+    prog.prof = [(index[r],) + tuple(rest) for (r, *rest) in prog.prof]
+    return index, {c: cutmap[c] for c in cuts}
+
+
+_EVENT_POOL = __import__("threading").local()
+
+
+def _bind_events(P, lib, nevents):
+    """Handles of ordering events (cg3d_event_create_sync, created once per thread and reused by every pass: a wait refers to
+    the record issued before it, and one thread issues one pass at a time) in place of the slot numbers of `_schedule`."""
+    if not nevents:
+        return P
+    pool = getattr(_EVENT_POOL, "h", None)
+    if pool is None or _EVENT_POOL.lib is not lib:
+        pool, _EVENT_POOL.lib = [], lib
+        _EVENT_POOL.h = pool
+    while len(pool) < nevents:
+        h = ctypes_i64()
+        lib.call("cg3d_event_create_sync", ctypes_ref(h))
+        pool.append(h.value)
+    op = P[:, 0] & OPCODE_MASK
+    m = ((op == OP_EVENT_RECORD) | (op == OP_EVENT_WAIT)) & (P[:, 2] == 1)
+    if m.any():
+        P[m, 1] = np.asarray(pool, dtype=np.int64)[P[m, 1]]
+        P[m, 2] = 0
+    return P
+
+
+_SIDE_STREAMS = {}
+
+
+def _lane_streams(lib):
+    """(ctypes array, count) of the queues of lanes 0, 1: torch's current stream and this process's side stream of the device."""
+    import ctypes
+    main = lib.stream()
+    if not lib.is_device:
+        return (ctypes.c_void_p * 2)(None, None), 2
+    dev = torch.cuda.current_device()
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        prio = int(os.environ.get("CG3D_LANE_PRIORITY", "0"))
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=prio)
+    return (ctypes.c_void_p * 2)(main, side.cuda_stream), 2
 
 
 # ------------------------------------------------------------------------------------------------ a compiled pass
@@ -965,13 +1185,19 @@ class Compiled:
 
     def __init__(self, b, out, out_key, n_in, c_in, mgr=None):
         self.mgr = mgr                   # the coordinate manager owns the maps / plans / pair lists the rows point into
+        # event edges between the lanes (no-ops for a one-lane pass); row indices recorded during emission follow
+        fidx, _ = _schedule(b.f, b.starts)
+        bidx, bcuts = _schedule(b.b, b.starts, tuple(b.marks.values()))
+        self.lanes = bool(b.f.nevents or b.b.nevents)
+        self.nevents = max(b.f.nevents, b.b.nevents)
         self.fwd, self.bwd = b.f.table(), b.b.table()
         self.fprof, self.bprof = b.f.prof, b.b.prof
         self.size = dict(b.size)
-        self.keep, self.params, self.late, self.marks = b.keep, b.params, b.late, b.marks
+        self.keep, self.params, self.late = b.keep, b.params, b.late
+        self.marks = {name: bcuts[row] for name, row in b.marks.items()}
         self.keep_cached = b.keep_cached
-        self.late_f = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.f]
-        self.late_b = [(r, c, fn) for (pg, r, c, fn) in b.late if pg is b.b]
+        self.late_f = [(fidx[r], c, fn) for (pg, r, c, fn) in b.late if pg is b.f]
+        self.late_b = [(bidx[r], c, fn) for (pg, r, c, fn) in b.late if pg is b.b]
         self.out = (out.p, out.n, out.c, out.p16)
         self.out_key = out_key
         self.n_in, self.c_in = n_in, c_in
@@ -1028,7 +1254,7 @@ def _with_events(P, prof, lib):
         ev = _Events(lib)
         out.append(P[last:row])
         e0 = np.zeros((1, STRIDE), dtype=np.int64)
-        e0[0, 0], e0[0, 1] = OP_EVENT_RECORD, ev.h[0]
+        e0[0, 0], e0[0, 1] = OP_EVENT_RECORD | (int(P[row, 0]) & ~OPCODE_MASK), ev.h[0]      # on the lane of the row it times
         e1 = e0.copy()
         e1[0, 1] = ev.h[1]
         out += [e0, P[row:row + 1], e1]
@@ -1038,16 +1264,23 @@ def _with_events(P, prof, lib):
     return np.concatenate(out), recs
 
 
-def _run(lib, P, nrows=None):
+def _run(lib, P, nrows=None, comp=None):
+    """comp: the compiled pass the rows come from (its ordering events are bound here; a pass with lanes goes to the lanes entry)."""
     P = np.ascontiguousarray(P)
     n = P.shape[0] if nrows is None else nrows
     if n == 0:
         return
     import ctypes
     fail = ctypes.c_int64(-1)
-    rc = lib.raw("cg3d_run_program")(P.ctypes.data, n, lib.stream(), ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    if comp is not None and comp.lanes:
+        P = _bind_events(P, lib, comp.nevents)
+        streams, ns = _lane_streams(lib)
+        rc = lib.raw("cg3d_run_program_lanes")(P.ctypes.data, n, ctypes.cast(streams, ctypes.c_void_p), ns if LANES_RUN else 1,
+                                               ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    else:
+        rc = lib.raw("cg3d_run_program")(P.ctypes.data, n, lib.stream(), ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
     if rc != 0:
-        raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, int(P[fail.value, 0]) if 0 <= fail.value < n else -1, rc))
+        raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, (int(P[fail.value, 0]) & OPCODE_MASK) if 0 <= fail.value < n else -1, rc))
 
 
 # ------------------------------------------------------------------------------------------------ parameter gradients
@@ -1123,7 +1356,7 @@ class BackboneFunction(torch.autograd.Function):
         if prof:
             P, recs = _with_events(P, comp.fprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]))
+        _run(lib, np.concatenate([head, P]), comp=comp)
         ctx.comp, ctx.arena, ctx.bases, ctx.feats, ctx.keep, ctx.hooks, ctx.prof = comp, arena, bases, feats, keep, hooks, prof
         p, n, c, p16 = comp.out
         shift = bases[R_ACT] - arena.data_ptr()
@@ -1173,7 +1406,7 @@ class BackboneFunction(torch.autograd.Function):
             if ctx.prof:
                 rows, recs = _with_events(rows, prof, lib)
                 ME.KernelProfile.records.extend(recs)
-            _run(lib, np.concatenate([head, rows]) if first else rows)
+            _run(lib, np.concatenate([head, rows]) if first else rows, comp=comp)
             first = False
             if name is not None:
                 fn, ids = hooks[name]
@@ -1217,9 +1450,14 @@ def compile_class_branches(head, nf, nc, c, km9, km5, km_up, ident, fine_bounds,
             for mods, up in ((head.cls_individual_out, False), (head.cls_individual_expand_out, False),
                              (head.cls_individual_up, True), (head.cls_individual_fuse, False)))
     ME.pairs_many([(km9, fine_bounds), (km5, coarse_bounds), (km_up, fine_bounds), (ident, fine_bounds)])    # one host read for the four
-    a = b.gbn_act(b.gconv(xf, L[0][0], km9, fine_bounds, True), L[0][1], fine_bounds, elu)
+    # two independent branches until the concatenation: the 9^3 convolution on the fine map streams its 18 classes' weights
+    # (HBM-bound, lane 0); the 5^3 convolution on the coarse map and the transposed convolution back are pair-kernel launches
+    # bound by their gather latency (lane 1)
+    b.set_lane(1)
     e = b.gbn_act(b.gconv(xc, L[1][0], km5, coarse_bounds, True), L[1][1], coarse_bounds, elu)
     u = b.gbn_act(b.gconv(e, L[2][0], km_up, fine_bounds, False), L[2][1], fine_bounds, elu)
+    b.set_lane(0)
+    a = b.gbn_act(b.gconv(xf, L[0][0], km9, fine_bounds, True), L[0][1], fine_bounds, elu)
     f = b.gbn_act(b.gconv(b.cat([u, a]), L[3][0], ident, fine_bounds, False), L[3][1], fine_bounds, elu)
     b.emit_backward(f)
     gin = (b.grad(xf), b.grad(xc))              # (may add the rows that sum several contributions: before the tables are cut)
@@ -1258,7 +1496,7 @@ class ClassBranchFunction(torch.autograd.Function):
         if prof:
             P, recs = _with_events(P, comp.fprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]))
+        _run(lib, np.concatenate([head, P]), comp=comp)
         ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (xf, xc), prof
         p, n, c, p16 = comp.out
         y = _arena_view(arena, bases, p, n, c)
@@ -1280,7 +1518,7 @@ class ClassBranchFunction(torch.autograd.Function):
         if ctx.prof:
             P, recs = _with_events(P, comp.bprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]))
+        _run(lib, np.concatenate([head, P]), comp=comp)
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
                 if prm.requires_grad:
@@ -1368,7 +1606,7 @@ class HeadPreFunction(torch.autograd.Function):
         if prof:
             P, recs = _with_events(P, comp.fprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]))
+        _run(lib, np.concatenate([head, P]), comp=comp)
         ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (x, x16), prof
         outs = []
         for p, n, c, p16 in (comp.out, comp.out2):
@@ -1399,7 +1637,7 @@ class HeadPreFunction(torch.autograd.Function):
         if ctx.prof:
             P, recs = _with_events(P, comp.bprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]))
+        _run(lib, np.concatenate([head, P]), comp=comp)
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
                 if prm.requires_grad:

@@ -52,16 +52,31 @@ enum {
     CG3D_OP_EVENT_RECORD = 23,     /* event handle from cg3d_event_create                       (hipEventRecord)      */
     CG3D_OP_TO_BF16_SPLIT = 24,    /* cg3d_to_bf16_split                                                              */
     CG3D_OP_FROM_BF16 = 25,        /* cg3d_from_bf16                                                                  */
+    CG3D_OP_EVENT_WAIT = 26,       /* event handle: the row's queue waits for the event         (hipStreamWaitEvent)  */
     CG3D_OP_COUNT
 };
+
+/* Lanes.  Bits 32-39 of a row's first word name the QUEUE the row is issued on (cg3d_run_program_lanes: lane l -> streams[l];
+ * cg3d_run_program, or a lane >= nstreams: everything on the one stream -- table order is always a valid sequential order).
+ * Rows of one lane run in table order; between lanes only CG3D_OP_EVENT_RECORD (on the producer's lane) followed, later in the
+ * table, by CG3D_OP_EVENT_WAIT (on the consumer's lane) orders anything.  The BiResNet backbone is two chains between its
+ * joins (reference biresnet.py:378-394: the stride-8/16/32 layers and the stride-4 layers): on one queue the stride-16/32
+ * launches (42-180 tiles) leave most of the 256 CUs idle one after the other; on two queues the stride-4 chain fills them. */
+#define CG3D_PROG_LANE_SHIFT 32
+#define CG3D_PROG_MAX_LANES 4
 
 /* Runs rows [0, nops) of `prog` in order on `stream`.  Returns CG3D_OK, or the status of the first failing call with its row
  * index in *fail_at (may be NULL); rows after it are not run.  An unknown opcode is CG3D_ERR_ARG. */
 int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, int64_t *fail_at);
 
+/* The same with one stream per lane (1 <= nstreams <= CG3D_PROG_MAX_LANES).  Nothing is synchronised with the host; the caller's
+ * table ends with the waits that bring every lane back to lane 0 (engine.py: _schedule). */
+int cg3d_run_program_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at);
+
 /* Timing events for the rows of a program (CG3D_OP_EVENT_RECORD): handles are hipEvent_t on the device library; the oracle
  * hands out dummies and reports 0 ms. */
 int cg3d_event_create(int64_t *handle);
+int cg3d_event_create_sync(int64_t *handle); /* ordering only, no time stamps (hipEventDisableTiming) */
 int cg3d_event_destroy(int64_t handle);
 int cg3d_event_elapsed_ms(int64_t start, int64_t stop, float *ms); /* waits for `stop` */
 
@@ -75,6 +90,7 @@ int cg3d_event_elapsed_ms(int64_t start, int64_t stop, float *ms); /* waits for 
  *   CG3D_PROG_MEMSET(dst, value, nbytes, stream)                      -> status
  *   CG3D_PROG_COPY2D(dst, dpitch, src, spitch, width, height, stream) -> status
  *   CG3D_PROG_EVENT_RECORD(handle, stream)                            -> status
+ *   CG3D_PROG_EVENT_WAIT(handle, stream)                              -> status
  * ------------------------------------------------------------------------------------------------------------------ */
 #ifdef CG3D_PROGRAM_IMPL
 static inline float cg3d_prog_f(int64_t v) {
@@ -174,6 +190,7 @@ static int cg3d_program_dispatch(const int64_t *row, cg3d_stream_t s) {
         return cg3d_scatter_mean_bwd(CG3D_A_P(const float *, 0), CG3D_A_P(const float *, 1), CG3D_A_P(const int32_t *, 2),
                                      CG3D_A_I(3), CG3D_A_P(float *, 4), CG3D_A_L(5), CG3D_A_L(6), CG3D_A_I(7), s);
     case CG3D_OP_EVENT_RECORD: return CG3D_PROG_EVENT_RECORD(CG3D_A_L(0), s);
+    case CG3D_OP_EVENT_WAIT: return CG3D_PROG_EVENT_WAIT(CG3D_A_L(0), s);
     case CG3D_OP_FROM_BF16: return cg3d_from_bf16(CG3D_A_P(const uint16_t *, 0), CG3D_A_P(float *, 1), CG3D_A_L(2), s);
     case CG3D_OP_TO_BF16_SPLIT:
         return cg3d_to_bf16_split(CG3D_A_P(const float *, 0), CG3D_A_P(uint16_t *, 1), CG3D_A_L(2), CG3D_A_I(3), s);
@@ -184,6 +201,19 @@ static int cg3d_program_run(const int64_t *prog, int64_t nops, cg3d_stream_t str
     if (nops < 0 || (nops > 0 && !prog)) return CG3D_ERR_ARG;
     for (int64_t i = 0; i < nops; i++) {
         const int rc = cg3d_program_dispatch(prog + i * CG3D_PROG_STRIDE, stream);
+        if (rc != CG3D_OK) {
+            if (fail_at) *fail_at = i;
+            return rc;
+        }
+    }
+    return CG3D_OK;
+}
+static int cg3d_program_run_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
+    if (nops < 0 || (nops > 0 && !prog) || !streams || nstreams < 1 || nstreams > CG3D_PROG_MAX_LANES) return CG3D_ERR_ARG;
+    for (int64_t i = 0; i < nops; i++) {
+        const int64_t *row = prog + i * CG3D_PROG_STRIDE;
+        const int lane = (int)((row[0] >> CG3D_PROG_LANE_SHIFT) & 0xff);
+        const int rc = cg3d_program_dispatch(row, streams[lane < nstreams ? lane : 0]);
         if (rc != CG3D_OK) {
             if (fail_at) *fail_at = i;
             return rc;

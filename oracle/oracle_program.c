@@ -22,14 +22,23 @@ static int op_event_record(int64_t handle, cg3d_stream_t s) {
     (void)s;
     return handle ? CG3D_OK : CG3D_ERR_ARG;
 }
+static int op_event_wait(int64_t handle, cg3d_stream_t s) {
+    (void)s;
+    return handle ? CG3D_OK : CG3D_ERR_ARG;
+}
 #define CG3D_PROG_MEMSET op_memset
 #define CG3D_PROG_COPY2D op_copy2d
 #define CG3D_PROG_EVENT_RECORD op_event_record
+#define CG3D_PROG_EVENT_WAIT op_event_wait
 #define CG3D_PROGRAM_IMPL
 #include "../include/cagroup3d_program.h"
 
 int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, int64_t *fail_at) {
     return cg3d_program_run(prog, nops, stream, fail_at);
+}
+/* lanes: the oracle runs the rows in table order (always a valid sequential order); the streams are passed on and ignored */
+int cg3d_run_program_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
+    return cg3d_program_run_lanes(prog, nops, streams, nstreams, fail_at);
 }
 int cg3d_event_create(int64_t *handle) {
     static int64_t next = 1;
@@ -37,6 +46,7 @@ int cg3d_event_create(int64_t *handle) {
     *handle = next++;
     return CG3D_OK;
 }
+int cg3d_event_create_sync(int64_t *handle) { return cg3d_event_create(handle); }
 int cg3d_event_destroy(int64_t handle) { return handle ? CG3D_OK : CG3D_ERR_ARG; }
 int cg3d_event_elapsed_ms(int64_t start, int64_t stop, float *ms) {
     if (!start || !stop || !ms) return CG3D_ERR_ARG;
