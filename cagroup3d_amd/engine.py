@@ -45,6 +45,13 @@ STATS = {"program_passes": 0, "compiled_ahead": 0, "compiled_inline": 0, "not_re
 LANES = os.environ.get("CG3D_LANES", "1") != "0"
 LANES_RUN = os.environ.get("CG3D_LANES_RUN", "1") != "0"     # 0: tables WITH their event edges, every lane on the one stream (A/B runs)
 LANE_SHIFT = 32
+MAX_LANES = 8               # CG3D_PROG_MAX_LANES
+# The weight gradient of a layer feeds nothing inside the pass: on lane 2 it runs beside the data-gradient chain instead of in
+# it (backbone backward 7.4 -> 7.0 ms for 4 x S50k, tools/backbone_lanes.py).  0: on the layer's lane.
+WGRAD_LANE = int(os.environ.get("CG3D_WGRAD_LANE", "2"))
+# lanes of DAPPM's pooled branches and shortcut (empty: with the rest of the coarse chain).  Two lanes: forward 4.35 -> 4.05 ms,
+# backward 7.05 -> 6.6 ms; four lanes, or eight hardware queues (GPU_MAX_HW_QUEUES, default 4), were slower.
+DAPPM_LANES = [int(x) for x in os.environ.get("CG3D_DAPPM_LANES", "3,2").split(",") if x]
 OPCODE_MASK = (1 << LANE_SHIFT) - 1
 # Pointer arguments of every opcode as (columns read, columns written) of a row (column 0 is the opcode): the `const T *` and the
 # `T *` parameters of the entry point the opcode names (tests/test_engine.py checks this table against include/cagroup3d_hip.h).
@@ -165,12 +172,15 @@ class Program:
         self.lane = 0           # lane of the rows being added (Builder.set_lane)
         self.prof = []          # (row index, flops, bytes, meta, per-pair bytes): conv launches (KernelProfile)
         self.nevents = 0        # ordering events the scheduled table refers to by slot number (_schedule)
+        self.scheduled = None   # the table with its event edges, when the library derived them (_schedule_native)
 
     def add(self, *row):
         self.rows.append(row)
         self.lanes.append(self.lane)
 
     def table(self):
+        if self.scheduled is not None:
+            return self.scheduled
         P = np.zeros((len(self.rows), STRIDE), dtype=np.int64)
         for i, r in enumerate(self.rows):
             P[i, :len(r)] = r
@@ -198,6 +208,7 @@ class Builder:
         self.tape = _Tape(self)
         self.size = {R_ACT: 0, R_ZF: 0, R_ZB: 0, R_PG: 0}
         self.starts = {R_ACT: [], R_ZF: [], R_ZB: [], R_PG: []}     # block starts per region, ascending (_schedule)
+        self.exact = {}                 # address `alloc` returned -> its block
         self.keep = []                  # tensors the rows point into (tables built at emission time)
         # tables out of me.py's host caches: held for their lifetime only (the caches publish an entry after its upload has
         # completed, and what frees one is this reference going away -- no stream hand-over needed: `keep` gets one)
@@ -220,7 +231,16 @@ class Builder:
         off = self.size[region]
         self.size[region] = off + ((int(nbytes) + ALIGN - 1) & ~(ALIGN - 1))
         self.starts[region].append(off)
+        self.exact[region + off] = (region >> TAG, off)
         return region + off
+
+    def wgrad_row(self, *row):
+        """A weight-gradient row of the backward table (see WGRAD_LANE)."""
+        prev = self.lane
+        if WGRAD_LANE:
+            self.set_lane(WGRAD_LANE)
+        self.b.add(*row)
+        self.set_lane(prev)
 
     def set_lane(self, lane):
         """Rows added from here on (to either table) go to `lane`; returns the lane that was current."""
@@ -498,8 +518,8 @@ class Builder:
             prog.prof.append((len(prog.rows), 2.0 * P * cin * cout, eb * (kmap.n_in * cin + kmap.n_out * cout) + 4.0 * K * cin * cout + 8.0 * P,
                               ("wgrad_bf16x3" if wprec == 3 else "wgrad_bf16" if wprec == 2 else ("wgrad_bf16_fp32rows" if wprec else "wgrad"), K, cin, cout, P, kmap.n_out, nseg),
                               eb * P * (cin + cout) + 4.0 * K * cin * cout))
-        prog.add(OP_PAIRS_WGRAD, xw, dyw, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), K, cin, cout,
-                 wprec | WGRAD_ACC)
+        self.wgrad_row(OP_PAIRS_WGRAD, xw, dyw, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), K, cin, cout,
+                       wprec | WGRAD_ACC)
 
     # ---------------------------------------------------------------- grouped layers (the class branches)
     def hold(self, t):
@@ -568,8 +588,8 @@ class Builder:
                 self.b.add(OP_PAIRS_FWD, dy16, wp, pout.data_ptr(), pin.data_ptr(), seg.data_ptr(), nseg, 0, dx, kmap.n_in, cout * self.kx, cin, 2, 1)
             self.gadd(x, dx)
         seg, nseg = kmap.segments(ME._wgrad_seg_len(P, cin, cout, 1, G * K), rb)
-        self.b.add(OP_PAIRS_WGRAD, self.rows16(x) if not x.p16 else x.p16, dy16, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg,
-                   self.pgrad_group(weights), G * K, cin, cout, (3 if self.kx == 3 else 2) | WGRAD_ACC)
+        self.wgrad_row(OP_PAIRS_WGRAD, self.rows16(x) if not x.p16 else x.p16, dy16, pin.data_ptr(), pout.data_ptr(), seg.data_ptr(), nseg,
+                       self.pgrad_group(weights), G * K, cin, cout, (3 if self.kx == 3 else 2) | WGRAD_ACC)
 
     def gbn_act(self, x, bns, bounds, act):
         """me.FusedBNActFunction over G row groups; the G modules' parameters and running statistics as [G, C] arrays (me.BNStack)."""
@@ -674,8 +694,8 @@ class Builder:
         elif not xc:
             raise NotReady("fp32 rows of a bf16-stored input are not kept for the backward pass")
         ar, seg, nseg = self._ident(n, ME._wgrad_seg_len(n, cin, cout, 1 if wprec else 0, 1))
-        prog.add(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
-                 wprec | WGRAD_ACC)
+        self.wgrad_row(OP_PAIRS_WGRAD, xc, dyc, ar.data_ptr(), ar.data_ptr(), seg.data_ptr(), nseg, self.pgrad(weight), 1, cin, cout,
+                       wprec | WGRAD_ACC)
 
     # ---------------------------------------------------------------- BatchNorm (+ residual) (+ activation) (me.FusedBNActFunction)
     def bn_act(self, x, bn, act, res=None):
@@ -979,12 +999,26 @@ class Emitter:
             res = x if m.downsample is None else self.module(m.downsample, x)
             return self.bn(m.norm3, self.conv(m.conv3, out), ME.ACT_NONE if m.no_relu else ME.ACT_RELU, res)
         if isinstance(m, B.DAPPM):
+            # ~75 launches of a few microseconds on 150-1 300 voxels, one behind the other in the module's order -- and the
+            # whole device waits for them (the stride-4 chain needs their sum).  Only the `process` convolutions form a chain:
+            # the four pooled branches (pool, BN, ReLU, 1x1x1, interpolation: 9 launches each) and the shortcut depend on x
+            # alone and go to the lanes of DAPPM_LANES, round robin.
+            here = self.b.lane
+            side = [l for l in DAPPM_LANES if l != here] if (LANES and here) else []
+            ups = []
+            for i, scale in enumerate((m.scale1, m.scale2, m.scale3, m.scale4)):
+                if side:
+                    self.b.set_lane(side[i % len(side)])
+                ups.append(self.at_coordinates(self.module(scale, x), x.key))
+            if side:
+                self.b.set_lane(side[len(ups) % len(side)])
+            short = self.module(m.shortcut, x)
+            self.b.set_lane(here)
             feats = [self.module(m.scale0, x)]
-            for scale, process in ((m.scale1, m.process1), (m.scale2, m.process2), (m.scale3, m.process3), (m.scale4, m.process4)):
-                up = self.at_coordinates(self.module(scale, x), x.key)
+            for up, process in zip(ups, (m.process1, m.process2, m.process3, m.process4)):
                 feats.append(self.module(process, self.add(up, feats[-1])))
             cat = _X(self.b.cat([f.t for f in feats]), x.key)
-            return self.add(self.module(m.compression, cat), self.module(m.shortcut, x))
+            return self.add(self.module(m.compression, cat), short)
         raise NotReady("no program form for %s" % type(m).__name__)
 
     def biresnet(self, net, x, mid_mark=False):
@@ -1028,17 +1062,17 @@ class Emitter:
 
 
 # ------------------------------------------------------------------------------------------------ lanes
-def _schedule(prog, starts, cuts=()):
+def _schedule(prog, starts, cuts=(), exact=None):
     """Event edges between the lanes of `prog` (rows still with region-relative addresses), in place.
 
-    Rows of one lane run in table order on their queue; a row needs an edge from the OTHER lane when it reads a block that lane
+    Rows of one lane run in table order on their queue; a row needs an edge from ANOTHER lane when it reads a block that lane
     wrote last, or writes a block that lane read or wrote (ROLES).  A block is what one `Builder.alloc` returned (`starts`) or,
     outside the regions (module buffers such as running statistics), an address.  An edge is an EVENT_RECORD right behind the
     producing row on its lane and an EVENT_WAIT in front of the consuming row on its lane; a lane that already waited for a
     later row of the other one needs none.  Every part of the table (cuts: row indices where the caller splits it to run a
-    callback between two halves of a backward pass) starts with lane 1 waiting for lane 0's position and ends with lane 0
-    waiting for the end of lane 1: what precedes the table on the stream (the zero-fill of its regions) and what follows it
-    (the framework's reads of the outputs) see one queue.
+    callback between two halves of a backward pass) has every other lane wait for lane 0's position at the start of the part
+    before its first row, and ends with lane 0 waiting for the end of every other lane: what precedes the table on the stream
+    (the zero-fill of its regions) and what follows it (the framework's reads of the outputs) see one queue.
 
     Events are numbered slots (row = opcode, slot, 1): `_bind_events` puts the handles in when the pass is run.
     Returns (old -> new row index, cut -> new row index at which the table is split there: behind the join of the part that
@@ -1048,11 +1082,6 @@ def _schedule(prog, starts, cuts=()):
     n = len(rows)
     if not any(lanes):
         return list(range(n)), {c: c for c in cuts}
-    assert max(lanes) <= 1, "two lanes"
-    before = [[] for _ in range(n + 1)]          # rows put in front of old row i
-    after = [[] for _ in range(n)]               # rows put right behind old row i
-    tail = [[] for _ in range(n + 1)]            # the join of the part that ends in front of old row i (index n: end of table)
-    nev = 0
 
     def block(addr):
         tag = addr >> TAG
@@ -1064,78 +1093,192 @@ def _schedule(prog, starts, cuts=()):
             return (tag, 0)
         return (tag, lst[bisect.bisect_right(lst, off) - 1])
 
+    # Every pointer of every row as the NUMBER of its block in order of first appearance.  Two tables with the same opcodes,
+    # lanes and block numbers have the same edges whatever the addresses are -- a step's tables differ from the previous step's
+    # in nothing else (the net is the same, the voxel counts moved) -- so the derivation below runs once per pattern and its
+    # result (where the event rows go, the issue order) is replayed on the new rows.
+    canon, exact = {}, (exact or {})
+    reads, writes, sig = [None] * n, [None] * n, [None] * n
+    for i in range(n):
+        row = rows[i]
+        rd, wr = ROLES[int(row[0]) & OPCODE_MASK]
+        nr = len(row)
+        br, bw = [], []
+        for cols, out in ((rd, br), (wr, bw)):
+            for c in cols:
+                if c < nr:
+                    a = row[c]
+                    if a:
+                        bk = exact.get(a)
+                        if bk is None:
+                            bk = block(a)
+                        k = canon.get(bk)
+                        if k is None:
+                            k = canon[bk] = len(canon)
+                        out.append(k)
+        reads[i], writes[i] = br, bw
+        sig[i] = (row[0], lanes[i], tuple(br), tuple(bw))
+    key = (tuple(sig), tuple(cuts))
+    hit = _SCHED_CACHE.get(key) if SCHED_CACHE else None
+    if hit is not None:
+        plan, out_lanes, index, cutmap, nev = hit
+        prog.rows = [rows[i] if i >= 0 else ev for i, ev in plan]
+        prog.lanes, prog.nevents = list(out_lanes), nev
+        prog.prof = [(index[r],) + tuple(rest) for (r, *rest) in prog.prof]
+        return index, dict(cutmap)
+    NL = max(lanes) + 1
+    assert NL <= MAX_LANES
+    before = [[] for _ in range(n + 1)]          # rows put in front of old row i
+    after = [[] for _ in range(n)]               # rows put right behind old row i
+    tail = [[] for _ in range(n + 1)]            # the join of the part that ends in front of old row i (index n: end of table)
+    nev = 0
     bounds = [0] + sorted(set(c for c in cuts if 0 < c < n)) + [n]
     for lo, hi in zip(bounds[:-1], bounds[1:]):
-        lastw, lastr = {}, {}                    # block -> [sequence number of the last writer / reader on lane 0, lane 1]
-        cnt = [0, 0]                             # rows seen per lane
-        where = [[None], [None]]                 # lane, sequence number -> old row index
-        seen = [0, 0]                            # seen[L]: lane L has waited for the other lane's row number seen[L]
-        forked = False
+        lastw, lastr = {}, {}                    # block -> per lane: sequence number of its last writer / reader there
+        cnt = [0] * NL                           # rows seen per lane
+        where = [[None] for _ in range(NL)]      # lane, sequence number -> old row index
+        seen = [[0] * NL for _ in range(NL)]     # seen[L][M]: lane L has waited for row number seen[L][M] of lane M
+        forked = [True] + [False] * (NL - 1)
+        fork_ev = None
         for i in range(lo, hi):
-            row, L = rows[i], lanes[i]
-            M = 1 - L
-            rd, wr = ROLES[int(row[0]) & OPCODE_MASK]
-            need = 0
-            blocks_r, blocks_w = [], []
-            for c in rd:
-                if c < len(row) and row[c]:
-                    bk = block(row[c])
-                    blocks_r.append(bk)
-                    w = lastw.get(bk)
-                    if w is not None and w[M] > need:
-                        need = w[M]
-            for c in wr:
-                if c < len(row) and row[c]:
-                    bk = block(row[c])
-                    blocks_w.append(bk)
-                    w, r = lastw.get(bk), lastr.get(bk)
-                    if w is not None and w[M] > need:
-                        need = w[M]
-                    if r is not None and r[M] > need:
-                        need = r[M]
-            if L == 1 and not forked:
+            L = lanes[i]
+            need = [0] * NL
+            blocks_r, blocks_w = reads[i], writes[i]
+            for bk in blocks_r:
+                w = lastw.get(bk)
+                if w is not None:
+                    for M in range(NL):
+                        if w[M] > need[M]:
+                            need[M] = w[M]
+            for bk in blocks_w:
+                for t in (lastw.get(bk), lastr.get(bk)):
+                    if t is not None:
+                        for M in range(NL):
+                            if t[M] > need[M]:
+                                need[M] = t[M]
+            if not forked[L]:
                 # the lane's first row of this part: behind everything lane 0 was given before the part (and the zero-fill)
-                before[lo].insert(0, ((OP_EVENT_RECORD, nev, 1), 0))
-                before[i].append(((OP_EVENT_WAIT, nev, 1), 1))
-                nev += 1
-                forked = True
-            if need > seen[L]:
-                after[where[M][need]].append(((OP_EVENT_RECORD, nev, 1), M))
-                before[i].append(((OP_EVENT_WAIT, nev, 1), L))
-                nev += 1
-                seen[L] = need
+                if fork_ev is None:
+                    fork_ev = nev
+                    nev += 1
+                    before[lo].insert(0, ((OP_EVENT_RECORD, fork_ev, 1), 0))
+                before[i].append(((OP_EVENT_WAIT, fork_ev, 1), L))
+                forked[L] = True
+            for M in range(NL):
+                if M != L and need[M] > seen[L][M]:
+                    after[where[M][need[M]]].append(((OP_EVENT_RECORD, nev, 1), M))
+                    before[i].append(((OP_EVENT_WAIT, nev, 1), L))
+                    nev += 1
+                    seen[L][M] = need[M]
             cnt[L] += 1
             where[L].append(i)
             q = cnt[L]
             for bk in blocks_r:
-                lastr.setdefault(bk, [0, 0])[L] = q
+                lastr.setdefault(bk, [0] * NL)[L] = q
             for bk in blocks_w:
-                lastw.setdefault(bk, [0, 0])[L] = q
-                lastr.setdefault(bk, [0, 0])[L] = q
-        if cnt[1] > seen[0]:                     # the join: lane 0 behind the last row of lane 1
-            after[where[1][cnt[1]]].append(((OP_EVENT_RECORD, nev, 1), 1))
-            tail[hi].append(((OP_EVENT_WAIT, nev, 1), 0))
-            nev += 1
-    out_rows, out_lanes, index, cutmap = [], [], [], {}
-    for i in range(n + 1):
-        for r, l in tail[i]:
+                lastw.setdefault(bk, [0] * NL)[L] = q
+                lastr.setdefault(bk, [0] * NL)[L] = q
+        for M in range(1, NL):                   # the join: lane 0 behind the last row of every other lane
+            if cnt[M] > seen[0][M]:
+                after[where[M][cnt[M]]].append(((OP_EVENT_RECORD, nev, 1), M))
+                tail[hi].append(((OP_EVENT_WAIT, nev, 1), 0))
+                nev += 1
+    # Issue order.  The table is also the order in which the HOST hands the rows to the queues, one foreign launch call after
+    # the other (~5 us each): in emission order the ~140 launches of DAPPM (lane 1) would all be handed over before the
+    # handful of stride-4 launches that can run beside them (lane 0) -- by then the device is through with DAPPM and nothing
+    # overlaps.  Inside a part the lanes' row sequences are therefore merged round robin, one row of every lane that can
+    # advance in turn (a WAIT advances once its RECORD has been placed: hipStreamWaitEvent refers to the record call before it
+    # on the host); every lane keeps its own order, so the table is still a valid sequential order (the oracle runs it as one).
+    out_rows, out_lanes, index, cutmap = [], [], [None] * n, {}
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        for r, l in tail[lo]:                    # (the join of the part that ended here)
             out_rows.append(r)
             out_lanes.append(l)
-        cutmap[i] = len(out_rows)
-        if i == n:
-            break
-        for r, l in before[i]:
-            out_rows.append(r)
-            out_lanes.append(l)
-        index.append(len(out_rows))
-        out_rows.append(rows[i])
-        out_lanes.append(lanes[i])
-        for r, l in after[i]:
-            out_rows.append(r)
-            out_lanes.append(l)
+        cutmap[lo] = len(out_rows)
+        queues = [[] for _ in range(NL)]
+        for i in range(lo, hi):
+            for r, l in before[i]:
+                queues[l].append((r, None))
+            queues[lanes[i]].append((rows[i], i))
+            for r, l in after[i]:
+                queues[l].append((r, None))
+        pos, placed = [0] * NL, set()
+        left = sum(len(q) for q in queues)
+        while left:
+            moved = False
+            for l in range(NL):
+                if pos[l] >= len(queues[l]):
+                    continue
+                r, orig = queues[l][pos[l]]
+                op = int(r[0]) & OPCODE_MASK
+                if orig is None and op == OP_EVENT_WAIT and r[1] not in placed:
+                    continue
+                if orig is None and op == OP_EVENT_RECORD:
+                    placed.add(r[1])
+                if orig is not None:
+                    index[orig] = len(out_rows)
+                out_rows.append(r)
+                out_lanes.append(l)
+                pos[l] += 1
+                left -= 1
+                moved = True
+            assert moved, "lanes deadlocked: a wait precedes its record on every lane"
+    for r, l in tail[n]:
+        out_rows.append(r)
+        out_lanes.append(l)
+    cutmap[n] = len(out_rows)
     prog.rows, prog.lanes, prog.nevents = out_rows, out_lanes, nev
     prog.prof = [(index[r],) + tuple(rest) for (r, *rest) in prog.prof]
+    if SCHED_CACHE:
+        if len(_SCHED_CACHE) >= 64:
+            _SCHED_CACHE.clear()
+        back = {v: k for k, v in enumerate(index)}
+        _SCHED_CACHE[key] = ([(back.get(j, -1), r) for j, r in enumerate(out_rows)], list(out_lanes), index, {c: cutmap[c] for c in cuts}, nev)
     return index, {c: cutmap[c] for c in cuts}
+
+
+SCHED_CACHE = os.environ.get("CG3D_SCHED_CACHE", "1") != "0"      # replay the schedule of a table with the same pattern (_schedule)
+_SCHED_CACHE = {}
+# The derivation in the library (cg3d_program_schedule, include/cagroup3d_program.h): the same algorithm as `_schedule` below --
+# which stays as its specification, tests/test_engine_lanes.py compares the two row for row -- in ~50 us and outside the
+# interpreter lock.  In Python it cost the thread that compiles the next batch's program 3-4 ms per step, and with the step
+# bound by what the two host threads get done under one lock that was most of what the second queue had won.
+SCHED_NATIVE = os.environ.get("CG3D_SCHED_NATIVE", "1") != "0"
+
+
+def _schedule_native(lib, prog, starts, cuts=()):
+    """`_schedule` by the library; leaves the scheduled table in `prog.scheduled`."""
+    import ctypes
+    n = len(prog.rows)
+    if not any(prog.lanes):
+        return list(range(n)), {c: c for c in cuts}
+    P = np.ascontiguousarray(prog.table())
+    nreg = 16                                               # CG3D_PROG_REGIONS
+    first = np.zeros(nreg + 1, dtype=np.int64)
+    parts = []
+    for r in range(nreg):
+        lst = starts.get(r << TAG) or ()
+        first[r + 1] = first[r] + len(lst)
+        if lst:
+            parts.append(np.asarray(lst, dtype=np.int64))
+    st = np.concatenate(parts) if parts else np.zeros(1, dtype=np.int64)
+    cs = np.asarray(sorted(cuts), dtype=np.int64)
+    NL = max(prog.lanes) + 1
+    cap = n * (1 + 2 * NL) + 16 * (len(cs) + 2)
+    out = np.empty((cap, STRIDE), dtype=np.int64)
+    index = np.empty(max(n, 1), dtype=np.int64)
+    cidx = np.empty(max(len(cs), 1), dtype=np.int64)
+    n_out, n_ev = ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = lib.raw("cg3d_program_schedule")(P.ctypes.data, n, st.ctypes.data, first.ctypes.data, cs.ctypes.data if len(cs) else None, len(cs),
+                                          out.ctypes.data, cap, index.ctypes.data, cidx.ctypes.data,
+                                          ctypes.cast(ctypes.pointer(n_out), ctypes.c_void_p), ctypes.cast(ctypes.pointer(n_ev), ctypes.c_void_p))
+    if rc != 0:
+        raise _lib.CG3DError("cg3d_program_schedule failed with status %d" % rc)
+    prog.scheduled = out[:n_out.value].copy()
+    prog.nevents = int(n_ev.value)
+    idx = index[:n].tolist()
+    prog.prof = [(idx[r],) + tuple(rest) for (r, *rest) in prog.prof]
+    return idx, {int(c): int(i) for c, i in zip(cs.tolist(), cidx.tolist())}
 
 
 _EVENT_POOL = __import__("threading").local()
@@ -1166,17 +1309,18 @@ _SIDE_STREAMS = {}
 
 
 def _lane_streams(lib):
-    """(ctypes array, count) of the queues of lanes 0, 1: torch's current stream and this process's side stream of the device."""
+    """(ctypes array, count) of the queues of lanes 0 .. MAX_LANES - 1: torch's current stream and this process's side streams of
+    the device (CG3D_LANE_PRIORITY: comma-separated stream priorities of lanes 1, 2, ...; default 0)."""
     import ctypes
     main = lib.stream()
     if not lib.is_device:
-        return (ctypes.c_void_p * 2)(None, None), 2
+        return (ctypes.c_void_p * MAX_LANES)(*([None] * MAX_LANES)), MAX_LANES
     dev = torch.cuda.current_device()
     side = _SIDE_STREAMS.get(dev)
     if side is None:
-        prio = int(os.environ.get("CG3D_LANE_PRIORITY", "0"))
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=prio)
-    return (ctypes.c_void_p * 2)(main, side.cuda_stream), 2
+        prio = [int(x) for x in os.environ.get("CG3D_LANE_PRIORITY", "0").split(",")]
+        side = _SIDE_STREAMS[dev] = [torch.cuda.Stream(device=dev, priority=prio[min(i, len(prio) - 1)]) for i in range(MAX_LANES - 1)]
+    return (ctypes.c_void_p * MAX_LANES)(main, *[x.cuda_stream for x in side]), MAX_LANES
 
 
 # ------------------------------------------------------------------------------------------------ a compiled pass
@@ -1186,8 +1330,12 @@ class Compiled:
     def __init__(self, b, out, out_key, n_in, c_in, mgr=None):
         self.mgr = mgr                   # the coordinate manager owns the maps / plans / pair lists the rows point into
         # event edges between the lanes (no-ops for a one-lane pass); row indices recorded during emission follow
-        fidx, _ = _schedule(b.f, b.starts)
-        bidx, bcuts = _schedule(b.b, b.starts, tuple(b.marks.values()))
+        if SCHED_NATIVE:
+            fidx, _ = _schedule_native(b.lib, b.f, b.starts)
+            bidx, bcuts = _schedule_native(b.lib, b.b, b.starts, tuple(b.marks.values()))
+        else:
+            fidx, _ = _schedule(b.f, b.starts, (), b.exact)
+            bidx, bcuts = _schedule(b.b, b.starts, tuple(b.marks.values()), b.exact)
         self.lanes = bool(b.f.nevents or b.b.nevents)
         self.nevents = max(b.f.nevents, b.b.nevents)
         self.fwd, self.bwd = b.f.table(), b.b.table()

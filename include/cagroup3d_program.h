@@ -63,7 +63,7 @@ enum {
  * joins (reference biresnet.py:378-394: the stride-8/16/32 layers and the stride-4 layers): on one queue the stride-16/32
  * launches (42-180 tiles) leave most of the 256 CUs idle one after the other; on two queues the stride-4 chain fills them. */
 #define CG3D_PROG_LANE_SHIFT 32
-#define CG3D_PROG_MAX_LANES 4
+#define CG3D_PROG_MAX_LANES 8
 
 /* Runs rows [0, nops) of `prog` in order on `stream`.  Returns CG3D_OK, or the status of the first failing call with its row
  * index in *fail_at (may be NULL); rows after it are not run.  An unknown opcode is CG3D_ERR_ARG. */
@@ -72,6 +72,30 @@ int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, in
 /* The same with one stream per lane (1 <= nstreams <= CG3D_PROG_MAX_LANES).  Nothing is synchronised with the host; the caller's
  * table ends with the waits that bring every lane back to lane 0 (engine.py: _schedule). */
 int cg3d_run_program_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at);
+
+/* The event edges between the lanes of a table and the order its rows are issued in, derived from what every row reads and
+ * writes (the const / non-const pointer parameters of the entry point its opcode names: cg3d_program_roles).
+ *   prog          int64 [n][CG3D_PROG_STRIDE]: rows in emission order (a valid sequential order), lanes in word 0.  An address
+ *                 >= 2^CG3D_PROG_REGION_SHIFT is region-relative (region = address >> CG3D_PROG_REGION_SHIFT, resolved by the
+ *                 caller when the pass is run); the others are absolute;
+ *   starts        the block starts (offsets) of the caller's allocations, region after region, ascending inside a region;
+ *   region_first  int64 [CG3D_PROG_REGIONS + 1]: starts[region_first[r] .. region_first[r + 1]) belong to region r.  A pointer
+ *                 refers to the block it falls into; an absolute pointer is a block by itself;
+ *   cuts          row indices at which the caller splits the table (a callback runs between the parts): every part starts with
+ *                 the other lanes waiting for lane 0's position and ends with lane 0 waiting for all of them;
+ *   out           int64 [cap][CG3D_PROG_STRIDE]: the rows plus EVENT_RECORD / EVENT_WAIT rows { opcode | lane, slot, 1 } -- the
+ *                 caller replaces the slot numbers 0 .. *n_events - 1 by event handles (cg3d_event_create_sync) before running;
+ *                 inside a part the lanes' sequences are merged round robin (the table is also the host's issue order);
+ *   index         int64 [n]: where row i went;   cut_index int64 [ncut]: where the table is to be split for cuts[k].
+ * A row needs an edge from another lane when it reads a block that lane wrote last, or writes a block that lane read or wrote.
+ * Returns CG3D_ERR_ARG when cap is too small (n + 2 * n * lanes always suffices) or a lane exceeds CG3D_PROG_MAX_LANES. */
+#define CG3D_PROG_REGION_SHIFT 56
+#define CG3D_PROG_REGIONS 16
+int cg3d_program_schedule(const int64_t *prog, int64_t n, const int64_t *starts, const int64_t *region_first, const int64_t *cuts,
+                          int32_t ncut, int64_t *out, int64_t cap, int64_t *index, int64_t *cut_index, int64_t *n_out,
+                          int64_t *n_events);
+/* bit c of *rd / *wr: column c of a row of `opcode` is a pointer the call reads / writes */
+int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr);
 
 /* Timing events for the rows of a program (CG3D_OP_EVENT_RECORD): handles are hipEvent_t on the device library; the oracle
  * hands out dummies and reports 0 ms. */
@@ -208,6 +232,279 @@ static int cg3d_program_run(const int64_t *prog, int64_t nops, cg3d_stream_t str
     }
     return CG3D_OK;
 }
+
+/* ---- cg3d_program_schedule ---------------------------------------------------------------------------------------------- */
+#include <stdlib.h>
+#include <string.h>
+#define CG3D_B(c) (1u << (c))
+static int cg3d_program_roles_impl(int32_t op, uint32_t *rd, uint32_t *wr) {
+    uint32_t r = 0, w = 0;
+    switch (op) {
+    case CG3D_OP_NOP: case CG3D_OP_EVENT_RECORD: case CG3D_OP_EVENT_WAIT: break;
+    case CG3D_OP_MEMSET: w = (CG3D_B(1)); break;
+    case CG3D_OP_COPY2D: r = (CG3D_B(3)); w = (CG3D_B(1)); break;
+    case CG3D_OP_TO_BF16: case CG3D_OP_TO_BF16_SPLIT: case CG3D_OP_FROM_BF16: r = (CG3D_B(1)); w = (CG3D_B(2)); break;
+    case CG3D_OP_TILE_FWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(5) | CG3D_B(6) | CG3D_B(7) | CG3D_B(10) | CG3D_B(12) | CG3D_B(13)); w = (CG3D_B(14) | CG3D_B(22)); break;
+    case CG3D_OP_SPCONV_FWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4)); w = (CG3D_B(5)); break;
+    case CG3D_OP_SPCONV_FWD_TILED: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(6)); w = (CG3D_B(7)); break;
+    case CG3D_OP_PAIRS_FWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(5) | CG3D_B(7)); w = (CG3D_B(8)); break;
+    case CG3D_OP_PAIRS_WGRAD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(5)); w = (CG3D_B(7)); break;
+    case CG3D_OP_LINEAR_FWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3)); w = (CG3D_B(4) | CG3D_B(9) | CG3D_B(10)); break;
+    case CG3D_OP_BN_SUMS: r = (CG3D_B(1) | CG3D_B(2)); w = (CG3D_B(6)); break;
+    case CG3D_OP_BN_APPLY_SUMS: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(7) | CG3D_B(8) | CG3D_B(10) | CG3D_B(11)); w = (CG3D_B(13) | CG3D_B(14) | CG3D_B(15) | CG3D_B(16) | CG3D_B(17) | CG3D_B(18) | CG3D_B(19)); break;
+    case CG3D_OP_BN_APPLY: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(6) | CG3D_B(7) | CG3D_B(9) | CG3D_B(10)); w = (CG3D_B(12) | CG3D_B(13)); break;
+    case CG3D_OP_BN_BWD_SUMS: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(8) | CG3D_B(9)); w = (CG3D_B(12)); break;
+    case CG3D_OP_BN_BWD_APPLY_SUMS: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(8) | CG3D_B(9) | CG3D_B(11) | CG3D_B(12) | CG3D_B(13)); w = (CG3D_B(16) | CG3D_B(17) | CG3D_B(18) | CG3D_B(19) | CG3D_B(20)); break;
+    case CG3D_OP_BN_BWD_APPLY: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3) | CG3D_B(4) | CG3D_B(7) | CG3D_B(8) | CG3D_B(10) | CG3D_B(11) | CG3D_B(12) | CG3D_B(13)); w = (CG3D_B(16) | CG3D_B(17) | CG3D_B(18)); break;
+    case CG3D_OP_INTERP_MAP: r = (CG3D_B(1) | CG3D_B(4) | CG3D_B(5)); w = (CG3D_B(7) | CG3D_B(8)); break;
+    case CG3D_OP_INTERP_FWD: case CG3D_OP_INTERP_BWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3)); w = (CG3D_B(4)); break;
+    case CG3D_OP_GATHER_ROWS: case CG3D_OP_SCATTER_ADD_ROWS: r = (CG3D_B(1) | CG3D_B(2)); w = (CG3D_B(3)); break;
+    case CG3D_OP_SCATTER_MEAN_FWD: r = (CG3D_B(1) | CG3D_B(2)); w = (CG3D_B(4) | CG3D_B(5)); break;
+    case CG3D_OP_SCATTER_MEAN_BWD: r = (CG3D_B(1) | CG3D_B(2) | CG3D_B(3)); w = (CG3D_B(5)); break;
+    default: return CG3D_ERR_ARG;
+    }
+    if (rd) *rd = r;
+    if (wr) *wr = w;
+    return CG3D_OK;
+}
+
+typedef struct { int64_t key; int32_t w[CG3D_PROG_MAX_LANES], r[CG3D_PROG_MAX_LANES]; } cg3d_sched_blk;
+typedef struct { int64_t after_row, before_row; int32_t rec_lane, wait_lane, ev, next_after, next_before; } cg3d_sched_edge;
+
+static int64_t cg3d_sched_block_of(int64_t a, const int64_t *starts, const int64_t *first) {
+    const int64_t tag = (int64_t)((uint64_t)a >> CG3D_PROG_REGION_SHIFT);
+    if (!tag) return a;
+    if (tag >= CG3D_PROG_REGIONS) return a;
+    const int64_t off = a - (tag << CG3D_PROG_REGION_SHIFT);
+    int64_t lo = first[tag], hi = first[tag + 1];
+    if (lo >= hi) return tag << CG3D_PROG_REGION_SHIFT;
+    while (hi - lo > 1) {                                  /* last start <= off (the first block when off lies before all) */
+        const int64_t mid = (lo + hi) >> 1;
+        if (starts[mid] <= off) lo = mid; else hi = mid;
+    }
+    return (tag << CG3D_PROG_REGION_SHIFT) | starts[lo];
+}
+static cg3d_sched_blk *cg3d_sched_find(cg3d_sched_blk *tab, int64_t mask, int64_t key, int make) {
+    uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ull;
+    int64_t i = (int64_t)(h >> 20) & mask;
+    for (;;) {
+        if (tab[i].key == key) return &tab[i];
+        if (tab[i].key == 0) {
+            if (!make) return NULL;
+            tab[i].key = key;
+            return &tab[i];
+        }
+        i = (i + 1) & mask;
+    }
+}
+static int cg3d_program_schedule_impl(const int64_t *prog, int64_t n, const int64_t *starts, const int64_t *first,
+                                      const int64_t *cuts, int32_t ncut, int64_t *out, int64_t cap, int64_t *index,
+                                      int64_t *cut_index, int64_t *n_out, int64_t *n_events) {
+    enum { S = CG3D_PROG_STRIDE, ML = CG3D_PROG_MAX_LANES };
+    if (n < 0 || ncut < 0 || (n > 0 && (!prog || !out || !index)) || (ncut > 0 && (!cuts || !cut_index)) || !first || !n_out || !n_events)
+        return CG3D_ERR_ARG;
+    int NL = 1;
+    for (int64_t i = 0; i < n; i++) {
+        const int l = (int)((prog[i * S] >> CG3D_PROG_LANE_SHIFT) & 0xff);
+        if (l >= ML) return CG3D_ERR_ARG;
+        if (l + 1 > NL) NL = l + 1;
+    }
+    for (int k = 0; k < ncut; k++)
+        if (cuts[k] < 0 || cuts[k] > n || (k > 0 && cuts[k] < cuts[k - 1])) return CG3D_ERR_ARG;      /* ascending */
+    if (NL == 1) {                                         /* one lane: nothing to order */
+        if (cap < n) return CG3D_ERR_ARG;
+        if (n) memcpy(out, prog, (size_t)n * S * sizeof(int64_t));
+        for (int64_t i = 0; i < n; i++) index[i] = i;
+        for (int k = 0; k < ncut; k++) cut_index[k] = cuts[k];
+        *n_out = n;
+        *n_events = 0;
+        return CG3D_OK;
+    }
+    int64_t hcap = 64;
+    while (hcap < n * 16) hcap <<= 1;
+    const int64_t max_edges = n * ML + 2 * (ncut + 2) * ML;
+    cg3d_sched_blk *tab = (cg3d_sched_blk *)malloc((size_t)hcap * sizeof(cg3d_sched_blk));
+    cg3d_sched_edge *edge = (cg3d_sched_edge *)malloc((size_t)max_edges * sizeof(cg3d_sched_edge));
+    /* per row: first / last edge whose RECORD goes behind it, whose WAIT goes in front of it; per lane and sequence number: row */
+    int32_t *lists = (int32_t *)malloc((size_t)(n + 1) * 4 * sizeof(int32_t));
+    int64_t *where = (int64_t *)malloc((size_t)(n + 1) * ML * sizeof(int64_t));
+    int64_t *queue = (int64_t *)malloc((size_t)(n + 2 * max_edges + 8) * sizeof(int64_t));       /* items of a part, lane after lane */
+    if (!tab || !edge || !lists || !where || !queue) {
+        free(tab); free(edge); free(lists); free(where); free(queue);
+        return CG3D_ERR_LAUNCH;
+    }
+    int32_t *a_head = lists, *a_tail = lists + (n + 1), *b_head = lists + 2 * (n + 1), *b_tail = lists + 3 * (n + 1);
+    for (int64_t i = 0; i < 4 * (n + 1); i++) lists[i] = -1;
+    int32_t nedge = 0, nev = 0;
+    int64_t no = 0;
+    int rc = CG3D_OK;
+#define CG3D_PUT(row_ptr)                                                                   \
+    do {                                                                                    \
+        if (no >= cap) { rc = CG3D_ERR_ARG; goto done; }                                    \
+        memcpy(out + no * S, (row_ptr), S * sizeof(int64_t));                               \
+        no++;                                                                               \
+    } while (0)
+#define CG3D_PUT_EV(opc, lane, slot)                                                        \
+    do {                                                                                    \
+        int64_t evrow[S];                                                                   \
+        memset(evrow, 0, sizeof(evrow));                                                    \
+        evrow[0] = (int64_t)(opc) | ((int64_t)(lane) << CG3D_PROG_LANE_SHIFT);              \
+        evrow[1] = (slot);                                                                  \
+        evrow[2] = 1;                                                                       \
+        CG3D_PUT(evrow);                                                                    \
+    } while (0)
+    int part = 0;
+    int64_t lo = 0;
+    for (;;) {
+        /* the part [lo, hi) */
+        while (part < ncut && cuts[part] <= lo) {           /* cuts at the start of the part (incl. duplicates, 0) */
+            cut_index[part] = no;
+            part++;
+        }
+        int64_t hi = part < ncut ? cuts[part] : n;
+        if (hi > n) hi = n;
+        memset(tab, 0, (size_t)hcap * sizeof(cg3d_sched_blk));
+        int64_t cnt[ML];
+        int64_t seen[ML][ML];
+        int forked[ML], fork_ev = -1;
+        const int32_t edge0 = nedge;
+        for (int l = 0; l < ML; l++) {
+            cnt[l] = 0;
+            forked[l] = l == 0;
+            for (int m = 0; m < ML; m++) seen[l][m] = 0;
+        }
+        for (int64_t i = lo; i < hi; i++) {
+            const int64_t *row = prog + i * S;
+            const int L = (int)((row[0] >> CG3D_PROG_LANE_SHIFT) & 0xff);
+            uint32_t rd = 0, wr = 0;
+            if (cg3d_program_roles_impl((int32_t)(row[0] & 0xffffffffll), &rd, &wr) != CG3D_OK) { rc = CG3D_ERR_ARG; goto done; }
+            int64_t need[ML];
+            for (int m = 0; m < ML; m++) need[m] = 0;
+            cg3d_sched_blk *br[S], *bw[S];
+            int nr = 0, nw = 0;
+            for (int c = 1; c < S; c++) {
+                if (!((rd | wr) >> c & 1u) || !row[c]) continue;
+                const int64_t key = cg3d_sched_block_of(row[c], starts, first);
+                cg3d_sched_blk *b = cg3d_sched_find(tab, hcap - 1, key ? key : 1, 1);
+                if ((wr >> c) & 1u) {
+                    bw[nw++] = b;
+                    for (int m = 0; m < NL; m++) {
+                        if (b->w[m] > need[m]) need[m] = b->w[m];
+                        if (b->r[m] > need[m]) need[m] = b->r[m];
+                    }
+                } else {
+                    br[nr++] = b;
+                    for (int m = 0; m < NL; m++)
+                        if (b->w[m] > need[m]) need[m] = b->w[m];
+                }
+            }
+            if (!forked[L]) {
+                /* the lane's first row of the part: behind everything lane 0 was given before the part (and the zero-fill) */
+                if (fork_ev < 0) fork_ev = nev++;
+                cg3d_sched_edge *e = &edge[nedge];
+                e->after_row = -1; e->before_row = i; e->rec_lane = 0; e->wait_lane = L; e->ev = fork_ev;
+                e->next_after = e->next_before = -1;
+                if (b_tail[i] < 0) b_head[i] = nedge; else edge[b_tail[i]].next_before = nedge;
+                b_tail[i] = nedge++;
+                forked[L] = 1;
+            }
+            for (int m = 0; m < NL; m++) {
+                if (m == L || need[m] <= seen[L][m]) continue;
+                const int64_t w = where[need[m] * ML + m];
+                cg3d_sched_edge *e = &edge[nedge];
+                e->after_row = w; e->before_row = i; e->rec_lane = m; e->wait_lane = L; e->ev = nev++;
+                e->next_after = e->next_before = -1;
+                if (a_tail[w] < 0) a_head[w] = nedge; else edge[a_tail[w]].next_after = nedge;
+                a_tail[w] = nedge;
+                if (b_tail[i] < 0) b_head[i] = nedge; else edge[b_tail[i]].next_before = nedge;
+                b_tail[i] = nedge++;
+                seen[L][m] = need[m];
+            }
+            cnt[L]++;
+            where[cnt[L] * ML + L] = i;
+            for (int k = 0; k < nr; k++) br[k]->r[L] = (int32_t)cnt[L];
+            for (int k = 0; k < nw; k++) { bw[k]->w[L] = (int32_t)cnt[L]; bw[k]->r[L] = (int32_t)cnt[L]; }
+        }
+        /* the join: lane 0 behind the last row of every other lane */
+        int32_t join_ev[ML];
+        for (int m = 1; m < NL; m++) {
+            join_ev[m] = -1;
+            if (cnt[m] > seen[0][m]) {
+                const int64_t w = where[cnt[m] * ML + m];
+                cg3d_sched_edge *e = &edge[nedge];
+                e->after_row = w; e->before_row = -2; e->rec_lane = m; e->wait_lane = 0; e->ev = nev++;
+                e->next_after = e->next_before = -1;
+                if (a_tail[w] < 0) a_head[w] = nedge; else edge[a_tail[w]].next_after = nedge;
+                a_tail[w] = nedge++;
+                join_ev[m] = e->ev;
+            }
+        }
+        /* issue order: the lanes' sequences merged round robin.  An item is a row (>= 0), a RECORD (-1 - 2 e) or a WAIT (-2 - 2 e)
+         * of edge e; the fork RECORD (edge -1 -> coded with e = max_edges) leads lane 0 */
+        {
+            int64_t qlen[ML], qpos[ML], *q[ML];
+            int64_t total = 0;
+            for (int l = 0; l < NL; l++) qlen[l] = 0;
+            /* count */
+            if (fork_ev >= 0) qlen[0]++;
+            for (int64_t i = lo; i < hi; i++) {
+                for (int32_t e = b_head[i]; e >= 0; e = edge[e].next_before) qlen[edge[e].wait_lane]++;
+                qlen[(prog[i * S] >> CG3D_PROG_LANE_SHIFT) & 0xff]++;
+                for (int32_t e = a_head[i]; e >= 0; e = edge[e].next_after) qlen[edge[e].rec_lane]++;
+            }
+            for (int l = 0; l < NL; l++) { q[l] = queue + total; total += qlen[l]; qpos[l] = 0; qlen[l] = 0; }
+            if (fork_ev >= 0) q[0][qlen[0]++] = -1 - 2 * (int64_t)max_edges;
+            for (int64_t i = lo; i < hi; i++) {
+                for (int32_t e = b_head[i]; e >= 0; e = edge[e].next_before) q[edge[e].wait_lane][qlen[edge[e].wait_lane]++] = -2 - 2 * (int64_t)e;
+                const int l = (int)((prog[i * S] >> CG3D_PROG_LANE_SHIFT) & 0xff);
+                q[l][qlen[l]++] = i;
+                for (int32_t e = a_head[i]; e >= 0; e = edge[e].next_after) q[edge[e].rec_lane][qlen[edge[e].rec_lane]++] = -1 - 2 * (int64_t)e;
+            }
+            /* placed[ev]: the RECORD of event ev has been put (reuse `where` is not possible: keep a byte map in `lists`' spare? no:
+             * events of this part are edge0 .. nedge - 1 plus the fork: one flag per edge, in the edges themselves) */
+            for (int32_t e = edge0; e < nedge; e++) edge[e].next_before = 0;      /* from here on: 1 = its RECORD is placed */
+            int fork_placed = 0;
+            int64_t left = total;
+            while (left) {
+                int moved = 0;
+                for (int l = 0; l < NL; l++) {
+                    if (qpos[l] >= qlen[l]) continue;
+                    const int64_t it = q[l][qpos[l]];
+                    if (it >= 0) {
+                        index[it] = no;
+                        CG3D_PUT(prog + it * S);
+                    } else if ((-it) & 1) {                /* RECORD */
+                        const int64_t e = (-1 - it) / 2;
+                        if (e == max_edges) { fork_placed = 1; CG3D_PUT_EV(CG3D_OP_EVENT_RECORD, 0, fork_ev); }
+                        else { edge[e].next_before = 1; CG3D_PUT_EV(CG3D_OP_EVENT_RECORD, edge[e].rec_lane, edge[e].ev); }
+                    } else {                               /* WAIT */
+                        const int64_t e = (-2 - it) / 2;
+                        const int ready = edge[e].after_row == -1 ? fork_placed : edge[e].next_before;
+                        if (!ready) continue;
+                        CG3D_PUT_EV(CG3D_OP_EVENT_WAIT, edge[e].wait_lane, edge[e].ev);
+                    }
+                    qpos[l]++;
+                    left--;
+                    moved = 1;
+                }
+                if (!moved) { rc = CG3D_ERR_ARG; goto done; }      /* (cannot happen: emission order is a witness) */
+            }
+        }
+        for (int m = 1; m < NL; m++)
+            if (join_ev[m] >= 0) CG3D_PUT_EV(CG3D_OP_EVENT_WAIT, 0, join_ev[m]);
+        if (hi >= n) break;
+        lo = hi;
+    }
+    while (part < ncut) cut_index[part++] = no;
+    *n_out = no;
+    *n_events = nev;
+done:
+#undef CG3D_PUT
+#undef CG3D_PUT_EV
+    free(tab); free(edge); free(lists); free(where); free(queue);
+    return rc;
+}
+#undef CG3D_B
 static int cg3d_program_run_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
     if (nops < 0 || (nops > 0 && !prog) || !streams || nstreams < 1 || nstreams > CG3D_PROG_MAX_LANES) return CG3D_ERR_ARG;
     for (int64_t i = 0; i < nops; i++) {

@@ -40,6 +40,12 @@ int cg3d_run_program(const int64_t *prog, int64_t nops, cg3d_stream_t stream, in
 int cg3d_run_program_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
     return cg3d_program_run_lanes(prog, nops, streams, nstreams, fail_at);
 }
+int cg3d_program_schedule(const int64_t *prog, int64_t n, const int64_t *starts, const int64_t *region_first, const int64_t *cuts,
+                          int32_t ncut, int64_t *out, int64_t cap, int64_t *index, int64_t *cut_index, int64_t *n_out,
+                          int64_t *n_events) {
+    return cg3d_program_schedule_impl(prog, n, starts, region_first, cuts, ncut, out, cap, index, cut_index, n_out, n_events);
+}
+int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr) { return cg3d_program_roles_impl(opcode, rd, wr); }
 int cg3d_event_create(int64_t *handle) {
     static int64_t next = 1;
     if (!handle) return CG3D_ERR_ARG;

@@ -100,7 +100,7 @@ def test_program_table_is_plain_data(oracle):
     for tab in (comp.fwd, comp.bwd):
         assert tab.dtype == np.int64 and tab.shape[1] == engine.STRIDE and tab.shape[0] > 100
         op, lane = tab[:, 0] & engine.OPCODE_MASK, tab[:, 0] >> engine.LANE_SHIFT
-        assert ((op > 0) & (op <= engine.OP_EVENT_WAIT)).all() and int(lane.max()) <= 1
+        assert ((op > 0) & (op <= engine.OP_EVENT_WAIT)).all() and int(lane.max()) < engine.MAX_LANES
         assert int((tab >> engine.TAG).max()) <= 6 and int(tab.min()) >= 0
     assert 0 < comp.marks["mid"] < comp.bwd.shape[0]
     assert comp.size[engine.R_PG] >= 4 * sum(p.numel() for p in model.backbone_3d.parameters())
