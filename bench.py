@@ -303,6 +303,8 @@ def main():
         opt = torch.optim.AdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY, fused=True)
     else:
         opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
+    if hasattr(model, "split_late_parameters"):
+        model.split_late_parameters(opt)            # the heads' AdamW rows and weight copies beside the next backbone pass (CG3D_LATE_WEIGHTS=0: off)
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
     batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)

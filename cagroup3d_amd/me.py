@@ -20,6 +20,7 @@ Conventions fixed by this engine (ME's own are unverifiable here -- "parity unpi
 """
 import itertools
 import math
+import os
 
 import numpy as np
 import ctypes
@@ -992,12 +993,20 @@ class _WeightPlan:
     live = False        # inside a detector forward that called prepare_weights(): arena answers are valid
     pending = True      # the weights may have changed since the last conversion
     gen = 0             # bumped whenever the arenas are rebuilt (addresses handed out before are stale: engine.Compiled.usable)
+    # Early / late rows.  The first module of the detector (the backbone) needs its own weights' copies only; everything else --
+    # six sevenths of the model's 126 M parameters sit in the class branches -- is first read milliseconds later.  `early` is the
+    # set of data_ptrs of the weights the first module reads (set_early_weights); their rows lead the table and are converted on
+    # the current stream, the rest on the late stream (late_stream()), behind the optimizer's update of the same parameters
+    # (optim.ClippedAdamW: the late rows of ITS table run there too) and beside the backbone's forward pass.
+    early = None        # None: no split
+    n_early = 0         # table rows [0, n_early) are early
 
     @classmethod
     def reset(cls):
         with _CACHE_LOCK:
             cls.singles, cls.groups, cls.table, cls.nrows, cls.dirty, cls.keep = {}, {}, None, 0, False, None
             cls.live, cls.pending = False, True
+            cls.n_early = 0
             cls.gen += 1
 
     @classmethod
@@ -1010,6 +1019,8 @@ class _WeightPlan:
         arena_t = torch.empty(max(n_t, 1), dtype=torch.int16, device=device)
         arena_p = torch.empty(max(n_p, 1), dtype=torch.int16, device=device)
         rows, ot, op = [], 0, 0
+        late_rows = []
+        early = cls.early
 
         def add(w, off_t, off_p, kind=0):
             K, cin, cout = w.shape
@@ -1023,7 +1034,7 @@ class _WeightPlan:
             r[:, 1] = 0 if off_t is None else arena_t.data_ptr() + (off_t + k * per * x) * 2
             r[:, 2] = 0 if off_p is None else arena_p.data_ptr() + (off_p + k * per * x) * 2
             r[:, 3], r[:, 4], r[:, 5] = cin, cout, t | ((3 << 29) if kind & 1 else 0) | ((1 << 28) if kind & 2 else 0)
-            rows.append(r)
+            (rows if (early is None or w.data_ptr() in early) else late_rows).append(r)
         for (_, kind), e in cls.singles.items():
             w = e[0]
             K, cin, cout = w.shape
@@ -1050,15 +1061,63 @@ class _WeightPlan:
                 g[2] = arena_p[op:op + tot].view(len(ws) * K, cin, cout * x)
                 op += tot
             g[1] = None
+        cls.n_early = sum(r.shape[0] for r in rows)
+        rows += late_rows
         tab = _np.concatenate(rows) if rows else _np.zeros((0, 6), dtype=_np.int64)
         cls.table, cls.nrows = h2d(torch.from_numpy(tab), torch.int64, device), int(tab.shape[0])
         cls.keep, cls.dirty = (arena_t, arena_p), False
         cls.gen += 1
 
 
-def prepare_weights(training=True):
+# Off by default: measured on one box over 3 x 120 pinned steps, median step 24.5 / 23.5 / 24.7 ms with the split against
+# 23.5 / 23.9 / 23.9 without (p10 equal: 23.3-23.8) -- the heads' AdamW + conversion rows (~1 ms of HBM streaming) beside the
+# backbone's forward pass slow that pass by what they save, and a sixth stream on four hardware queues adds outliers.  Kept
+# behind CG3D_LATE_WEIGHTS=1 with its tests (tests/test_hip_parity.py, tests/test_train_driver.py).
+_LATE_STREAMS = {}
+LATE_WEIGHTS = os.environ.get("CG3D_LATE_WEIGHTS", "0") == "1"
+
+
+def late_stream(device):
+    """This process's stream for work on parameters the step reads late (the heads' AdamW rows and weight copies)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _LATE_STREAMS.get(idx)
+    if s is None:
+        s = _LATE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+_LATE_PENDING = set()         # device indices whose late stream holds work the main stream has not waited for
+
+
+def late_mark(device):
+    """Something was put on the late stream of `device` that the main stream must wait for before it reads late parameters."""
+    dev = torch.device(device)
+    _LATE_PENDING.add(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def set_early_weights(params):
+    """Declare the parameters whose copies the detector's FIRST module reads (an iterable of tensors; None: no split)."""
+    P = _WeightPlan
+    with _CACHE_LOCK:
+        P.early = None if params is None else {p.data_ptr() for p in params}
+        P.dirty = bool(P.singles or P.groups)
+
+
+def late_weights_ready():
+    """The current stream waits for the late rows of this forward's conversion (no-op when there were none).  The detector
+    calls it between its first module and the second; `finish_weights()` does for a forward that ends before."""
+    while _LATE_PENDING:
+        idx = _LATE_PENDING.pop()
+        torch.cuda.current_stream(idx).wait_stream(_LATE_STREAMS[idx])
+
+
+def prepare_weights(training=True, split=False):
     """Start of a detector forward: convert the recorded convolution weights -- one launch -- and let the per-layer
     requests of THIS forward be answered from the arena (until `finish_weights()`).
+
+    split: the caller promises `late_weights_ready()` before anything but the early weights' copies is read (set_early_weights):
+    the late rows are then converted on the late stream.
 
     Training forwards always convert: a fused optimizer step changes the weights WITHOUT bumping their tensor version
     (checked: torch.optim.AdamW(fused=True) leaves `_version` at 0), so versions cannot tell.  Inference forwards
@@ -1082,7 +1141,16 @@ def prepare_weights(training=True):
         need = training or P.pending or any(e[2] != e[0]._version for e in P.singles.values()) or \
             any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
         if need:
-            lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
+            ne = P.n_early if (split and LATE_WEIGHTS and P.early is not None) else P.nrows
+            if 0 < ne < P.nrows:
+                lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(ne), lib.stream())
+                ls = late_stream(P.table.device)
+                ls.wait_stream(torch.cuda.current_stream())             # behind the optimizer's early rows / whatever wrote the weights here
+                lib.call("cg3d_spconv_prep_weights_bf16_table", P.table.data_ptr() + ne * 6 * 8, c_int64(P.nrows - ne), ls.cuda_stream)
+                late_mark(P.table.device)
+            else:
+                late_weights_ready()                   # (an optimizer step may have left the late parameters' update on the late stream)
+                lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
             for e in P.singles.values():
                 e[2] = e[0]._version
             for g in P.groups.values():
@@ -1093,6 +1161,7 @@ def prepare_weights(training=True):
 
 def finish_weights():
     """End of the detector forward: from here on the arena may be stale (an optimizer step may follow)."""
+    late_weights_ready()
     _WeightPlan.live = False
 
 

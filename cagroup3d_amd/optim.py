@@ -22,6 +22,7 @@ import torch
 CHUNK = 1 << 15          # elements per table row of the fused step (one 256-thread workgroup each)
 FUSED_NORM = os.environ.get("CG3D_FUSED_NORM", "1") != "0"      # gradient norm + clip coefficient by cg3d_grad_norm_clip
 FUSED_STEP = os.environ.get("CG3D_FUSED_ADAMW", "1") != "0"
+LATE_ROWS = os.environ.get("CG3D_LATE_WEIGHTS", "0") == "1"      # set_early(): the late parameters' rows on the late stream
 
 
 class ClippedAdamW(torch.optim.AdamW):
@@ -29,6 +30,31 @@ class ClippedAdamW(torch.optim.AdamW):
         kw.setdefault("fused", True)
         super().__init__(params, **kw)
         self._lean = None
+        self._early = None          # ids of the parameters the next forward reads first (set_early)
+        self._late_hold = None      # what the late rows of the last step read (kept until the next step: see _fused_step)
+
+    def set_early(self, params):
+        """Split the fused update in two: the rows of `params` (the detector's first module -- they must lead the parameter
+        list) on the current stream, the rest on `me.late_stream()`, where the next forward's conversion of the same weights
+        follows (me.prepare_weights(split=True)) and the current stream joins at me.late_weights_ready().  The late parameters
+        -- 107 of the detector's 126 M sit in the class branches, first read ~5 ms into the step -- are then updated and
+        converted beside the backbone's forward pass instead of in front of it.  The caller owns the consequence: after
+        clip_and_step() the late parameters are final only once the current stream has waited (`finish_late()`, or the next
+        detector forward); `state_dict()` waits by itself.  None: one launch for all rows, as before."""
+        self._early = None if params is None else {id(p) for p in params}
+        self._plan = None
+
+    def finish_late(self):
+        """The current stream waits for the late rows of the last step (call before reading parameters outside a detector
+        forward: checkpoints, evaluation of another module, parameter statistics)."""
+        from . import me
+        if self._late_hold is not None:
+            me.late_weights_ready()
+            self._late_hold = None
+
+    def state_dict(self):
+        self.finish_late()
+        return super().state_dict()
 
     def _lists(self):
         if self._lean is None:
@@ -94,8 +120,15 @@ class ClippedAdamW(torch.optim.AdamW):
                 plan = self._plan = None
         if plan is None:
             rows, pid, k = [], [], 0
+            split, seen_late = 0, False          # split: first row of the late parameters (0: no split)
             for group, ps, m1, m2, steps in lean:
                 for p, a, b in zip(ps, m1, m2):
+                    if self._early is not None:
+                        if id(p) not in self._early:
+                            if not seen_late:
+                                seen_late, split = True, len(rows)
+                        elif seen_late:
+                            split = -1               # an early parameter behind a late one: no split
                     if not (p.dtype == a.dtype == b.dtype == torch.float32 and p.is_contiguous() and a.is_contiguous() and b.is_contiguous()):
                         self._plan = False
                         return None
@@ -106,7 +139,8 @@ class ClippedAdamW(torch.optim.AdamW):
                     k += 1
             plan = self._plan = (me.h2d(np.asarray(rows, dtype=np.int64), torch.int64, dev), me.h2d(np.asarray(pid, dtype=np.int32), torch.int32, dev),
                                  len(rows), [g["params"] for g in self.param_groups],
-                                 [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts])
+                                 [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts],
+                                 split if (split > 0 and LATE_ROWS) else 0)
         if plan is False:
             return None
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in flat_grads):
@@ -138,16 +172,33 @@ class ClippedAdamW(torch.optim.AdamW):
             lib.call("cg3d_grad_norm_clip", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), c_float(max_norm),
                      sc.data_ptr(), nc[0:1].data_ptr(), nc[1:2].data_ptr(), lib.stream())
             total, coef = nc[0], nc[1:2]
-        lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), coef.data_ptr(),
-                 c_float(g0["lr"]), c_float(beta1), c_float(beta2), c_float(g0["eps"]), c_float(g0["weight_decay"]),
-                 c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t), lib.stream())
+        hyper = (c_float(g0["lr"]), c_float(beta1), c_float(beta2), c_float(g0["eps"]), c_float(g0["weight_decay"]),
+                 c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t))
+        ne = plan[5]
+        self.finish_late()                  # (a previous step's late rows nobody waited for: they read the buffers we are about to drop)
+        if ne:
+            # early rows here, late rows on the late stream behind the norm (= behind every gradient).  What the late rows read --
+            # the gradients (zero_grad(set_to_none=True) drops the parameters' references right after this call, and the allocator
+            # would hand their memory to the next allocation on THIS stream), the pointer table, the coefficient -- stays
+            # referenced until the next step
+            lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(ne), gp.data_ptr(), coef.data_ptr(), *hyper, lib.stream())
+            ls = me.late_stream(dev)
+            ls.wait_stream(torch.cuda.current_stream())
+            lib.call("cg3d_adamw_step", plan[0].data_ptr() + ne * 5 * 8, plan[1].data_ptr() + ne * 4, c_int64(plan[2] - ne), gp.data_ptr(),
+                     coef.data_ptr(), *hyper, ls.cuda_stream)
+            me.late_mark(dev)
+            self._late_hold = (dev, flat_grads, gp, coef, total)
+        else:
+            lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), coef.data_ptr(), *hyper, lib.stream())
         return total
 
     def step(self, closure=None):
+        self.finish_late()
         self._host_step = None            # torch advances the step counters itself here: re-read them at the next fused step
         return super().step(closure)
 
     def load_state_dict(self, state_dict):
+        self.finish_late()
         super().load_state_dict(state_dict)
         self._lean = None
         self._plan = None

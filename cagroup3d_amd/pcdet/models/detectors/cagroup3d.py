@@ -98,6 +98,16 @@ class CAGroup3D(Detector3DTemplate):
         self.semantic_iter_value = self.model_cfg.SEMANTIC_ITER_VALUE
         self.semantic_value = self.model_cfg.SEMANTIC_THR
 
+    def split_late_parameters(self, optimizer=None):
+        """Everything but the backbone's parameters is first read behind the backbone's forward pass: their optimizer rows
+        (optim.ClippedAdamW.set_early) and their bf16 / split copies (me.set_early_weights) go to the late stream and run beside
+        that pass; `forward` joins the streams between its first and its second module.  Whoever reads parameters outside a
+        detector forward after an optimizer step calls `optimizer.finish_late()` first (train.checkpoint_state does)."""
+        early = list(self.backbone_3d.parameters())
+        ME.set_early_weights(early)
+        if optimizer is not None and hasattr(optimizer, "set_early"):
+            optimizer.set_early(early)
+
     def voxelization(self, points, prepared=None):
         """points (N,7) = (b,x,y,z,r,g,b) -> sparse tensor on the 0.02 m grid; one (the first) point's
         colour per voxel (cagroup3d.py:18-25).  `prepared`: the coordinate side from `prefetch_coordinates`."""
@@ -207,7 +217,7 @@ class CAGroup3D(Detector3DTemplate):
         ME.zero_arena().reset()                     # a fresh zero block for this step's statistics tables
         ME.WANT_BN_STATS = bool(self.training)      # evaluation: no BatchNorm takes the conv epilogue's partial sums
         # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
-        ME.prepare_weights(self.training)
+        ME.prepare_weights(self.training, split=True)   # (late rows: ME.late_weights_ready() behind the backbone, below)
         try:
             return self._forward(batch_dict, cur_epoch)
         finally:
@@ -226,6 +236,8 @@ class CAGroup3D(Detector3DTemplate):
             # the two heads (and their losses) under ME.HEAD_PRECISION when that is set ("bf16 backbone", fp32 heads)
             with ME.precision_scope(ME.HEAD_PRECISION if i > 0 else None):
                 batch_dict.update(module(batch_dict))
+            if i == 0:
+                ME.late_weights_ready()                 # the heads' weight copies (and, in training, their AdamW update) are behind us
             if i == 0 and self.training:
                 # the per-scene views of the raw points (the losses' scene_points) cost one host read of the scene sizes.  The
                 # dense head takes it where its own first blocking read is -- after the backbone AND its coordinate-independent

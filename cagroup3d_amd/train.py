@@ -170,6 +170,8 @@ def build_scheduler(optimizer, iters_per_epoch, optim_cfg, last_it=-1):
 
 def checkpoint_state(model, optimizer, epoch, it):
     m = model.module if hasattr(model, "module") else model
+    if hasattr(optimizer, "finish_late"):
+        optimizer.finish_late()                 # (the late parameters' update may still be on its own stream: optim.ClippedAdamW.set_early)
     return {"epoch": epoch, "it": it, "model_state": {k: v.cpu() for k, v in m.state_dict().items()},
             "optimizer_state": optimizer.state_dict() if optimizer is not None else None, "version": CHECKPOINT_VERSION}
 
@@ -321,6 +323,8 @@ def main(argv=None):
     else:
         ds = SyntheticIndoorDataset(args.config, args.scenes, bs, rank, world)
     optimizer = build_optimizer(model, oc)
+    if hasattr(model, "split_late_parameters"):
+        model.split_late_parameters(optimizer)
     start_epoch, it = 0, 0
     if args.resume:
         it, start_epoch = model.load_params_with_optimizer(args.resume, to_cpu=dev.type == "cpu", optimizer=optimizer)

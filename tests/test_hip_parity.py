@@ -599,6 +599,59 @@ def test_pinned_staging_ring_survives_wraparound(hip):
 
 
 @pytest.mark.gpu
+def test_weight_plan_early_and_late_rows_equal_the_single_launch(hip):
+    """me.set_early_weights + prepare_weights(split=True): the early weights' rows lead the table and are converted on the current
+    stream, the others on the late stream; after late_weights_ready() every copy holds the bits of the one-launch conversion,
+    and an unsplit call (split=False) waits for the late stream by itself."""
+    me._WeightPlan.reset()
+    me.PRECISION = 1
+    flag, me.LATE_WEIGHTS = me.LATE_WEIGHTS, True
+    try:
+        torch.manual_seed(0)
+        ws = [torch.randn(27, 64, 64, device="cuda"), torch.randn(8, 72, 48, device="cuda"), torch.randn(27, 128, 256, device="cuda")]
+        grp = [torch.randn(125, 64, 64, device="cuda") for _ in range(3)]
+        for w in ws:
+            me._prep_bf16_both(w)
+        me._prep_bf16_group(grp, True), me._prep_bf16_group(grp, False)
+        me.prepare_weights()
+        ref = [tuple(t.clone() for t in me._prep_bf16_both(w)) for w in ws]
+        ref_g = (me._prep_bf16_group(grp, True).clone(), me._prep_bf16_group(grp, False).clone())
+        me.finish_weights()
+        nrows = me._WeightPlan.nrows
+        me.set_early_weights([ws[1]])                        # (not the first recorded: its rows must move to the front)
+        for w in ws + grp:
+            w.add_(0.5)
+        for step in range(2):
+            me.prepare_weights(training=True, split=True)
+            assert me._WeightPlan.nrows == nrows and me._WeightPlan.n_early == 8 * 2, (me._WeightPlan.nrows, me._WeightPlan.n_early)
+            assert me._LATE_PENDING, "the late rows must be on the late stream"
+            early = me._prep_bf16_both(ws[1])                # early: valid without the join
+            me.late_weights_ready()
+            assert not me._LATE_PENDING
+            got = [me._prep_bf16_both(w) for w in ws]
+            got_g = (me._prep_bf16_group(grp, True), me._prep_bf16_group(grp, False))
+            me.finish_weights()
+            with torch.no_grad():
+                exp = [me._prep_bf16_both(w) for w in ws]    # converted on the spot (the arena is not trusted outside a forward)
+            for (a_t, a_p), (b_t, b_p), (r_t, r_p) in zip(got, exp, ref):
+                assert torch.equal(a_t, b_t) and torch.equal(a_p, b_p) and not torch.equal(a_t, r_t)
+            assert torch.equal(early[0], exp[1][0])
+            assert not torch.equal(got_g[0], ref_g[0]) and not torch.equal(got_g[1], ref_g[1])
+            for w in ws + grp:
+                w.add_(0.25)
+        me.prepare_weights(training=True, split=True)
+        assert me._LATE_PENDING
+        me.prepare_weights(training=True)                    # unsplit: joins first, one launch
+        assert not me._LATE_PENDING
+        me.finish_weights()
+    finally:
+        me.LATE_WEIGHTS = flag
+        me.set_early_weights(None)
+        me._WeightPlan.reset()
+        me.PRECISION = 0
+
+
+@pytest.mark.gpu
 def test_weight_plan_single_launch_equals_per_layer_conversion(hip):
     """me.prepare_weights(): every recorded conv weight converted by ONE table-driven launch into the arena -- the same
     bits as the per-layer launches, refreshed exactly when a weight's version changes."""
