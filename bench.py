@@ -324,22 +324,34 @@ def main():
         torch.cuda.synchronize()
 
     # live HIP-event timing of every conv launch (the roofline figures) -- on ~3 of the timed steps, spread evenly over the
-    # timed region: two events per launch add up (a profiled step records ~440 events and takes ~2 ms longer; 20 k live events
+    # timed region (CG3D_BENCH_PROFILE_STEPS, default 2): two events per launch add up (a profiled step records ~440 events and takes ~2 ms longer; 20 k live events
     # in a 100-step run slowed the run itself).  3 steps x 67 launches of the dominant kernel is plenty for an average.
     rank_ms = []
 
-    def timed_run(steps, batches=None):
+    # Lanes (engine.py: the backbone's two chains, DAPPM's branches and the weight gradients on queues of their own): two
+    # launches that run at once share the device, and an event pair around one of them then measures how long the PAIR took to
+    # let it through -- not the kernel.  The profiled steps therefore run tables WITHOUT lanes (engine.LANES off while their
+    # programs are compiled: the dry run of the step before, and the step itself -- emission order on one stream, what a
+    # CG3D_LANES=0 run issues and what rocprofv3 sees in one, profiles/): `roofline` is the kernel alone;
+    # `roofline.on_lanes` gives the same launches' average with the lanes on their queues (two extra, untimed steps).
+    from cagroup3d_amd import engine as _engine
+
+    def timed_run(steps, batches=None, lanes_while_profiling=False):
         batches = batches or [batch]
         me.KernelProfile.reset()
         me.KernelProfile.wgrad = True               # the weight gradient is part of the step's 8(d) work
-        stride = max(1, -(-steps // int(os.environ.get("CG3D_BENCH_PROFILE_STEPS", "3"))))
+        stride = max(1, -(-steps // int(os.environ.get("CG3D_BENCH_PROFILE_STEPS", "2"))))
+        first = 1 if (stride > 1 and steps > 1) else 0       # (step 0's program was compiled before the run began)
         profiled = 0
+        lanes = _engine.LANES
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            me.KernelProfile.enabled = i % stride == 0
+            me.KernelProfile.enabled = i % stride == first
             profiled += int(me.KernelProfile.enabled)
+            _engine.LANES = lanes and (lanes_while_profiling or not (me.KernelProfile.enabled or (i + 1) % stride == first))
             tb_ = train_step(net, opt, batches[i % len(batches)], clip, batches[(i + 1) % len(batches)])
+        _engine.LANES = lanes
         pending = _PREPARED.get(id(net.module if hasattr(net, "module") else net))
         if pending is not None:
             pending[0].result()                     # the worker thread's dry run of the next batch belongs to the timed work
@@ -446,6 +458,17 @@ def main():
     dt, profiled_steps, tb = timed_run(args.steps)
     per_rank_ms = list(rank_ms)
     roof = roofline_of(dt, profiled_steps, args.steps, me.PRECISION) if rank == 0 else None
+    if _engine.LANES and _engine.LANES_RUN and os.environ.get("CG3D_BENCH_ON_LANES", "1") != "0":
+        keep_ms = list(rank_ms)
+        dt_l, prof_l, _ = timed_run(2, lanes_while_profiling=True)       # (every rank: the steps hold collectives)
+        rank_ms[:] = keep_ms
+        if rank == 0:
+            r_l = roofline_of(dt_l, prof_l, 2, me.PRECISION)
+            roof["queues"] = ("profiled steps: launch programs compiled without lanes, every launch alone on the one stream; all other "
+                              "steps: lanes on their own queues")
+            roof["on_lanes"] = {"kernel": r_l["kernel"], "avg_launch_ms": r_l["avg_launch_ms"], "frac": r_l["frac"], "launches": r_l["launches"],
+                                "note": "the same launches timed while the other lanes' kernels run beside them (2 untimed steps): the "
+                                        "time a launch takes to get through a shared device, not a property of the kernel"}
 
     fp32 = None
     if me.PRECISION == 1 and not args.no_fp32 and os.environ.get("CG3D_BENCH_FP32", "1") != "0":

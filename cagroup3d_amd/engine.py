@@ -1398,7 +1398,8 @@ def _with_events(P, prof, lib):
     if not prof:
         return P, []
     out, recs, last = [], [], 0
-    for (row, flops, nbytes, meta, pbytes) in prof:
+    # (ascending rows: the issue order of a table with lanes is not the emission order the entries were recorded in)
+    for (row, flops, nbytes, meta, pbytes) in sorted(prof, key=lambda t: t[0]):
         ev = _Events(lib)
         out.append(P[last:row])
         e0 = np.zeros((1, STRIDE), dtype=np.int64)

@@ -50,6 +50,26 @@ def test_role_table_follows_the_const_qualifiers_of_the_header():
     assert "#define CG3D_PROG_LANE_SHIFT %d" % engine.LANE_SHIFT in prog_h and "#define CG3D_PROG_MAX_LANES %d" % engine.MAX_LANES in prog_h
 
 
+def test_timing_events_keep_every_row_once_and_in_order(oracle):
+    """engine._with_events (bench.py's live timing of the conv launches): the profile entries of a table with lanes are recorded
+    in emission order but refer to rows of the ISSUE order -- wrapped out of order, rows ran twice."""
+    comp, _ = _compiled_backbone(oracle, 2)
+    for tab, prof in ((comp.fwd, comp.fprof), (comp.bwd, comp.bprof)):
+        assert len(prof) > 20
+        rows = [p[0] for p in prof]
+        if engine.LANES:
+            assert rows != sorted(rows), "the round-robin issue order should have moved profiled rows past each other"
+        with _lib.use_library(oracle):
+            P, recs = engine._with_events(tab, prof, oracle)
+        assert len(recs) == len(prof) and P.shape[0] == tab.shape[0] + 2 * len(prof)
+        timing = ((P[:, 0] & engine.OPCODE_MASK) == engine.OP_EVENT_RECORD) & (P[:, 2] == 0)
+        assert int(timing.sum()) == 2 * len(prof)
+        assert np.array_equal(P[~timing], tab)                           # every row once, in the table's order
+        at = np.nonzero(timing)[0]
+        for a, b in zip(at[0::2], at[1::2]):                              # an event pair around ONE row, on that row's lane
+            assert b == a + 2 and (P[a, 0] >> engine.LANE_SHIFT) == (P[a + 1, 0] >> engine.LANE_SHIFT) == (P[b, 0] >> engine.LANE_SHIFT)
+
+
 # ------------------------------------------------------------------------------------------------ happens-before walk
 def _blocks_of(comp_starts):
     def block(addr):
