@@ -323,9 +323,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # live HIP-event timing of every conv launch (the roofline figures) -- on ~3 of the timed steps, spread evenly over the
-    # timed region (CG3D_BENCH_PROFILE_STEPS, default 2): two events per launch add up (a profiled step records ~440 events and takes ~2 ms longer; 20 k live events
-    # in a 100-step run slowed the run itself).  3 steps x 67 launches of the dominant kernel is plenty for an average.
+    # live HIP-event timing of every conv launch (the roofline figures) -- on two of the timed steps (CG3D_BENCH_PROFILE_STEPS),
+    # spread evenly over the timed region: two events per launch add up (a profiled step records ~440 events and takes ~2 ms
+    # longer; 20 k live events in a 100-step run slowed the run itself).  2 steps x 67 launches of the dominant kernel is plenty
+    # for an average.
     rank_ms = []
 
     # Lanes (engine.py: the backbone's two chains, DAPPM's branches and the weight gradients on queues of their own): two

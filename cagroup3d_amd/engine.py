@@ -1310,7 +1310,9 @@ _SIDE_STREAMS = {}
 
 def _lane_streams(lib):
     """(ctypes array, count) of the queues of lanes 0 .. MAX_LANES - 1: torch's current stream and this process's side streams of
-    the device (CG3D_LANE_PRIORITY: comma-separated stream priorities of lanes 1, 2, ...; default 0)."""
+    the device (CG3D_LANE_PRIORITY: comma-separated stream priorities of lanes 1, 2, ...; default 0).  Only the lanes in use get
+    a stream of their own (the device has four hardware queues by default, and every stream created takes a turn on them: the
+    main stream, the dry run's stream and three lanes already share); the others fall back to lane 0's."""
     import ctypes
     main = lib.stream()
     if not lib.is_device:
@@ -1318,9 +1320,10 @@ def _lane_streams(lib):
     dev = torch.cuda.current_device()
     side = _SIDE_STREAMS.get(dev)
     if side is None:
+        used = max([1, WGRAD_LANE] + DAPPM_LANES)
         prio = [int(x) for x in os.environ.get("CG3D_LANE_PRIORITY", "0").split(",")]
-        side = _SIDE_STREAMS[dev] = [torch.cuda.Stream(device=dev, priority=prio[min(i, len(prio) - 1)]) for i in range(MAX_LANES - 1)]
-    return (ctypes.c_void_p * MAX_LANES)(main, *[x.cuda_stream for x in side]), MAX_LANES
+        side = _SIDE_STREAMS[dev] = [torch.cuda.Stream(device=dev, priority=prio[min(i, len(prio) - 1)]) for i in range(used)]
+    return (ctypes.c_void_p * MAX_LANES)(main, *[x.cuda_stream for x in side], *([main] * (MAX_LANES - 1 - len(side)))), MAX_LANES
 
 
 # ------------------------------------------------------------------------------------------------ a compiled pass

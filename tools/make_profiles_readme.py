@@ -33,6 +33,8 @@ for tag in ("bf16", "fp32"):
     if not os.path.exists(f):
         continue
     rows = list(csv.DictReader(open(f)))
+    f0 = os.path.join(P, "%s_bench_%s_lanes0_kernel_stats.csv" % (RN, tag))
+    rows0 = list(csv.DictReader(open(f0))) if os.path.exists(f0) else rows       # the run compiled without lanes: every kernel alone
     b = json.loads(rd("%s_bench_%s.json" % (RN, tag)).strip().splitlines()[-1])
     steps = b["steps"] + b["warmup"]
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
@@ -44,8 +46,17 @@ for tag in ("bf16", "fp32"):
                "%.0f %% of the step.  Sum of the 8(d) bounds of ALL conv launches / their measured time: %.1f %%; / the whole step: %.1f %%.\n\n"
                % (b["value"], b["ms_per_step"], b["steps"], r["kernel"].split(" ")[0], r["bound"], r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["unit"],
                   r["avg_launch_ms"], r["launches"],
-                  ", ".join("%.3f ms" % (float(x["AverageNs"]) / 1e6) for x in rows if r["kernel"].split(" ")[0] in x["Name"])[:60] or "n/a",
+                  ", ".join("%.3f ms" % (float(x["AverageNs"]) / 1e6) for x in rows0 if r["kernel"].split(" ")[0] in x["Name"])[:60] or "n/a",
                   100 * r["kernel_time_share"], 100 * r.get("conv_bound_over_conv_time", 0), 100 * r.get("conv_bound_over_step_time", 0)))
+    if tag == "bf16" and rows0 is not rows:
+        ol = r.get("on_lanes") or {}
+        out.append("The CSV averages quoted above are those of `%s_bench_bf16_lanes0_kernel_stats.csv` (the same command under `CG3D_LANES=0`: launch programs compiled "
+                   "without lanes, every kernel alone on the one stream -- what `roofline` times, on steps compiled that way).  In the default run the backbone's coarse chain, "
+                   "DAPPM's branches and the weight gradients run on queues of their own beside the stride-4 chain (engine.py, lanes): the table below is that run, and a launch's "
+                   "duration in it is the time it took to get through a shared device (`roofline.on_lanes`: %.3f ms per launch of the dominant kernel, %.1f %% -- not a property of the kernel; "
+                   "its averages in this table: %s).\n\n"
+                   % (RN, ol.get("avg_launch_ms", float("nan")), 100 * ol.get("frac", float("nan")),
+                      ", ".join("%.3f ms" % (float(x["AverageNs"]) / 1e6) for x in rows if r["kernel"].split(" ")[0] in x["Name"])[:60] or "n/a"))
     if tag == "bf16":
         for kn in ("k_spconv_tile", "k_spconv_implicit_bf16", "k_spconv_pairs_wgrad_rows16"):
             t, _src = _b.pmc_traffic(kn)
@@ -154,6 +165,9 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_ops_by_site.txt" % RN, "framework ops, fills / copies, library GEMMs, reductions and sorts per source line; C-ABI calls per entry point (one step)"),
                    ("%s_sync_waits.txt" % RN, "every blocking read of the issuing thread: position in the step, time inside it (long = the host was ahead of the device, tens of us = the device was idle)"),
                    ("%s_gpu_gaps.txt" % RN, "kernel-trace timeline: launches per step, time with a kernel running on either queue, idle time by the launch that ended the gap"),
+                   ("%s_backbone_lanes.txt" % RN, "device time of the backbone's forward / backward table on one stream and on their lanes (tools/backbone_lanes.py): DAPPM's branches with the coarse chain / on lanes 3, 2; weight gradients with their layer / on lane 2"),
+                   ("%s_lane_timeline.txt" % RN, "one forward and one backward pass of the backbone under rocprofv3 --kernel-trace: kernel time per queue, time with more than one queue busy (tools/lane_timeline.py)"),
+                   ("%s_lanes_ab.txt" % RN, "per-step wall time of the training step with and without lanes, alternating on one box (tools/ab_steps.sh -> tools/step_times.py, 100 steps each)"),
                    ("%s_backward_nodes.txt" % RN, "host time of the backward pass per autograd node (torch.profiler)"),
                    ("%s_class_branch_sections.txt" % RN, "host time and device tail per section of the class branches (a device sync per section)")):
     if os.path.exists(os.path.join(P, name)):

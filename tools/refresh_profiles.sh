@@ -12,6 +12,16 @@ for prec in bf16 fp32; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$prec -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 --precision $prec > $O/rocprof_$prec.log 2>&1
   find /tmp/prof_$prec -name "*kernel_stats.csv" -exec cp {} $O/${RN}_bench_${prec}_kernel_stats.csv \;
 done
+# the same run with every launch program compiled without lanes: each kernel alone on the one stream -- the averages bench.py's
+# `roofline` (timed on steps compiled that way) is to be compared with
+rm -rf /tmp/prof_l0
+CG3D_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l0 -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 --rotate 0 > $O/rocprof_lanes0.log 2>&1
+find /tmp/prof_l0 -name "*kernel_stats.csv" -exec cp {} $O/${RN}_bench_bf16_lanes0_kernel_stats.csv \;
+# lanes: device time of the backbone passes on one queue / on their lanes, the per-queue timeline of one pass, the step A/B
+( for d in "" "3,2"; do for w in 0 2; do python $R/tools/backbone_lanes.py --wgrad-lanes $w --dappm-lanes "$d" 2>&1 | grep "DAPPM lanes"; done; done ) > $O/${RN}_backbone_lanes.txt 2>&1
+rm -rf /tmp/bl; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bl -o bl -- python $R/tools/backbone_lanes.py --marks --iters 2 --wgrad-lanes 2 --dappm-lanes 3,2 > /dev/null 2>&1
+python $R/tools/lane_timeline.py $(find /tmp/bl -name "bl_kernel_trace.csv" | head -1) --step -1 > $O/${RN}_lane_timeline.txt 2>&1
+( cd $R; STEPS=100 bash tools/ab_steps.sh 2 "-" "CG3D_LANES=0" ) > $O/${RN}_lanes_ab.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 600 rocprofv3 --pmc $c --kernel-include-regex "k_spconv_(tile|implicit_bf16|pairs_bf16|pairs_wgrad_rows16)" --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 > $O/pmc_$c.log 2>&1
