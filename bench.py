@@ -549,7 +549,12 @@ def main():
                                         "; activations, weights, gradients, BatchNorm, losses and the optimizer stay fp32"
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
                           "last_loss": tb.get("loss_all"),
-                          "backbone_issue": dict(__import__("cagroup3d_amd.engine", fromlist=["STATS"]).STATS)},
+                          "backbone_issue": dict(__import__("cagroup3d_amd.engine", fromlist=["STATS"]).STATS),
+                          # launch programs on several queues (engine.py, lanes): compiled with lanes / run on them, and what the
+                          # first passes' timing said (forward table in ms: on its lanes, on one stream)
+                          "lanes": {"compiled": bool(_engine.LANES), "on_queues": bool(_engine.LANES and _engine.LANES_RUN),
+                                    "weight_gradient_lane": _engine.WGRAD_LANE, "dappm_lanes": list(_engine.DAPPM_LANES),
+                                    "autotune_forward_ms": list(_engine._LaneTuner.verdict) if _engine._LaneTuner.verdict else None}},
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32

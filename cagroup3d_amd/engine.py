@@ -1416,7 +1416,50 @@ def _with_events(P, prof, lib):
     return np.concatenate(out), recs
 
 
-def _run(lib, P, nrows=None, comp=None):
+# Whether the lanes pay is decided by the device's queues, not by this file: streams are mapped onto a few hardware queues in
+# creation order, and a process with other streams around (a communication library's, a framework's) -- or an explicit
+# GPU_MAX_HW_QUEUES, or stream priorities -- can end up with two lanes on one queue: measured 29 ms per step instead of 23.5.
+# The first backbone passes of a process are therefore timed alternately on their lanes and on the one stream (events on the
+# current stream around the table: it ends with the join), and the lanes stay only if they are not slower.
+AUTOTUNE = os.environ.get("CG3D_LANES_AUTOTUNE", "1") != "0"
+
+
+class _LaneTuner:
+    skip, samples, decided, verdict = 1, [], False, None
+
+    @classmethod
+    def begin(cls, comp, lib):
+        """None (no measurement: run as LANES_RUN says) or (lanes_run, start event) for this pass."""
+        if cls.decided or not (AUTOTUNE and LANES_RUN and comp.lanes and lib.is_device) or ME.KernelProfile.enabled:
+            return None
+        if cls.skip > 0:
+            cls.skip -= 1
+            return None
+        if len(cls.samples) >= 6:
+            on = sorted(e0.elapsed_time(e1) for m, e0, e1 in cls.samples if m)
+            off = sorted(e0.elapsed_time(e1) for m, e0, e1 in cls.samples if not m)
+            cls.verdict = (on[len(on) // 2], off[len(off) // 2])
+            cls.decided = True
+            if cls.verdict[0] > 1.05 * cls.verdict[1]:
+                import sys
+                globals()["LANES_RUN"] = False
+                sys.stderr.write("cagroup3d_amd.engine: lanes off -- the backbone's forward table took %.2f ms on its lanes against %.2f ms on one "
+                                 "stream (queues shared with other streams of this process?)\n" % cls.verdict)
+            return None
+        mode = len(cls.samples) % 2 == 0
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return mode, e0
+
+    @classmethod
+    def end(cls, tok):
+        if tok is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            cls.samples.append((tok[0], tok[1], e1))
+
+
+def _run(lib, P, nrows=None, comp=None, lanes_run=None):
     """comp: the compiled pass the rows come from (its ordering events are bound here; a pass with lanes goes to the lanes entry)."""
     P = np.ascontiguousarray(P)
     n = P.shape[0] if nrows is None else nrows
@@ -1427,7 +1470,7 @@ def _run(lib, P, nrows=None, comp=None):
     if comp is not None and comp.lanes:
         P = _bind_events(P, lib, comp.nevents)
         streams, ns = _lane_streams(lib)
-        rc = lib.raw("cg3d_run_program_lanes")(P.ctypes.data, n, ctypes.cast(streams, ctypes.c_void_p), ns if LANES_RUN else 1,
+        rc = lib.raw("cg3d_run_program_lanes")(P.ctypes.data, n, ctypes.cast(streams, ctypes.c_void_p), ns if (LANES_RUN if lanes_run is None else lanes_run) else 1,
                                                ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
     else:
         rc = lib.raw("cg3d_run_program")(P.ctypes.data, n, lib.stream(), ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
@@ -1508,7 +1551,9 @@ class BackboneFunction(torch.autograd.Function):
         if prof:
             P, recs = _with_events(P, comp.fprof, lib)
             ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]), comp=comp)
+        tok = _LaneTuner.begin(comp, lib)
+        _run(lib, np.concatenate([head, P]), comp=comp, lanes_run=tok[0] if tok else None)
+        _LaneTuner.end(tok)
         ctx.comp, ctx.arena, ctx.bases, ctx.feats, ctx.keep, ctx.hooks, ctx.prof = comp, arena, bases, feats, keep, hooks, prof
         p, n, c, p16 = comp.out
         shift = bases[R_ACT] - arena.data_ptr()

@@ -402,7 +402,7 @@ def test_lanes_on_their_queues_equal_the_one_queue_run_on_the_device(hip, wgrad_
     prec, me.PRECISION = me.PRECISION, 1
     rows16, me.BF16_ROWS = me.BF16_ROWS, True
     wl, engine.WGRAD_LANE = engine.WGRAD_LANE, wgrad_lane
-    lr = engine.LANES_RUN
+    lr, at, engine.AUTOTUNE = engine.LANES_RUN, engine.AUTOTUNE, False       # (the test chooses the queues itself)
     try:
         _backbone_step(model, batch, True, dev)                  # (first step: weights enter the arena)
         out = []
@@ -414,7 +414,7 @@ def test_lanes_on_their_queues_equal_the_one_queue_run_on_the_device(hip, wgrad_
             assert engine.STATS["program_passes"] == passes + 1, "the program path did not run"
             torch.cuda.synchronize()
     finally:
-        engine.LANES_RUN = lr
+        engine.LANES_RUN, engine.AUTOTUNE = lr, at
         engine.WGRAD_LANE = wl
         me.PRECISION, me.BF16_ROWS = prec, rows16
     a, b, c = out

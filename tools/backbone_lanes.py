@@ -29,6 +29,7 @@ def main():
                     help="a k_clip_coef launch before and after each pass: cuts for tools/lane_timeline.py in a rocprofv3 kernel trace")
     args = ap.parse_args()
     dev = "cuda"
+    engine.AUTOTUNE = False                 # (this tool chooses the queues itself)
     engine.DAPPM_LANES = [int(x) for x in args.dappm_lanes.split(",") if x]
     me.PRECISION, me.BF16_ROWS = 1, True
     model, _ = build_model.build_cagroup3d(args.dataset, seed=0)

@@ -27,6 +27,12 @@ model.train()
 opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
 model.split_late_parameters(opt)            # as bench.py does
 batch = build_model.synthetic_batch("S50k", 4, device=dev)
+main_prio = int(os.environ.get("CG3D_MAIN_PRIORITY", "0"))
+if main_prio:
+    # the whole step on a high-priority stream (the dry run's stream stays at normal priority)
+    torch.cuda.synchronize()
+    _s = torch.cuda.Stream(priority=main_prio)
+    torch.cuda.set_stream(_s)
 for _ in range(6):
     bench.train_step(model, opt, batch, 10.0)
 import gc
