@@ -208,7 +208,6 @@ class Builder:
         self.tape = _Tape(self)
         self.size = {R_ACT: 0, R_ZF: 0, R_ZB: 0, R_PG: 0}
         self.starts = {R_ACT: [], R_ZF: [], R_ZB: [], R_PG: []}     # block starts per region, ascending (_schedule)
-        self.exact = {}                 # address `alloc` returned -> its block
         self.keep = []                  # tensors the rows point into (tables built at emission time)
         # tables out of me.py's host caches: held for their lifetime only (the caches publish an entry after its upload has
         # completed, and what frees one is this reference going away -- no stream hand-over needed: `keep` gets one)
@@ -231,7 +230,6 @@ class Builder:
         off = self.size[region]
         self.size[region] = off + ((int(nbytes) + ALIGN - 1) & ~(ALIGN - 1))
         self.starts[region].append(off)
-        self.exact[region + off] = (region >> TAG, off)
         return region + off
 
     def wgrad_row(self, *row):
@@ -1062,7 +1060,7 @@ class Emitter:
 
 
 # ------------------------------------------------------------------------------------------------ lanes
-def _schedule(prog, starts, cuts=(), exact=None):
+def _schedule(prog, starts, cuts=()):
     """Event edges between the lanes of `prog` (rows still with region-relative addresses), in place.
 
     Rows of one lane run in table order on their queue; a row needs an edge from ANOTHER lane when it reads a block that lane
@@ -1093,39 +1091,12 @@ def _schedule(prog, starts, cuts=(), exact=None):
             return (tag, 0)
         return (tag, lst[bisect.bisect_right(lst, off) - 1])
 
-    # Every pointer of every row as the NUMBER of its block in order of first appearance.  Two tables with the same opcodes,
-    # lanes and block numbers have the same edges whatever the addresses are -- a step's tables differ from the previous step's
-    # in nothing else (the net is the same, the voxel counts moved) -- so the derivation below runs once per pattern and its
-    # result (where the event rows go, the issue order) is replayed on the new rows.
-    canon, exact = {}, (exact or {})
-    reads, writes, sig = [None] * n, [None] * n, [None] * n
+    reads, writes = [None] * n, [None] * n
     for i in range(n):
         row = rows[i]
         rd, wr = ROLES[int(row[0]) & OPCODE_MASK]
-        nr = len(row)
-        br, bw = [], []
-        for cols, out in ((rd, br), (wr, bw)):
-            for c in cols:
-                if c < nr:
-                    a = row[c]
-                    if a:
-                        bk = exact.get(a)
-                        if bk is None:
-                            bk = block(a)
-                        k = canon.get(bk)
-                        if k is None:
-                            k = canon[bk] = len(canon)
-                        out.append(k)
-        reads[i], writes[i] = br, bw
-        sig[i] = (row[0], lanes[i], tuple(br), tuple(bw))
-    key = (tuple(sig), tuple(cuts))
-    hit = _SCHED_CACHE.get(key) if SCHED_CACHE else None
-    if hit is not None:
-        plan, out_lanes, index, cutmap, nev = hit
-        prog.rows = [rows[i] if i >= 0 else ev for i, ev in plan]
-        prog.lanes, prog.nevents = list(out_lanes), nev
-        prog.prof = [(index[r],) + tuple(rest) for (r, *rest) in prog.prof]
-        return index, dict(cutmap)
+        reads[i] = [block(row[c]) for c in rd if c < len(row) and row[c]]
+        writes[i] = [block(row[c]) for c in wr if c < len(row) and row[c]]
     NL = max(lanes) + 1
     assert NL <= MAX_LANES
     before = [[] for _ in range(n + 1)]          # rows put in front of old row i
@@ -1229,20 +1200,13 @@ def _schedule(prog, starts, cuts=(), exact=None):
     cutmap[n] = len(out_rows)
     prog.rows, prog.lanes, prog.nevents = out_rows, out_lanes, nev
     prog.prof = [(index[r],) + tuple(rest) for (r, *rest) in prog.prof]
-    if SCHED_CACHE:
-        if len(_SCHED_CACHE) >= 64:
-            _SCHED_CACHE.clear()
-        back = {v: k for k, v in enumerate(index)}
-        _SCHED_CACHE[key] = ([(back.get(j, -1), r) for j, r in enumerate(out_rows)], list(out_lanes), index, {c: cutmap[c] for c in cuts}, nev)
     return index, {c: cutmap[c] for c in cuts}
 
 
-SCHED_CACHE = os.environ.get("CG3D_SCHED_CACHE", "1") != "0"      # replay the schedule of a table with the same pattern (_schedule)
-_SCHED_CACHE = {}
 # The derivation in the library (cg3d_program_schedule, include/cagroup3d_program.h): the same algorithm as `_schedule` below --
-# which stays as its specification, tests/test_engine_lanes.py compares the two row for row -- in ~50 us and outside the
-# interpreter lock.  In Python it cost the thread that compiles the next batch's program 3-4 ms per step, and with the step
-# bound by what the two host threads get done under one lock that was most of what the second queue had won.
+# which stays as its specification (CG3D_SCHED_NATIVE=0 runs it; tests/test_engine_lanes.py compares the two row for row) --
+# in ~50 us and outside the interpreter lock.  In Python it cost the thread that compiles the next batch's program 3-4 ms per
+# step, and with the step bound by what the two host threads get done under one lock that was most of what the lanes had won.
 SCHED_NATIVE = os.environ.get("CG3D_SCHED_NATIVE", "1") != "0"
 
 
@@ -1337,8 +1301,8 @@ class Compiled:
             fidx, _ = _schedule_native(b.lib, b.f, b.starts)
             bidx, bcuts = _schedule_native(b.lib, b.b, b.starts, tuple(b.marks.values()))
         else:
-            fidx, _ = _schedule(b.f, b.starts, (), b.exact)
-            bidx, bcuts = _schedule(b.b, b.starts, tuple(b.marks.values()), b.exact)
+            fidx, _ = _schedule(b.f, b.starts)
+            bidx, bcuts = _schedule(b.b, b.starts, tuple(b.marks.values()))
         self.lanes = bool(b.f.nevents or b.b.nevents)
         self.nevents = max(b.f.nevents, b.b.nevents)
         self.fwd, self.bwd = b.f.table(), b.b.table()
