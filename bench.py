@@ -309,6 +309,11 @@ def main():
     # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
     batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)
 
+    # backward nodes on the issuing thread: the autograd engine otherwise hands every node to its per-device thread, and the ~120
+    # nodes of this step are Python functions -- an interpreter-lock hand-over each, inside the host-bound stretch of the step
+    # (100 pinned steps, three alternating pairs: median 23.2 / 23.3 / 23.2 ms against 23.7 / 23.4 / 23.4)
+    if os.environ.get("CG3D_AUTOGRAD_ST", "1") != "0":
+        torch.autograd.set_multithreading_enabled(False)
     for _ in range(args.warmup):
         tb = train_step(net, opt, batch, clip)
     # the model, the optimizer state and the cached tables are permanent: take them out of the cyclic collector's

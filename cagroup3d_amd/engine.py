@@ -1400,9 +1400,11 @@ class _LaneTuner:
             cls.skip -= 1
             return None
         if len(cls.samples) >= 6:
-            on = sorted(e0.elapsed_time(e1) for m, e0, e1 in cls.samples if m)
-            off = sorted(e0.elapsed_time(e1) for m, e0, e1 in cls.samples if not m)
-            cls.verdict = (on[len(on) // 2], off[len(off) // 2])
+            # (per input row: the batches of a training run differ in size; the verdict is reported for the median batch)
+            rows = sorted(n for _, _, _, n in cls.samples)[len(cls.samples) // 2]
+            on = sorted(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if m)
+            off = sorted(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if not m)
+            cls.verdict = (on[len(on) // 2] * rows, off[len(off) // 2] * rows)
             cls.decided = True
             if cls.verdict[0] > 1.05 * cls.verdict[1]:
                 import sys
@@ -1413,14 +1415,14 @@ class _LaneTuner:
         mode = len(cls.samples) % 2 == 0
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        return mode, e0
+        return mode, e0, max(int(comp.n_in), 1)
 
     @classmethod
     def end(cls, tok):
         if tok is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            cls.samples.append((tok[0], tok[1], e1))
+            cls.samples.append((tok[0], tok[1], e1, tok[2]))
 
 
 def _run(lib, P, nrows=None, comp=None, lanes_run=None):

@@ -27,6 +27,10 @@ model.train()
 opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
 model.split_late_parameters(opt)            # as bench.py does
 batch = build_model.synthetic_batch("S50k", 4, device=dev)
+if os.environ.get("CG3D_SWITCH_US"):
+    sys.setswitchinterval(float(os.environ["CG3D_SWITCH_US"]) * 1e-6)
+if os.environ.get("CG3D_AUTOGRAD_ST", "1") == "1":
+    torch.autograd.set_multithreading_enabled(False)        # backward nodes on the calling thread
 main_prio = int(os.environ.get("CG3D_MAIN_PRIORITY", "0"))
 if main_prio:
     # the whole step on a high-priority stream (the dry run's stream stays at normal priority)
