@@ -1711,10 +1711,11 @@ def run_class_branches(head, xf, xc, km9, km5, km_up, ident, fine_bounds, coarse
 
 
 # ------------------------------------------------------------------------------------------------ the head's first layers
-# Off by default: measured at 153.6 against 153.7 scenes/s over three alternating runs (the seven layers' backward nodes cost the
-# issuing thread 0.55 ms, the program's node 0.35 ms, and compiling it inline adds to the start of the step) -- kept for the
-# test that pins it and for a host slower than the bench boxes.
-HEAD_PROGRAM = os.environ.get("CG3D_HEAD_PROGRAM", "0") == "1"
+# Round 4: measured at 153.6 against 153.7 scenes/s on one queue (the seven layers' backward nodes cost the issuing thread
+# 0.55 ms, the program's node 0.35 ms, and compiling it inline adds to the start of the step) -- off.  Round 5, with the two
+# branches on two lanes (three 1x1x1 layers beside one 3^3 convolution, both inside the device-bound half of the step): per-step
+# medians 23.6 / 23.3 / 23.3 ms against 24.1 / 23.8 / 23.6 over 100 pinned steps, alternating -- on (CG3D_HEAD_PROGRAM=0: off).
+HEAD_PROGRAM = os.environ.get("CG3D_HEAD_PROGRAM", "1") == "1"
 HEAD_STATS = {"program_passes": 0, "not_ready": 0}
 
 
@@ -1738,7 +1739,9 @@ def compile_head_pre(head, sp, has16):
         xt.p16 = R_IN2
     em = Emitter(b, sp.coordinate_manager)
     x = _X(xt, sp.coordinate_map_key)
+    b.set_lane(1)                       # two branches on the same rows: three 1x1x1 layers beside one 3^3 convolution
     off = em.seq(head.offset_block, x)
+    b.set_lane(0)
     fo = em.seq(head.feature_offset, x)
     b.emit_backward([off.t, fo.t])
     gin = b.grad(xt)
