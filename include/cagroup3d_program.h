@@ -320,8 +320,10 @@ static int cg3d_program_schedule_impl(const int64_t *prog, int64_t n, const int6
         *n_events = 0;
         return CG3D_OK;
     }
-    int64_t hcap = 64;
-    while (hcap < n * 16) hcap <<= 1;
+    int64_t hcap = 64, nptr = 0;                          /* open addressing: at most half full */
+    for (int64_t i = 0; i < n; i++)
+        for (int c = 1; c < S; c++) nptr += prog[i * S + c] != 0;
+    while (hcap < 2 * nptr + 64) hcap <<= 1;
     const int64_t max_edges = n * ML + 2 * (ncut + 2) * ML;
     cg3d_sched_blk *tab = (cg3d_sched_blk *)malloc((size_t)hcap * sizeof(cg3d_sched_blk));
     cg3d_sched_edge *edge = (cg3d_sched_edge *)malloc((size_t)max_edges * sizeof(cg3d_sched_edge));

@@ -344,6 +344,78 @@ def test_reorder_helper_detects_a_dropped_edge(oracle):
     assert not torch.equal(ref[1], got[1])
 
 
+# ------------------------------------------------------------------------------------------------ the tuner
+class _FakeEvent:
+    clock = [0.0]
+
+    def __init__(self, enable_timing=False):
+        self.t = None
+
+    def record(self):
+        self.t = _FakeEvent.clock[0]
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def _tune(monkeypatch, ms_of):
+    """Drive engine._LaneTuner with scripted pass times: ms_of(lanes_run, n_in, k) for the k-th measured pass."""
+    class Lib:
+        is_device = True
+
+    class Comp:
+        lanes = True
+
+        def __init__(self, n):
+            self.n_in = n
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    monkeypatch.setattr(engine, "AUTOTUNE", True)
+    monkeypatch.setattr(engine, "LANES_RUN", True)
+    T = engine._LaneTuner
+    monkeypatch.setattr(T, "skip", 1)
+    monkeypatch.setattr(T, "samples", [])
+    monkeypatch.setattr(T, "decided", False)
+    monkeypatch.setattr(T, "verdict", None)
+    modes, k = [], 0
+    for i in range(12):
+        comp = Comp(100000 + 9000 * (i % 3))                 # batches of different sizes, as in training
+        tok = T.begin(comp, Lib())
+        if tok is not None:
+            modes.append(tok[0])
+            _FakeEvent.clock[0] += ms_of(tok[0], comp.n_in, k)
+            k += 1
+        T.end(tok)
+    return T, modes
+
+
+def test_the_tuner_keeps_lanes_that_win_and_drops_lanes_that_lose(monkeypatch, capsys):
+    T, modes = _tune(monkeypatch, lambda on, n, k: (4.0 if on else 4.7) * n / 100000.0)
+    assert modes == [True, False, True, False, True, False] and T.decided and engine.LANES_RUN is True
+    assert 0.80 < T.verdict[0] / T.verdict[1] < 0.90
+    # two lanes on one hardware queue: slower than one stream -> off, and said so
+    T, _ = _tune(monkeypatch, lambda on, n, k: (6.1 if on else 4.5) * n / 100000.0)
+    assert T.decided and engine.LANES_RUN is False
+    assert "lanes off" in capsys.readouterr().err
+    # equal within 5 %: the lanes stay (they cost nothing when they do not win)
+    T, _ = _tune(monkeypatch, lambda on, n, k: (4.6 if on else 4.5) * n / 100000.0)
+    assert T.decided and engine.LANES_RUN is True
+    # a profiled step is not sampled, a pass without lanes neither
+    monkeypatch.setattr(T, "decided", False)
+    monkeypatch.setattr(T, "samples", [])
+    monkeypatch.setattr(T, "skip", 0)
+    monkeypatch.setattr(me.KernelProfile, "enabled", True)
+
+    class Lib:
+        is_device = True
+
+    class Comp:
+        lanes, n_in = True, 1000
+    assert T.begin(Comp(), Lib()) is None
+    monkeypatch.setattr(me.KernelProfile, "enabled", False)
+    Comp.lanes = False
+    assert T.begin(Comp(), Lib()) is None
+
+
 # ------------------------------------------------------------------------------------------------ the class branches
 def test_class_branch_tables_have_their_edges(oracle):
     if not engine.LANES:
