@@ -52,8 +52,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="scenes per GPU (CAGroup3D.yaml BATCH_SIZE_PER_GPU)")
     ap.add_argument("--config", default="S50k")
     ap.add_argument("--dataset", default="scannet")

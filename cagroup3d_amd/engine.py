@@ -1399,12 +1399,14 @@ class _LaneTuner:
         if cls.skip > 0:
             cls.skip -= 1
             return None
-        if len(cls.samples) >= 6:
-            # (per input row: the batches of a training run differ in size; the verdict is reported for the median batch)
+        if len(cls.samples) >= 4:
+            # (per input row: the batches of a training run differ in size; the verdict is reported for the median batch.  Two
+            # passes each way and the faster of the two: a pass can only be disturbed towards slower, and the decision should
+            # fall inside a handful of warm-up steps)
             rows = sorted(n for _, _, _, n in cls.samples)[len(cls.samples) // 2]
-            on = sorted(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if m)
-            off = sorted(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if not m)
-            cls.verdict = (on[len(on) // 2] * rows, off[len(off) // 2] * rows)
+            on = min(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if m)
+            off = min(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if not m)
+            cls.verdict = (on * rows, off * rows)
             cls.decided = True
             if cls.verdict[0] > 1.05 * cls.verdict[1]:
                 import sys

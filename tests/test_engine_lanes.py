@@ -390,7 +390,7 @@ def _tune(monkeypatch, ms_of):
 
 def test_the_tuner_keeps_lanes_that_win_and_drops_lanes_that_lose(monkeypatch, capsys):
     T, modes = _tune(monkeypatch, lambda on, n, k: (4.0 if on else 4.7) * n / 100000.0)
-    assert modes == [True, False, True, False, True, False] and T.decided and engine.LANES_RUN is True
+    assert modes == [True, False, True, False] and T.decided and engine.LANES_RUN is True
     assert 0.80 < T.verdict[0] / T.verdict[1] < 0.90
     # two lanes on one hardware queue: slower than one stream -> off, and said so
     T, _ = _tune(monkeypatch, lambda on, n, k: (6.1 if on else 4.5) * n / 100000.0)
