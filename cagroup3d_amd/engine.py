@@ -1203,7 +1203,7 @@ def _schedule(prog, starts, cuts=()):
     return index, {c: cutmap[c] for c in cuts}
 
 
-# The derivation in the library (cg3d_program_schedule, include/cagroup3d_program.h): the same algorithm as `_schedule` below --
+# The derivation in the library (cg3d_program_schedule, include/cagroup3d_program.h): the same algorithm as `_schedule` above --
 # which stays as its specification (CG3D_SCHED_NATIVE=0 runs it; tests/test_engine_lanes.py compares the two row for row) --
 # in ~50 us and outside the interpreter lock.  In Python it cost the thread that compiles the next batch's program 3-4 ms per
 # step, and with the step bound by what the two host threads get done under one lock that was most of what the lanes had won.
