@@ -388,6 +388,7 @@ class Builder:
     # ---------------------------------------------------------------- weights of the step's arena
     def _planned(self, w3, frag, need_plain):
         P = ME._WeightPlan
+        ME._late_needed(w3)
         e = P.singles.get((w3.data_ptr(), ME._wkind(frag)))
         if e is None or e[0].shape != w3.shape or (need_plain and not e[1]) or e[3] is None or P.dirty or P.gen != self.gen:
             ME._planned_single(w3, need_plain, frag)          # records it: converted from the next forward on

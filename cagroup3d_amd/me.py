@@ -1069,12 +1069,58 @@ class _WeightPlan:
         cls.gen += 1
 
 
-# Off by default: measured on one box over 3 x 120 pinned steps, median step 24.5 / 23.5 / 24.7 ms with the split against
-# 23.5 / 23.9 / 23.9 without (p10 equal: 23.3-23.8) -- the heads' AdamW + conversion rows (~1 ms of HBM streaming) beside the
-# backbone's forward pass slow that pass by what they save, and a sixth stream on four hardware queues adds outliers.  Kept
-# behind CG3D_LATE_WEIGHTS=1 with its tests (tests/test_hip_parity.py, tests/test_train_driver.py).
+# Two ways of keeping the late parameters' work out of the device-bound half of the step (CG3D_LATE_WEIGHTS; both measured, both
+# bit-identical to the one-launch forms, neither on by default):
+#   defer   the late rows of the optimizer's update and of the weight conversion are NOT launched where the early rows are; they
+#           wait in `_DEFERRED` and are launched -- on the late stream, in the order they were deferred -- by `run_late()`, which
+#           the dense head calls right after its first blocking read: the device-bound half of the step is over there, the
+#           host-bound half begins, and the device has room for the HBM streaming under the host's work (on the CURRENT stream
+#           the ten blocking reads that follow each wait for it: no gain at all).  Five alternating 30-step bench pairs on a quiet
+#           box: 23.58-23.66 ms per step against 23.55-23.83 (-0.14 ms, 0.6 %) -- for an optimizer step that returns with the class
+#           branches' 73 M parameters not yet updated.  Not worth a default;
+#   stream  the late rows on a stream of their own beside the next backbone forward (round 5, first try): median step 24.5 /
+#           23.5 / 24.7 ms against 23.5 / 23.9 / 23.9 -- the HBM streaming beside the backbone's first layers slows them by what
+#           it saves, and one more stream on four hardware queues adds outliers;
+#   0       (default) one launch for all rows.
+# Whatever reads a late parameter outside this order runs `run_late()` first: the arena look-ups of late weights do, an
+# evaluation forward does at its start, `finish_weights()` and `optim.ClippedAdamW.finish_late()` do.
 _LATE_STREAMS = {}
-LATE_WEIGHTS = os.environ.get("CG3D_LATE_WEIGHTS", "0") == "1"
+LATE_MODE = os.environ.get("CG3D_LATE_WEIGHTS", "0")
+LATE_MODE = {"1": "stream", "": "0"}.get(LATE_MODE, LATE_MODE)
+LATE_WEIGHTS = LATE_MODE in ("stream", "defer")
+_DEFERRED = []                # launches of late rows, in order (LATE_MODE "defer")
+
+
+def defer(fn):
+    _DEFERRED.append(fn)
+
+
+def run_late(join=True):
+    """Launch the deferred late rows.  They go to the late stream (behind the current stream's position): the blocking reads that
+    follow on the current stream -- ten of them between the head's first read and the class program -- must not wait for a
+    millisecond of HBM streaming nobody needs yet.  join: the current stream waits for them (whoever is about to read a late
+    parameter: `_late_needed`, `finish_weights`, the optimizer's `finish_late`); the head passes False right after its first
+    read and lets the first look-up of a late weight join.  Only the issuing thread launches: the dry run's worker reads early
+    weights only, and its current stream is not the step's."""
+    import threading
+    if threading.current_thread() is not threading.main_thread():
+        return
+    if _DEFERRED:
+        dev = torch.cuda.current_device()
+        ls = late_stream(dev)
+        ls.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ls):
+            while _DEFERRED:
+                _DEFERRED.pop(0)()
+        late_mark(dev)
+    if join:
+        late_weights_ready()
+
+
+def _late_needed(w):
+    """A look-up of a late weight's copies while late rows are still deferred or in flight: launch them / wait for them first."""
+    if (_DEFERRED or _LATE_PENDING) and _WeightPlan.early is not None and w.data_ptr() not in _WeightPlan.early:
+        run_late()
 
 
 def late_stream(device):
@@ -1097,7 +1143,8 @@ def late_mark(device):
 
 
 def set_early_weights(params):
-    """Declare the parameters whose copies the detector's FIRST module reads (an iterable of tensors; None: no split)."""
+    """Declare the parameters whose copies the detector reads in the device-bound half of its step (an iterable of tensors;
+    None: no split).  Everything else is late."""
     P = _WeightPlan
     with _CACHE_LOCK:
         P.early = None if params is None else {p.data_ptr() for p in params}
@@ -1105,8 +1152,7 @@ def set_early_weights(params):
 
 
 def late_weights_ready():
-    """The current stream waits for the late rows of this forward's conversion (no-op when there were none).  The detector
-    calls it between its first module and the second; `finish_weights()` does for a forward that ends before."""
+    """The current stream waits for the late stream (stream mode; no-op when nothing is pending there)."""
     while _LATE_PENDING:
         idx = _LATE_PENDING.pop()
         torch.cuda.current_stream(idx).wait_stream(_LATE_STREAMS[idx])
@@ -1142,14 +1188,18 @@ def prepare_weights(training=True, split=False):
             any(g[1] != tuple(w._version for w in g[0]) for g in P.groups.values())
         if need:
             ne = P.n_early if (split and LATE_WEIGHTS and P.early is not None) else P.nrows
-            if 0 < ne < P.nrows:
+            if 0 < ne < P.nrows and LATE_MODE == "defer":
+                lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(ne), lib.stream())
+                tab, late_ptr, nlate = P.table, P.table.data_ptr() + ne * 6 * 8, P.nrows - ne        # (the closure keeps the table alive)
+                defer(lambda: (tab, lib.call("cg3d_spconv_prep_weights_bf16_table", late_ptr, c_int64(nlate), lib.stream())))
+            elif 0 < ne < P.nrows:
                 lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(ne), lib.stream())
                 ls = late_stream(P.table.device)
                 ls.wait_stream(torch.cuda.current_stream())             # behind the optimizer's early rows / whatever wrote the weights here
                 lib.call("cg3d_spconv_prep_weights_bf16_table", P.table.data_ptr() + ne * 6 * 8, c_int64(P.nrows - ne), ls.cuda_stream)
                 late_mark(P.table.device)
             else:
-                late_weights_ready()                   # (an optimizer step may have left the late parameters' update on the late stream)
+                run_late()                             # (an optimizer step may have left the late parameters' update pending)
                 lib.call("cg3d_spconv_prep_weights_bf16_table", ptr(P.table), c_int64(P.nrows), lib.stream())
             for e in P.singles.values():
                 e[2] = e[0]._version
@@ -1161,7 +1211,7 @@ def prepare_weights(training=True, split=False):
 
 def finish_weights():
     """End of the detector forward: from here on the arena may be stale (an optimizer step may follow)."""
-    late_weights_ready()
+    run_late()
     _WeightPlan.live = False
 
 
@@ -1172,6 +1222,7 @@ def _wkind(frag):
 
 def _planned_single(w3, need_plain, frag=False):
     P = _WeightPlan
+    _late_needed(w3)
     kind = _wkind(frag)
     e = P.singles.get((w3.data_ptr(), kind))
     if e is not None and e[0].shape == w3.shape and (e[1] or not need_plain):
@@ -1230,6 +1281,7 @@ def _prep_bf16_group(weights, transposed, frag=False):
     (the tile kernel's operand, cg3d_spconv_prep_weights_frag)."""
     lib = _lib.get()
     G, (K, cin, cout) = len(weights), weights[0].shape
+    _late_needed(weights[0])
     key = tuple(w.data_ptr() for w in weights)
     kind = _wkind(frag)
     g = _WeightPlan.groups.get((key, transposed, kind))

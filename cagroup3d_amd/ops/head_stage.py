@@ -10,6 +10,7 @@ from ctypes import c_float, c_int32, c_int64
 import torch
 
 from .. import _lib
+from .. import me as _me
 from .._lib import ptr
 
 
@@ -32,6 +33,9 @@ def class_rows(hit, coords, pad_row, offsets, n_vote, voxel_size, ts, vs_tab, ex
         # stage's read -- the first of the step that waits for the device -- finds its result ready when they return
         before_read()
     sel = totals[:C].tolist()                                     # the stage's host read (the reference: torch.nonzero)
+    # the device-bound half of the step ends with this read: what was kept out of it (the class branches' optimizer rows and
+    # weight copies, me.LATE_MODE "defer") is launched now, under the host's work on the class maps
+    _me.run_late(join=False)
     T = (sum(sel) + C * n_batch) * (n_vote + 1)
     out = torch.empty((T, 9), dtype=torch.int32, device=dev)      # one allocation: fine | coarse | src (16-byte aligned rows first)
     flat = out.view(-1)

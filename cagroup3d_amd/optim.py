@@ -22,7 +22,6 @@ import torch
 CHUNK = 1 << 15          # elements per table row of the fused step (one 256-thread workgroup each)
 FUSED_NORM = os.environ.get("CG3D_FUSED_NORM", "1") != "0"      # gradient norm + clip coefficient by cg3d_grad_norm_clip
 FUSED_STEP = os.environ.get("CG3D_FUSED_ADAMW", "1") != "0"
-LATE_ROWS = os.environ.get("CG3D_LATE_WEIGHTS", "0") == "1"      # set_early(): the late parameters' rows on the late stream
 
 
 class ClippedAdamW(torch.optim.AdamW):
@@ -34,13 +33,12 @@ class ClippedAdamW(torch.optim.AdamW):
         self._late_hold = None      # what the late rows of the last step read (kept until the next step: see _fused_step)
 
     def set_early(self, params):
-        """Split the fused update in two: the rows of `params` (the detector's first module -- they must lead the parameter
-        list) on the current stream, the rest on `me.late_stream()`, where the next forward's conversion of the same weights
-        follows (me.prepare_weights(split=True)) and the current stream joins at me.late_weights_ready().  The late parameters
-        -- 107 of the detector's 126 M sit in the class branches, first read ~5 ms into the step -- are then updated and
-        converted beside the backbone's forward pass instead of in front of it.  The caller owns the consequence: after
-        clip_and_step() the late parameters are final only once the current stream has waited (`finish_late()`, or the next
-        detector forward); `state_dict()` waits by itself.  None: one launch for all rows, as before."""
+        """Split the fused update in two: the rows of `params` (everything the next step reads in its device-bound half) now, on
+        the current stream; the rest -- 107 of the detector's 126.5 M parameters sit in the class branches, first read behind the
+        dense head's first blocking read -- deferred to `me.run_late()` (me.LATE_MODE "defer": launched by the head after that
+        read, on the current stream, in front of the conversion of the same weights), or on `me.late_stream()` ("stream").  The
+        caller owns the consequence: after clip_and_step() the late parameters are final only once `finish_late()` has run (the
+        next detector forward does by itself, `state_dict()` too).  None: one launch for all rows, as before."""
         self._early = None if params is None else {id(p) for p in params}
         self._plan = None
 
@@ -49,7 +47,7 @@ class ClippedAdamW(torch.optim.AdamW):
         forward: checkpoints, evaluation of another module, parameter statistics)."""
         from . import me
         if self._late_hold is not None:
-            me.late_weights_ready()
+            me.run_late()
             self._late_hold = None
 
     def state_dict(self):
@@ -120,27 +118,24 @@ class ClippedAdamW(torch.optim.AdamW):
                 plan = self._plan = None
         if plan is None:
             rows, pid, k = [], [], 0
-            split, seen_late = 0, False          # split: first row of the late parameters (0: no split)
+            late_rows, late_pid = [], []         # the late parameters' rows trail the table (pid keeps the parameter's place in `grads`)
             for group, ps, m1, m2, steps in lean:
                 for p, a, b in zip(ps, m1, m2):
-                    if self._early is not None:
-                        if id(p) not in self._early:
-                            if not seen_late:
-                                seen_late, split = True, len(rows)
-                        elif seen_late:
-                            split = -1               # an early parameter behind a late one: no split
                     if not (p.dtype == a.dtype == b.dtype == torch.float32 and p.is_contiguous() and a.is_contiguous() and b.is_contiguous()):
                         self._plan = False
                         return None
                     n = p.numel()
+                    late = self._early is not None and id(p) not in self._early
                     for o in range(0, n, CHUNK):
-                        rows.append((p.data_ptr(), a.data_ptr(), b.data_ptr(), o, min(CHUNK, n - o)))
-                        pid.append(k)
+                        (late_rows if late else rows).append((p.data_ptr(), a.data_ptr(), b.data_ptr(), o, min(CHUNK, n - o)))
+                        (late_pid if late else pid).append(k)
                     k += 1
+            split = len(rows) if (late_rows and rows) else 0
+            rows, pid = rows + late_rows, pid + late_pid
             plan = self._plan = (me.h2d(np.asarray(rows, dtype=np.int64), torch.int64, dev), me.h2d(np.asarray(pid, dtype=np.int32), torch.int32, dev),
                                  len(rows), [g["params"] for g in self.param_groups],
                                  [t.data_ptr() for _, ps, m1, m2, _ in lean for ts in (ps, m1, m2) for t in ts],
-                                 split if (split > 0 and LATE_ROWS) else 0)
+                                 split if (split > 0 and me.LATE_WEIGHTS) else 0)
         if plan is False:
             return None
         if any(g.dtype != torch.float32 or not g.is_contiguous() for g in flat_grads):
@@ -175,19 +170,24 @@ class ClippedAdamW(torch.optim.AdamW):
         hyper = (c_float(g0["lr"]), c_float(beta1), c_float(beta2), c_float(g0["eps"]), c_float(g0["weight_decay"]),
                  c_float(1.0 - beta1 ** t), c_float(1.0 - beta2 ** t))
         ne = plan[5]
-        self.finish_late()                  # (a previous step's late rows nobody waited for: they read the buffers we are about to drop)
+        self.finish_late()                  # (a previous step's late rows nobody asked for yet: they read the buffers we are about to drop)
         if ne:
-            # early rows here, late rows on the late stream behind the norm (= behind every gradient).  What the late rows read --
-            # the gradients (zero_grad(set_to_none=True) drops the parameters' references right after this call, and the allocator
-            # would hand their memory to the next allocation on THIS stream), the pointer table, the coefficient -- stays
-            # referenced until the next step
+            # early rows here; the late rows behind the norm (= behind every gradient) but NOT now: deferred to me.run_late()
+            # (the dense head calls it when the device-bound half of the next step is over), or -- stream mode -- on the late
+            # stream.  What the late rows read -- the gradients (zero_grad(set_to_none=True) drops the parameters' references right
+            # after this call, and the allocator would hand their memory to the next allocation on THIS stream), the pointer
+            # table, the coefficient -- stays referenced until they have been launched and the next step begins
             lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(ne), gp.data_ptr(), coef.data_ptr(), *hyper, lib.stream())
-            ls = me.late_stream(dev)
-            ls.wait_stream(torch.cuda.current_stream())
-            lib.call("cg3d_adamw_step", plan[0].data_ptr() + ne * 5 * 8, plan[1].data_ptr() + ne * 4, c_int64(plan[2] - ne), gp.data_ptr(),
-                     coef.data_ptr(), *hyper, ls.cuda_stream)
-            me.late_mark(dev)
-            self._late_hold = (dev, flat_grads, gp, coef, total)
+            late = (plan[0].data_ptr() + ne * 5 * 8, plan[1].data_ptr() + ne * 4, c_int64(plan[2] - ne), gp.data_ptr(), coef.data_ptr()) + hyper
+            hold = (dev, flat_grads, gp, coef, total, plan)
+            if me.LATE_MODE == "defer":
+                me.defer(lambda: (hold, lib.call("cg3d_adamw_step", *late, lib.stream())))
+            else:
+                ls = me.late_stream(dev)
+                ls.wait_stream(torch.cuda.current_stream())
+                lib.call("cg3d_adamw_step", *late, ls.cuda_stream)
+                me.late_mark(dev)
+            self._late_hold = hold
         else:
             lib.call("cg3d_adamw_step", plan[0].data_ptr(), plan[1].data_ptr(), c_int64(plan[2]), gp.data_ptr(), coef.data_ptr(), *hyper, lib.stream())
         return total

@@ -99,11 +99,15 @@ class CAGroup3D(Detector3DTemplate):
         self.semantic_value = self.model_cfg.SEMANTIC_THR
 
     def split_late_parameters(self, optimizer=None):
-        """Everything but the backbone's parameters is first read behind the backbone's forward pass: their optimizer rows
-        (optim.ClippedAdamW.set_early) and their bf16 / split copies (me.set_early_weights) go to the late stream and run beside
-        that pass; `forward` joins the streams between its first and its second module.  Whoever reads parameters outside a
-        detector forward after an optimizer step calls `optimizer.finish_late()` first (train.checkpoint_state does)."""
-        early = list(self.backbone_3d.parameters())
+        """The class branches' parameters -- 107 of the detector's 126.5 M, the per-class 9^3 / 5^3 / transposed / fuse
+        convolutions and their BatchNorms (`cagroup_head.py:227-282`) -- are first read behind the dense head's first blocking read,
+        i.e. after the device-bound half of the step.  Their optimizer rows (optim.ClippedAdamW.set_early) and their bf16 / split
+        copies (me.set_early_weights) are kept out of that half: deferred until `me.run_late()` (called by the head right after
+        that read; me.LATE_MODE).  Whoever reads parameters outside a detector forward after an optimizer step calls
+        `optimizer.finish_late()` first (train.checkpoint_state does)."""
+        names = ("cls_individual_out", "cls_individual_expand_out", "cls_individual_up", "cls_individual_fuse")
+        late = {id(p) for n, p in self.dense_head.named_parameters() if n.startswith(names)}
+        early = [p for p in self.parameters() if id(p) not in late]
         ME.set_early_weights(early)
         if optimizer is not None and hasattr(optimizer, "set_early"):
             optimizer.set_early(early)
@@ -214,6 +218,8 @@ class CAGroup3D(Detector3DTemplate):
         ME._ROWS16.clear()
         ME._ROWS48.clear()
         ME._STATS.clear()
+        if not self.training:
+            ME.run_late()                           # (an optimizer step's late rows may still be deferred: evaluation reads everything)
         ME.zero_arena().reset()                     # a fresh zero block for this step's statistics tables
         ME.WANT_BN_STATS = bool(self.training)      # evaluation: no BatchNorm takes the conv epilogue's partial sums
         # the bf16 copies of every conv weight in one launch; the layers of THIS forward take them from the arena
@@ -237,7 +243,7 @@ class CAGroup3D(Detector3DTemplate):
             with ME.precision_scope(ME.HEAD_PRECISION if i > 0 else None):
                 batch_dict.update(module(batch_dict))
             if i == 0:
-                ME.late_weights_ready()                 # the heads' weight copies (and, in training, their AdamW update) are behind us
+                ME.late_weights_ready()                 # (stream mode: the late stream's work is behind us; defer mode: see head_stage.class_rows)
             if i == 0 and self.training:
                 # the per-scene views of the raw points (the losses' scene_points) cost one host read of the scene sizes.  The
                 # dense head takes it where its own first blocking read is -- after the backbone AND its coordinate-independent

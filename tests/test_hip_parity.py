@@ -599,13 +599,16 @@ def test_pinned_staging_ring_survives_wraparound(hip):
 
 
 @pytest.mark.gpu
-def test_weight_plan_early_and_late_rows_equal_the_single_launch(hip):
-    """me.set_early_weights + prepare_weights(split=True): the early weights' rows lead the table and are converted on the current
-    stream, the others on the late stream; after late_weights_ready() every copy holds the bits of the one-launch conversion,
-    and an unsplit call (split=False) waits for the late stream by itself."""
+@pytest.mark.parametrize("mode", ["defer", "stream"])
+def test_weight_plan_early_and_late_rows_equal_the_single_launch(hip, mode):
+    """me.set_early_weights + prepare_weights(split=True): the early weights' rows lead the table and are converted now, the
+    others when me.run_late() says so (defer) or on the late stream (stream); afterwards every copy holds the bits of the
+    one-launch conversion.  A look-up of a late weight while its rows are deferred launches them by itself, and an unsplit call
+    (split=False) flushes first."""
     me._WeightPlan.reset()
     me.PRECISION = 1
-    flag, me.LATE_WEIGHTS = me.LATE_WEIGHTS, True
+    keep = (me.LATE_MODE, me.LATE_WEIGHTS)
+    me.LATE_MODE, me.LATE_WEIGHTS = mode, True
     try:
         torch.manual_seed(0)
         ws = [torch.randn(27, 64, 64, device="cuda"), torch.randn(8, 72, 48, device="cuda"), torch.randn(27, 128, 256, device="cuda")]
@@ -624,13 +627,16 @@ def test_weight_plan_early_and_late_rows_equal_the_single_launch(hip):
         for step in range(2):
             me.prepare_weights(training=True, split=True)
             assert me._WeightPlan.nrows == nrows and me._WeightPlan.n_early == 8 * 2, (me._WeightPlan.nrows, me._WeightPlan.n_early)
-            assert me._LATE_PENDING, "the late rows must be on the late stream"
-            early = me._prep_bf16_both(ws[1])                # early: valid without the join
-            me.late_weights_ready()
-            assert not me._LATE_PENDING
-            got = [me._prep_bf16_both(w) for w in ws]
+            assert (len(me._DEFERRED) == 1) if mode == "defer" else bool(me._LATE_PENDING), "the late rows must not have run here"
+            early = me._prep_bf16_both(ws[1])                # early: valid without anything else
+            assert (len(me._DEFERRED) == 1) if mode == "defer" else bool(me._LATE_PENDING)
+            if step == 0:
+                me.run_late()
+            got = [me._prep_bf16_both(w) for w in ws]        # (step 1: the look-up of a late weight launches the deferred rows)
+            assert not me._DEFERRED
             got_g = (me._prep_bf16_group(grp, True), me._prep_bf16_group(grp, False))
             me.finish_weights()
+            assert not me._LATE_PENDING
             with torch.no_grad():
                 exp = [me._prep_bf16_both(w) for w in ws]    # converted on the spot (the arena is not trusted outside a forward)
             for (a_t, a_p), (b_t, b_p), (r_t, r_p) in zip(got, exp, ref):
@@ -640,12 +646,13 @@ def test_weight_plan_early_and_late_rows_equal_the_single_launch(hip):
             for w in ws + grp:
                 w.add_(0.25)
         me.prepare_weights(training=True, split=True)
-        assert me._LATE_PENDING
-        me.prepare_weights(training=True)                    # unsplit: joins first, one launch
-        assert not me._LATE_PENDING
+        assert me._DEFERRED or me._LATE_PENDING
+        me.prepare_weights(training=True)                    # unsplit: flushes first, one launch
+        assert not me._DEFERRED and not me._LATE_PENDING
         me.finish_weights()
     finally:
-        me.LATE_WEIGHTS = flag
+        me._DEFERRED.clear()
+        me.LATE_MODE, me.LATE_WEIGHTS = keep
         me.set_early_weights(None)
         me._WeightPlan.reset()
         me.PRECISION = 0

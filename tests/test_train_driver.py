@@ -252,50 +252,62 @@ def test_fused_clip_adamw_launch_matches_torch_on_device(hip):
 
 
 @pytest.mark.gpu
-def test_late_rows_of_the_fused_step_equal_the_one_launch_step(hip):
-    """ClippedAdamW.set_early: the early parameters' rows on the current stream, the others on the late stream -- the SAME
-    kernel over two row ranges, so parameters and moments are bit-identical to the one-launch step; the gradients the late
-    rows read survive zero_grad(set_to_none=True) and a burst of allocations on the current stream."""
-    from cagroup3d_amd import me, optim
+@pytest.mark.parametrize("mode", ["defer", "stream"])
+def test_late_rows_of_the_fused_step_equal_the_one_launch_step(hip, mode):
+    """ClippedAdamW.set_early: the early parameters' rows now, the others deferred to me.run_late() (or on the late stream) --
+    the SAME kernel over two row ranges, so parameters and moments are bit-identical to the one-launch step; the gradients the
+    late rows read survive zero_grad(set_to_none=True) and a burst of allocations on the current stream; in the defer mode the
+    late parameters do not move until run_late()."""
+    from cagroup3d_amd import me
     from cagroup3d_amd.optim import ClippedAdamW
-    flag, optim.LATE_ROWS = optim.LATE_ROWS, True
-    with _lib.use_library(hip):
-        torch.manual_seed(3)
-        shapes = [(3,), (70001,), (129, 257), (27, 64, 64), (5,), (32768,), (2_000_000,)]
-        pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
-        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
-        oa, ob = ClippedAdamW(pa, lr=1e-2, weight_decay=0.02), ClippedAdamW(pb, lr=1e-2, weight_decay=0.02)
-        ob.set_early(pb[:3])
-        for it in range(5):
-            gs = [torch.randn_like(p) * (30.0 if it % 2 else 0.01) for p in pa]
-            for ps in (pa, pb):
-                for p, g in zip(ps, gs):
-                    p.grad = g.clone()
-            na = oa.clip_and_step(1.0)
-            nb = ob.clip_and_step(1.0)
-            oa.zero_grad(set_to_none=True)
-            ob.zero_grad(set_to_none=True)
-            junk = [torch.full((2_000_000,), float("nan"), device="cuda") for _ in range(4)]      # would land in freed gradients
-            del junk
-            assert torch.equal(na, nb)
-            if it >= 1:
-                assert ob._plan[5] > 0 and ob._late_hold is not None, "the split step must have run"
-            ob.finish_late()
-            assert ob._late_hold is None
-        torch.cuda.synchronize()
-        for a, b in zip(pa, pb):
-            assert torch.equal(a, b)
-            assert torch.equal(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) and torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"])
-        # an early parameter behind a late one: no split (one launch), same results
-        oc = ClippedAdamW(pb, lr=1e-2, weight_decay=0.02)
-        oc.set_early([pb[0], pb[4]])
-        for it in range(3):
+    keep = (me.LATE_MODE, me.LATE_WEIGHTS)
+    me.LATE_MODE, me.LATE_WEIGHTS = mode, True
+    try:
+        with _lib.use_library(hip):
+            torch.manual_seed(3)
+            shapes = [(3,), (70001,), (129, 257), (27, 64, 64), (5,), (32768,), (2_000_000,)]
+            pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+            pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+            oa, ob = ClippedAdamW(pa, lr=1e-2, weight_decay=0.02), ClippedAdamW(pb, lr=1e-2, weight_decay=0.02)
+            early = [pb[0], pb[2], pb[5]]                       # not a prefix of the parameter list: the late rows trail the TABLE
+            ob.set_early(early)
+            for it in range(5):
+                gs = [torch.randn_like(p) * (30.0 if it % 2 else 0.01) for p in pa]
+                for ps in (pa, pb):
+                    for p, g in zip(ps, gs):
+                        p.grad = g.clone()
+                before = [p.detach().clone() for p in pb]
+                na = oa.clip_and_step(1.0)
+                nb = ob.clip_and_step(1.0)
+                oa.zero_grad(set_to_none=True)
+                ob.zero_grad(set_to_none=True)
+                junk = [torch.full((2_000_000,), float("nan"), device="cuda") for _ in range(4)]      # would land in freed gradients
+                del junk
+                assert torch.equal(na, nb)
+                if it >= 1:
+                    assert ob._plan[5] > 0 and ob._late_hold is not None, "the split step must have run"
+                    if mode == "defer":
+                        torch.cuda.synchronize()
+                        for p, q in zip(pb, before):
+                            assert torch.equal(p, q) == (not any(p is e for e in early)), "late parameters wait for run_late()"
+                        assert len(me._DEFERRED) == 1
+                ob.finish_late()
+                assert ob._late_hold is None and not me._DEFERRED and not me._LATE_PENDING
+            torch.cuda.synchronize()
+            for a, b in zip(pa, pb):
+                assert torch.equal(a, b)
+                assert torch.equal(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) and torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"])
+            # state_dict() flushes by itself
             for p in pb:
                 p.grad = torch.randn_like(p)
-            oc.clip_and_step(1.0)
-        assert oc._plan[5] == 0 and oc._late_hold is None
+            ob.clip_and_step(1.0)
+            assert ob._late_hold is not None
+            ob.state_dict()
+            assert ob._late_hold is None and not me._DEFERRED
+    finally:
+        me._DEFERRED.clear()
         me._LATE_PENDING.clear()
-    optim.LATE_ROWS = flag
+        me.LATE_MODE, me.LATE_WEIGHTS = keep
 
 
 def _worker_eval(rank, world, port, out):

@@ -22,6 +22,7 @@ dev = torch.device("cuda", 0)
 model, cfg = bench.make_model("scannet", True, dev)
 model.train()
 opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
+model.split_late_parameters(opt)            # as bench.py does
 batch = build_model.synthetic_batch("S50k", int(os.environ.get("BATCH", "4")), device=dev)
 for _ in range(6):
     bench.train_step(model, opt, batch, 10.0)
