@@ -304,7 +304,7 @@ def main():
     else:
         opt = ClippedAdamW(model.parameters(), lr=cfg.OPTIMIZATION.LR, weight_decay=cfg.OPTIMIZATION.WEIGHT_DECAY)
     if hasattr(model, "split_late_parameters"):
-        model.split_late_parameters(opt)            # the heads' AdamW rows and weight copies beside the next backbone pass (CG3D_LATE_WEIGHTS=0: off)
+        model.split_late_parameters(opt)            # (only with CG3D_LATE_WEIGHTS=defer / stream: the class branches' AdamW rows and weight copies out of the device-bound half)
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
     batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)
