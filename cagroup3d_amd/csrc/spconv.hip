@@ -528,9 +528,22 @@ extern "C" int cg3d_spconv_prep_weights_bf16_multi(const float *W0, const float 
 // spend 55 launches of 15 us on them).  Row b of the table describes the 64 x 64 tile block b converts:
 //   { address of the fp32 slot [cin][cout], address of its transposed bf16 copy or 0, address of its plain bf16 copy or
 //     0, cin, cout, tile index = ci_tile * ceil(cout / 64) + co_tile }
-__global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__restrict__ table) {
+// PREP_ROWS table rows per workgroup: one 64 x 64 tile is 16 KB in and 8-48 KB out -- at one tile per workgroup the launch was
+// 48 495 workgroups of a few hundred nanoseconds each for the model's 126.5 M parameters (492 us, 3.6 TB/s against the 5.8 TB/s
+// of the optimiser's pass over the same parameters).  Four tiles per workgroup: 463 us; sixteen: 488 -- what is left is the
+// 16-byte pieces of the transposed / fragment-order copies, not the workgroup count.
+#define PREP_ROWS 4
+__device__ static void prep_weights_tile(const int64_t *__restrict__ row, uint16_t (*T)[64][72]);
+__global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__restrict__ table, int64_t nrows) {
     __shared__ __attribute__((aligned(16))) uint16_t T[2][64][72];       // 144-byte rows: 16-byte aligned pieces; [1]: the lo parts (split rows)
-    const int64_t *row = table + (int64_t)blockIdx.x * 6;
+    for (int q = 0; q < PREP_ROWS; q++) {
+        const int64_t b = (int64_t)blockIdx.x * PREP_ROWS + q;
+        if (b >= nrows) return;                                           // (uniform)
+        if (q) __syncthreads();                                           // the previous tile's readers are done with T
+        prep_weights_tile(table + b * 6, T);
+    }
+}
+__device__ static void prep_weights_tile(const int64_t *__restrict__ row, uint16_t (*T)[64][72]) {
     const float *src = reinterpret_cast<const float *>(row[0]);
     uint16_t *Wb_t = reinterpret_cast<uint16_t *>(row[1]);
     uint16_t *Wb = reinterpret_cast<uint16_t *>(row[2]);
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(256) void k_prep_weights_table(const int64_t *__res
 extern "C" int cg3d_spconv_prep_weights_bf16_table(const int64_t *table, int64_t nrows, cg3d_stream_t stream) {
     if (nrows < 0 || nrows > 0x7fffffffll || (nrows > 0 && !table)) return CG3D_ERR_ARG;
     if (nrows == 0) return CG3D_OK;
-    hipLaunchKernelGGL(k_prep_weights_table, dim3((unsigned)nrows), dim3(256), 0, cg3d_hs(stream), table);
+    hipLaunchKernelGGL(k_prep_weights_table, dim3((unsigned)((nrows + PREP_ROWS - 1) / PREP_ROWS)), dim3(256), 0, cg3d_hs(stream), table, nrows);
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;
 }
