@@ -43,6 +43,10 @@ extern "C" int cg3d_program_schedule(const int64_t *prog, int64_t n, const int64
                                      int64_t *cut_index, int64_t *n_out, int64_t *n_events) {
     return cg3d_program_schedule_impl(prog, n, starts, region_first, cuts, ncut, out, cap, index, cut_index, n_out, n_events);
 }
+extern "C" int cg3d_host_segments(const int64_t *off, int32_t K, int32_t G, int64_t maxlen, int32_t xcd_order, const int64_t *row_bounds,
+                                  int64_t n_rows, int32_t *out, int64_t cap, int64_t *nseg) {
+    return cg3d_host_segments_impl(off, K, G, maxlen, xcd_order, row_bounds, n_rows, out, cap, nseg);
+}
 extern "C" int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr) { return cg3d_program_roles_impl(opcode, rd, wr); }
 extern "C" int cg3d_event_create_sync(int64_t *handle) {
     if (!handle) return CG3D_ERR_ARG;

@@ -290,23 +290,48 @@ class KernelMap:
         if seg is None:
             pin, _, off, _ = self.pairs(row_bounds)
             G = 1 if row_bounds is None else len(row_bounds) - 1
-            nslot = self.K * G
-            counts = off[1:] - off[:-1]
-            nseg_s = (counts + maxlen - 1) // maxlen
-            slot = np.repeat(np.arange(nslot, dtype=np.int64), nseg_s)
-            first = np.repeat(np.cumsum(nseg_s) - nseg_s, nseg_s)
-            start = off[slot] + (np.arange(slot.shape[0], dtype=np.int64) - first) * maxlen
-            cnt = np.minimum(maxlen, off[slot + 1] - start)
-            widx = (slot % G) * self.K + slot // G
-            tab = np.stack([widx, start, cnt], 1).astype(np.int32)
-            if SEG_XCD_ORDER and 64 <= tab.shape[0] <= 4096 and maxlen >= 256 and _lib.get().is_device:
-                tab = tab[_xcd_order(slot, start, cnt, off, G, row_bounds, self.n_out)]
+            # by the library (cg3d_host_segments: C, outside the interpreter lock) or by its numpy specification
+            # (tests/test_me_host.py compares them entry for entry)
+            build = _segments_native if SEG_NATIVE else _segments_numpy
+            tab = build(off, self.K, G, maxlen, SEG_XCD_ORDER and _lib.get().is_device, row_bounds, self.n_out)
             seg = (h2d(torch.from_numpy(tab), torch.int32, pin.device), int(tab.shape[0]))
             self._segs[ck] = seg
         return seg
 
 
 SEG_XCD_ORDER = __import__("os").environ.get("CG3D_SEG_XCD", "1") != "0"
+SEG_NATIVE = __import__("os").environ.get("CG3D_SEG_NATIVE", "1") != "0"
+
+
+def _segments_numpy(off, K, G, maxlen, xcd, row_bounds, n_out):
+    """The segment table of `KernelMap.segments` (the specification of cg3d_host_segments)."""
+    nslot = K * G
+    counts = off[1:] - off[:-1]
+    nseg_s = (counts + maxlen - 1) // maxlen
+    slot = np.repeat(np.arange(nslot, dtype=np.int64), nseg_s)
+    first = np.repeat(np.cumsum(nseg_s) - nseg_s, nseg_s)
+    start = off[slot] + (np.arange(slot.shape[0], dtype=np.int64) - first) * maxlen
+    cnt = np.minimum(maxlen, off[slot + 1] - start)
+    widx = (slot % G) * K + slot // G
+    tab = np.stack([widx, start, cnt], 1).astype(np.int32)
+    if xcd and 64 <= tab.shape[0] <= 4096 and maxlen >= 256:
+        tab = tab[_xcd_order(slot, start, cnt, off, G, row_bounds, n_out)]
+    return tab
+
+
+def _segments_native(off, K, G, maxlen, xcd, row_bounds, n_out):
+    """int32 [nseg, 3] segment table of `KernelMap.segments` built by cg3d_host_segments."""
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    cap = int(K) * int(G) + int(off[-1] - off[0]) // int(maxlen) + 1
+    out = np.empty((max(cap, 1), 3), dtype=np.int32)
+    rb = None if row_bounds is None else np.asarray(row_bounds, dtype=np.int64)
+    n = ctypes.c_int64(0)
+    rc = _lib.get().raw("cg3d_host_segments")(off.ctypes.data, int(K), int(G), int(maxlen), 1 if xcd else 0,
+                                              None if rb is None else rb.ctypes.data, int(n_out), out.ctypes.data, cap,
+                                              ctypes.cast(ctypes.pointer(n), ctypes.c_void_p))
+    if rc != 0:
+        raise _lib.CG3DError("cg3d_host_segments failed with status %d" % rc)
+    return out[:n.value]
 SELF_MAP_HALF = __import__("os").environ.get("CG3D_SELF_MAP_HALF", "1") != "0"
 # Off by default: measured on MI355X (82107 rows, 128 -> 128) the row-block order cuts the memory-side traffic of the launch
 # from 3.4 x to 1.4 x the tensors' bytes (L2 hit rate of the gathers 33 % -> 68 %) but runs 97 us against 78 us -- 2.7 x more

@@ -97,6 +97,16 @@ int cg3d_program_schedule(const int64_t *prog, int64_t n, const int64_t *starts,
 /* bit c of *rd / *wr: column c of a row of `opcode` is a pointer the call reads / writes */
 int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr);
 
+/* Host-side table of a pair-list launch (no device work; the host language's numpy form cost the issuing thread ~80 us per
+ * table, ~70 tables per training step over its two threads).  Rows { weight index, start, count <= maxlen } cover the pairs of
+ * every (offset k, group g) slot in slot order (slot = k * G + g; off int64 [K * G + 1] = the slots' first pairs; weight index
+ * = g * K + k).  xcd_order != 0 and 64 <= rows <= 4096 and maxlen >= 256: the rows are re-ordered so that workgroup i (XCD
+ * i % 8) sweeps ONE eighth of the tensor's rows through all offsets -- sorted (stable) by the position of a segment inside its
+ * slot's list (mapped through row_bounds [G + 1] / n_rows when the groups are row ranges), cut into 8 runs, dealt out round
+ * robin.  out int32 [cap][3]; *nseg rows written; CG3D_ERR_ARG when cap is too small (K * G + pairs / maxlen + 1 suffices). */
+int cg3d_host_segments(const int64_t *off, int32_t K, int32_t G, int64_t maxlen, int32_t xcd_order, const int64_t *row_bounds,
+                       int64_t n_rows, int32_t *out, int64_t cap, int64_t *nseg);
+
 /* Timing events for the rows of a program (CG3D_OP_EVENT_RECORD): handles are hipEvent_t on the device library; the oracle
  * hands out dummies and reports 0 ms. */
 int cg3d_event_create(int64_t *handle);
@@ -507,6 +517,75 @@ done:
     return rc;
 }
 #undef CG3D_B
+
+/* ---- cg3d_host_segments -------------------------------------------------------------------------------------------------- */
+static void cg3d_seg_msort(int64_t *idx, int64_t *tmp, const double *key, int64_t n) {       /* stable, by key */
+    for (int64_t w = 1; w < n; w <<= 1) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            const int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int64_t a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) tmp[o++] = key[idx[b]] < key[idx[a]] ? idx[b++] : idx[a++];
+            while (a < mid) tmp[o++] = idx[a++];
+            while (b < hi) tmp[o++] = idx[b++];
+        }
+        memcpy(idx, tmp, (size_t)n * sizeof(int64_t));
+    }
+}
+static int cg3d_host_segments_impl(const int64_t *off, int32_t K, int32_t G, int64_t maxlen, int32_t xcd_order,
+                                   const int64_t *row_bounds, int64_t n_rows, int32_t *out, int64_t cap, int64_t *nseg) {
+    if (!off || !out || !nseg || K < 1 || G < 1 || maxlen < 1 || cap < 0) return CG3D_ERR_ARG;
+    const int64_t nslot = (int64_t)K * G;
+    int64_t n = 0;
+    for (int64_t s = 0; s < nslot; s++) {
+        const int64_t c = off[s + 1] - off[s];
+        if (c < 0) return CG3D_ERR_ARG;
+        n += (c + maxlen - 1) / maxlen;
+    }
+    if (n > cap) return CG3D_ERR_ARG;
+    *nseg = n;
+    const int reorder = xcd_order && n >= 64 && n <= 4096 && maxlen >= 256;
+    int32_t *tab = out;
+    double *pos = NULL;
+    int64_t *idx = NULL, *tmp = NULL, *place = NULL;
+    int32_t *plain = NULL;
+    if (reorder) {
+        const int64_t run = (n + 7) / 8;
+        pos = (double *)malloc((size_t)n * sizeof(double));
+        idx = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+        tmp = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+        place = (int64_t *)malloc((size_t)run * 8 * sizeof(int64_t));
+        plain = (int32_t *)malloc((size_t)n * 3 * sizeof(int32_t));
+        if (!pos || !idx || !tmp || !place || !plain) { free(pos); free(idx); free(tmp); free(place); free(plain); return CG3D_ERR_LAUNCH; }
+        tab = plain;
+    }
+    int64_t i = 0;
+    for (int64_t s = 0; s < nslot; s++) {
+        const int64_t c = off[s + 1] - off[s], k = s / G, g = s % G;
+        for (int64_t start = off[s]; start < off[s + 1]; start += maxlen, i++) {
+            const int64_t cnt = off[s + 1] - start < maxlen ? off[s + 1] - start : maxlen;
+            tab[3 * i] = (int32_t)(g * K + k);
+            tab[3 * i + 1] = (int32_t)start;
+            tab[3 * i + 2] = (int32_t)cnt;
+            if (reorder) {
+                double p = ((double)(start - off[s]) + 0.5 * (double)cnt) / (double)(c > 1 ? c : 1);
+                if (row_bounds) p = ((double)row_bounds[g] + p * ((double)row_bounds[g + 1] - (double)row_bounds[g])) / (n_rows > 1 ? (double)n_rows : 1.0);
+                pos[i] = p;
+                idx[i] = i;
+            }
+        }
+    }
+    if (reorder) {
+        const int64_t run = (n + 7) / 8;
+        cg3d_seg_msort(idx, tmp, pos, n);
+        for (int64_t q = 0; q < run * 8; q++) place[q] = -1;
+        for (int64_t r = 0; r < n; r++) place[(r % run) * 8 + r / run] = idx[r];      /* rank r -> run r / run, place r % run in it */
+        int64_t o = 0;
+        for (int64_t q = 0; q < run * 8; q++)
+            if (place[q] >= 0) { memcpy(out + 3 * o, plain + 3 * place[q], 3 * sizeof(int32_t)); o++; }
+        free(pos); free(idx); free(tmp); free(place); free(plain);
+    }
+    return CG3D_OK;
+}
 static int cg3d_program_run_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
     if (nops < 0 || (nops > 0 && !prog) || !streams || nstreams < 1 || nstreams > CG3D_PROG_MAX_LANES) return CG3D_ERR_ARG;
     for (int64_t i = 0; i < nops; i++) {
