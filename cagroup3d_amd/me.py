@@ -2210,7 +2210,10 @@ BN_RED_CHUNKS = int(__import__("os").environ.get("CG3D_BN_RED_CHUNKS", "512"))
 _chunk_cache = {}
 
 
-def _bn_chunks(bounds, device, C=64):
+BN_CHUNKS_NATIVE = __import__("os").environ.get("CG3D_BN_CHUNKS_NATIVE", "1") != "0"
+
+
+def _bn_chunks(bounds, device, C=64, _force_numpy=False):
     """Chunk tables for row groups `bounds` (host tuple of G+1 offsets), cached on the device:
     reduce table (<=1024 chunks per group: few, long chunks for the statistics kernels + their group offsets),
     apply table (many workgroups for the streaming kernels), group_n float32 [G].
@@ -2220,6 +2223,30 @@ def _bn_chunks(bounds, device, C=64):
     rpb = 256 // max(1, min(C // 4, 256))
     step_rows = max(8, min(128 * BN_CHUNK_SCALE, 8 * rpb * BN_CHUNK_SCALE))
     ck = (bounds, device, step_rows, C if BN_RED_DIV else 0)
+
+    def build_native():
+        # the five tables by the library (cg3d_host_bn_chunks: C, outside the interpreter lock); `build` below is the specification
+        b = np.asarray(bounds, dtype=np.int64)
+        G = b.shape[0] - 1
+        cap = 6 * (int(b[-1] - b[0]) // step_rows + G + 2) + 4 * G + 32
+        flat = np.empty(cap, np.int32)
+        offs, sizes = np.zeros(5, np.int64), np.zeros(5, np.int64)
+        nred, napp, tot = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+
+        def ref(x):
+            return ctypes.cast(ctypes.pointer(x), ctypes.c_void_p)
+        rc = _lib.get().raw("cg3d_host_bn_chunks")(b.ctypes.data, G, step_rows, max(step_rows, C // BN_RED_DIV if BN_RED_DIV else 0),
+                                                   BN_RED_CHUNKS, flat.ctypes.data, cap, offs.ctypes.data, sizes.ctypes.data,
+                                                   ref(nred), ref(napp), ref(tot))
+        if rc != 0:
+            raise _lib.CG3DError("cg3d_host_bn_chunks failed with status %d" % rc)
+        dev_flat = h2d(torch.from_numpy(flat[:tot.value]), torch.int32, device)
+        o, z = offs.tolist(), sizes.tolist()
+
+        def piece(i):
+            return dev_flat[o[i]:o[i] + z[i]]
+        return (piece(0).view(-1, 3), int(nred.value), piece(2), piece(3).view(torch.float32), piece(1).view(-1, 3), int(napp.value),
+                piece(4).view(torch.float32).view(-1, 1))
 
     def build():
         b = np.asarray(bounds, dtype=np.int64)
@@ -2257,7 +2284,7 @@ def _bn_chunks(bounds, device, C=64):
             return dev_flat[offs[i]:offs[i] + parts[i].size]
         return (piece(0).view(-1, 3), nred, piece(2), piece(3).view(torch.float32), piece(1).view(-1, 3), napp,
                 piece(4).view(torch.float32).view(-1, 1))
-    return _cached(_chunk_cache, ck, build, 512)
+    return _cached(_chunk_cache, ck, build_native if (BN_CHUNKS_NATIVE and not _force_numpy) else build, 512)
 
 
 class FusedBNActFunction(torch.autograd.Function):

@@ -107,6 +107,16 @@ int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr);
 int cg3d_host_segments(const int64_t *off, int32_t K, int32_t G, int64_t maxlen, int32_t xcd_order, const int64_t *row_bounds,
                        int64_t n_rows, int32_t *out, int64_t cap, int64_t *nseg);
 
+/* Host-side chunk tables of the grouped BatchNorm launches (cg3d_bn_sums / _apply_sums / _bwd_*; no device work), packed for ONE
+ * upload: flat int32 [*total] holds five pieces, each starting at a multiple of 4 words --
+ *   0 reduce chunks [max(nred, 1)][3] = { group, first row, rows }: rows per chunk of group g = max(red_min_rows,
+ *     ceil(rows_g / red_chunks)) (few, long chunks for the statistics kernels);
+ *   1 apply chunks [max(napp, 1)][3]: step_rows rows per chunk;  2 the reduce table's first chunk per group, int32 [G + 1];
+ *   3 max(rows_g, 1) as float32 [G];  4 rows_g / max(rows_g - 1, 1) as float32 [G] (biased -> unbiased variance).
+ * bounds int64 [G + 1] ascending; offs / sizes int64 [5] (words); cap = words available in flat. */
+int cg3d_host_bn_chunks(const int64_t *bounds, int32_t G, int64_t step_rows, int64_t red_min_rows, int64_t red_chunks, int32_t *flat,
+                        int64_t cap, int64_t *offs, int64_t *sizes, int64_t *nred, int64_t *napp, int64_t *total);
+
 /* Timing events for the rows of a program (CG3D_OP_EVENT_RECORD): handles are hipEvent_t on the device library; the oracle
  * hands out dummies and reports 0 ms. */
 int cg3d_event_create(int64_t *handle);
@@ -584,6 +594,57 @@ static int cg3d_host_segments_impl(const int64_t *off, int32_t K, int32_t G, int
             if (place[q] >= 0) { memcpy(out + 3 * o, plain + 3 * place[q], 3 * sizeof(int32_t)); o++; }
         free(pos); free(idx); free(tmp); free(place); free(plain);
     }
+    return CG3D_OK;
+}
+
+/* ---- cg3d_host_bn_chunks ------------------------------------------------------------------------------------------------- */
+static int64_t cg3d_bn_chunk_rows(const int64_t *b, int32_t G, int which, int64_t step_rows, int64_t red_min_rows, int64_t red_chunks,
+                                  int32_t *rows, int32_t *gco) {
+    int64_t n = 0;
+    for (int32_t g = 0; g < G; g++) {
+        const int64_t ng = b[g + 1] - b[g];
+        int64_t step = step_rows;
+        if (which == 0) {
+            const int64_t per = (ng + red_chunks - 1) / red_chunks;      /* ceil; numpy: -(-ng // red_chunks) */
+            step = red_min_rows > per ? red_min_rows : per;
+        }
+        if (step < 1) step = 1;
+        const int64_t nch = (ng + step - 1) / step;
+        if (gco) gco[g] = (int32_t)n;
+        if (rows)
+            for (int64_t j = 0; j < nch; j++) {
+                const int64_t r0 = b[g] + j * step;
+                rows[3 * (n + j)] = g;
+                rows[3 * (n + j) + 1] = (int32_t)r0;
+                rows[3 * (n + j) + 2] = (int32_t)(step < b[g + 1] - r0 ? step : b[g + 1] - r0);
+            }
+        n += nch;
+    }
+    if (gco) gco[G] = (int32_t)n;
+    return n;
+}
+static int cg3d_host_bn_chunks_impl(const int64_t *bounds, int32_t G, int64_t step_rows, int64_t red_min_rows, int64_t red_chunks,
+                                    int32_t *flat, int64_t cap, int64_t *offs, int64_t *sizes, int64_t *nred, int64_t *napp, int64_t *total) {
+    if (!bounds || G < 1 || step_rows < 1 || red_chunks < 1 || !flat || !offs || !sizes || !nred || !napp || !total) return CG3D_ERR_ARG;
+    for (int32_t g = 0; g < G; g++)
+        if (bounds[g + 1] < bounds[g]) return CG3D_ERR_ARG;
+    const int64_t nr = cg3d_bn_chunk_rows(bounds, G, 0, step_rows, red_min_rows, red_chunks, NULL, NULL);
+    const int64_t na = cg3d_bn_chunk_rows(bounds, G, 1, step_rows, red_min_rows, red_chunks, NULL, NULL);
+    sizes[0] = 3 * (nr > 0 ? nr : 1); sizes[1] = 3 * (na > 0 ? na : 1); sizes[2] = G + 1; sizes[3] = G; sizes[4] = G;
+    int64_t tot = 0;
+    for (int q = 0; q < 5; q++) { offs[q] = tot; tot += (sizes[q] + 3) & ~(int64_t)3; }
+    if (tot > cap) return CG3D_ERR_ARG;
+    memset(flat, 0, (size_t)tot * sizeof(int32_t));
+    cg3d_bn_chunk_rows(bounds, G, 0, step_rows, red_min_rows, red_chunks, flat + offs[0], flat + offs[2]);
+    cg3d_bn_chunk_rows(bounds, G, 1, step_rows, red_min_rows, red_chunks, flat + offs[1], NULL);
+    for (int32_t g = 0; g < G; g++) {
+        const int64_t ng = bounds[g + 1] - bounds[g];
+        const double ns = (double)(ng > 1 ? ng : 1), d = ns - 1.0 > 1.0 ? ns - 1.0 : 1.0;
+        const float a = (float)ns, u = (float)(ns / d);
+        memcpy(flat + offs[3] + g, &a, sizeof(float));
+        memcpy(flat + offs[4] + g, &u, sizeof(float));
+    }
+    *nred = nr; *napp = na; *total = tot;
     return CG3D_OK;
 }
 static int cg3d_program_run_lanes(const int64_t *prog, int64_t nops, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {

@@ -49,6 +49,10 @@ int cg3d_host_segments(const int64_t *off, int32_t K, int32_t G, int64_t maxlen,
                        int64_t n_rows, int32_t *out, int64_t cap, int64_t *nseg) {
     return cg3d_host_segments_impl(off, K, G, maxlen, xcd_order, row_bounds, n_rows, out, cap, nseg);
 }
+int cg3d_host_bn_chunks(const int64_t *bounds, int32_t G, int64_t step_rows, int64_t red_min_rows, int64_t red_chunks, int32_t *flat,
+                        int64_t cap, int64_t *offs, int64_t *sizes, int64_t *nred, int64_t *napp, int64_t *total) {
+    return cg3d_host_bn_chunks_impl(bounds, G, step_rows, red_min_rows, red_chunks, flat, cap, offs, sizes, nred, napp, total);
+}
 int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr) { return cg3d_program_roles_impl(opcode, rd, wr); }
 int cg3d_event_create(int64_t *handle) {
     static int64_t next = 1;

@@ -48,3 +48,26 @@ def test_segment_table_refuses_a_short_buffer_and_decreasing_offsets(oracle):
     bad = np.array([0, 600, 500, 1800], dtype=np.int64)
     big = np.empty((64, 3), dtype=np.int32)
     assert f(bad.ctypes.data, 3, 1, 256, 0, None, 10, big.ctypes.data, 64, ctypes.cast(ctypes.pointer(n), ctypes.c_void_p)) != 0
+
+
+@pytest.mark.parametrize("C", [64, 128, 512, 1024])
+def test_bn_chunk_tables_of_the_library_equal_the_numpy_form(oracle, C):
+    import torch
+    rng = np.random.default_rng(C)
+    dev = torch.device("cpu")
+    with _lib.use_library(oracle):
+        cases = [(0, 82107), (0, 1), (0, 0), (0, 5330)]
+        for G in (2, 18):
+            sizes = rng.integers(0, 4000, size=G)
+            sizes[rng.random(G) < 0.2] = 0                      # empty groups
+            cases.append(tuple(np.concatenate([[0], np.cumsum(sizes)]).tolist()))
+        for bounds in cases:
+            me._chunk_cache.clear()
+            a = me._bn_chunks(tuple(bounds), dev, C, _force_numpy=True)
+            me._chunk_cache.clear()
+            b = me._bn_chunks(tuple(bounds), dev, C)
+            me._chunk_cache.clear()
+            assert a[1] == b[1] and a[5] == b[5], (bounds, a[1], b[1], a[5], b[5])
+            for x, y in zip(a, b):
+                if torch.is_tensor(x):
+                    assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), bounds
