@@ -127,6 +127,7 @@ _SIGNATURES = {
     "cg3d_run_program_lanes": (c_int32, [P, c_int64, P, c_int32, P]),
     "cg3d_program_schedule": (c_int32, [P, c_int64, P, P, P, c_int32, P, c_int64, P, P, P, P]),
     "cg3d_program_roles": (c_int32, [c_int32, P, P]),
+    "cg3d_run_program_bound": (c_int32, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int32, P]),
     "cg3d_host_bn_chunks": (c_int32, [P, c_int32, c_int64, c_int64, c_int64, P, c_int64, P, P, P, P, P]),
     "cg3d_host_segments": (c_int32, [P, c_int32, c_int32, c_int64, c_int32, P, c_int64, P, c_int64, P]),
     "cg3d_event_create": (c_int32, [P]),

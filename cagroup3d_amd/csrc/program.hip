@@ -51,6 +51,10 @@ extern "C" int cg3d_host_bn_chunks(const int64_t *bounds, int32_t G, int64_t ste
                                    int64_t cap, int64_t *offs, int64_t *sizes, int64_t *nred, int64_t *napp, int64_t *total) {
     return cg3d_host_bn_chunks_impl(bounds, G, step_rows, red_min_rows, red_chunks, flat, cap, offs, sizes, nred, napp, total);
 }
+extern "C" int cg3d_run_program_bound(const int64_t *prog, int64_t nops, const int64_t *bases, const int64_t *events, int64_t nevents,
+                                      void *zero_ptr, int64_t zero_bytes, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
+    return cg3d_program_run_bound(prog, nops, bases, events, nevents, zero_ptr, zero_bytes, streams, nstreams, fail_at);
+}
 extern "C" int cg3d_program_roles(int32_t opcode, uint32_t *rd, uint32_t *wr) { return cg3d_program_roles_impl(opcode, rd, wr); }
 extern "C" int cg3d_event_create_sync(int64_t *handle) {
     if (!handle) return CG3D_ERR_ARG;

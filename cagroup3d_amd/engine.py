@@ -1447,6 +1447,47 @@ def _run(lib, P, nrows=None, comp=None, lanes_run=None):
         raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, (int(P[fail.value, 0]) & OPCODE_MASK) if 0 <= fail.value < n else -1, rc))
 
 
+# A pass without run-time operands and without timing events is issued from its compiled table as it is: the library applies the
+# region bases and the event handles row by row (cg3d_run_program_bound).  The numpy form -- copy, shift, five masked adds, the
+# event scan, a concatenation with the zero-fill row -- cost the issuing thread ~0.15 ms per pass, seven passes per step, four of
+# them inside the host-bound half.
+BOUND = os.environ.get("CG3D_PROGRAM_BOUND", "1") != "0"
+
+
+def _run_bound(lib, comp, table, bases, zero_ptr, zero_bytes, lo=0, hi=None, lanes_run=None):
+    """Rows [lo, hi) of the compiled (unresolved) `table` with `bases` = {region tag: address}; the zero-fill first (0 bytes: none)."""
+    import ctypes
+    hi = table.shape[0] if hi is None else hi
+    b = np.zeros(16, dtype=np.int64)
+    for r, a in bases.items():
+        b[r >> TAG] = a
+    ev_ptr, nev = None, 0
+    if comp.nevents:
+        pool = getattr(_EVENT_POOL, "h", None)
+        if pool is None or _EVENT_POOL.lib is not lib:
+            pool, _EVENT_POOL.lib = [], lib
+            _EVENT_POOL.h = pool
+        grown = False
+        while len(pool) < comp.nevents:
+            h = ctypes_i64()
+            lib.call("cg3d_event_create_sync", ctypes_ref(h))
+            pool.append(h.value)
+            grown = True
+        arr = getattr(_EVENT_POOL, "arr", None)
+        if arr is None or grown or arr.shape[0] != len(pool):
+            arr = _EVENT_POOL.arr = np.asarray(pool, dtype=np.int64)
+        ev_ptr, nev = arr.ctypes.data, arr.shape[0]
+    streams, ns = _lane_streams(lib)
+    use = ns if (comp.lanes and (LANES_RUN if lanes_run is None else lanes_run)) else 1
+    fail = ctypes.c_int64(-1)
+    rc = lib.raw("cg3d_run_program_bound")(table.ctypes.data + lo * STRIDE * 8, hi - lo, b.ctypes.data, ev_ptr, nev, zero_ptr or None, int(zero_bytes),
+                                           ctypes.cast(streams, ctypes.c_void_p), use, ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    if rc != 0:
+        f = fail.value
+        raise _lib.CG3DError("cg3d_run_program_bound: row %d (opcode %d) failed with status %d"
+                             % (lo + f, (int(table[lo + f, 0]) & OPCODE_MASK) if 0 <= f < hi - lo else -1, rc))
+
+
 # ------------------------------------------------------------------------------------------------ parameter gradients
 # A backward table writes every parameter gradient of its pass into ONE zero-filled buffer.  Handing 200+ parameters a fresh
 # slice each (slice + view + attribute) cost the issuing thread ~1 ms per pass -- inside the stretch of the step where the
@@ -1508,20 +1549,23 @@ class BackboneFunction(torch.autograd.Function):
         arena = torch.empty(zf + zb + act + ALIGN, dtype=torch.uint8, device=feats.device)
         base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
         bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: feats.data_ptr()}
-        P = _resolve(comp.fwd, bases)
         keep = []
-        for r, c, fn in comp.late_f:
-            t = fn()
-            keep.append(t)
-            P[r, c] = t.data_ptr()
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, base, 0, zf)
         prof = bool(ME.KernelProfile.enabled and lib.is_device)
-        if prof:
-            P, recs = _with_events(P, comp.fprof, lib)
-            ME.KernelProfile.records.extend(recs)
         tok = _LaneTuner.begin(comp, lib)
-        _run(lib, np.concatenate([head, P]), comp=comp, lanes_run=tok[0] if tok else None)
+        if BOUND and not comp.late_f and not prof:
+            _run_bound(lib, comp, comp.fwd, bases, base, zf, lanes_run=tok[0] if tok else None)
+        else:
+            P = _resolve(comp.fwd, bases)
+            for r, c, fn in comp.late_f:
+                t = fn()
+                keep.append(t)
+                P[r, c] = t.data_ptr()
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, base, 0, zf)
+            if prof:
+                P, recs = _with_events(P, comp.fprof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, P]), comp=comp, lanes_run=tok[0] if tok else None)
         _LaneTuner.end(tok)
         ctx.comp, ctx.arena, ctx.bases, ctx.feats, ctx.keep, ctx.hooks, ctx.prof = comp, arena, bases, feats, keep, hooks, prof
         p, n, c, p16 = comp.out
@@ -1541,20 +1585,27 @@ class BackboneFunction(torch.autograd.Function):
         bases = dict(ctx.bases)
         pg, views, _ = _pg_views(comp, dy.device)
         bases[R_PG], bases[R_DOUT] = pg.data_ptr(), dy.data_ptr()
-        P = _resolve(comp.bwd, bases)
+        fast = BOUND and not comp.late_b and not ctx.prof
         keep = []
-        for r, c, fn in comp.late_b:
-            t = fn()
-            keep.append(t)
-            P[r, c] = t.data_ptr()
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
         cuts = sorted((row, name) for name, row in comp.marks.items() if name in hooks)
         parts, last = [], 0
-        for row, name in cuts:
-            parts.append((P[last:row], comp_prof_slice(comp.bprof, last, row), name))
-            last = row
-        parts.append((P[last:], comp_prof_slice(comp.bprof, last, P.shape[0]), None))
+        if fast:
+            for row, name in cuts:
+                parts.append(((last, row), None, name))
+                last = row
+            parts.append(((last, comp.bwd.shape[0]), None, None))
+        else:
+            P = _resolve(comp.bwd, bases)
+            for r, c, fn in comp.late_b:
+                t = fn()
+                keep.append(t)
+                P[r, c] = t.data_ptr()
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+            for row, name in cuts:
+                parts.append((P[last:row], comp_prof_slice(comp.bprof, last, row), name))
+                last = row
+            parts.append((P[last:], comp_prof_slice(comp.bprof, last, P.shape[0]), None))
         given = set()
 
         def give(ids):
@@ -1569,10 +1620,13 @@ class BackboneFunction(torch.autograd.Function):
                     given.add(k)
         first = True
         for rows, prof, name in parts:
-            if ctx.prof:
-                rows, recs = _with_events(rows, prof, lib)
-                ME.KernelProfile.records.extend(recs)
-            _run(lib, np.concatenate([head, rows]) if first else rows, comp=comp)
+            if fast:
+                _run_bound(lib, comp, comp.bwd, bases, bases[R_ZB] if first else 0, comp.size[R_ZB] if first else 0, rows[0], rows[1])
+            else:
+                if ctx.prof:
+                    rows, recs = _with_events(rows, prof, lib)
+                    ME.KernelProfile.records.extend(recs)
+                _run(lib, np.concatenate([head, rows]) if first else rows, comp=comp)
             first = False
             if name is not None:
                 fn, ids = hooks[name]
@@ -1655,14 +1709,17 @@ class ClassBranchFunction(torch.autograd.Function):
         arena = torch.empty(zf + zb + act + ALIGN, dtype=torch.uint8, device=xf.device)
         base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
         bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: xf.data_ptr(), R_IN2: xc.data_ptr()}
-        P = _resolve(comp.fwd, bases)
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, base, 0, zf)
         prof = bool(ME.KernelProfile.enabled and lib.is_device)
-        if prof:
-            P, recs = _with_events(P, comp.fprof, lib)
-            ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]), comp=comp)
+        if BOUND and not comp.late_f and not prof:
+            _run_bound(lib, comp, comp.fwd, bases, base, zf)
+        else:
+            P = _resolve(comp.fwd, bases)
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, base, 0, zf)
+            if prof:
+                P, recs = _with_events(P, comp.fprof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, P]), comp=comp)
         ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (xf, xc), prof
         p, n, c, p16 = comp.out
         y = _arena_view(arena, bases, p, n, c)
@@ -1678,13 +1735,16 @@ class ClassBranchFunction(torch.autograd.Function):
         bases = dict(ctx.bases)
         pg, views, _ = _pg_views(comp, dy.device)
         bases[R_PG], bases[R_DOUT] = pg.data_ptr(), dy.data_ptr()
-        P = _resolve(comp.bwd, bases)
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
-        if ctx.prof:
-            P, recs = _with_events(P, comp.bprof, lib)
-            ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]), comp=comp)
+        if BOUND and not comp.late_b and not ctx.prof:
+            _run_bound(lib, comp, comp.bwd, bases, bases[R_ZB], comp.size[R_ZB])
+        else:
+            P = _resolve(comp.bwd, bases)
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+            if ctx.prof:
+                P, recs = _with_events(P, comp.bprof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, P]), comp=comp)
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
                 if prm.requires_grad:
@@ -1768,14 +1828,17 @@ class HeadPreFunction(torch.autograd.Function):
         base = (arena.data_ptr() + ALIGN - 1) & ~(ALIGN - 1)
         bases = {R_ZF: base, R_ZB: base + zf, R_ACT: base + zf + zb, R_IN: x.data_ptr(),
                  R_IN2: x16.data_ptr() if x16 is not None else 0}
-        P = _resolve(comp.fwd, bases)
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, base, 0, zf)
         prof = bool(ME.KernelProfile.enabled and lib.is_device)
-        if prof:
-            P, recs = _with_events(P, comp.fprof, lib)
-            ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]), comp=comp)
+        if BOUND and not comp.late_f and not prof:
+            _run_bound(lib, comp, comp.fwd, bases, base, zf)
+        else:
+            P = _resolve(comp.fwd, bases)
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, base, 0, zf)
+            if prof:
+                P, recs = _with_events(P, comp.fprof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, P]), comp=comp)
         ctx.comp, ctx.arena, ctx.bases, ctx.inputs, ctx.prof = comp, arena, bases, (x, x16), prof
         outs = []
         for p, n, c, p16 in (comp.out, comp.out2):
@@ -1795,18 +1858,21 @@ class HeadPreFunction(torch.autograd.Function):
         d1 = d1.contiguous() if d1 is not None else torch.zeros(shapes[1], dtype=torch.float32, device=ctx.arena.device)
         pg, views, _ = _pg_views(comp, d0.device)
         bases[R_PG], bases[R_DOUT], bases[R_DOUT2] = pg.data_ptr(), d0.data_ptr(), d1.data_ptr()
-        P = _resolve(comp.bwd, bases)
         keep = []
-        for r, c, fn in comp.late_b:
-            t = fn()
-            keep.append(t)
-            P[r, c] = t.data_ptr()
-        head = np.zeros((1, STRIDE), dtype=np.int64)
-        head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
-        if ctx.prof:
-            P, recs = _with_events(P, comp.bprof, lib)
-            ME.KernelProfile.records.extend(recs)
-        _run(lib, np.concatenate([head, P]), comp=comp)
+        if BOUND and not comp.late_b and not ctx.prof:
+            _run_bound(lib, comp, comp.bwd, bases, bases[R_ZB], comp.size[R_ZB])
+        else:
+            P = _resolve(comp.bwd, bases)
+            for r, c, fn in comp.late_b:
+                t = fn()
+                keep.append(t)
+                P[r, c] = t.data_ptr()
+            head = np.zeros((1, STRIDE), dtype=np.int64)
+            head[0, :4] = (OP_MEMSET, bases[R_ZB], 0, comp.size[R_ZB])
+            if ctx.prof:
+                P, recs = _with_events(P, comp.bprof, lib)
+                ME.KernelProfile.records.extend(recs)
+            _run(lib, np.concatenate([head, P]), comp=comp)
         with torch.no_grad():
             for (prm, _), g in zip(comp.params, views):
                 if prm.requires_grad:

@@ -117,6 +117,13 @@ int cg3d_host_segments(const int64_t *off, int32_t K, int32_t G, int64_t maxlen,
 int cg3d_host_bn_chunks(const int64_t *bounds, int32_t G, int64_t step_rows, int64_t red_min_rows, int64_t red_chunks, int32_t *flat,
                         int64_t cap, int64_t *offs, int64_t *sizes, int64_t *nred, int64_t *napp, int64_t *total);
 
+/* cg3d_run_program_lanes on a table that still holds region-relative addresses and event slots: every word >= 2^CG3D_PROG_REGION_SHIFT
+ * of a row becomes bases[word >> shift] + (word's low bits) -- the host language's copy / mask / add over the whole table cost
+ * ~0.15 ms per pass, seven passes per training step -- and RECORD / WAIT rows { opcode, slot, 1 } take events[slot].  Before the
+ * first row zero_bytes bytes at zero_ptr are cleared on streams[0] (the pass's zero-filled region; 0 bytes: nothing). */
+int cg3d_run_program_bound(const int64_t *prog, int64_t nops, const int64_t *bases, const int64_t *events, int64_t nevents,
+                           void *zero_ptr, int64_t zero_bytes, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at);
+
 /* Timing events for the rows of a program (CG3D_OP_EVENT_RECORD): handles are hipEvent_t on the device library; the oracle
  * hands out dummies and reports 0 ms. */
 int cg3d_event_create(int64_t *handle);
@@ -651,6 +658,43 @@ static int cg3d_program_run_lanes(const int64_t *prog, int64_t nops, const cg3d_
     if (nops < 0 || (nops > 0 && !prog) || !streams || nstreams < 1 || nstreams > CG3D_PROG_MAX_LANES) return CG3D_ERR_ARG;
     for (int64_t i = 0; i < nops; i++) {
         const int64_t *row = prog + i * CG3D_PROG_STRIDE;
+        const int lane = (int)((row[0] >> CG3D_PROG_LANE_SHIFT) & 0xff);
+        const int rc = cg3d_program_dispatch(row, streams[lane < nstreams ? lane : 0]);
+        if (rc != CG3D_OK) {
+            if (fail_at) *fail_at = i;
+            return rc;
+        }
+    }
+    return CG3D_OK;
+}
+static int cg3d_program_run_bound(const int64_t *prog, int64_t nops, const int64_t *bases, const int64_t *events, int64_t nevents,
+                                  void *zero_ptr, int64_t zero_bytes, const cg3d_stream_t *streams, int32_t nstreams, int64_t *fail_at) {
+    if (nops < 0 || (nops > 0 && !prog) || !bases || !streams || nstreams < 1 || nstreams > CG3D_PROG_MAX_LANES || nevents < 0 ||
+        (nevents > 0 && !events) || zero_bytes < 0)
+        return CG3D_ERR_ARG;
+    if (zero_bytes > 0) {
+        const int rc = CG3D_PROG_MEMSET(zero_ptr, 0, zero_bytes, streams[0]);
+        if (rc != CG3D_OK) {
+            if (fail_at) *fail_at = -1;
+            return rc;
+        }
+    }
+    for (int64_t i = 0; i < nops; i++) {
+        int64_t row[CG3D_PROG_STRIDE];
+        memcpy(row, prog + i * CG3D_PROG_STRIDE, sizeof(row));
+        for (int c = 1; c < CG3D_PROG_STRIDE; c++) {
+            const uint64_t v = (uint64_t)row[c], tag = v >> CG3D_PROG_REGION_SHIFT;
+            if (tag && tag < CG3D_PROG_REGIONS) row[c] = bases[tag] + (int64_t)(v & ((1ull << CG3D_PROG_REGION_SHIFT) - 1));
+        }
+        const int op = (int)(row[0] & 0xffffffffll);
+        if ((op == CG3D_OP_EVENT_RECORD || op == CG3D_OP_EVENT_WAIT) && row[2] == 1) {
+            if (row[1] < 0 || row[1] >= nevents) {
+                if (fail_at) *fail_at = i;
+                return CG3D_ERR_ARG;
+            }
+            row[1] = events[row[1]];
+            row[2] = 0;
+        }
         const int lane = (int)((row[0] >> CG3D_PROG_LANE_SHIFT) & 0xff);
         const int rc = cg3d_program_dispatch(row, streams[lane < nstreams ? lane : 0]);
         if (rc != CG3D_OK) {

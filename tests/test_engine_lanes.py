@@ -276,6 +276,7 @@ def test_other_orders_the_edges_allow_give_identical_results_on_the_oracle(oracl
         prec, me.PRECISION = me.PRECISION, 0
         wl, engine.WGRAD_LANE = engine.WGRAD_LANE, wgrad_lane
         run = engine._run
+        bound, engine.BOUND = engine.BOUND, False              # (the passes go through engine._run, where this test re-orders them)
         try:
             model, _ = build_model.build_cagroup3d("scannet", seed=0)
             batch = build_model.synthetic_batch("S5k", 1, device="cpu")
@@ -297,6 +298,7 @@ def test_other_orders_the_edges_allow_give_identical_results_on_the_oracle(oracl
             assert sum(1 for m in moved if m >= 20) >= 6, moved          # forward + backward table of each order, really reordered
         finally:
             engine._run = run
+            engine.BOUND = bound
             engine.WGRAD_LANE = wl
             me.PRECISION = prec
     ref = results[0]
@@ -317,6 +319,7 @@ def test_reorder_helper_detects_a_dropped_edge(oracle):
     with _lib.use_library(oracle):
         prec, me.PRECISION = me.PRECISION, 0
         run = engine._run
+        bound, engine.BOUND = engine.BOUND, False
         try:
             model, _ = build_model.build_cagroup3d("scannet", seed=0)
             batch = build_model.synthetic_batch("S5k", 1, device="cpu")
@@ -340,8 +343,35 @@ def test_reorder_helper_detects_a_dropped_edge(oracle):
             got = _backbone_step(model, batch, True, "cpu")
         finally:
             engine._run = run
+            engine.BOUND = bound
             me.PRECISION = prec
     assert not torch.equal(ref[1], got[1])
+
+
+def test_a_pass_issued_from_its_compiled_table_equals_the_resolved_copy(oracle):
+    """cg3d_run_program_bound (region bases and event handles applied by the library, row by row) against the numpy path
+    (engine._resolve + _bind_events + cg3d_run_program_lanes): bit-identical outputs, gradients and running statistics."""
+    with _lib.use_library(oracle):
+        prec, me.PRECISION = me.PRECISION, 0
+        bound = engine.BOUND
+        try:
+            model, _ = build_model.build_cagroup3d("scannet", seed=0)
+            batch = build_model.synthetic_batch("S5k", 1, device="cpu")
+            state = {k: v.clone() for k, v in model.state_dict().items()}
+            out = []
+            for b in (True, False):
+                engine.BOUND = b
+                model.load_state_dict(state)
+                out.append(_backbone_step(model, batch, True, "cpu"))
+        finally:
+            engine.BOUND = bound
+            me.PRECISION = prec
+    a, b = out
+    assert torch.equal(a[1], b[1]) and set(a[2]) == set(b[2])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
 
 
 # ------------------------------------------------------------------------------------------------ the tuner
