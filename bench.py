@@ -1,7 +1,7 @@
 """bench.py -- scenes/s forward+backward(+optimiser step) of CAGroup3D on synthetic ScanNet-shaped
 scenes (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5        (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,8 +13,9 @@ one batch per rank (weak scaling); the only collectives are DDP's gradient all-r
 fused 3-scalar reduce_mean per scene, over RCCL.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the conv kernel that accumulates the most time (bf16: k_spconv_tile),
-every conv launch (forward, data gradient, weight gradient) timed live with HIP events on the launch stream on up to six of
-the timed steps spread over the timed region (`roofline.timed_steps`).  Work per launch follows SURVEY.md 8(d): flops =
+every conv launch (forward, data gradient, weight gradient) timed live with HIP events on the launch stream on two of
+the timed steps spread over the timed region (`roofline.timed_steps`; those steps' launch programs are compiled without lanes,
+so that a launch is timed alone -- `roofline.queues`, `roofline.on_lanes`).  Work per launch follows SURVEY.md 8(d): flops =
 2 P Cin Cout, bytes = every tensor once (input rows + output rows + weights + the map); the bound of a launch is
 max(flops / MFMA peak, bytes / HBM peak), `frac` = achieved / peak of whichever bounds the dominant kernel, and
 `frac_8d_per_layer` = sum of the launches' bounds / sum of their measured times.  `fp32` is the parity configuration timed
