@@ -42,6 +42,18 @@ for _ in range(6):
 import gc
 gc.collect()
 gc.freeze()
+if os.environ.get("CG3D_GC_MANUAL") == "1":
+    gc.disable()
+    _ts = bench.train_step
+
+    def _step(*a, **k):
+        gc.collect(1)                 # the young generations, at the start of the step: the issuing thread has slack there
+        return _ts(*a, **k)
+    bench.train_step = _step
+elif os.environ.get("CG3D_GC_OFF") == "1":
+    gc.disable()
+elif os.environ.get("CG3D_GC_THRESHOLD"):
+    gc.set_threshold(int(os.environ["CG3D_GC_THRESHOLD"]), 50, 50)
 torch.cuda.synchronize()
 N = int(os.environ.get("STEPS", "80"))
 ts = []
