@@ -374,6 +374,42 @@ def test_a_pass_issued_from_its_compiled_table_equals_the_resolved_copy(oracle):
         assert torch.equal(a[3][k], b[3][k]), k
 
 
+def test_bound_run_applies_bases_and_events_and_refuses_bad_slots(oracle):
+    """cg3d_run_program_bound on a hand-written table: the zero-fill first, region-relative words resolved through `bases`, event
+    slots through `events` (an unknown slot is an argument error with its row in *fail_at), a lane beyond nstreams on stream 0."""
+    import ctypes
+    f = oracle.raw("cg3d_run_program_bound")
+    buf = np.full(64, 7, dtype=np.uint8)
+    src = np.arange(16, dtype=np.float32)
+    dst = np.zeros(16, dtype=np.uint16)
+    R = 3                                                           # a region tag
+    tab = np.zeros((4, engine.STRIDE), dtype=np.int64)
+    tab[0, :3] = (engine.OP_EVENT_RECORD, 0, 1)
+    tab[1, :4] = (engine.OP_TO_BF16 | (1 << engine.LANE_SHIFT), (R << engine.TAG) + 0, (R << engine.TAG) + 64, 16)      # lane 1 of 1 stream
+    tab[2, :3] = (engine.OP_EVENT_WAIT | (1 << engine.LANE_SHIFT), 0, 1)
+    tab[3, :4] = (engine.OP_MEMSET, (2 << engine.TAG) + 8, 1, 4)
+    arena = np.zeros(64 + 32, dtype=np.uint8)
+    arena[:64] = src.view(np.uint8)
+    bases = np.zeros(16, dtype=np.int64)
+    bases[R], bases[2] = arena.ctypes.data, buf.ctypes.data
+    events = np.array([1234], dtype=np.int64)
+    streams = (ctypes.c_void_p * 8)(*([None] * 8))
+    fail = ctypes.c_int64(-5)
+    rc = f(tab.ctypes.data, 4, bases.ctypes.data, events.ctypes.data, 1, buf.ctypes.data, 32, ctypes.cast(streams, ctypes.c_void_p), 1,
+           ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    assert rc == 0
+    assert (buf[:8] == 0).all() and (buf[8:12] == 1).all() and (buf[12:32] == 0).all() and (buf[32:] == 7).all()
+    got = arena[64:].view(np.uint16)
+    assert np.array_equal(got, (src.view(np.uint32) >> 16).astype(np.uint16))        # exact for small integers
+    assert tab[0, 1] == 0 and tab[0, 2] == 1, "the caller's table is not written to"
+    rc = f(tab.ctypes.data, 4, bases.ctypes.data, events.ctypes.data, 0, None, 0, ctypes.cast(streams, ctypes.c_void_p), 1,
+           ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    assert rc != 0 and fail.value == 0                              # slot 0 of zero events
+    rc = f(tab.ctypes.data, 4, bases.ctypes.data, events.ctypes.data, 1, None, 0, ctypes.cast(streams, ctypes.c_void_p), 0,
+           ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
+    assert rc != 0                                                  # no stream
+
+
 # ------------------------------------------------------------------------------------------------ the tuner
 class _FakeEvent:
     clock = [0.0]
