@@ -268,7 +268,7 @@ def _reorder(P, priority):
     return Q, order
 
 
-@pytest.mark.parametrize("wgrad_lane", [0, 2])
+@pytest.mark.parametrize("wgrad_lane", [2])
 def test_other_orders_the_edges_allow_give_identical_results_on_the_oracle(oracle, wgrad_lane):
     if not engine.LANES:
         pytest.skip("CG3D_LANES=0")
