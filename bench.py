@@ -73,8 +73,9 @@ def parse():
     ap.add_argument("--cpu-sample-1t", default="S5k:1", help="config:scenes of the single-thread CPU leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--rotate", type=int, default=8,
-                    help="sub-record `rotate`: K DIFFERENT synthetic batches cycled inside the timed region (the headline repeats one "
-                         "fixed batch; sizes, cache keys and allocator requests then never change) -- 0 skips it")
+                    help="the headline cycles K DIFFERENT synthetic batches inside the timed region (map sizes, cache keys, allocator "
+                         "requests and the class branches' loads change from step to step, as in training); the one fixed batch of "
+                         "rounds 1-5 is timed as the sub-record `fixed_batch`.  0 / 1: the headline repeats the one fixed batch")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the cpu_baseline leg
     return ap.parse_args()
 
@@ -309,14 +310,19 @@ def main():
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     # every rank owns different scenes (scene i -> rank i mod W), fixed across steps
     batch = build_model.synthetic_batch(args.config, args.batch, first_scene=rank * args.batch, device=dev)
+    # the headline's batches: `batch` and rotate - 1 others (rank r's j-th batch starts at scene (r + W j) * batch: no scene twice)
+    rot_batches = [batch] + [build_model.synthetic_batch(args.config, args.batch, first_scene=(rank + world * j) * args.batch, device=dev)
+                             for j in range(1, max(args.rotate, 1))]
+    nb = len(rot_batches)
 
     # backward nodes on the issuing thread: the autograd engine otherwise hands every node to its per-device thread, and the ~120
     # nodes of this step are Python functions -- an interpreter-lock hand-over each, inside the host-bound stretch of the step
     # (100 pinned steps, three alternating pairs: median 23.2 / 23.3 / 23.2 ms against 23.7 / 23.4 / 23.4)
     if os.environ.get("CG3D_AUTOGRAD_ST", "1") != "0":
         torch.autograd.set_multithreading_enabled(False)
-    for _ in range(args.warmup):
-        tb = train_step(net, opt, batch, clip)
+    n_warm = max(args.warmup, nb if nb > 1 else 0)          # every batch at least once: its cache entries and allocator sizes exist
+    for i in range(n_warm):
+        tb = train_step(net, opt, rot_batches[i % nb], clip, rot_batches[(i + 1) % nb])
     # the model, the optimizer state and the cached tables are permanent: take them out of the cyclic collector's
     # generations, or every gen-2 pass walks them again (measured: one 75 ms pause per ~100 steps)
     import gc
@@ -388,14 +394,17 @@ def main():
         "wgrad": ("k_spconv_pairs_wgrad / _t128 (weight gradient, fp32 MFMA)", "k_spconv_pairs_wgrad"),
     }
     # "...x3" kinds: the same kernels on split operands (the heads, me.PREC_SPLIT): a launch multiplies a three times longer
-    # contraction -- three bf16 products per fp32-accurate product.  Such a launch is priced at the bf16 peak for the 3 x flops
-    # it performs (equivalently: its 2 P Cin Cout at a third of the peak); `roofline.split_launches` states their share.
+    # contraction -- three bf16 products per fp32-accurate product.  Priced at 1 x their 2 P Cin Cout (flops_of);
+    # `roofline.split_launches` states their share.
 
     def base_kind(k):
         return k[:-2] if k.endswith("x3") else k
 
     def flops_of(k, f):
-        return 3.0 * f if k.endswith("x3") else f
+        # 2 P Cin Cout per launch, whatever arithmetic delivers it.  A split-operand launch issues three bf16 products
+        # per fp32-accurate product; rounds 4-5 priced those launches at 3 x (CG3D_ROOFLINE_SPLIT_3X=1 restores that): the extra
+        # two thirds are the price of fp32 accuracy on bf16 pipes, not algorithmic work
+        return 3.0 * f if (k.endswith("x3") and os.environ.get("CG3D_ROOFLINE_SPLIT_3X") == "1") else f
 
     def roofline_of(dt_, profiled, steps, precision):
         """per launch flops = 2 P Cin Cout, bytes = every tensor once; bound = max(flops / MFMA peak, bytes / HBM peak)."""
@@ -453,7 +462,7 @@ def main():
         roof["traffic_by_variant"] = getattr(pmc_traffic, "by_variant", None) if bf16 else None
         roof["split_launches"] = {"launches": prof["split_launches"], "ms_per_step": prof["split_ms"] / profiled,
                                   "note": "launches of this kernel on split operands (the two heads): 3 bf16 products per fp32-accurate "
-                                          "product, counted as the 3 x 2 P Cin Cout bf16 flops the launch performs"}
+                                          "product, counted at 1 x 2 P Cin Cout (SURVEY 8(d)) since round 6 (rounds 4-5: 3 x)"}
         bound_all = sum(v[0] for k, v in per_kind.items() if k in kinds)
         meas_all = sum(v[1] for k, v in per_kind.items() if k in kinds)
         # every sparse convolution of the step (forward, data and weight gradient): their 8(d) bounds over their measured
@@ -462,7 +471,7 @@ def main():
         roof["conv_bound_over_step_time"] = (bound_all / profiled) / (dt_ / steps)
         return roof
 
-    dt, profiled_steps, tb = timed_run(args.steps)
+    dt, profiled_steps, tb = timed_run(args.steps, rot_batches)
     per_rank_ms = list(rank_ms)
     roof = roofline_of(dt, profiled_steps, args.steps, me.PRECISION) if rank == 0 else None
     if _engine.LANES and _engine.LANES_RUN and os.environ.get("CG3D_BENCH_ON_LANES", "1") != "0":
@@ -509,34 +518,46 @@ def main():
                 other_heads[name] = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
                                      "warmup": 3, "heads": name}
         me.HEAD_PRECISION = keep
-    rotate = None
-    if args.rotate > 1:
-        # K different batches cycled inside the timed region (same precision as the headline): map sizes, cache keys and
-        # allocator requests change from step to step, and so does the forced selection's load on the class branches
-        K = args.rotate
-        batches = [build_model.synthetic_batch(args.config, args.batch, first_scene=(rank + world * (j + 1)) * args.batch, device=dev)
-                   for j in range(K)]
-        nrot = max(3, min(args.steps, 20))
-        for j in range(K):                                      # every batch once: its cache entries and allocator sizes exist
-            train_step(net, opt, batches[j], clip, batches[(j + 1) % K])
-        dtr, _, _ = timed_run(nrot, batches)
+    fp32_rows = None
+    if me.PRECISION == 1 and _engine.ACT_BF16 and not args.no_fp32 and os.environ.get("CG3D_BENCH_FP32", "1") != "0":
+        # the headline's arithmetic with the backbone's activations / activation gradients STORED as fp32 rows (CG3D_ACT_BF16=0:
+        # BASELINE.json configs[1] read as "bf16 MFMA operands only"); the programs are compiled per step, so the switch applies
+        # from the next step on
+        _engine.ACT_BF16 = False
+        n2 = max(3, min(args.steps, 20))
+        for _ in range(3):
+            train_step(net, opt, batch, clip)
+        dt2, _, _ = timed_run(n2)
+        _engine.ACT_BF16 = True
+        for _ in range(2):
+            train_step(net, opt, batch, clip)
         if rank == 0:
-            rotate = {"value": world * args.batch * nrot / dtr, "unit": "scenes/s", "ms_per_step": dtr / nrot * 1e3, "steps": nrot,
-                      "warmup": K, "batches": K, "voxels_per_batch": None,
-                      "note": "%d different synthetic batches of %d x %s scenes cycled inside the timed region, next batch's "
-                              "coordinate dry run on the worker thread as in training (S50k x 4: the fixed batch of the headline is the "
-                              "smallest of the nine at tensor stride 4 -- 82 107 voxels against a mean of 89 081 -- so the gap is mostly work)"
-                              % (K, args.batch, args.config)}
+            fp32_rows = {"value": world * args.batch * n2 / dt2, "unit": "scenes/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2, "warmup": 3,
+                         "note": "CG3D_ACT_BF16=0: bf16 MFMA operands in the backbone, every feature matrix and gradient stored as fp32 rows"}
+    fixed = None
+    if nb > 1:
+        # rounds 1-5's headline: ONE fixed batch repeated (the lightest of the nine S50k x 4 batches at tensor stride 4: 82 107
+        # voxels against a mean of 89 081) -- sizes, cache keys and allocator requests never change
+        nfix = max(3, min(args.steps, 20))
+        for _ in range(2):
+            train_step(net, opt, batch, clip)
+        dtf, _, _ = timed_run(nfix)
+        if rank == 0:
+            fixed = {"value": world * args.batch * nfix / dtf, "unit": "scenes/s", "ms_per_step": dtf / nfix * 1e3, "steps": nfix, "warmup": 2,
+                     "note": "the first of the headline's %d batches repeated (the headline of rounds 1-5)" % nb}
     finish_prefetch(net)            # the worker thread is done and joined before anything else happens (cpu_baseline, exit)
 
     if rank == 0:
         out = {"metric": "scenes/s fwd+bwd ScanNet ~50k pts", "value": world * args.batch * args.steps / dt,
-               "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if me.PRECISION == 1 else "f32", "data": "synthetic",
                "config": {"workload": "%s CAGroup3D.yaml, %d x %s scenes per GPU, %s" % (
                    {"scannet": "ScanNetV2", "sunrgbd": "SUN RGB-D"}.get(args.dataset, args.dataset), args.batch, args.config, "forced GT selection (replaces the net's own selection: sizes independent of the weights) + own-class logit boost (trained-like loads)" if forced
                    else "natural selection of the untrained net"),
+                          "batches": nb, "batches_note": ("%d different synthetic batches of %d x %s scenes cycled inside the timed region, the next "
+                                                          "batch's coordinate dry run on the worker thread as in training" % (nb, args.batch, args.config)
+                                                          if nb > 1 else "one fixed batch repeated"),
                           "scenes_per_gpu": args.batch, "points_per_scene": int("".join(ch for ch in args.config.split("-")[0] if ch.isdigit())) * 1000,
                           "voxel_size_m": float(model.voxel_size), "parallelism": "dp%d" % world, "optimizer": "AdamW+clip10",
                           "precision": (("bf16 MFMA operands (fp32 accumulate) in the convolutions (>= 16 input channels) of the BACKBONE "
@@ -552,8 +573,16 @@ def main():
                                          "bf16 MFMA operands (fp32 accumulate) in every sparse convolution with >= 16 input channels -- "
                                          "backbone, class branches, RoI pooling and the 1x1x1 layers; forward, data gradient AND weight "
                                          "gradient (k_spconv_pairs_wgrad_rows16 on the bf16 row copies)") +
-                                        "; activations, weights, gradients, BatchNorm, losses and the optimizer stay fp32"
+                                        ("; STORAGE inside the backbone's launch program: activations and activation gradients are "
+                                         "bf16 rows only (feature matrices of >= %d rows; convolution sums rounded on the store, BatchNorm "
+                                         "statistics summed from the unrounded fp32 sums, normalisation on the rounded rows), fp32 for "
+                                         "smaller matrices, the 3-channel input, the 64-channel output, pooling / interpolation; weights, "
+                                         "parameter gradients, statistics, both heads' rows, losses and the optimizer state are fp32 "
+                                         "(CG3D_ACT_BF16=0 = fp32 rows everywhere: sub-record `fp32_rows` of this line)"
+                                         % _engine.ACT16_MIN_ROWS if _engine.ACT_BF16 else
+                                         "; activations, weights, gradients, BatchNorm, losses and the optimizer stay fp32 (CG3D_ACT_BF16=0)")
                                         if me.PRECISION == 1 else "fp32 everywhere (parity configuration)"),
+                          "act_bf16": bool(_engine.ACT_BF16) and me.PRECISION == 1, "act16_min_rows": int(_engine.ACT16_MIN_ROWS),
                           "last_loss": tb.get("loss_all"),
                           "backbone_issue": dict(__import__("cagroup3d_amd.engine", fromlist=["STATS"]).STATS),
                           # launch programs on several queues (engine.py, lanes): compiled with lanes / run on them, and what the
@@ -564,9 +593,10 @@ def main():
                "roofline": roof}
         if fp32 is not None:
             out["fp32"] = fp32
-        if rotate is not None:
-            rotate.pop("voxels_per_batch", None)
-            out["rotate"] = rotate
+        if fixed is not None:
+            out["fixed_batch"] = fixed
+        if fp32_rows is not None:
+            out["fp32_rows"] = fp32_rows
         for name, rec in other_heads.items():
             out[{"fp32": "bf16_backbone_fp32_heads", "bf16": "bf16_all_convolutions", "split": "bf16_backbone_split_heads"}[name]] = rec
         if use_dist and getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "report"):

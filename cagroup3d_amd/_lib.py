@@ -159,6 +159,11 @@ class Library:
             fn.argtypes = args
         self.is_device = bool(self._dll.cg3d_is_device_library())
         self.device_type = "cuda" if self.is_device else "cpu"
+        # Which KERNELS the host side picks (tile plans + fragment-ordered weights, bf16 row copies, the step's weight arena,
+        # launch programs in the bench precision): the device library's choice.  `device_path()` lets tests bind a second
+        # handle of the CPU oracle that takes the same choices, so that the path the benchmark times -- not only its kernels one
+        # call at a time -- is compared with the oracle's arithmetic (tests/test_timed_path_oracle.py).  Never set by the product.
+        self.device_kernels = self.is_device
 
     def raw(self, name):
         return getattr(self._dll, name)
@@ -211,6 +216,12 @@ _active = None
 
 def bind(path):
     return Library(path)
+
+
+def device_path(lib):
+    """Test aid: `lib` (the CPU oracle) flagged to follow the device library's kernel selection.  Returns the same handle."""
+    lib.device_kernels = True
+    return lib
 
 
 def get():

@@ -48,7 +48,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     hdrs = [os.path.join(HERE, "cg3d_common.h"), os.path.join(HERE, "dg_geom.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_hip.h"),
-            os.path.join(HERE, "..", "..", "include", "cagroup3d_program.h")]
+            os.path.join(HERE, "..", "..", "include", "cagroup3d_program.h"), os.path.join(HERE, "..", "..", "include", "cagroup3d_stages.h")]
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)

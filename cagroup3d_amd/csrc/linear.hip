@@ -89,6 +89,27 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
     }
     // ---- the wave's 32 rows, 64 channels at a time, row-major in its own 8 KB region, then 16-byte stores
     __syncthreads();
+    // BatchNorm statistics EARLY (as in spconv_tile2.hip: the workgroup's global atomics then travel while it lays out and stores
+    // its rows, instead of being the tail every workgroup ends with): from the accumulators, rows past the end masked (they
+    // hold a duplicate of the last row).  With a bias the store loop's path below stays.
+    const bool early_stats = stats != nullptr && !(bias && zi == 0 && !part);
+    if (early_stats) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float v = (wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg < rows) ? acc[nb][e] : 0.f;
+                s0 += v; s1 += v * v;
+            }
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            if (kg == 0) { unsafeAtomicAdd(sacc + nb * 32 + r, s0); unsafeAtomicAdd(sacc + NC + nb * 32 + r, s1); }
+        }
+        __syncthreads();
+        if (tid < 2 * NC)
+            unsafeAtomicAdd(&stats[((blockIdx.x % CG3D_BN_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);
+    }
     float *tb = reinterpret_cast<float *>(smem) + (size_t)wave * 2048;          // [32][64]
     const int c4 = (lane & 15) * 4, rq = lane >> 4;      // 16 threads per row, 4 rows per iteration of the wave
 #pragma unroll
@@ -122,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void k_linear_tile(const uint16_t *__restri
                 t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
             }
         }
-        if (stats) {
+        if (stats && !early_stats) {
             float *s0 = sacc + h * 64 + c4, *s1 = sacc + NC + h * 64 + c4;
             unsafeAtomicAdd(s0, t0.x); unsafeAtomicAdd(s0 + 1, t0.y); unsafeAtomicAdd(s0 + 2, t0.z); unsafeAtomicAdd(s0 + 3, t0.w);
             unsafeAtomicAdd(s1, t1.x); unsafeAtomicAdd(s1 + 1, t1.y); unsafeAtomicAdd(s1 + 2, t1.z); unsafeAtomicAdd(s1 + 3, t1.w);
         }
     }
-    if (stats) {
+    if (stats && !early_stats) {
         __syncthreads();
         if (tid < 2 * NC)
             unsafeAtomicAdd(&stats[((blockIdx.x % CG3D_BN_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);

@@ -28,6 +28,12 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define T2_TM 128            // output rows per tile
 #define T2_KB 32             // offsets whose slot table is resident in LDS at a time
 #define T2_NLV 16            // row granules a thread stages per pass and chunk: 256 threads x 16 = 4096 = 512 rows x 8
+#ifndef T2_STAT_SLOTS
+#define T2_STAT_SLOTS CG3D_BN_SLOTS      // (dev: more slots than the table's consumers add up, to measure the atomics' same-address queueing)
+#endif
+#ifndef T2_DBG
+#define T2_DBG 0             // dev knock-outs (tools/mb_tile_dbg.sh): 1 no weight loads in the loop, 2 conflict-free A reads, 4 no MFMA, 8 no row staging, 16 no exchange / store, 64 no global stores (exchange + row-major pass kept), 128 no exchange (rows + stores kept)
+#endif
 
 #ifdef CG3D_TILE_TRACE
 // dev build only (CG3D_HIPCC_EXTRA=-DCG3D_TILE_TRACE): per workgroup {shader-clock start, end, 100 MHz start, end, HW_ID | XCC_ID << 32, unit}
@@ -155,7 +161,7 @@ __device__ __forceinline__ void t2_unit(
                 // wave-uniform base + lane * 16).  Lane i of request j owns PHYSICAL granule i & 7 of row slot (i >> 3) + 1
                 // and fetches the logical granule the XOR swizzle maps there (granule g of slot s sits at g ^ ((s >> 1) & 7):
                 // 16 lanes reading one channel granule of 16 consecutive slots hit 16 different bank groups).
-                if (stage_rows && ngran > 0) {
+                if (stage_rows && ngran > 0 && !(T2_DBG & 8)) {
 #pragma unroll
                     for (int j = 0; j < T2_NLV; j++) {
                         if (j * 256 < ngran) {                               // uniform
@@ -223,6 +229,13 @@ __device__ __forceinline__ void t2_unit(
                         Rows R;
                         R.a[0] = (s2.x & 0xffffu) ^ kg16; R.a[1] = (s2.x >> 16) ^ kg16;
                         R.a[2] = (s2.y & 0xffffu) ^ kg16; R.a[3] = (s2.y >> 16) ^ kg16;
+#if T2_DBG & 2
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+                            const uint32_t sl = (uint32_t)(m * 32 + r + 1) + (R.a[m] & 1u);       // (bit 0 is always clear: keeps the table read alive)
+                            R.a[m] = ((sl << 7) | (((sl >> 1) & 7u) << 4)) ^ kg16;
+                        }
+#endif
                         return R;
                     };
                     auto load_b = [&](uint4 (&b)[2], int kk, int ks) {
@@ -266,8 +279,12 @@ __device__ __forceinline__ void t2_unit(
 #pragma unroll
                             for (int m = 0; m < 4; m++)
                                 if ((MASK >> m) & 1) {
+#if T2_DBG & 4
+                                    asm volatile("" :: "v"(a[m]), "v"(b0), "v"(b1));
+#else
                                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b0, acc[m][0], 0, 0, 0);
                                     acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b1, acc[m][1], 0, 0, 0);
+#endif
                                 }
                         };
                         auto sched = [&](auto NDS_) {                          // 2 NM MFMAs, NDS LDS reads, 2 weight loads
@@ -292,22 +309,22 @@ __device__ __forceinline__ void t2_unit(
                         using K3 = std::integral_constant<int, 3>;
                         read_live(aB, R, K1{});
                         mma(aA, b[0]);
-                        load_b(b[0], knext, 0);
+                        if (!(T2_DBG & 1)) load_b(b[0], knext, 0);
                         sched(std::integral_constant<int, NM>{});
                         read_live(aA, R, K2{});
                         mma(aB, b[1]);
-                        load_b(b[1], knext, 1);
+                        if (!(T2_DBG & 1)) load_b(b[1], knext, 1);
                         sched(std::integral_constant<int, NM>{});
                         read_live(aB, R, K3{});
                         const Rows Rn = rows_from(sraw_n);
                         mma(aA, b[2]);
-                        load_b(b[2], knext, 2);
+                        if (!(T2_DBG & 1)) load_b(b[2], knext, 2);
                         sched(std::integral_constant<int, NM>{});
 #pragma unroll
                         for (int m = 0; m < 4; m++) aA[m] = *reinterpret_cast<const bf16x8 *>(As + Rn.a[m]);
                         sraw_n = slot_raw(knn);
                         mma(aB, b[3]);
-                        load_b(b[3], knext, 3);
+                        if (!(T2_DBG & 1)) load_b(b[3], knext, 3);
                         sched(std::integral_constant<int, 5>{});
                         R = Rn;
                         knext = knn;
@@ -376,14 +393,50 @@ __device__ __forceinline__ void t2_unit(
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // BatchNorm statistics of the unit's output (per-channel sum / sum of squares of the rows this workgroup owns), EARLY: from
+    // the accumulators right after the exchange, so that the workgroup's 2 NC global atomics are in flight while it lays its
+    // rows out and stores them.  Issued at the very end (round 3-5: accumulated in the store loop) their round trip was the
+    // tail of EVERY workgroup -- the slot it holds on its CU stays taken until they return: 64 -> 64 @ 155 773 rows 45 -> 56 us,
+    // 128 -> 128 @ 82 107 rows 70 -> 78 us with statistics on, whatever the number of table slots (1 ... 1024 slots: the same
+    // times, profiles/r06_tile2_stats_slots.txt -- not a same-address queue).  Rows past the end of the last tile multiply the
+    // zero row: they add nothing.  With a bias the sums are those of acc + bias: the store loop's path below stays.
+    const bool early_stats = stats != nullptr && bias == nullptr && !(T2_DBG & 128);
+    auto stats_from_acc = [&](auto LO, auto CNT) {
+        constexpr int lo = decltype(LO)::value, cnt = decltype(CNT)::value;
+        float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < cnt; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) { const float v = acc[lo + m][n][e]; s0[n] += v; s1[n] += v * v; }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {                   // lanes (r, kg = 0 / 1) hold different rows of channel n * 32 + r
+            s0[n] += __shfl_xor(s0[n], 32);
+            s1[n] += __shfl_xor(s1[n], 32);
+            if (kg == 0) {                              // the KG waves of this channel block meet in LDS
+                unsafeAtomicAdd(sacc + h * 64 + n * 32 + r, s0[n]);
+                unsafeAtomicAdd(sacc + NC + h * 64 + n * 32 + r, s1[n]);
+            }
+        }
+    };
+    auto stats_flush = [&]() {
+        if (tid < 2 * NC)
+            unsafeAtomicAdd(&stats[((blockIdx.x % T2_STAT_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);
+    };
     __syncthreads();                                    // every wave has left the multiply loop: the row tile is free
     T2_STAMP();
-    if constexpr (KG == 2) {
+    if ((T2_DBG & 16) && n_out >= 0) return;
+    if (T2_DBG & 128) {
+        if (g == 0) to_rows(I0{}, I1{}); else if (g == 1) to_rows(I1{}, I1{}); else if (g == 2) to_rows(I2{}, I1{}); else to_rows(I3{}, I1{});
+    } else if constexpr (KG == 2) {
         const int partner = (g ^ 1) * NCO + h;
         if (g == 0) give(I2{}, I2{}); else give(I0{}, I2{});
         __syncthreads();
         if (g == 0) take(I0{}, I2{}, partner); else take(I2{}, I2{}, partner);
-        __syncthreads();                                // the partner has read my region
+        if (early_stats) { if (g == 0) stats_from_acc(I0{}, I2{}); else stats_from_acc(I2{}, I2{}); }
+        __syncthreads();                                // the partner has read my region (and the LDS sums are complete)
+        if (early_stats) stats_flush();
         if (g == 0) to_rows(I0{}, I2{}); else to_rows(I2{}, I2{});
     } else {
         // KG == 4 (NCO == 1): level 0 between g and g ^ 2 (halves), level 1 between g and g ^ 1 (quarters)
@@ -397,7 +450,12 @@ __device__ __forceinline__ void t2_unit(
         __syncthreads();
         if ((g & 2) == 0) { if ((g & 1) == 0) take(I0{}, I1{}, p1); else take(I1{}, I1{}, p1); }
         else              { if ((g & 1) == 0) take(I2{}, I1{}, p1); else take(I3{}, I1{}, p1); }
+        if (early_stats) {
+            if (g == 0) stats_from_acc(I0{}, I1{}); else if (g == 1) stats_from_acc(I1{}, I1{});
+            else if (g == 2) stats_from_acc(I2{}, I1{}); else stats_from_acc(I3{}, I1{});
+        }
         __syncthreads();
+        if (early_stats) stats_flush();
         if (g == 0) to_rows(I0{}, I1{}); else if (g == 1) to_rows(I1{}, I1{}); else if (g == 2) to_rows(I2{}, I1{}); else to_rows(I3{}, I1{});
     }
     // ------------------------------------------------------------------------------------------------ store
@@ -415,7 +473,7 @@ __device__ __forceinline__ void t2_unit(
             float4 v = *reinterpret_cast<const float4 *>(tb + (i * 4 + rq) * 64 + c4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             const int pos = g * rows_per + i * 4 + rq;   // position in the tile -> output row (permuted tiles: `order`)
-            if (pos < rows) {
+            if (pos < rows && !((T2_DBG & 64) && n_out >= 0)) {
                 const int64_t orow = order ? (int64_t)order[row0 + pos] : row0 + pos;
                 float *dst = Y + orow * cout + col0;
                 if (wrev & CG3D_TILE_OUT_BF16) {          // Y holds bf16 rows: 8 bytes per lane, a row's 64 channels are one 128-byte line
@@ -431,7 +489,7 @@ __device__ __forceinline__ void t2_unit(
                 t1.x += v.x * v.x; t1.y += v.y * v.y; t1.z += v.z * v.z; t1.w += v.w * v.w;
             }
         }
-        if (stats) {
+        if (stats && !early_stats) {
             // per-channel sum / sum of squares of the rows this workgroup stored (BatchNorm statistics of the layer's
             // output): 4 lanes x KG waves share a column quad -> LDS atomics, then 2 NC global atomics per workgroup into
             // slot (workgroup % CG3D_BN_SLOTS) of the layer's zero-based table stats[slots][2][cout] (cg3d_bn_apply_sums
@@ -441,7 +499,7 @@ __device__ __forceinline__ void t2_unit(
             unsafeAtomicAdd(a1, t1.x); unsafeAtomicAdd(a1 + 1, t1.y); unsafeAtomicAdd(a1 + 2, t1.z); unsafeAtomicAdd(a1 + 3, t1.w);
             __syncthreads();
             if (tid < 2 * NC)
-                unsafeAtomicAdd(&stats[((blockIdx.x % CG3D_BN_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);
+                unsafeAtomicAdd(&stats[((blockIdx.x % T2_STAT_SLOTS) * 2 + tid / NC) * (int64_t)cout + yb * NC + tid % NC], sacc[tid]);
         }
     }
 #ifdef CG3D_TILE_TRACE

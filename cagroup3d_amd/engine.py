@@ -631,7 +631,7 @@ class Builder:
     # ---------------------------------------------------------------- 1x1x1 convolution (me.LinearFunction)
     def linear(self, x, weight, cin, cout):
         n = x.n
-        own = ME.LinearFunction._own(n, cin, cout) and self.lib.is_device
+        own = ME.LinearFunction._own(n, cin, cout) and self.lib.device_kernels
         w2 = weight.view(cin, cout)
         if own:
             wt, wp = self._planned(w2.view(1, cin, cout), True, x.need)
@@ -1249,19 +1249,36 @@ def _schedule_native(lib, prog, starts, cuts=()):
 _EVENT_POOL = __import__("threading").local()
 
 
+def _event_pool(lib, nevents):
+    """(handles, int64 array of them) of at least `nevents` ordering events of the calling thread for (`lib`, current device): an
+    event belongs to the device that was current when it was created, so a thread that issues passes on two devices keeps one
+    pool per device."""
+    dev = torch.cuda.current_device() if lib.is_device else -1
+    pools = getattr(_EVENT_POOL, "pools", None)
+    if pools is None or _EVENT_POOL.lib is not lib:
+        pools, _EVENT_POOL.lib = {}, lib
+        _EVENT_POOL.pools = pools
+    ent = pools.get(dev)
+    if ent is None:
+        ent = pools[dev] = [[], None]
+    pool = ent[0]
+    grown = False
+    while len(pool) < nevents:
+        h = ctypes_i64()
+        lib.call("cg3d_event_create_sync", ctypes_ref(h))
+        pool.append(h.value)
+        grown = True
+    if ent[1] is None or grown:
+        ent[1] = np.asarray(pool, dtype=np.int64)
+    return pool, ent[1]
+
+
 def _bind_events(P, lib, nevents):
     """Handles of ordering events (cg3d_event_create_sync, created once per thread and reused by every pass: a wait refers to
     the record issued before it, and one thread issues one pass at a time) in place of the slot numbers of `_schedule`."""
     if not nevents:
         return P
-    pool = getattr(_EVENT_POOL, "h", None)
-    if pool is None or _EVENT_POOL.lib is not lib:
-        pool, _EVENT_POOL.lib = [], lib
-        _EVENT_POOL.h = pool
-    while len(pool) < nevents:
-        h = ctypes_i64()
-        lib.call("cg3d_event_create_sync", ctypes_ref(h))
-        pool.append(h.value)
+    pool = _event_pool(lib, nevents)[0]
     op = P[:, 0] & OPCODE_MASK
     m = ((op == OP_EVENT_RECORD) | (op == OP_EVENT_WAIT)) & (P[:, 2] == 1)
     if m.any():
@@ -1404,6 +1421,8 @@ class _LaneTuner:
             # (per input row: the batches of a training run differ in size; the verdict is reported for the median batch.  Two
             # passes each way and the faster of the two: a pass can only be disturbed towards slower, and the decision should
             # fall inside a handful of warm-up steps)
+            for _, _, e1, _ in cls.samples:
+                e1.synchronize()             # (a one-off in warm-up: nothing guarantees that a host read followed the sampled passes)
             rows = sorted(n for _, _, _, n in cls.samples)[len(cls.samples) // 2]
             on = min(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if m)
             off = min(e0.elapsed_time(e1) / n for m, e0, e1, n in cls.samples if not m)
@@ -1444,6 +1463,8 @@ def _run(lib, P, nrows=None, comp=None, lanes_run=None):
     else:
         rc = lib.raw("cg3d_run_program")(P.ctypes.data, n, lib.stream(), ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
     if rc != 0:
+        if lib.is_device:
+            torch.cuda.synchronize()         # (as in _run_bound: side lanes may still be running rows of this pass)
         raise _lib.CG3DError("cg3d_run_program: row %d (opcode %d) failed with status %d" % (fail.value, (int(P[fail.value, 0]) & OPCODE_MASK) if 0 <= fail.value < n else -1, rc))
 
 
@@ -1463,19 +1484,7 @@ def _run_bound(lib, comp, table, bases, zero_ptr, zero_bytes, lo=0, hi=None, lan
         b[r >> TAG] = a
     ev_ptr, nev = None, 0
     if comp.nevents:
-        pool = getattr(_EVENT_POOL, "h", None)
-        if pool is None or _EVENT_POOL.lib is not lib:
-            pool, _EVENT_POOL.lib = [], lib
-            _EVENT_POOL.h = pool
-        grown = False
-        while len(pool) < comp.nevents:
-            h = ctypes_i64()
-            lib.call("cg3d_event_create_sync", ctypes_ref(h))
-            pool.append(h.value)
-            grown = True
-        arr = getattr(_EVENT_POOL, "arr", None)
-        if arr is None or grown or arr.shape[0] != len(pool):
-            arr = _EVENT_POOL.arr = np.asarray(pool, dtype=np.int64)
+        arr = _event_pool(lib, comp.nevents)[1]
         ev_ptr, nev = arr.ctypes.data, arr.shape[0]
     streams, ns = _lane_streams(lib)
     use = ns if (comp.lanes and (LANES_RUN if lanes_run is None else lanes_run)) else 1
@@ -1484,6 +1493,8 @@ def _run_bound(lib, comp, table, bases, zero_ptr, zero_bytes, lo=0, hi=None, lan
                                            ctypes.cast(streams, ctypes.c_void_p), use, ctypes.cast(ctypes.pointer(fail), ctypes.c_void_p))
     if rc != 0:
         f = fail.value
+        if lib.is_device:
+            torch.cuda.synchronize()         # rows issued before the failing one may still run on side lanes: the caller frees the arena next
         raise _lib.CG3DError("cg3d_run_program_bound: row %d (opcode %d) failed with status %d"
                              % (lo + f, (int(table[lo + f, 0]) & OPCODE_MASK) if 0 <= f < hi - lo else -1, rc))
 
@@ -1648,7 +1659,7 @@ def class_branches_applicable(head):
         return False
     if not (ME._prec() in (1, 3) and ME.BF16_ROWS and ME.GROUPED_BN_STACK):
         return False
-    return _lib.get().is_device or os.environ.get("CG3D_ENGINE_ANY") == "1"
+    return _lib.get().device_kernels or os.environ.get("CG3D_ENGINE_ANY") == "1"
 
 
 def compile_class_branches(head, nf, nc, c, km9, km5, km_up, ident, fine_bounds, coarse_bounds, device):
@@ -1786,7 +1797,7 @@ def head_pre_applicable(head):
     """Training step in the bench precision on the device library."""
     if not (ENABLED and HEAD_PROGRAM and head.training and torch.is_grad_enabled()) or ME.coords_only():
         return False
-    return _lib.get().is_device and ME._prec() in (1, 3) and ME.BF16_ROWS
+    return _lib.get().device_kernels and ME._prec() in (1, 3) and ME.BF16_ROWS
 
 
 def compile_head_pre(head, sp, has16):
@@ -1935,6 +1946,6 @@ def applicable(net, compiling=False):
     if not ENABLED or not net.training or ME.coords_only() or not (compiling or torch.is_grad_enabled()):
         return False
     lib = _lib.get()
-    if lib.is_device and ME.PRECISION in (1, 3) and ME.BF16_ROWS:
+    if lib.device_kernels and ME.PRECISION in (1, 3) and ME.BF16_ROWS:
         return True
     return os.environ.get("CG3D_ENGINE_ANY") == "1" and ME.PRECISION == 0

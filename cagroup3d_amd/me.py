@@ -615,7 +615,9 @@ FWD_SEG = 128  # pairs per workgroup of cg3d_spconv_pairs_fwd
 #       (3 c channels), the contraction side of the weights [Whi ; Whi ; Wlo], and every bf16 kernel runs unchanged on the three
 #       times longer contraction.  The two heads run under it (HEAD_PRECISION = 3): configs[1] words its precision as "bf16
 #       backbone", the reference's heads are fp32 (cagroup_head.py:227-282), and fp32 MFMA operands cost 16 x the bf16 rate.
-# Features, weights, gradients stay fp32 in all modes.
+# Weights, parameter gradients and statistics stay fp32 in all modes; so do the feature rows of the per-layer path of this file.
+# Inside the backbone's launch program (engine.ACT_BF16, default on) activations and activation gradients are STORED as bf16
+# rows only (DESIGN.md section 2 "Features, round 5"); CG3D_ACT_BF16=0 keeps fp32 rows there too.
 PRECISION = 0
 PREC_SPLIT = 3
 # Precision of a PART of the step: `precision_scope(p)` overrides PRECISION for the calling thread (the detector runs the two
@@ -1113,6 +1115,7 @@ _LATE_STREAMS = {}
 LATE_MODE = os.environ.get("CG3D_LATE_WEIGHTS", "0")
 LATE_MODE = {"1": "stream", "": "0"}.get(LATE_MODE, LATE_MODE)
 LATE_WEIGHTS = LATE_MODE in ("stream", "defer")
+PREFETCH_THREAD_NAME = "cg3d-coordinate-prefetch"        # (pcdet/models/detectors/cagroup3d.py: the dry run's worker)
 _DEFERRED = []                # launches of late rows, in order (LATE_MODE "defer")
 
 
@@ -1129,6 +1132,11 @@ def run_late(join=True):
     weights only, and its current stream is not the step's."""
     import threading
     if threading.current_thread() is not threading.main_thread():
+        # the dry run's worker only ever looks up early weights; anybody else on another thread (a checkpoint thread serialising
+        # parameters after clip_and_step) would read class-branch parameters whose AdamW rows have not run: refuse, loudly
+        if join and _DEFERRED and threading.current_thread().name != PREFETCH_THREAD_NAME:
+            raise RuntimeError("cagroup3d_amd.me.run_late: deferred late-parameter work exists and the caller is not the issuing thread -- "
+                               "call optimizer.finish_late() on the training thread before reading parameters elsewhere")
         return
     if _DEFERRED:
         dev = torch.cuda.current_device()
@@ -1197,7 +1205,7 @@ def prepare_weights(training=True, split=False):
     lib = _lib.get()
     P = _WeightPlan
     P.live = False
-    if not lib.is_device or (PRECISION not in (1, 3) and HEAD_PRECISION not in (1, 3)) or not (P.singles or P.groups):
+    if not lib.device_kernels or (PRECISION not in (1, 3) and HEAD_PRECISION not in (1, 3)) or not (P.singles or P.groups):
         return
     if len(P.singles) + len(P.groups) > 512:
         P.reset()
@@ -1254,7 +1262,7 @@ def _planned_single(w3, need_plain, frag=False):
         if P.live and e[3] is not None and e[2] == w3._version:
             return e
         return None
-    if _lib.get().is_device and w3.dim() == 3:
+    if _lib.get().device_kernels and w3.dim() == 3:
         with _CACHE_LOCK:
             P.singles[(w3.data_ptr(), kind)] = [w3.detach(), need_plain or (e is not None and e[1]), -1, None, None]
             P.dirty = True
@@ -1313,7 +1321,7 @@ def _prep_bf16_group(weights, transposed, frag=False):
     if g is not None:
         if _WeightPlan.live and g[2] is not None and g[1] == tuple(w._version for w in weights):
             return g[2]
-    elif lib.is_device:
+    elif lib.device_kernels:
         with _CACHE_LOCK:
             _WeightPlan.groups[(key, transposed, kind)] = [[w.detach() for w in weights], None, None]
             _WeightPlan.dirty = True
@@ -1462,7 +1470,7 @@ def _use_tile(kmap, K, cin, cout, n_rows, row_bounds):
     covers (64-channel chunks in, 64 or multiples of 128 out), enough rows to give every CU a tile.  Since the rows reach
     LDS by LDS-DMA it beats the dense-map kernel on every S50k layer shape -- same-map, strided (2-3 passes per tile) and
     transposed maps, 64 channels included (`profiles/r02_tile_vs_dense_map.txt`)."""
-    return (TILE_KERNEL and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS and row_bounds is None
+    return (TILE_KERNEL and _lib.get().device_kernels and _prec() in (1, 3) and BF16_ROWS and row_bounds is None
             and 1 < K <= TILE_MAX_K and cin % 64 == 0 and cout % 64 == 0 and n_rows >= TILE_MIN_ROWS)
 
 
@@ -1617,7 +1625,7 @@ class GroupedConvFunction(torch.autograd.Function):
         row groups), bf16 row copies, channel counts the kernel's register tile covers.  The rows of a pass are staged once
         for all of its slot-table blocks, so the 5^3 / 9^3 class convolutions (K = 125 / 729) gather each distinct
         neighbour row once per pass instead of once per offset."""
-        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().is_device and _prec() in (1, 3) and BF16_ROWS
+        return (GROUP_TILE_KERNEL and closed and kmap.same_map and K > 1 and _lib.get().device_kernels and _prec() in (1, 3) and BF16_ROWS
                 and cin % 64 == 0 and cout % 64 == 0 and (cin == 64 or cin % 128 == 0) and (cout == 64 or cout % 128 == 0))
 
     @staticmethod
@@ -1690,7 +1698,7 @@ def grouped_conv(x, weights, kmap, row_bounds, closed=False):
     atomic-free output-stationary kernel is used on dense enough maps."""
     weights = [w.view(-1, w.shape[-2], w.shape[-1]) for w in weights]
     cin, cout = weights[0].shape[1], weights[0].shape[2]
-    if _use_bf16(cin) and _use_bf16(cout) and _lib.get().is_device:
+    if _use_bf16(cin) and _use_bf16(cout) and _lib.get().device_kernels:
         return GroupedConvFunction.apply(x, kmap, row_bounds, bool(closed), *weights)
     w = torch.stack(weights, dim=0)
     return SparseConvFunction.apply(x, w.view(-1, cin, cout), None, kmap, row_bounds)
@@ -1728,7 +1736,7 @@ class LinearFunction(torch.autograd.Function):
     def _skinny(n, a, b):
         """Many rows x (few channels on one side): the library picks 16 x 256 tiles for these (0.25 ms for a
         155 k x 64 x 3 product); the identity-map pair kernel streams the rows once instead."""
-        return n >= LinearFunction.MIN_ROWS and min(a, b) < 32 and _lib.get().is_device
+        return n >= LinearFunction.MIN_ROWS and min(a, b) < 32 and _lib.get().device_kernels
 
     @staticmethod
     def _rows_gemm(x, w, bias):
@@ -1807,7 +1815,7 @@ class LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n, (cin, cout) = x.shape[0], w.shape
             lib = _lib.get()
-            if (n < LinearFunction.MIN_ROWS and not (ctx.own and LINEAR_WGRAD_SMALL)) or not lib.is_device:
+            if (n < LinearFunction.MIN_ROWS and not (ctx.own and LINEAR_WGRAD_SMALL)) or not lib.device_kernels:
                 dw = x.t() @ dy
             else:
                 xc, dyc = x.contiguous(), dy.contiguous()

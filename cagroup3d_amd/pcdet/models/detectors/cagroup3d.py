@@ -42,7 +42,7 @@ class _PrefetchWorker:
                 finally:
                     del d
                     handle.done.set()
-        self.thread = threading.Thread(target=loop, name="cg3d-coordinate-prefetch", daemon=True)
+        self.thread = threading.Thread(target=loop, name=ME.PREFETCH_THREAD_NAME, daemon=True)
         self.thread.start()
         # the thread must be OUT of the HIP runtime and of torch before the interpreter tears them down (a daemon thread
         # still inside a launch at exit corrupted the heap: "corrupted size vs. prev_size" after the last bench line)
@@ -105,6 +105,8 @@ class CAGroup3D(Detector3DTemplate):
         copies (me.set_early_weights) are kept out of that half: deferred until `me.run_late()` (called by the head right after
         that read; me.LATE_MODE).  Whoever reads parameters outside a detector forward after an optimizer step calls
         `optimizer.finish_late()` first (train.checkpoint_state does)."""
+        if not ME.LATE_WEIGHTS:
+            return                       # the feature is off: no process-wide state is touched
         names = ("cls_individual_out", "cls_individual_expand_out", "cls_individual_up", "cls_individual_fuse")
         late = {id(p) for n, p in self.dense_head.named_parameters() if n.startswith(names)}
         early = [p for p in self.parameters() if id(p) not in late]

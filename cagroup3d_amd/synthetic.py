@@ -14,6 +14,7 @@ CONFIGS = {
     "S100k-yaw": (4, 100000, 10, True, True),     # SUN RGB-D shaped: one depth camera in a room corner
     "S200k": (5, 200000, 18, False, False),
     "S5k": (9, 5000, 18, False, False),   # small parity-test scene
+    "S2k": (13, 2000, 18, False, False),  # the smallest scene that still has rows at every stride (CPU tests of whole launch programs)
     "S5k-yaw": (8, 5000, 10, True, False),
     "S5k-yaw-sv": (7, 5000, 10, True, True),      # small single-view scene (tests)
     # LEARNABLE variants (the convergence / mAP evidence runs, tools/synthetic_convergence.py): the class of an object is

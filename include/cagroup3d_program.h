@@ -295,6 +295,14 @@ static int cg3d_program_roles_impl(int32_t op, uint32_t *rd, uint32_t *wr) {
     return CG3D_OK;
 }
 
+/* Hazard keys of the scheduler -- THE SINGLE-BLOCK INVARIANT.  A pointer argument is ordered between lanes by ONE key: the
+ * allocation block of its region that holds the pointer's FIRST byte (region-tagged pointers), or its exact address (absolute
+ * pointers: weights, statistics tables, tensors of the caller).  The emitter must therefore keep every access inside the block
+ * its pointer starts in, and must not hand two lanes two DIFFERENT absolute addresses into one buffer (slices of one tensor at
+ * different offsets are not ordered against each other).  cagroup3d_amd/engine.py's Builder allocates one block per matrix
+ * and passes block starts only; absolute pointers are whole tensors.  Nothing here can check the extent of an access: an
+ * emitter that breaks the invariant gets no edge and a race.  (tests/test_engine_lanes.py walks the tables of the backbone
+ * and the class branches with the Python specification of the same rule.) */
 typedef struct { int64_t key; int32_t w[CG3D_PROG_MAX_LANES], r[CG3D_PROG_MAX_LANES]; } cg3d_sched_blk;
 typedef struct { int64_t after_row, before_row; int32_t rec_lane, wait_lane, ev, next_after, next_before; } cg3d_sched_edge;
 

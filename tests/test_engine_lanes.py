@@ -421,7 +421,13 @@ class _FakeEvent:
         self.t = _FakeEvent.clock[0]
 
     def elapsed_time(self, other):
+        assert other.synced, "elapsed_time on an end event nobody synchronised"
         return other.t - self.t
+
+    synced = False
+
+    def synchronize(self):
+        self.synced = True
 
 
 def _tune(monkeypatch, ms_of):
