@@ -1727,7 +1727,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void k_spconv_pairs_wgrad
             for (int e = 0; e < 16; e++) {
                 const int ci = ci0 + wi * (TM / 2) + i * 32 + perm32((e & 3) + 8 * (e >> 2) + 4 * h);
                 const int co = co0 + wj * (TN / WJ) + j * 32 + pr;
+#if defined(W_DBG) && (W_DBG & 1)        // dev knock-outs (tools/build_tile_dbg.sh, SRC=spconv.hip DEF=W_DBG): 1 no atomics, 2 plain stores
+                if (ci < cin && co < cout && ldx < 0) dst[(int64_t)ci * cout + co] = acc[i][j][e];
+#elif defined(W_DBG) && (W_DBG & 2)
+                if (ci < cin && co < cout) dst[(int64_t)ci * cout + co] = acc[i][j][e];
+#else
                 if (ci < cin && co < cout) unsafeAtomicAdd(&dst[(int64_t)ci * cout + co], acc[i][j][e]);
+#endif
             }
 }
 

@@ -132,10 +132,17 @@ __device__ __forceinline__ void t2_unit(
             if (i0 < ucnt) idx_s[i0] = ulist[uoff + i0];
             if (i0 + 1 < ucnt) idx_s[i0 + 1] = ulist[uoff + i0 + 1];
         }
-        for (int kb = k0; kb < k1 || kb == k0; kb += T2_KB) {          // (an empty pass still is one stage)
-            const int nk = k1 - kb < T2_KB ? (k1 - kb > 0 ? k1 - kb : 0) : T2_KB;
-            for (int c = 0; c < nchunk; c++) {
-                const bool stage_rows = nchunk > 1 || kb == k0;           // else: the rows of this pass are already there
+        // Stage order: channel chunk OUTSIDE, slot-table block INSIDE -- the rows of (pass, chunk) are staged once and stay while the
+        // pass's blocks of T2_KB offsets walk over them.  (Rounds 3-5 had the block outside: a pass of more than T2_KB offsets
+        // over several chunks -- the 5^3 / 9^3 class convolutions on split rows, 192 channels: 4 / 23 blocks x 3 chunks -- staged
+        // the same <= 64 KB of rows again for EVERY block.)  The table of a block stays resident only when the pass has ONE
+        // block (every 3^3 layer: nothing changes there); else it is re-laid per (chunk, block): 8 KB against the rows' 64.
+        const bool one_block = k1 - k0 <= T2_KB;
+        for (int c = 0; c < nchunk; c++) {
+            for (int kb = k0; kb < k1 || kb == k0; kb += T2_KB) {      // (an empty pass still is one stage)
+                const int nk = k1 - kb < T2_KB ? (k1 - kb > 0 ? k1 - kb : 0) : T2_KB;
+                const bool stage_rows = kb == k0;                       // else: the rows of this (pass, chunk) are already there
+                const bool stage_slots = c == 0 || !one_block;
                 // ------------------------------------------------------------------------------------ stage
                 __syncthreads();                        // every wave has finished reading the row tile / slot table; idx_s is written
                 // an opaque copy of the thread id for everything the staging code addresses: without it the compiler hoists
@@ -147,7 +154,7 @@ __device__ __forceinline__ void t2_unit(
                 // 32+r, 64+r, 96+r as ONE 8-byte word); requested before the rows so that it returns first
                 uint4 sv[2];
                 int lv = 0;
-                if (c == 0) {
+                if (stage_slots) {
                     const uint16_t *slots_t = slots + (tile * K + kb) * (int64_t)T2_TM;
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
@@ -177,7 +184,7 @@ __device__ __forceinline__ void t2_unit(
                     }
                 }
                 if (stid < 8 && stage_rows) reinterpret_cast<uint4 *>(As)[stid] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
-                if (c == 0) {
+                if (stage_slots) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const int i = j * 256 + stid;

@@ -36,3 +36,32 @@ def test_scarce_cpus_are_left_alone():
 def test_overrides():
     assert _layout(64, 1, {"CG3D_HOST_PIN": "0"}) == []
     assert _layout(64, 1, {"CG3D_HOST_PIN": "20-21,30"}) == [[20, 21, 30]]
+
+
+def test_threads_started_after_the_pin_stay_inside_the_ranks_block():
+    """The coordinate-prefetch worker (and every helper thread the runtime starts later) is created AFTER bench.py / train.py pin
+    the process: it inherits the rank's CPU block, so eight ranks' issuing threads and workers never share a core.  Real
+    affinity calls, on whatever CPUs this process may use (skipped where there are too few to narrow anything)."""
+    import threading
+    import pytest
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no affinity calls on this OS")
+    allowed = os.sched_getaffinity(0)
+    if len(allowed) < 16:
+        pytest.skip("too few CPUs to pin a block")
+    blocks = []
+    try:
+        for r in (0, 1):
+            with mock.patch.dict(os.environ, {"LOCAL_WORLD_SIZE": "2"}):
+                os.environ.pop("CG3D_HOST_PIN", None)
+                os.sched_setaffinity(0, allowed)
+                _, pinned = hostpin.pin_host_threads(r)
+            seen = []
+            t = threading.Thread(target=lambda: seen.append(os.sched_getaffinity(threading.get_native_id())), name="cg3d-coordinate-prefetch")
+            t.start()
+            t.join()
+            assert seen[0] == pinned and len(pinned) == 6
+            blocks.append(pinned)
+        assert not (blocks[0] & blocks[1])
+    finally:
+        os.sched_setaffinity(0, allowed)

@@ -25,6 +25,27 @@ from cagroup3d_amd import _lib, build_model, engine, me
 from test_engine import _backbone_step, _class_branch_inputs, _class_branch_step, _l2
 
 
+@pytest.fixture(autouse=True)
+def _sixteen_threads():
+    """The oracle's OpenMP loops anti-scale on a many-core host (256 hardware threads on the GPU box: 2.1 s per step at 16 threads,
+    14 s at 128 -- profiles/r03_cpu_thread_scaling.txt; bench.py's cpu_baseline leg caps them the same way)."""
+    import ctypes
+    n = min(os.cpu_count() or 1, 16)
+    keep = torch.get_num_threads()
+    torch.set_num_threads(n)
+    gomp = None
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        kept = gomp.omp_get_max_threads()
+        gomp.omp_set_num_threads(n)
+    except OSError:
+        pass
+    yield
+    torch.set_num_threads(keep)
+    if gomp is not None:
+        gomp.omp_set_num_threads(kept)
+
+
 @pytest.fixture(scope="module")
 def oracle_dev(oracle):
     """A second handle of the oracle that takes the device library's kernel choices (the session's `oracle` stays as it is)."""
@@ -50,38 +71,42 @@ def _oracle_backbone(oracle_dev, model, batch, state, act16):
             me._WeightPlan.reset()
 
 
-def test_the_oracle_runs_the_bench_precision_program(oracle, oracle_dev):
-    """CPU: the oracle executes the backbone's tables in the bench precision (tile plans, fragment weights, bf16 rows); with
-    fp32 row storage the program equals the oracle's per-layer path (same calls, same operands, sequential sums), and bf16 row
-    storage moves the result by no more than rounded activations can."""
+def test_the_oracle_runs_the_bench_precision_program(oracle_dev):
+    """CPU: the oracle executes the backbone's tables in the bench precision (tile plans, fragment weights, the step's weight
+    arena).  With fp32 row storage the program equals the oracle's per-layer path (same calls, same operands, sequential sums);
+    bf16 row storage moves the result by no more than rounded activations can (a few 1e-2 through 70 untrained layers)."""
     model, _ = build_model.build_cagroup3d("scannet", seed=0)
     batch = build_model.synthetic_batch("S2k", 1, device="cpu")
     state = {k: v.clone() for k, v in model.state_dict().items()}
-    p32 = _oracle_backbone(oracle_dev, model, batch, state, False)
     keep = (me.PRECISION, engine.ACT_BF16)
     with _lib.use_library(oracle_dev):
         me.PRECISION, engine.ACT_BF16 = 1, False
         try:
+            # pass 1: nothing is in the weight arena yet -> engine.NotReady -> the per-layer path of me.py (the specification of the
+            # fp32-row program), which records the weights; pass 2: the program
+            before = dict(engine.STATS)
+            ref = _backbone_step(model, batch, True, "cpu")
+            assert engine.STATS["program_passes"] == before["program_passes"] and engine.STATS["not_ready"] == before["not_ready"] + 1
             model.load_state_dict(state)
-            ref = _backbone_step(model, batch, False, "cpu")        # the per-layer path of me.py: the specification of the fp32-row program
+            p32 = _backbone_step(model, batch, True, "cpu")
+            assert engine.STATS["program_passes"] == before["program_passes"] + 1
+            engine.ACT_BF16 = True
+            model.load_state_dict(state)
+            p16 = _backbone_step(model, batch, True, "cpu")
+            assert engine.STATS["program_passes"] == before["program_passes"] + 2
         finally:
             me.PRECISION, engine.ACT_BF16 = keep
             me._WeightPlan.reset()
-    assert torch.equal(ref[0], p32[0])
+    assert torch.equal(ref[0], p32[0]) and torch.equal(ref[0], p16[0])
     assert _l2(ref[1], p32[1]) <= 2e-3, _l2(ref[1], p32[1])
     for k in ref[3]:
         assert _l2(ref[3][k].float(), p32[3][k].float()) <= 2e-3, k
-    # the per-layer path on the plain oracle handle (pair kernels throughout, no plans): same products in another order
-    with _lib.use_library(oracle):
-        me.PRECISION = 1
-        try:
-            model.load_state_dict(state)
-            plain = _backbone_step(model, batch, False, "cpu")
-        finally:
-            me.PRECISION = keep[0]
-            me._WeightPlan.reset()
-    assert torch.equal(plain[0], p32[0])
-    assert _l2(plain[1], p32[1]) <= 5e-2, _l2(plain[1], p32[1])
+    bad = {k: _l2(ref[2][k], p32[2][k]) for k in ref[2] if float(ref[2][k].norm()) > 1e-3 and _l2(ref[2][k], p32[2][k]) > 2e-2}
+    assert not bad, bad
+    assert _l2(p32[1], p16[1]) <= 1e-1, _l2(p32[1], p16[1])
+    for k in ref[3]:
+        if "running_" in k:
+            assert _l2(p32[3][k].float(), p16[3][k].float()) <= 5e-2, k
 
 
 def _device_backbone(model_cuda, batch_cuda, state, runs=2):

@@ -4,7 +4,10 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctypes import c_int32, c_int64
 import torch
-from cagroup3d_amd import me, synthetic, _lib
+from cagroup3d_amd import _lib
+if os.environ.get("CG3D_DEV_LIB"):
+    _lib.HIP_LIB_PATH = os.path.abspath(os.environ["CG3D_DEV_LIB"])
+from cagroup3d_amd import me, synthetic
 from cagroup3d_amd._lib import ptr
 from microbench_conv import timeit
 me.PRECISION = 1
