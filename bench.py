@@ -192,7 +192,7 @@ def pmc_traffic(kernel_substr):
     guide prescribes), so the figure is read from the newest pair of CSVs committed under profiles/ and `traffic_source`
     names them.  gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B for 16-B/lane reads -> doubled."""
     import csv
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         names = [os.path.join("profiles", "%s_pmc_%s.csv" % (rnd, c)) for c in ("FETCH_SIZE", "WRITE_SIZE")]
         if not all(os.path.exists(os.path.join(ROOT, n)) for n in names):
             continue
@@ -263,6 +263,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if os.environ.get("CG3D_BENCH_WATCHDOG"):       # dev aid: every thread's stack to stderr after N seconds, then exit (a hung rank says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CG3D_BENCH_WATCHDOG"]), exit=True)
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args, not args.natural)), flush=True)
         return
@@ -474,7 +477,14 @@ def main():
     dt, profiled_steps, tb = timed_run(args.steps, rot_batches)
     per_rank_ms = list(rank_ms)
     roof = roofline_of(dt, profiled_steps, args.steps, me.PRECISION) if rank == 0 else None
-    if _engine.LANES and _engine.LANES_RUN and os.environ.get("CG3D_BENCH_ON_LANES", "1") != "0":
+    on_lanes = bool(_engine.LANES and _engine.LANES_RUN and os.environ.get("CG3D_BENCH_ON_LANES", "1") != "0")
+    if use_dist:
+        # the lane tuner decides per process (two ranks on one device share its queues and may decide differently): the extra steps
+        # hold collectives, so the ranks take them together or not at all (a rank that skipped them once left the other in a barrier)
+        flag = torch.tensor([int(on_lanes)], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        on_lanes = bool(int(flag.item()))
+    if on_lanes:
         keep_ms = list(rank_ms)
         dt_l, prof_l, _ = timed_run(2, lanes_while_profiling=True)       # (every rank: the steps hold collectives)
         rank_ms[:] = keep_ms

@@ -15,7 +15,9 @@ from ctypes import c_float, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libcagroup3d_hip.so")
+# CG3D_HIP_LIB: dev aid -- another BUILD of the same HIP library (tools/ab_libs.sh: two builds alternated on one box); it must
+# be a device library (cg3d_is_device_library), so this cannot route the product to the oracle
+HIP_LIB_PATH = os.environ.get("CG3D_HIP_LIB") or os.path.join(_HERE, "csrc", "libcagroup3d_hip.so")
 
 CG3D_OK = 0
 _ERRORS = {-1: "CG3D_ERR_ARG (bad argument)", -2: "CG3D_ERR_LAUNCH (HIP launch/runtime error)",
@@ -233,7 +235,22 @@ def get():
                 "libcagroup3d_hip.so not found at %s -- build it with `python cagroup3d_amd/csrc/build.py` "
                 "(hipcc --offload-arch=gfx950).  The product path has no CPU fallback." % HIP_LIB_PATH)
         _active = Library(HIP_LIB_PATH)
+        if not _active.is_device:
+            _active = None
+            raise CG3DError("%s is not a device library -- the product path has no CPU fallback" % HIP_LIB_PATH)
     return _active
+
+
+# Callbacks run whenever the active library CHANGES (me.py registers the reset of the step's weight plan: its arena and the
+# recorded weights belong to one library's memory -- a plan that still listed device weights once handed the oracle a table of
+# device addresses, which the CPU then read through the PCIe aperture for minutes: tests/test_timed_path_oracle.py, round 6).
+on_switch = []
+
+
+def _switched(old, new):
+    if old is not new:
+        for fn in on_switch:
+            fn()
 
 
 class use_library:
@@ -249,9 +266,11 @@ class use_library:
         global _active
         self.prev = _active
         _active = self.lib
+        _switched(self.prev, _active)
         return self.lib
 
     def __exit__(self, *exc):
         global _active
-        _active = self.prev
+        was, _active = _active, self.prev
+        _switched(was, _active)
         return False

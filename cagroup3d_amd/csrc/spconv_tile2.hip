@@ -26,7 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define T2_TM 128            // output rows per tile
-#define T2_KB 32             // offsets whose slot table is resident in LDS at a time
+#define T2_KB 32             // offsets whose slot table is resident in LDS at a time (template parameter KBT of the unit: 32, or
+#define T2_KB_BIG 128        // 128 for kernels of more than CG3D_TILE_KB_BIG_MIN_K offsets -- the 5^3 / 9^3 class convolutions)
 #define T2_NLV 16            // row granules a thread stages per pass and chunk: 256 threads x 16 = 4096 = 512 rows x 8
 #ifndef T2_STAT_SLOTS
 #define T2_STAT_SLOTS CG3D_BN_SLOTS      // (dev: more slots than the table's consumers add up, to measure the atomics' same-address queueing)
@@ -46,7 +47,7 @@ extern "C" int cg3d_tile2_trace_set(unsigned long long *buf) {
 // LDS: row tile (ucap + 1) x 128 B, >= 64 KB (it doubles as the exchange / output buffer) | slot table [T2_KB][32][4] uint16
 // | list of live offsets | BatchNorm partial sums [2][128]
 __host__ __device__ static inline int t2_a_bytes(int ucap) { return (ucap + 1) * 128 > 65536 ? (ucap + 1) * 128 : 65536; }
-#define T2_TAB_BYTES (T2_KB * T2_TM * 2 + 80)         // slot table + klist (T2_KB + 2 entries, padded to 16 B)
+#define T2_TAB_BYTES_OF(KB) ((KB) * T2_TM * 2 + 16 + 2 * (KB))      // slot table + klist (KB + 2 entries, padded to 16 B)
 #define T2_IDX_BYTES (512 * 4)                        // row indices of the current pass
 
 // Workgroup = one unit = (tile of 128 output rows, block of 128 (NCO == 2) or 64 (NCO == 1) output channels, offset share
@@ -56,7 +57,7 @@ __host__ __device__ static inline int t2_a_bytes(int ucap) { return (ucap + 1) *
 // through the row tile (free by then), leave their rows row-major in LDS and store them 16 bytes per lane.
 // bx: index of the workgroup among the workgroups of ITS unit kind; tile_base: first tile of that kind (a launch may mix
 // units of both kinds: k_spconv_tile2_mix)
-template <int NCO>
+template <int NCO, int KBT>
 __device__ __forceinline__ void t2_unit(
     const uint16_t *__restrict__ X, const uint16_t *__restrict__ Wf, const uint16_t *__restrict__ slots,
     const uint8_t *__restrict__ live, const int32_t *__restrict__ pass_tab, const int32_t *__restrict__ npass,
@@ -69,7 +70,8 @@ __device__ __forceinline__ void t2_unit(
     const int a_bytes = t2_a_bytes(ucap);
     uint8_t *const As = smem;
     uint16_t *const slot_s = reinterpret_cast<uint16_t *>(smem + a_bytes);
-    uint16_t *const klist = slot_s + T2_KB * T2_TM;
+    constexpr int T2_TAB_BYTES = T2_TAB_BYTES_OF(KBT);
+    uint16_t *const klist = slot_s + KBT * T2_TM;
     int32_t *const idx_s = reinterpret_cast<int32_t *>(smem + a_bytes + T2_TAB_BYTES);
     float *const sacc = reinterpret_cast<float *>(smem + a_bytes + T2_TAB_BYTES + T2_IDX_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,8 +90,8 @@ __device__ __forceinline__ void t2_unit(
     // pipe idles while both gather, and is contended while both multiply (profiles/r03_tile_trace.txt).  The workgroups
     // that land in a CU's second slot (dispatch fills every CU of an XCD once before it doubles up: 32 workgroups per XCD =
     // 256 per round) start a few microseconds late, so that one's gather / exchange / store falls into the other's multiply.
-    if (stagger > 0 && ((blockIdx.x >> 8) & 1))
-        for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles ~ 2.2 us each
+    if ((stagger & 255) > 0 && ((blockIdx.x >> 8) & 1))
+        for (int i = 0; i < (stagger & 255); i++) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles ~ 2.2 us each
     const int64_t tile = tile_base + u / (ny * gz);
     const int yb = (u / gz) % ny, zi = u % gz;
     int64_t row0 = tile * T2_TM, wslot0 = 0;
@@ -132,17 +134,24 @@ __device__ __forceinline__ void t2_unit(
             if (i0 < ucnt) idx_s[i0] = ulist[uoff + i0];
             if (i0 + 1 < ucnt) idx_s[i0 + 1] = ulist[uoff + i0 + 1];
         }
-        // Stage order: channel chunk OUTSIDE, slot-table block INSIDE -- the rows of (pass, chunk) are staged once and stay while the
-        // pass's blocks of T2_KB offsets walk over them.  (Rounds 3-5 had the block outside: a pass of more than T2_KB offsets
-        // over several chunks -- the 5^3 / 9^3 class convolutions on split rows, 192 channels: 4 / 23 blocks x 3 chunks -- staged
-        // the same <= 64 KB of rows again for EVERY block.)  The table of a block stays resident only when the pass has ONE
-        // block (every 3^3 layer: nothing changes there); else it is re-laid per (chunk, block): 8 KB against the rows' 64.
-        const bool one_block = k1 - k0 <= T2_KB;
-        for (int c = 0; c < nchunk; c++) {
-            for (int kb = k0; kb < k1 || kb == k0; kb += T2_KB) {      // (an empty pass still is one stage)
-                const int nk = k1 - kb < T2_KB ? (k1 - kb > 0 ? k1 - kb : 0) : T2_KB;
-                const bool stage_rows = kb == k0;                       // else: the rows of this (pass, chunk) are already there
-                const bool stage_slots = c == 0 || !one_block;
+        // Stage order.  Default: slot-table block OUTSIDE, channel chunk inside -- the table of a block is re-laid once and the rows
+        // of the pass are staged again for every (block, chunk) of a pass of several chunks.  CG3D_TILE_CHUNK_OUTER=1 (stagger
+        // bit 8) turns it round: rows of (pass, chunk) staged once, the table re-laid per (chunk, block).  Measured on the 9^3 / 5^3
+        // class convolutions on split rows (192 channels; profiles/r06_ab_rocprof_tile.txt): with blocks of 128 offsets 298 us
+        // per launch block-outside against 324 chunk-outside -- re-laying a 32 KB table through registers (64 two-byte LDS
+        // stores per thread) costs more than another asynchronous LDS-DMA fill of the rows; with blocks of 32 offsets (23 blocks
+        // per pass) chunk-outside wins by 8 %, but blocks of 128 beat both (404 -> 298 us).
+        const int nblk = k1 - k0 > KBT ? (k1 - k0 + KBT - 1) / KBT : 1;      // (an empty pass still is one stage)
+        const bool chunk_outer = (stagger & 256) != 0;
+        {
+            for (int sidx = 0; sidx < nblk * nchunk; sidx++) {
+                const int c = chunk_outer ? sidx / nblk : sidx % nchunk, bi = chunk_outer ? sidx % nblk : sidx / nchunk;
+                const int kb = k0 + bi * KBT;
+                const int nk = k1 - kb < KBT ? (k1 - kb > 0 ? k1 - kb : 0) : KBT;
+                // rows of (pass, chunk): staged at the chunk's first block and kept (block-outside order: at every stage of a
+                // pass of several chunks); table of a block: resident over the chunks only when the pass is ONE block
+                const bool stage_rows = chunk_outer ? bi == 0 : (nchunk > 1 || bi == 0);
+                const bool stage_slots = chunk_outer ? (c == 0 || nblk > 1) : c == 0;
                 // ------------------------------------------------------------------------------------ stage
                 __syncthreads();                        // every wave has finished reading the row tile / slot table; idx_s is written
                 // an opaque copy of the thread id for everything the staging code addresses: without it the compiler hoists
@@ -152,17 +161,21 @@ __device__ __forceinline__ void t2_unit(
                 asm volatile("" : "+v"(stid));
                 // slot table of offsets [kb, kb+nk): global [k][row] -> LDS [kk][r][m] (lane r reads the slots of rows r,
                 // 32+r, 64+r, 96+r as ONE 8-byte word); requested before the rows so that it returns first
-                uint4 sv[2];
-                int lv = 0;
+                constexpr int NSV = KBT / 16;            // 16-byte pieces of the block's table per thread
+                uint4 sv[NSV];
+                int lv = 0, lv2 = 0;
                 if (stage_slots) {
                     const uint16_t *slots_t = slots + (tile * K + kb) * (int64_t)T2_TM;
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < NSV; j++) {
                         const int i = j * 256 + stid;
                         const int ic = i < nk * (T2_TM / 8) ? i : 0;
                         sv[j] = *reinterpret_cast<const uint4 *>(slots_t + (int64_t)(ic >> 4) * T2_TM + (ic & 15) * 8);
                     }
-                    if (wave == 0) lv = lane < nk ? live[tile * (int64_t)K + kb + lane] : 0;
+                    if (wave == 0) {
+                        lv = lane < nk ? live[tile * (int64_t)K + kb + lane] : 0;
+                        if (KBT > 64) lv2 = lane + 64 < nk ? live[tile * (int64_t)K + kb + 64 + lane] : 0;
+                    }
                 }
                 // rows: global memory -> LDS row tile by LDS-DMA (global_load_lds_dwordx4: no data registers; a request fills
                 // wave-uniform base + lane * 16).  Lane i of request j owns PHYSICAL granule i & 7 of row slot (i >> 3) + 1
@@ -186,7 +199,7 @@ __device__ __forceinline__ void t2_unit(
                 if (stid < 8 && stage_rows) reinterpret_cast<uint4 *>(As)[stid] = make_uint4(0u, 0u, 0u, 0u);      // the zero row
                 if (stage_slots) {
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < NSV; j++) {
                         const int i = j * 256 + stid;
                         if (i < nk * (T2_TM / 8)) {
                             const int kk = i >> 4, row8 = (i & 15) * 8;
@@ -201,10 +214,16 @@ __device__ __forceinline__ void t2_unit(
                             }
                         }
                     }
-                    if (wave == 0) {                    // the live offsets of the block, compacted with one ballot
+                    if (wave == 0) {                    // the live offsets of the block, compacted with one ballot (two: 128 offsets)
                         const uint64_t bal = __ballot(lv != 0);
                         if (lv) klist[__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(lane | (lv << 8));
-                        if (lane == 0) klist[T2_KB] = (uint16_t)__popcll(bal);
+                        int total = __popcll(bal);
+                        if (KBT > 64) {
+                            const uint64_t bal2 = __ballot(lv2 != 0);
+                            if (lv2) klist[total + __popcll(bal2 & ((1ull << lane) - 1ull))] = (uint16_t)((lane + 64) | (lv2 << 8));
+                            total += __popcll(bal2);
+                        }
+                        if (lane == 0) klist[KBT] = (uint16_t)total;
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0);          // the LDS-DMA requests of this wave have landed (vmcnt), its LDS writes too
@@ -212,7 +231,7 @@ __device__ __forceinline__ void t2_unit(
                 T2_STAMP();                             // staged
 
                 // ---------------------------------------------------------------------------------- multiply
-                const int nlive = __builtin_amdgcn_readfirstlane(klist[T2_KB]);       // (uniform: keeps the step loop a scalar loop)
+                const int nlive = __builtin_amdgcn_readfirstlane(klist[KBT]);       // (uniform: keeps the step loop a scalar loop)
                 const int nstep = first < nlive ? (nlive - first + stride - 1) / stride : 0;     // offsets of this wave
                 if (nstep > 0) {
                     // weight fragments of (offset kk, 16-channel group ks, output block n): Wf[slot][nt][ks][lane][8]
@@ -407,7 +426,7 @@ __device__ __forceinline__ void t2_unit(
     // 128 -> 128 @ 82 107 rows 70 -> 78 us with statistics on, whatever the number of table slots (1 ... 1024 slots: the same
     // times, profiles/r06_tile2_stats_slots.txt -- not a same-address queue).  Rows past the end of the last tile multiply the
     // zero row: they add nothing.  With a bias the sums are those of acc + bias: the store loop's path below stays.
-    const bool early_stats = stats != nullptr && bias == nullptr && !(T2_DBG & 128);
+    const bool early_stats = stats != nullptr && bias == nullptr && (stagger & 512) && !(T2_DBG & 128);      // (bit 9 clear: CG3D_TILE_EARLY_STATS=0, A/B)
     auto stats_from_acc = [&](auto LO, auto CNT) {
         constexpr int lo = decltype(LO)::value, cnt = decltype(CNT)::value;
         float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};
@@ -530,10 +549,14 @@ __device__ __forceinline__ void t2_unit(
         int32_t cin, int32_t cout
 #define T2_ARGS X, Wf, slots, live, pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout
 
-template <int NCO>
+// KBT = T2_KB_BIG (kernels of more than 64 offsets): a pass of the 9^3 class convolution on split rows is 6 table blocks x 3
+// chunks = 18 stages instead of 23 x 3 = 69, each one two barriers, a table re-lay and a weight-stream restart around what were
+// ~4 offsets of work per wave; the 24 KB of extra table cost the second workgroup of a CU (101 KB of LDS) -- these launches
+// have about one unit per CU anyway (240 tiles of 18 classes x 4 scenes).
+template <int NCO, int KBT>
 __global__ __launch_bounds__(256, 2) void k_spconv_tile2(T2_PARAMS, int32_t nunit, int32_t ny, int32_t gz, int32_t wrev,
                                                          float *__restrict__ stats, int32_t stagger) {
-    t2_unit<NCO>(T2_ARGS, nunit, ny, gz, wrev, stats, stagger, blockIdx.x, 0);
+    t2_unit<NCO, KBT>(T2_ARGS, nunit, ny, gz, wrev, stats, stagger, blockIdx.x, 0);
 }
 // The tail of a launch in half units.  Workgroups are dispatched in index order onto 512 slots (two per CU): a launch of
 // 642 full units (the 128 -> 128 layers at tensor stride 4) runs one full round and then 130 units on half-empty CUs -- 1.65
@@ -543,13 +566,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2(T2_PARAMS, int32_t nuni
 __global__ __launch_bounds__(256, 2) void k_spconv_tile2_mix(T2_PARAMS, int32_t grid2, int32_t nunit2, int32_t ny2, int32_t nunit1,
                                                              int32_t ny1, int32_t tile_split, int32_t wrev,
                                                              float *__restrict__ stats, int32_t stagger) {
-    if ((int)blockIdx.x < grid2) t2_unit<2>(T2_ARGS, nunit2, ny2, 1, wrev, stats, stagger, blockIdx.x, 0);
-    else t2_unit<1>(T2_ARGS, nunit1, ny1, 1, wrev, stats, 0, blockIdx.x - grid2, tile_split);
+    if ((int)blockIdx.x < grid2) t2_unit<2, T2_KB>(T2_ARGS, nunit2, ny2, 1, wrev, stats, stagger, blockIdx.x, 0);
+    else t2_unit<1, T2_KB>(T2_ARGS, nunit1, ny1, 1, wrev, stats, stagger & ~255, blockIdx.x - grid2, tile_split);
 }
 
-extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) {
-    return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES + T2_IDX_BYTES + 2 * 128 * sizeof(float);
+static int64_t t2_lds_bytes(int32_t ucap, int kb) {
+    return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES_OF(kb) + T2_IDX_BYTES + 2 * 128 * sizeof(float);
 }
+extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) { return t2_lds_bytes(ucap, T2_KB); }
 
 // rows of [2][cout] floats of the `stats` table of cg3d_spconv_tile_fwd (accumulated with atomics; the caller zero-fills it)
 extern "C" int32_t cg3d_spconv_tile_grid(int64_t ntile, int32_t cout, int32_t ksplit) {
@@ -571,7 +595,9 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     if (ntile == 0) return CG3D_OK;
     hipStream_t s = cg3d_hs(stream);
     if (ksplit > 1 && hipMemsetAsync(Y, 0, (size_t)n_out * cout * sizeof(float), s) != hipSuccess) return CG3D_ERR_LAUNCH;
-    const size_t lds = (size_t)cg3d_spconv_tile_lds_bytes(ucap);
+    static const int kb_big_min_k = getenv("CG3D_TILE_KB_BIG_MIN_K") ? atoi(getenv("CG3D_TILE_KB_BIG_MIN_K")) : 64;
+    const bool big = K > kb_big_min_k;                // table blocks of 128 offsets (one workgroup per CU): the 5^3 / 9^3 kernels
+    const size_t lds = (size_t)t2_lds_bytes(ucap, big ? T2_KB_BIG : T2_KB);
     // units of 128 output channels, or of 64 when the count is not a multiple of 128 (64, 192: the 64 -> 3 x 64 feature-offset
     // convolution of the yaw datasets, cagroup_head.py:170-172)
     // A launch of at most CG3D_TILE_NARROW units of 128 channels (fewer than one per CU: the 512-channel layers at tensor stride
@@ -583,28 +609,30 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     if (nunit > 0x7ffffff0ll) return CG3D_ERR_ARG;
     const unsigned grid = (unsigned)((nunit + 7) / 8 * 8);
     static const int stagger_env = getenv("CG3D_TILE_STAGGER") ? atoi(getenv("CG3D_TILE_STAGGER")) : 2;
-    const int32_t stagger = nunit > 256 ? stagger_env : 0;
-#define T2_LAUNCH(NW)                                                                                                          \
+    static const int chunk_outer_env = getenv("CG3D_TILE_CHUNK_OUTER") ? atoi(getenv("CG3D_TILE_CHUNK_OUTER")) : 0;
+    static const int early_stats_env = getenv("CG3D_TILE_EARLY_STATS") ? atoi(getenv("CG3D_TILE_EARLY_STATS")) : 1;
+    const int32_t stagger = (nunit > 256 ? (stagger_env & 255) : 0) | (chunk_outer_env ? 256 : 0) | (early_stats_env ? 512 : 0);
+#define T2_LAUNCH(NW, KB)                                                                                                      \
     do {                                                                                                                       \
         static bool attr = false;                                                                                              \
         if (!attr) {                                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_tile2<NW>),                                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spconv_tile2<NW, KB>),                                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (KB > T2_KB ? 104 : 80) * 1024) != hipSuccess) \
                 return CG3D_ERR_LAUNCH;                                                                                        \
             attr = true;                                                                                                       \
             if (getenv("CG3D_TILE_INFO")) {                                                                                    \
                 int nb = -1;                                                                                                   \
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spconv_tile2<NW>, 256, lds);                         \
-                fprintf(stderr, "k_spconv_tile2<%d>: lds %zu B, occupancy %d workgroups/CU\n", NW, lds, nb);                  \
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_spconv_tile2<NW, KB>, 256, lds);                     \
+                fprintf(stderr, "k_spconv_tile2<%d, %d>: lds %zu B, occupancy %d workgroups/CU\n", NW, KB, lds, nb);          \
             }                                                                                                                  \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_spconv_tile2<NW>), dim3(grid), dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist,    \
+        hipLaunchKernelGGL((k_spconv_tile2<NW, KB>), dim3(grid), dim3(256), lds, s, X, Wf, slots, live, pass_tab, npass, ulist, \
                            maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, (int32_t)nunit, ny, ksplit, wrev, stats, stagger); \
     } while (0)
     // tail in half units (see k_spconv_tile2_mix): only when the last round is at most half full
     static const int tail_env = getenv("CG3D_TILE_TAIL") ? atoi(getenv("CG3D_TILE_TAIL")) : 1;
     const int64_t SLOTS = 512, rem = nunit % SLOTS;
-    const int64_t tail_tiles = (tail_env && wide && ksplit == 1 && nunit > SLOTS && rem > 0 && 2 * rem <= SLOTS) ? rem / ny : 0;
+    const int64_t tail_tiles = (tail_env && !big && wide && ksplit == 1 && nunit > SLOTS && rem > 0 && 2 * rem <= SLOTS) ? rem / ny : 0;
     if (tail_tiles > 0) {
         static bool attr_mix = false;
         if (!attr_mix) {
@@ -619,7 +647,9 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
         hipLaunchKernelGGL(k_spconv_tile2_mix, dim3((unsigned)(grid2 + (nunit1 + 7) / 8 * 8)), dim3(256), lds, s, X, Wf, slots, live,
                            pass_tab, npass, ulist, maxpass, ucap, tiles, order, bias, Y, n_out, K, cin, cout, grid2, nunit2, ny, nunit1,
                            ny1, tile_split, wrev, stats, stagger);
-    } else if (wide) T2_LAUNCH(2); else T2_LAUNCH(1);
+    } else if (big) {
+        if (wide) T2_LAUNCH(2, T2_KB_BIG); else T2_LAUNCH(1, T2_KB_BIG);
+    } else if (wide) T2_LAUNCH(2, T2_KB); else T2_LAUNCH(1, T2_KB);
 #undef T2_LAUNCH
     CG3D_CHECK_LAUNCH();
     return CG3D_OK;

@@ -1191,6 +1191,9 @@ def late_weights_ready():
         torch.cuda.current_stream(idx).wait_stream(_LATE_STREAMS[idx])
 
 
+_lib.on_switch.append(lambda: _WeightPlan.reset())      # the plan's arena and recorded weights live in ONE library's memory
+
+
 def prepare_weights(training=True, split=False):
     """Start of a detector forward: convert the recorded convolution weights -- one launch -- and let the per-layer
     requests of THIS forward be answered from the arena (until `finish_weights()`).

@@ -128,7 +128,7 @@ def _device_backbone(model_cuda, batch_cuda, state, runs=2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfgname,n", [("S5k", 2), ("S50k", 1)])
+@pytest.mark.parametrize("cfgname,n", [("S5k", 2), (os.environ.get("CG3D_TIMED_PATH_CFG", "S50k"), 1)])
 def test_backbone_program_on_lanes_with_bf16_rows_follows_the_oracle(oracle_dev, hip, cfgname, n):
     """The timed backbone pass (lanes on, bf16 row storage, bench precision) on the device against the same tables on the oracle:
     per-layer forward statistics (every BatchNorm's running mean / variance after the step: one check per convolution of the
@@ -137,7 +137,10 @@ def test_backbone_program_on_lanes_with_bf16_rows_follows_the_oracle(oracle_dev,
     model, _ = build_model.build_cagroup3d("scannet", seed=0)
     batch = build_model.synthetic_batch(cfgname, n, device="cpu")
     state = {k: v.clone() for k, v in model.state_dict().items()}
+    import time
+    t0 = time.time()
     ref = _oracle_backbone(oracle_dev, model, batch, state, True)
+    print("%s x %d: oracle passes %.1f s" % (cfgname, n, time.time() - t0))
     model = model.cuda()
     dstate = {k: v.cuda() for k, v in state.items()}
     d1, d2 = _device_backbone(model, {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}, dstate)

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): regenerates everything profiles/ holds for this round.  Outputs land in gpurun_out/refresh/;
 # copy them into profiles/ afterwards (tools/make_profiles_readme.py rebuilds the README from them).
 set -x
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/refresh; mkdir -p $O; RN=${ROUND:-r05}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/refresh; mkdir -p $O; RN=${ROUND:-r06}
 cd /tmp; export TMPDIR=/tmp
 python $R/tools/stream_bw.py > $O/${RN}_stream_bw.txt 2>&1
 python $R/bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/${RN}_bench_bf16.json
@@ -15,7 +15,8 @@ done
 # the same run with every launch program compiled without lanes: each kernel alone on the one stream -- the averages bench.py's
 # `roofline` (timed on steps compiled that way) is to be compared with
 rm -rf /tmp/prof_l0
-CG3D_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l0 -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 --rotate 0 > $O/rocprof_lanes0.log 2>&1
+CG3D_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l0 -o bench -- python $R/bench.py --no-cpu-baseline --no-fp32 > $O/rocprof_lanes0.log 2>&1
+tail -1 $O/rocprof_lanes0.log | grep '^{' > $O/${RN}_bench_bf16_lanes0_under_rocprof.json
 find /tmp/prof_l0 -name "*kernel_stats.csv" -exec cp {} $O/${RN}_bench_bf16_lanes0_kernel_stats.csv \;
 # lanes: device time of the backbone passes on one queue / on their lanes, the per-queue timeline of one pass, the step A/B
 ( for d in "" "3,2"; do for w in 0 2; do python $R/tools/backbone_lanes.py --wgrad-lanes $w --dappm-lanes "$d" 2>&1 | grep "DAPPM lanes"; done; done ) > $O/${RN}_backbone_lanes.txt 2>&1
