@@ -176,9 +176,9 @@ def test_backbone_program_on_lanes_with_bf16_rows_follows_the_oracle(oracle_dev,
 
 
 @pytest.mark.gpu
-def test_class_branch_program_in_the_split_precision_follows_the_fp32_oracle_program(oracle, hip):
+def test_class_branch_program_in_the_split_precision_follows_the_fp32_oracle(oracle, hip):
     """The class branches' launch program as the benchmark runs it (split operands: fp32-accurate products from three bf16 passes)
-    on the device against the FP32 program on the oracle (fp32 MFMA-free sequential sums): four grouped convolution + BatchNorm
+    on the device against the oracle's per-layer path in FP32 arithmetic (sequential sums): four grouped convolution + BatchNorm
     + ELU stages of all 18 classes -- output rows, input gradient, every parameter gradient, running statistics at 1e-3."""
     model, _ = build_model.build_cagroup3d("scannet", seed=0)
     head = model.dense_head.train()
@@ -186,16 +186,11 @@ def test_class_branch_program_in_the_split_precision_follows_the_fp32_oracle_pro
     fine, coarse, feat, up = _class_branch_inputs(head, "cpu", base=60)
     prec = me.PRECISION
     with _lib.use_library(oracle):
-        me.PRECISION = 0
-        os.environ["CG3D_ENGINE_ANY"] = "1"
+        me.PRECISION = 0                 # (the class program has no fp32 form: the reference is the per-layer path in fp32 arithmetic)
         try:
-            before = engine.CLASS_STATS["program_passes"]
-            ref = _class_branch_step(head, fine, coarse, feat, up, True, 2)
-            assert engine.CLASS_STATS["program_passes"] == before + 1
+            ref = _class_branch_step(head, fine, coarse, feat, up, False, 2)
         finally:
             me.PRECISION = prec
-            os.environ.pop("CG3D_ENGINE_ANY", None)
-            me._WeightPlan.reset()
     head = head.cuda()
     dstate = {k: v.cuda() for k, v in state.items()}
     me.PRECISION = me.PREC_SPLIT

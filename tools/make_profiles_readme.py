@@ -4,7 +4,7 @@ import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-RN = os.environ.get("ROUND", "r05")
+RN = os.environ.get("ROUND", "r06")
 
 
 def rd(name):
@@ -169,7 +169,14 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_lane_timeline.txt" % RN, "one forward and one backward pass of the backbone under rocprofv3 --kernel-trace: kernel time per queue, time with more than one queue busy (tools/lane_timeline.py)"),
                    ("%s_lanes_ab.txt" % RN, "per-step wall time of the training step with and without lanes, alternating on one box (tools/ab_steps.sh -> tools/step_times.py, 100 steps each)"),
                    ("%s_backward_nodes.txt" % RN, "host time of the backward pass per autograd node (torch.profiler)"),
-                   ("%s_class_branch_sections.txt" % RN, "host time and device tail per section of the class branches (a device sync per section)")):
+                   ("%s_class_branch_sections.txt" % RN, "host time and device tail per section of the class branches (a device sync per section)"),
+                   ("%s_tile2_knockout.txt" % RN, "k_spconv_tile2 with parts knocked out at compile time: where a launch's time goes (DESIGN.md section 5, round 6)"),
+                   ("%s_tile2_epilogue.txt" % RN, "the tile kernel's epilogue taken apart: statistics, exchange, stores, stagger, tail, 255-row passes"),
+                   ("%s_tile2_stats_slots.txt" % RN, "statistics epilogue against the number of table slots: not a same-address queue"),
+                   ("%s_tile2_early_stats.txt" % RN, "statistics taken from the accumulators right after the exchange"),
+                   ("%s_ab_rocprof_tile.txt" % RN, "per-kernel totals of one box under five environments: early statistics, stage order, 128-offset table blocks, round 5's kernel"),
+                   ("%s_ab_r05_vs_now.txt" % RN, "bench.py alternated between the round-5 build of the library and this round's"),
+                   ("%s_wgrad_knockout.txt" % RN, "weight gradient without its atomic epilogue / with plain stores")):
     if os.path.exists(os.path.join(P, name)):
         out.append("\n### `%s` — %s\n\n```\n%s\n```\n" % (name, what, "\n".join(l for l in rd(name).splitlines() if "amdgpu.ids" not in l)[:6000]))
 open(os.path.join(P, "README.md"), "w").write("".join(out))
