@@ -7,7 +7,7 @@ i=0
 for e in "$@"; do
   i=$((i+1)); [ "$e" = "-" ] && ee="" || ee="$e"
   rm -rf /tmp/abp_$i
-  env $ee CG3D_LANES=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$i -o b -- python $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-fp32 --rotate 0 > /tmp/abp_$i.log 2>&1
+  env $ee CG3D_LANES=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$i -o b -- python $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-fp32 --rotate 0 ${AB_ARGS} > /tmp/abp_$i.log 2>&1
   f=$(find /tmp/abp_$i -name "*kernel_stats.csv" | head -1)
   echo "== [$e]  $(tail -1 /tmp/abp_$i.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f scenes/s %.2f ms/step (under rocprof, lanes off)' % (d['value'], d['ms_per_step']))" 2>/dev/null)"
   python - "$f" "$K" <<'PY'

@@ -175,6 +175,7 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_tile2_stats_slots.txt" % RN, "statistics epilogue against the number of table slots: not a same-address queue"),
                    ("%s_tile2_early_stats.txt" % RN, "statistics taken from the accumulators right after the exchange"),
                    ("%s_ab_rocprof_tile.txt" % RN, "per-kernel totals of one box under five environments: early statistics, stage order, 128-offset table blocks, round 5's kernel"),
+                   ("%s_ab_rocprof_tile_other_configs.txt" % RN, "the same A/B on S200k x 4 and S100k-yaw x 8"),
                    ("%s_ab_r05_vs_now.txt" % RN, "bench.py alternated between the round-5 build of the library and this round's"),
                    ("%s_wgrad_knockout.txt" % RN, "weight gradient without its atomic epilogue / with plain stores")):
     if os.path.exists(os.path.join(P, name)):
