@@ -47,7 +47,12 @@ extern "C" int cg3d_tile2_trace_set(unsigned long long *buf) {
 // LDS: row tile (ucap + 1) x 128 B, >= 64 KB (it doubles as the exchange / output buffer) | slot table [T2_KB][32][4] uint16
 // | list of live offsets | BatchNorm partial sums [2][128]
 __host__ __device__ static inline int t2_a_bytes(int ucap) { return (ucap + 1) * 128 > 65536 ? (ucap + 1) * 128 : 65536; }
-#define T2_TAB_BYTES_OF(KB) ((KB) * T2_TM * 2 + 16 + 2 * (KB))      // slot table + klist (KB + 2 entries, padded to 16 B)
+// row tile + slot table [KB][32][4] uint16 (see t2_unit)
+__host__ __device__ static inline int t2_main_bytes(int ucap, int kb) {
+    if (kb <= 32) return t2_a_bytes(ucap) + kb * 128 * 2;
+    const int m = (ucap + 1) * 128 + kb * 128 * 2;
+    return m > 65536 ? m : 65536;
+}
 #define T2_IDX_BYTES (512 * 4)                        // row indices of the current pass
 
 // Workgroup = one unit = (tile of 128 output rows, block of 128 (NCO == 2) or 64 (NCO == 1) output channels, offset share
@@ -67,13 +72,17 @@ __device__ __forceinline__ void t2_unit(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int KG = 4 / NCO;
     constexpr int NC = NCO * 64;                        // output channels of the unit
-    const int a_bytes = t2_a_bytes(ucap);
+    // LDS layout (t2_main_bytes): [row tile | slot table] | klist | idx_s | sacc.  Blocks of 32 offsets: the row tile is at least the
+    // 64 KB the exchange needs.  Blocks of 128: the exchange (after the last multiply: the table is dead by then) runs over
+    // row tile AND table, so a plan of <= 255 rows per pass takes 32 + 32 KB and two workgroups fit a CU again.
+    const int a_bytes = KBT > T2_KB ? (ucap + 1) * 128 : t2_a_bytes(ucap);
+    const int main_bytes = t2_main_bytes(ucap, KBT);
     uint8_t *const As = smem;
     uint16_t *const slot_s = reinterpret_cast<uint16_t *>(smem + a_bytes);
-    constexpr int T2_TAB_BYTES = T2_TAB_BYTES_OF(KBT);
-    uint16_t *const klist = slot_s + KBT * T2_TM;
-    int32_t *const idx_s = reinterpret_cast<int32_t *>(smem + a_bytes + T2_TAB_BYTES);
-    float *const sacc = reinterpret_cast<float *>(smem + a_bytes + T2_TAB_BYTES + T2_IDX_BYTES);
+    constexpr int T2_KL_BYTES = 16 + 2 * KBT;
+    uint16_t *const klist = reinterpret_cast<uint16_t *>(smem + main_bytes);
+    int32_t *const idx_s = reinterpret_cast<int32_t *>(smem + main_bytes + T2_KL_BYTES);
+    float *const sacc = reinterpret_cast<float *>(smem + main_bytes + T2_KL_BYTES + T2_IDX_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction: lets everything derived from it live in SGPRs
     const int nt_total = cout >> 5, ks_total = cin >> 4, nchunk = cin >> 6;
@@ -365,7 +374,11 @@ __device__ __forceinline__ void t2_unit(
                     //    to the compiler, no spills): correct, but a branch per 64 cycles of MFMA and no sched_group_barrier
                     //    interleave cost as much as the skipped blocks save (128 -> 128: 87 vs 88 us, 256 -> 256: 98 vs 88 us).
                     // `MASK` stays a template parameter of the body for that reason only.  
+                    // (stagger bit 10, CG3D_TILE_SETPRIO=1: the multiply loop at wave priority 1 -- the other workgroup of the CU is
+                    // usually in a phase of plain VALU / LDS work then; measured)
+                    if (stagger & 1024) __builtin_amdgcn_s_setprio(1);
                     for (int st = 0; st < nstep; st++) step(std::integral_constant<int, 15>{}, kk_of(st + 2));
+                    if (stagger & 1024) __builtin_amdgcn_s_setprio(0);
                 }
                 T2_STAMP();                             // multiplied
             }
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tile2_mix(T2_PARAMS, int32_t 
 }
 
 static int64_t t2_lds_bytes(int32_t ucap, int kb) {
-    return (int64_t)t2_a_bytes(ucap) + T2_TAB_BYTES_OF(kb) + T2_IDX_BYTES + 2 * 128 * sizeof(float);
+    return (int64_t)t2_main_bytes(ucap, kb) + 16 + 2 * kb + T2_IDX_BYTES + 2 * 128 * sizeof(float);
 }
 extern "C" int64_t cg3d_spconv_tile_lds_bytes(int32_t ucap) { return t2_lds_bytes(ucap, T2_KB); }
 
@@ -611,7 +624,8 @@ extern "C" int cg3d_spconv_tile_fwd(const uint16_t *X, const uint16_t *Wf, const
     static const int stagger_env = getenv("CG3D_TILE_STAGGER") ? atoi(getenv("CG3D_TILE_STAGGER")) : 2;
     static const int chunk_outer_env = getenv("CG3D_TILE_CHUNK_OUTER") ? atoi(getenv("CG3D_TILE_CHUNK_OUTER")) : 0;
     static const int early_stats_env = getenv("CG3D_TILE_EARLY_STATS") ? atoi(getenv("CG3D_TILE_EARLY_STATS")) : 1;
-    const int32_t stagger = (nunit > 256 ? (stagger_env & 255) : 0) | (chunk_outer_env ? 256 : 0) | (early_stats_env ? 512 : 0);
+    static const int setprio_env = getenv("CG3D_TILE_SETPRIO") ? atoi(getenv("CG3D_TILE_SETPRIO")) : 0;
+    const int32_t stagger = (nunit > 256 ? (stagger_env & 255) : 0) | (chunk_outer_env ? 256 : 0) | (early_stats_env ? 512 : 0) | (setprio_env ? 1024 : 0);
 #define T2_LAUNCH(NW, KB)                                                                                                      \
     do {                                                                                                                       \
         static bool attr = false;                                                                                              \

@@ -267,7 +267,9 @@ class KernelMap:
                     # every other map: the tiles keep their rows (and the distinct input rows they stage), but inside a tile
                     # rows with the same live offsets share 32-row blocks, whose dead (offset, block) pairs the kernel skips
                     sort_rows = 128
-            pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds), sort_rows=sort_rows)
+            # (kernels of more than 64 offsets, the 5^3 / 9^3 class convolutions: TILE_UCAP_BIGK)
+            pl = build_tile_plan(nbr.contiguous(), P, None if row_bounds is None else self.tiles(row_bounds), sort_rows=sort_rows,
+                                 ucap=TILE_UCAP_BIGK if self.K > 64 else None)
             self._segs[ck] = pl
         return pl
 
@@ -772,6 +774,10 @@ TILE_ROWS = 128
 TILE_UCAP = int(__import__("os").environ.get("CG3D_TILE_UCAP", "511"))    # LDS rows per pass: (ucap+1) x 128 B = 64 KB
 
 
+# rows per pass for K > 64.  255 would let two workgroups of the 128-offset-block kernel share a CU (32 KB of rows + 32 KB of table under
+# the exchange's 64 KB) -- measured: 307-317 -> 515-541 us per launch on the 9^3 class maps (profiles/r06_ab_bigk_two_wgs.txt): a
+# 128-row tile of a 9^3 map touches ~1 000 distinct rows, and twice the passes cost far more than the second workgroup returns
+TILE_UCAP_BIGK = int(__import__("os").environ.get("CG3D_TILE_UCAP_BIGK", "511"))
 TILE_SORT_ROWS = __import__("os").environ.get("CG3D_TILE_SORT_ROWS", "1") != "0"
 TILE_SORT_MAX_OCCUPANCY = 0.2       # pairs / (K * rows) below which a map's tiles are cut from signature-sorted rows
 # (window 128 = inside the tile: only useful to a kernel that skips dead 32-row blocks -- tried, not kept: spconv_tile2.hip)
@@ -1634,7 +1640,7 @@ class GroupedConvFunction(torch.autograd.Function):
     @staticmethod
     def _ksplit(plan, K):
         """Offset shares per tile (atomics into a zeroed output) when the tiles alone cannot fill the chip."""
-        ncu = 256
+        ncu = 512 if (K > 64 and plan.ucap <= 255) else 256        # (workgroup slots: two per CU for the 128-offset-block kernel on 255-row passes)
         return max(1, min(8, K // 16, ncu // max(plan.ntile, 1)))
 
     @staticmethod
