@@ -535,10 +535,12 @@ def main():
         # from the next step on
         _engine.ACT_BF16 = False
         n2 = max(3, min(args.steps, 20))
-        for _ in range(3):
-            train_step(net, opt, batch, clip)
-        dt2, _, _ = timed_run(n2)
-        _engine.ACT_BF16 = True
+        try:
+            for _ in range(3):
+                train_step(net, opt, batch, clip)
+            dt2, _, _ = timed_run(n2)
+        finally:
+            _engine.ACT_BF16 = True
         for _ in range(2):
             train_step(net, opt, batch, clip)
         if rank == 0:
