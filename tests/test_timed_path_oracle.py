@@ -109,6 +109,28 @@ def test_the_oracle_runs_the_bench_precision_program(oracle_dev):
             assert _l2(p32[3][k].float(), p16[3][k].float()) <= 5e-2, k
 
 
+def test_the_weight_plan_does_not_outlive_its_library(oracle, oracle_dev):
+    """The step's weight plan (recorded weights + their arena) belongs to one library's memory: changing the active library resets
+    it (`_lib.on_switch`).  It did not until round 6, and a plan that still listed the previous test's DEVICE weights handed the
+    oracle a conversion table of device addresses."""
+    w = torch.randn(27, 64, 64)
+    with _lib.use_library(oracle_dev):
+        keep, me.PRECISION = me.PRECISION, 1
+        try:
+            assert me._planned_single(w, False, True) is None and me._WeightPlan.singles       # recorded, converted from the next forward on
+            gen = me._WeightPlan.gen
+            with _lib.use_library(oracle):                                                      # another library: nothing carried over
+                assert not me._WeightPlan.singles and me._WeightPlan.gen > gen
+            assert not me._WeightPlan.singles                                                   # ... nor back
+        finally:
+            me.PRECISION = keep
+    with _lib.use_library(oracle_dev):
+        with _lib.use_library(oracle_dev):                                                      # the same library again: no reset
+            me._WeightPlan.singles[("probe", 0)] = None
+        assert ("probe", 0) in me._WeightPlan.singles
+    me._WeightPlan.reset()
+
+
 def _device_backbone(model_cuda, batch_cuda, state, runs=2):
     keep = me.PRECISION
     me.PRECISION = 1
