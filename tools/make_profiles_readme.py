@@ -174,6 +174,11 @@ for name, what in (("%s_conv_shapes.txt" % RN, "per-shape conv table"), ("%s_pmc
                    ("%s_tile2_epilogue.txt" % RN, "the tile kernel's epilogue taken apart: statistics, exchange, stores, stagger, tail, 255-row passes"),
                    ("%s_tile2_stats_slots.txt" % RN, "statistics epilogue against the number of table slots: not a same-address queue"),
                    ("%s_tile2_early_stats.txt" % RN, "statistics taken from the accumulators right after the exchange"),
+                   ("%s_pmc_sq_tile_128_stats_late.txt" % RN, "SQ counters of the tile kernel WITH the statistics epilogue, statistics at the end of the workgroup (round 5)"),
+                   ("%s_pmc_sq_tile_128_stats_early.txt" % RN, "the same with the statistics taken right after the exchange (round 6)"),
+                   ("%s_ab_bigk_two_wgs.txt" % RN, "two workgroups per CU for the 128-offset-block kernel (255-row plans): a loss"),
+                   ("%s_ab_kb_k125.txt" % RN, "5^3 kernels on 128- vs 32-offset blocks"),
+                   ("%s_tile2_setprio.txt" % RN, "multiply loop at wave priority 1"),
                    ("%s_ab_rocprof_tile.txt" % RN, "per-kernel totals of one box under five environments: early statistics, stage order, 128-offset table blocks, round 5's kernel"),
                    ("%s_ab_rocprof_tile_other_configs.txt" % RN, "the same A/B on S200k x 4 and S100k-yaw x 8"),
                    ("%s_ab_r05_vs_now.txt" % RN, "bench.py alternated between the round-5 build of the library and this round's"),
